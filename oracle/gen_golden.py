@@ -1,0 +1,179 @@
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE PYTHON REFERENCE
+(imported from /root/reference; possible only in the build container).
+
+    python oracle/gen_golden.py
+
+The fixtures pin the CPU oracle (and through it the HIP path) to the real
+reference: every array stored here is either an input or a tensor the
+reference's own code returned.  Nothing from the reference's source is copied.
+
+Files
+-----
+grid_cases.npz   GridBasedPooling.{occupancies,directional,social} outputs and
+                 "tag grids" (occupancy() called with other_values = neighbour
+                 index + 1, which exposes which neighbour won each cell and so
+                 pins cell ids, last-writer-wins and the cell-0 clobber).
+lstm_<kind>.npz  LSTM.forward outputs (both n_predict and teacher-forced mode)
+                 for small models, with the full state_dict.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import  # noqa: E402
+from trajnetplusplusbaselines_amd import synth  # noqa: E402
+
+NAN = float('nan')
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def grid_cases(ref):
+    rng = np.random.RandomState(1234)
+    cases = []
+
+    def add(name, type_, obs1, obs2, n, cell_side, pool_size=1, blur_size=1, constant=0, front=False,
+            hidden=None, latent=4):
+        obs1 = torch.tensor(np.asarray(obs1, dtype=np.float32))
+        obs2 = torch.tensor(np.asarray(obs2, dtype=np.float32))
+        B, N = obs2.shape[0], obs2.shape[1]
+        hd = 8
+        torch.manual_seed(len(cases))
+        pool = ref.GridBasedPooling(cell_side=cell_side, n=n, hidden_dim=hd, type_=type_, pool_size=pool_size,
+                                    blur_size=blur_size, front=front, constant=constant, latent_dim=latent,
+                                    embedding_arch='one_layer', out_dim=8)
+        rec = dict(name=name, type=type_, n=n, cell_side=cell_side, pool_size=pool_size, blur_size=blur_size,
+                   constant=constant, front=int(front), obs1=obs1.numpy().copy(), obs2=obs2.numpy().copy())
+        with torch.no_grad():
+            if type_ == 'occupancy':
+                g = pool.occupancies(obs1.clone(), obs2.clone())
+            elif type_ == 'directional':
+                g = pool.directional(obs1.clone(), obs2.clone())
+            else:
+                if hidden is None:
+                    hidden = rng.randn(B, N, hd).astype(np.float32)
+                    # padded slots carry NaN hidden states (lstm/lstm.py:33)
+                    hidden[np.isnan(obs2.numpy()).any(-1) & (rng.rand(B, N) < 0.5)] = NAN
+                hidden_t = torch.tensor(hidden)
+                g = pool.social(hidden_t.clone(), obs1.clone(), obs2.clone())
+                rec['hidden'] = hidden
+                rec['Wh'] = pool.hidden_dim_encoding.weight.detach().numpy().copy()
+                rec['bh'] = pool.hidden_dim_encoding.bias.detach().numpy().copy()
+            rec['grid'] = g.numpy().copy()
+            # tag grid: which neighbour (1-based slot j') won each cell
+            if N > 1 and pool_size == 1 and blur_size == 1:
+                tagpool = ref.GridBasedPooling(cell_side=cell_side, n=n, hidden_dim=hd, type_='occupancy',
+                                               front=front, constant=constant)
+                tags = torch.arange(1, N, dtype=torch.float32).view(1, 1, N - 1, 1).repeat(B, N, 1, 1)
+                rec['tag_grid'] = tagpool.occupancy(obs2.clone(), tags, past_obs=obs1.clone()).numpy().copy()
+        cases.append(rec)
+
+    # 1-3: adapted known-answer inputs of reference tests/test_pooling.py:9-22, 65-83, 86-99
+    o = [[[0.0, 0.0], [-1.0, -1.0]]]
+    add('simple', 'occupancy', o, o, n=2, cell_side=2.0, pool_size=4, blur_size=3)
+    o = [[[0.0, 0.0], [-1.0, 0.0]]]
+    add('midpoint', 'occupancy', o, o, n=2, cell_side=2.0, pool_size=100, blur_size=99)
+    o = [[[0.0, 0.0], [NAN, NAN]]]
+    add('nan', 'occupancy', o, o, n=2, cell_side=2.0)
+    # 4: directional known-answer inputs (test_pooling.py:45-62; current code stores v_j - v_i)
+    add('dir_simple', 'directional', [[[0.0, 0.0], [-1.0, -1.0]]], [[[0.1, 0.1], [-1.1, -1.1]]], n=2,
+        cell_side=2.0, pool_size=4)
+    # 5: SURVEY quirk 9 -- cell-0 clobber depends on neighbour order
+    add('clobber_a', 'occupancy', np.zeros((1, 3, 2)), [[[0, 0], [-1.5, -1.5], [50, 50]]], n=4, cell_side=1.0)
+    add('clobber_b', 'occupancy', np.zeros((1, 3, 2)), [[[0, 0], [50, 50], [-1.5, -1.5]]], n=4, cell_side=1.0)
+    # 6: exact cell-edge coordinates (multiples of float32(0.6)), n=12 and n=16
+    for n in (12, 16):
+        ks = np.arange(-n // 2 - 1, n // 2 + 2)
+        edge = np.float32(0.6) * ks.astype(np.float32)
+        pts = np.stack([edge, edge[::-1]], -1)
+        pts = np.concatenate([[[0.0, 0.0]], pts]).astype(np.float32)[None]
+        add('edges_n%d' % n, 'occupancy', pts, pts, n=n, cell_side=0.6)
+        add('edges_dir_n%d' % n, 'directional', pts - 0.05, pts, n=n, cell_side=0.6)
+    # 7: random crowds, all types, with NaNs, ragged padding, duplicates, constant != 0, front
+    for k in range(12):
+        B, N = int(rng.randint(1, 5)), int(rng.randint(2, 14))
+        type_ = ['occupancy', 'directional', 'social'][k % 3]
+        n = [4, 8, 12, 16][k % 4]
+        cs = [0.6, 0.6, 1.0, 2.0][(k // 3) % 4]
+        ext = n * cs * 0.45
+        obs2 = (rng.rand(B, N, 2) * 2 - 1).astype(np.float32) * ext
+        obs1 = obs2 - rng.randn(B, N, 2).astype(np.float32) * 0.3
+        # snap some agents to the same spot (duplicate cells) and onto cell edges
+        obs2[:, 1::4] = obs2[:, 0:1] + np.float32(0.1)
+        obs2[:, 2::5] = np.round(obs2[:, 2::5] / np.float32(cs)) * np.float32(cs)
+        # absent agents: NaN in obs2 and/or obs1; trailing padded slots
+        drop2 = rng.rand(B, N) < 0.2
+        drop1 = rng.rand(B, N) < 0.15
+        obs2[drop2] = NAN
+        obs1[drop1] = NAN
+        if N > 3:
+            obs2[-1, -2:] = NAN
+            obs1[-1, -2:] = NAN
+        add('rand%d' % k, type_, obs1, obs2, n=n, cell_side=cs, constant=[0, 0, 0, 1][k % 4],
+            front=(k % 6 == 5))
+    # 8: single track (gridbased_pooling.py:252-253)
+    add('single', 'occupancy', [[[0.3, 0.2]]], [[[0.4, 0.1]]], n=4, cell_side=1.0)
+
+    flat = {'num_cases': np.int64(len(cases))}
+    for i, rec in enumerate(cases):
+        for k, v in rec.items():
+            flat['c%d_%s' % (i, k)] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, 'grid_cases.npz'), **flat)
+    print('grid_cases.npz: %d cases' % len(cases))
+
+
+def lstm_case(ref, kind):
+    torch.manual_seed({'vanilla': 1, 'occupancy': 2, 'directional': 3, 'social': 4, 'social_goals': 5}[kind])
+    goal_flag = kind == 'social_goals'
+    cfg = dict(kind=kind, type='', n=0, cell_side=0.6, goal_flag=int(goal_flag))
+    pool = None
+    if kind == 'occupancy':
+        cfg.update(type='occupancy', n=8)
+        pool = ref.GridBasedPooling(type_='occupancy', hidden_dim=128, cell_side=0.6, n=8, out_dim=32,
+                                    embedding_arch='one_layer')
+    elif kind == 'directional':
+        cfg.update(type='directional', n=12)
+        pool = ref.GridBasedPooling(type_='directional', hidden_dim=128, cell_side=0.6, n=12, out_dim=64,
+                                    embedding_arch='one_layer')
+    elif kind in ('social', 'social_goals'):
+        cfg.update(type='social', n=8)
+        pool = ref.GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=8, out_dim=64,
+                                    embedding_arch='two_layer', layer_dims=[128], latent_dim=8)
+    model = ref.LSTM(pool=pool, goal_flag=goal_flag).eval()
+    out = {'cfg_' + k: np.asarray(v) for k, v in cfg.items()}
+    for k, v in model.state_dict().items():
+        out['sd_' + k] = v.numpy().copy()
+    # two batches: dense linear crowd and ragged crowd with entering/leaving tracks
+    for tag, (xy, split) in (('lin', synth.linear_crowd(3, 6, seed=11)),
+                             ('rag', synth.ragged_crowd(5, 1 if kind != 'vanilla' else 2, 9, seed=12))):
+        M = xy.shape[1]
+        g = torch.Generator().manual_seed(5)
+        goals = (torch.rand(M, 2, generator=g) * 10 - 5) if goal_flag else torch.zeros(M, 2)
+        with torch.no_grad():
+            rel_n, pred_n = model(xy[:9].clone(), goals.clone(), split, n_predict=12)
+            rel_t, pred_t = model(xy[:9].clone(), goals.clone(), split, prediction_truth=xy[9:20].clone())
+        out.update({tag + '_xy': xy.numpy(), tag + '_split': split.numpy(), tag + '_goals': goals.numpy(),
+                    tag + '_rel_npredict': rel_n.numpy(), tag + '_pred_npredict': pred_n.numpy(),
+                    tag + '_rel_truth': rel_t.numpy(), tag + '_pred_truth': pred_t.numpy()})
+    np.savez_compressed(os.path.join(OUT, 'lstm_%s.npz' % kind), **out)
+    print('lstm_%s.npz' % kind)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = ref_import.import_reference()
+    grid_cases(ref)
+    for kind in ('vanilla', 'occupancy', 'directional', 'social', 'social_goals'):
+        lstm_case(ref, kind)
+    with open(os.path.join(OUT, 'PROVENANCE.txt'), 'w') as f:
+        f.write('generated by oracle/gen_golden.py from the reference at %s\n' % ref_import.REFERENCE_ROOT)
+        f.write('torch %s, numpy %s\n' % (torch.__version__, np.__version__))
+
+
+if __name__ == '__main__':
+    main()

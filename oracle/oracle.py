@@ -1,0 +1,204 @@
+"""ctypes front-end of the CPU oracle (oracle/trajnet_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the product package.
+All arrays are numpy; weights are given as a dict keyed like the reference's
+``LSTM.state_dict()``, so a reference checkpoint feeds it as is.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+POOL_TYPES = {'occupancy': 0, 'directional': 1, 'social': 2, None: -1}
+
+_f = ctypes.POINTER(ctypes.c_float)
+
+
+class _Model(ctypes.Structure):
+    _fields_ = [
+        ('E', ctypes.c_int), ('H', ctypes.c_int), ('goal_flag', ctypes.c_int), ('goal_dim', ctypes.c_int),
+        ('pool_type', ctypes.c_int), ('n', ctypes.c_int), ('C', ctypes.c_int), ('P', ctypes.c_int),
+        ('n_layers', ctypes.c_int), ('dims', ctypes.c_int * 4), ('front', ctypes.c_int),
+        ('pool_size', ctypes.c_int), ('blur_size', ctypes.c_int), ('constant', ctypes.c_float),
+        ('cell_side', ctypes.c_double),
+        ('We', _f), ('be', _f), ('Wg', _f), ('bg', _f),
+        ('enc_Wih', _f), ('enc_Whh', _f), ('enc_bih', _f), ('enc_bhh', _f),
+        ('dec_Wih', _f), ('dec_Whh', _f), ('dec_bih', _f), ('dec_bhh', _f),
+        ('Wn', _f), ('bn', _f), ('Wh', _f), ('bh', _f),
+        ('Wp', _f * 3), ('bp', _f * 3),
+        ('WpT', _f * 3), ('enc_WihT', _f), ('enc_WhhT', _f), ('dec_WihT', _f), ('dec_WhhT', _f),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, 'liboracle.so')
+    srcs = [os.path.join(_HERE, s) for s in ('trajnet_oracle.c', 'classical_oracle.c')]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(['make', '-C', _HERE, '-B', 'liboracle.so'], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        _LIB.orc_lstm_forward.restype = ctypes.c_int
+        _LIB.orc_grid.restype = ctypes.c_int
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(_f) if a is not None else ctypes.cast(None, _f)
+
+
+def _c32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+class OracleModel(object):
+    """Holds fp32 copies of the weights and the ctypes struct that points at them."""
+
+    def __init__(self, state_dict, pool_type=None, n=4, cell_side=2.0, constant=0.0, front=False,
+                 pool_size=1, blur_size=1, goal_flag=False, embedding_dim=64, hidden_dim=128):
+        sd = {k: _c32(v.detach().cpu().numpy() if hasattr(v, 'detach') else v) for k, v in state_dict.items()}
+        self._keep = sd
+        m = _Model()
+        m.E, m.H = embedding_dim, hidden_dim
+        m.goal_flag = int(goal_flag)
+        m.goal_dim = sd['goal_embedding.input_embeddings.0.weight'].shape[0] + 2
+        m.pool_type = POOL_TYPES[pool_type]
+        m.n, m.front, m.pool_size, m.blur_size = n, int(front), pool_size, blur_size
+        m.constant, m.cell_side = float(constant), float(cell_side)
+        m.We, m.be = _p(sd['input_embedding.input_embeddings.0.weight']), _p(sd['input_embedding.input_embeddings.0.bias'])
+        m.Wg, m.bg = _p(sd['goal_embedding.input_embeddings.0.weight']), _p(sd['goal_embedding.input_embeddings.0.bias'])
+        for pre in ('enc', 'dec'):
+            full = 'encoder' if pre == 'enc' else 'decoder'
+            setattr(m, pre + '_Wih', _p(sd[full + '.weight_ih']))
+            setattr(m, pre + '_Whh', _p(sd[full + '.weight_hh']))
+            for kind in ('ih', 'hh'):
+                sd[full + '.weight_%s.T' % kind] = np.ascontiguousarray(sd[full + '.weight_' + kind].T)
+                setattr(m, pre + '_W%sT' % kind, _p(sd[full + '.weight_%s.T' % kind]))
+            setattr(m, pre + '_bih', _p(sd[full + '.bias_ih']))
+            setattr(m, pre + '_bhh', _p(sd[full + '.bias_hh']))
+        m.Wn, m.bn = _p(sd['hidden2normal.linear.weight']), _p(sd['hidden2normal.linear.bias'])
+        m.C, m.P, m.n_layers = 1, 0, 0
+        if pool_type is not None:
+            if pool_type == 'directional':
+                m.C = 2
+            elif pool_type == 'social':
+                m.C = sd['pool.hidden_dim_encoding.weight'].shape[0]
+                m.Wh, m.bh = _p(sd['pool.hidden_dim_encoding.weight']), _p(sd['pool.hidden_dim_encoding.bias'])
+            layers = sorted(int(k.split('.')[2]) for k in sd if k.startswith('pool.embedding.') and k.endswith('.weight'))
+            m.n_layers = len(layers)
+            m.dims[0] = m.C * n * n
+            for li, idx in enumerate(layers):
+                w = sd['pool.embedding.%d.weight' % idx]
+                assert w.shape[1] == m.dims[li], (w.shape, m.dims[li])
+                m.dims[li + 1] = w.shape[0]
+                m.Wp[li] = _p(w)
+                sd['pool.embedding.%d.weight.T' % idx] = np.ascontiguousarray(w.T)
+                m.WpT[li] = _p(sd['pool.embedding.%d.weight.T' % idx])
+                m.bp[li] = _p(sd['pool.embedding.%d.bias' % idx])
+            m.P = m.dims[m.n_layers]
+        self.c = m
+
+    # -- LSTM.forward (lstm/lstm.py:170-264) --------------------------------
+    def forward(self, observed, goals, batch_split, prediction_truth=None, n_predict=None):
+        assert (prediction_truth is None) + (n_predict is None) == 1
+        observed = _c32(observed)
+        T_obs, M = observed.shape[0], observed.shape[1]
+        goals = _c32(goals if goals is not None else np.zeros((M, 2)))
+        split = np.ascontiguousarray(np.asarray(batch_split, dtype=np.int64))
+        B = len(split) - 1
+        if prediction_truth is not None:
+            truth = _c32(prediction_truth)
+            T_dec = truth.shape[0]
+        else:
+            truth, T_dec = None, n_predict - 1
+        nn = T_obs - 1 + T_dec
+        rel = np.empty((nn, M, 5), dtype=np.float32)
+        pred = np.empty((nn + 1, M, 2), dtype=np.float32)
+        npos = lib().orc_lstm_forward(ctypes.byref(self.c), _p(observed), T_obs, M, _p(goals),
+                                      split.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), B,
+                                      _p(truth), T_dec, _p(rel), _p(pred))
+        return rel, pred[:npos]
+
+    # -- LSTM.step (lstm/lstm.py:91-168) on dense state ----------------------
+    def step(self, decoder, h, c, obs1, obs2, goals, batch_split, want_grid=False):
+        h, c = _c32(h).copy(), _c32(c).copy()
+        obs1, obs2 = _c32(obs1), _c32(obs2)
+        M = obs1.shape[0]
+        goals = _c32(goals if goals is not None else np.zeros((M, 2)))
+        split = np.ascontiguousarray(np.asarray(batch_split, dtype=np.int64))
+        B = len(split) - 1
+        normal = np.empty((M, 5), dtype=np.float32)
+        grid = None
+        if want_grid:
+            N = int((split[1:] - split[:-1]).max())
+            grid = np.zeros((B * N, self.c.C * self.c.n * self.c.n), dtype=np.float32)
+        lib().orc_lstm_step(ctypes.byref(self.c), int(decoder), _p(h), _p(c), _p(obs1), _p(obs2), _p(goals),
+                            split.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), B, M, _p(normal), _p(grid))
+        return h, c, normal, grid
+
+
+def cell_ids(obs, n, cell_side, pool_size=1, front=False):
+    """GridBasedPooling.occupancy cell indexing (gridbased_pooling.py:245-288). obs [B,N,2]."""
+    obs = _c32(obs)
+    B, N = obs.shape[0], obs.shape[1]
+    G = n * pool_size
+    oi = np.zeros((B, N, max(N - 1, 0)), dtype=np.int64)
+    inr = np.zeros((B, N, max(N - 1, 0)), dtype=np.uint8)
+    cell = np.float32(cell_side / pool_size)
+    half = np.float32(G / 2)
+    lib().orc_cell_ids(_p(obs), B, N, G, ctypes.c_float(cell), ctypes.c_float(half),
+                       ctypes.c_float(0.0 if front else half),
+                       oi.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                       inr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    return oi, inr
+
+
+def grid(type_, obs1, obs2, values=None, n=4, cell_side=2.0, pool_size=1, blur_size=1, constant=0.0,
+         front=False, C=None):
+    """GridBasedPooling.{occupancies,directional,social} -> [B*N, C, n, n]. values = enc [B,N,C] (social)."""
+    obs1, obs2 = _c32(obs1), _c32(obs2)
+    B, N = obs2.shape[0], obs2.shape[1]
+    if C is None:
+        C = {'occupancy': 1, 'directional': 2}.get(type_, None) or values.shape[-1]
+    vals = _c32(values) if values is not None else None
+    out = np.empty((B * N, C, n, n), dtype=np.float32)
+    rc = lib().orc_grid(POOL_TYPES[type_], _p(obs1), _p(obs2), _p(vals), B, N, C, n, pool_size, blur_size,
+                        ctypes.c_double(cell_side), ctypes.c_float(constant), int(front), _p(out))
+    assert rc == 0, rc
+    return out
+
+
+def linear(x, W, b, relu=False):
+    x, W = _c32(x), _c32(W)
+    b = _c32(b) if b is not None else None
+    y = np.empty((x.shape[0], W.shape[0]), dtype=np.float32)
+    lib().orc_linear(_p(x), x.shape[0], x.shape[1], _p(W), _p(b), W.shape[0], int(relu), _p(y))
+    return y
+
+
+def constant_velocity(xy, n_predict=12):
+    xy = np.ascontiguousarray(np.asarray(xy, dtype=np.float64))
+    T, N = xy.shape[0], xy.shape[1]
+    out = np.empty((n_predict, N, 2), dtype=np.float64)
+    d = ctypes.POINTER(ctypes.c_double)
+    lib().orc_constant_velocity(xy.ctypes.data_as(d), T, N, n_predict, out.ctypes.data_as(d))
+    return out
+
+
+# --------------------------------------------------------------------------
+# metric oracle: evaluator/eval_utils.py:3-19 (ade / fde of the primary row)
+# --------------------------------------------------------------------------
+def ade_fde(pred, gt):
+    """pred, gt [T, 2] -> (ADE, FDE) in metres."""
+    d = np.linalg.norm(np.asarray(pred, dtype=np.float64) - np.asarray(gt, dtype=np.float64), axis=-1)
+    return float(np.mean(d)), float(d[-1])

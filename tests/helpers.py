@@ -1,0 +1,56 @@
+"""Shared helpers for the parity tests (loading golden fixtures, building oracle models)."""
+import os
+
+import numpy as np
+
+from oracle import oracle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_grid_cases():
+    z = np.load(os.path.join(GOLDEN, 'grid_cases.npz'), allow_pickle=False)
+    cases = []
+    for i in range(int(z['num_cases'])):
+        pre = 'c%d_' % i
+        rec = {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
+        for k in ('name', 'type'):
+            rec[k] = str(rec[k])
+        for k in ('n', 'pool_size', 'blur_size', 'front'):
+            rec[k] = int(rec[k])
+        rec['cell_side'] = float(rec['cell_side'])
+        rec['constant'] = float(rec['constant'])
+        cases.append(rec)
+    return cases
+
+
+def load_lstm_case(kind):
+    z = np.load(os.path.join(GOLDEN, 'lstm_%s.npz' % kind), allow_pickle=False)
+    sd = {k[3:]: z[k] for k in z.files if k.startswith('sd_')}
+    cfg = {k[4:]: z[k] for k in z.files if k.startswith('cfg_')}
+    cfg = dict(kind=str(cfg['kind']), type=(str(cfg['type']) or None), n=int(cfg['n']),
+               cell_side=float(cfg['cell_side']), goal_flag=bool(int(cfg['goal_flag'])))
+    data = {k: z[k] for k in z.files if not (k.startswith('sd_') or k.startswith('cfg_'))}
+    return sd, cfg, data
+
+
+def oracle_model(sd, cfg):
+    return oracle.OracleModel(sd, pool_type=cfg['type'], n=cfg['n'] or 4, cell_side=cfg['cell_side'],
+                              goal_flag=cfg['goal_flag'])
+
+
+def social_enc(rec):
+    """hidden_dim_encoding(nan_to_num(hidden)) for a social grid case -> [B,N,C]."""
+    h = np.nan_to_num(rec['hidden'].astype(np.float32), nan=0.0)
+    B, N, H = h.shape
+    return oracle.linear(h.reshape(B * N, H), rec['Wh'], rec['bh']).reshape(B, N, -1)
+
+
+def assert_close_nan(a, b, atol, what=''):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    na, nb = np.isnan(a), np.isnan(b)
+    assert (na == nb).all(), '%s: NaN pattern differs at %d entries' % (what, int((na != nb).sum()))
+    if (~na).any():
+        err = np.abs(a[~na].astype(np.float64) - b[~nb].astype(np.float64)).max()
+        assert err <= atol, '%s: max abs err %.3e > %.1e' % (what, err, atol)

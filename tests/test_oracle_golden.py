@@ -1,0 +1,106 @@
+"""Pins the CPU oracle (oracle/trajnet_oracle.c) to the real reference through the
+fixtures that oracle/gen_golden.py produced by running the Python reference, and to
+the reference's own (adapted) known-answer vectors -- SURVEY.md section 4 / 8(c)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import helpers
+
+GRID_CASES = helpers.load_grid_cases()
+
+
+@pytest.mark.parametrize('rec', GRID_CASES, ids=[r['name'] for r in GRID_CASES])
+def test_grid_matches_reference(rec):
+    vals = helpers.social_enc(rec) if rec['type'] == 'social' else None
+    g = oracle.grid(rec['type'], rec['obs1'], rec['obs2'], vals, n=rec['n'], cell_side=rec['cell_side'],
+                    pool_size=rec['pool_size'], blur_size=rec['blur_size'], constant=rec['constant'],
+                    front=bool(rec['front']), C=rec['grid'].shape[1])
+    ref = rec['grid']
+    if ref.shape[0] == 1 and g.shape[0] != 1:   # single-track shortcut returns one row
+        g = g[:1]
+    if rec['type'] == 'social' or rec['blur_size'] != 1:
+        np.testing.assert_allclose(g, ref, rtol=0, atol=2e-6)
+    else:
+        # occupancy / directional values are copies or single fp32 subtractions: bit-exact
+        assert np.array_equal(g, ref), np.abs(g - ref).max()
+
+
+@pytest.mark.parametrize('rec', [r for r in GRID_CASES if 'tag_grid' in r],
+                         ids=[r['name'] for r in GRID_CASES if 'tag_grid' in r])
+def test_cell_ids_bit_exact(rec):
+    """Rebuild the reference's tag grid (winner neighbour per cell) from the oracle's
+    integer cell ids: pins fp32 indexing, last-writer-wins and the cell-0 clobber."""
+    obs2 = rec['obs2']
+    B, N = obs2.shape[:2]
+    n = rec['n']
+    oi, inr = oracle.cell_ids(obs2, n, rec['cell_side'], front=bool(rec['front']))
+    tag = np.full((B * N, n * n), rec['constant'], dtype=np.float32)
+    for r in range(B * N):
+        for jj in range(N - 1):
+            o = oi.reshape(B * N, N - 1)[r, jj]
+            tag[r, o] = (jj + 1) if inr.reshape(B * N, N - 1)[r, jj] else rec['constant']
+    assert np.array_equal(tag.reshape(B * N, 1, n, n), rec['tag_grid'])
+
+
+def test_known_answer_simple_grid():
+    # reference tests/test_pooling.py:9-22 adapted to the current (obs1, obs2) API
+    rec = next(r for r in GRID_CASES if r['name'] == 'simple')
+    g = oracle.grid('occupancy', rec['obs1'], rec['obs2'], n=2, cell_side=2.0, pool_size=4, blur_size=3)
+    assert g.reshape(2, 4).tolist() == [[1, 0, 0, 0], [0, 0, 0, 1]]
+
+
+def test_known_answer_nan_grid():
+    # reference tests/test_pooling.py:86-99
+    o = np.array([[[0.0, 0.0], [np.nan, np.nan]]], dtype=np.float32)
+    g = oracle.grid('occupancy', o, o, n=2, cell_side=2.0)
+    assert g.reshape(2, 4).tolist() == [[0, 0, 0, 0], [0, 0, 0, 0]]
+
+
+def test_known_answer_midpoint():
+    # reference tests/test_pooling.py:65-83 (abs 0.01)
+    o = np.array([[[0.0, 0.0], [-1.0, 0.0]]], dtype=np.float32)
+    g = oracle.grid('occupancy', o, o, n=2, cell_side=2.0, pool_size=100, blur_size=99)
+    np.testing.assert_allclose(g.reshape(2, 4), [[0.5, 0.5, 0, 0], [0, 0, 0.5, 0.5]], atol=0.01)
+
+
+def test_known_answer_clobber_order():
+    # SURVEY.md 8(a) quirk 9, demonstrated on the reference itself
+    a = next(r for r in GRID_CASES if r['name'] == 'clobber_a')
+    b = next(r for r in GRID_CASES if r['name'] == 'clobber_b')
+    ga = oracle.grid('occupancy', a['obs1'], a['obs2'], n=4, cell_side=1.0)
+    gb = oracle.grid('occupancy', b['obs1'], b['obs2'], n=4, cell_side=1.0)
+    assert ga[0, 0, 0, 0] == 0.0 and gb[0, 0, 0, 0] == 1.0
+
+
+def test_fp32_cell_edges():
+    # float32(-6*0.6)/0.6+6 -> cell 0 ; float32(-7*0.6)/0.6+6 -> out of range
+    cs = np.float32(0.6)
+    obs = np.array([[[0, 0], [np.float32(-6) * cs, 0], [np.float32(-7) * cs, 0], [np.float32(6) * cs, 0]]],
+                   dtype=np.float32)
+    oi, inr = oracle.cell_ids(obs, 12, 0.6)
+    assert inr[0, 0].tolist() == [1, 0, 0]
+    assert oi[0, 0, 0] == 0 * 12 + 6
+
+
+@pytest.mark.parametrize('kind', ['vanilla', 'occupancy', 'directional', 'social', 'social_goals'])
+@pytest.mark.parametrize('batch', ['lin', 'rag'])
+def test_lstm_forward_matches_reference(kind, batch):
+    sd, cfg, d = helpers.load_lstm_case(kind)
+    om = helpers.oracle_model(sd, cfg)
+    xy, split, goals = d[batch + '_xy'], d[batch + '_split'], d[batch + '_goals']
+    rel, pred = om.forward(xy[:9], goals, split, n_predict=12)
+    helpers.assert_close_nan(rel, d[batch + '_rel_npredict'], 2e-5, 'rel n_predict')
+    helpers.assert_close_nan(pred, d[batch + '_pred_npredict'], 2e-5, 'pred n_predict')
+    rel, pred = om.forward(xy[:9], goals, split, prediction_truth=xy[9:20])
+    helpers.assert_close_nan(rel, d[batch + '_rel_truth'], 2e-5, 'rel truth')
+    helpers.assert_close_nan(pred, d[batch + '_pred_truth'], 2e-5, 'pred truth')
+
+
+def test_constant_velocity():
+    # classical/constant_velocity.py:4-20
+    rng = np.random.RandomState(0)
+    xy = rng.randn(9, 5, 2)
+    out = oracle.constant_velocity(xy, 12)
+    want = np.stack([xy[-1] + t * (xy[-1] - xy[-2]) for t in range(1, 13)])
+    assert np.array_equal(out, want)
