@@ -1,0 +1,194 @@
+"""Headline benchmark: scene-steps/s of the Social-LSTM hot path (BASELINE.json configs[1]) on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one LSTM.forward (8 encoder + 11 decoder recurrent steps = 21 frames) over one batch of synthetic
+scenes per GPU (scenes are independent -> pure data-parallel sharding, no collective on the inference data path;
+weak scaling).  Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline     : the dominant kernel (first pooling-embedding GEMM on the fp32 matrix cores) timed with HIP
+                 events on the launch stream over a repeat of the timed region,
+  cpu_baseline : the CPU oracle (a C port of the reference algorithm, OpenMP over tracks) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from trajnetplusplusbaselines_amd import _lib, synth  # noqa: E402
+from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling  # noqa: E402
+
+CONFIGS = {
+    # BASELINE.json configs[1]
+    'social': dict(type_='social', n=16, arch='two_layer', layer_dims=[1024], out_dim=256, scenes=64, agents=32,
+                   name='Social-LSTM n=16 two_layer 1024'),
+    # BASELINE.json configs[2], per-GPU shard of 256 scenes x 64 agents over 8 GPUs
+    'directional': dict(type_='directional', n=12, arch='one_layer', layer_dims=None, out_dim=256, scenes=32,
+                        agents=64, name='D-LSTM directional n=12 one_layer'),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+
+
+def build_model(cfg, device):
+    torch.manual_seed(0)
+    pool = GridBasedPooling(type_=cfg['type_'], hidden_dim=128, cell_side=0.6, n=cfg['n'], out_dim=cfg['out_dim'],
+                            embedding_arch=cfg['arch'], layer_dims=cfg['layer_dims'], latent_dim=16)
+    return LSTM(pool=pool).eval().to(device)
+
+
+def cpu_baseline(cfg, xy, split, budget_s=20.0):
+    """Oracle (kind 'port') on the host cores, same workload, bounded to ~budget_s seconds."""
+    import numpy as np
+    from oracle import oracle
+    torch.manual_seed(0)
+    pool = GridBasedPooling(type_=cfg['type_'], hidden_dim=128, cell_side=0.6, n=cfg['n'], out_dim=cfg['out_dim'],
+                            embedding_arch=cfg['arch'], layer_dims=cfg['layer_dims'], latent_dim=16)
+    sd = {k: v.numpy() for k, v in LSTM(pool=pool).state_dict().items()}
+    om = oracle.OracleModel(sd, pool_type=cfg['type_'], n=cfg['n'], cell_side=0.6)
+    obs = xy[:9].cpu().numpy()
+    sp = split.cpu().numpy()
+    scenes = len(sp) - 1
+    t0 = time.perf_counter()
+    om.forward(obs, None, sp, n_predict=12)          # warm-up, also sizes the sample
+    first = time.perf_counter() - t0
+    reps = max(1, min(3, int(budget_s / max(first, 1e-3)) - 1))
+    best = first
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        om.forward(obs, None, sp, n_predict=12)
+        best = min(best, time.perf_counter() - t0)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    threads = int(os.environ.get('OMP_NUM_THREADS', cores))
+    return dict(value=scenes * 21 / best, unit='scene-steps/s', cores=threads, kind='port',
+                sample='%d full forwards of the same %d-scene batch (best of %d), oracle/trajnet_oracle.c with '
+                       'OpenMP over tracks' % (reps + 1, scenes, reps + 1),
+                seconds_per_forward=best)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='social', choices=sorted(CONFIGS))
+    ap.add_argument('--variant', type=int, default=0, help='kernel variant selector (DESIGN.md)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch multi-GPU runs with python -m torch.distributed.run --nproc-per-node %d' % args.gpus)
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    cfg = CONFIGS[args.config]
+    model = build_model(cfg, device)
+    model.kernel_variant = args.variant
+    # every rank gets its own shard of scenes (different seed): weak scaling, no data-path collective
+    xy, split = synth.linear_crowd(cfg['scenes'], cfg['agents'], seed=100 + rank)
+    M = xy.shape[1]
+    observed = xy[:9].to(device)
+    goals = torch.zeros(M, 2, device=device)
+
+    def step():
+        return model(observed, goals, split, n_predict=12)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        if distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+        # ---- roofline leg: same region again with HIP events around every launch of the dominant kernel ----
+        L = _lib.lib()
+        roof = None
+        if rank == 0:
+            import ctypes
+            _lib.check(L.tnp_profile_begin(0), 'tnp_profile_begin')
+            torch.cuda.synchronize()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+            _lib.check(L.tnp_profile_read(ctypes.byref(ms), ctypes.byref(n)), 'tnp_profile_read')
+            L.tnp_profile_end()
+            K0 = cfg['n'] * cfg['n'] * model.pool.pooling_dim
+            N0 = model.pool.embedding_layers()[0].weight.shape[0]
+            flops = 2.0 * M * N0 * K0                      # dense algorithmic FLOPs of one launch
+            if n.value > 0 and ms.value > 0:
+                avg_s = ms.value / n.value * 1e-3
+                achieved = flops / avg_s / 1e12
+                roof = dict(bound='mfma', achieved=achieved, peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                            frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=None,
+                            kernel='gemm_nt_kernel (pool.embedding.0: [%d,%d]x[%d,%d]^T)' % (M, K0, N0, K0),
+                            launches=n.value, avg_launch_us=avg_s * 1e6, flops_per_launch=flops,
+                            share_of_step=ms.value * 1e-3 / elapsed)
+
+    if rank == 0:
+        scenes_total = cfg['scenes'] * world
+        value = scenes_total * 21 * args.steps / elapsed
+        out = {
+            'metric': 'scene-steps/sec (9 obs + 12 pred)',
+            'value': value,
+            'unit': 'scene-steps/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': '%s, %d scenes x %d agents x (9 obs + 12 pred) per GPU, inference forward '
+                                   '(LSTM.forward, n_predict=12)' % (cfg['name'], cfg['scenes'], cfg['agents']),
+                       'scenes_per_gpu': cfg['scenes'], 'agents_per_scene': cfg['agents'],
+                       'recurrent_steps_per_forward': 19, 'parallelism': 'dp%d (scene sharding)' % world,
+                       'kernel_variant': args.variant},
+            'recurrent_scene_steps_per_s': scenes_total * 19 * args.steps / elapsed,
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg, xy, split)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

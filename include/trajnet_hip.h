@@ -1,0 +1,158 @@
+/*
+ * trajnet_hip.h -- C ABI of libtrajnet_hip.so, the MI355X (gfx950) implementation of the
+ * TrajNet++ baselines hot path: the per-timestep recurrent step of trajnetbaselines.lstm,
+ * its grid-based interaction pooling, and the classical rollouts.
+ *
+ * The reference (vita-epfl/trajnetplusplusbaselines) is pure Python/PyTorch and has no FFI;
+ * each entry point below names the reference interface it replaces (file:line relative to
+ * the reference's trajnetbaselines/ package).  INTEGRATION.md shows the ctypes binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue
+ *     work on it -- no host synchronisation, no allocation -- so they are graph-capturable;
+ *   - all floating point is IEEE fp32, cell indices are exact (IEEE division, truncation);
+ *   - return value 0 = success, <0 = error; tnp_last_error() gives the message
+ *     (the Python host layer raises RuntimeError / ValueError with it);
+ *   - weights use the PyTorch layout [out_features, in_features], LSTM gate order i,f,g,o,
+ *     i.e. the tensors of the reference's state_dict are passed in place.
+ */
+#ifndef TRAJNET_HIP_H
+#define TRAJNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TNP_ABI_VERSION 1
+#define TNP_API __attribute__((visibility("default")))
+
+/* pooling types: GridBasedPooling(type_=...)  lstm/gridbased_pooling.py:16-19,55-66 */
+#define TNP_POOL_NONE        (-1)
+#define TNP_POOL_OCCUPANCY   0
+#define TNP_POOL_DIRECTIONAL 1
+#define TNP_POOL_SOCIAL      2
+
+TNP_API int tnp_abi_version(void);
+TNP_API const char *tnp_last_error(void);
+
+/* -------------------------------------------------------------------------------------------
+ * Scene index.  The reference describes a batch by `batch_split` (int64 [B+1], lstm/lstm.py:
+ * 170-187); the kernels use int32 scene starts plus a per-track primary flag.
+ *   scene_start [B+1] int32 (device), primary_flag [M] uint8 (device, written)
+ * ----------------------------------------------------------------------------------------- */
+TNP_API int tnp_mark_primaries(const int32_t *scene_start, int B, int M, uint8_t *primary_flag, void *stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Grid build: GridBasedPooling.occupancy / occupancies / directional / social
+ * (lstm/gridbased_pooling.py:112-170, 227-305), pool_size = blur_size = 1.
+ *   obs1, obs2   [rows,2]   previous / current positions, NaN = absent track
+ *   values       [rows,ldv] social: hidden_dim_encoding(hidden) per track (C columns used)
+ *   scene_start  [B+1]      rows of scene s are [scene_start[s], scene_start[s+1])
+ *   n_max        number of slots the reference would pad every scene to (lstm/lstm.py:29);
+ *                scenes with fewer tracks get the reference's padded-slot cell-0 clobber
+ *   cell         float32(cell_side / pool_size); half_x/half_y = n/2 (front: half_y = 0)
+ *   grid         [rows,ldg] out, feature = c*n*n + cell_x*n + cell_y   (may be NULL)
+ *   winners      [rows,n*n] out, int16: scene-local index of the neighbour that owns the
+ *                cell, -1 = background `constant`                       (may be NULL)
+ * ----------------------------------------------------------------------------------------- */
+TNP_API int tnp_pool_grid_forward(int type, const float *obs1, const float *obs2, const float *values, int ldv,
+                          const int32_t *scene_start, int B, int n_max, int n, int C, float cell,
+                          float half_x, float half_y, float constant, float *grid, int ldg,
+                          int16_t *winners, void *stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Dense layer on the matrix cores: torch.nn.Linear (+ReLU) as used by the grid embedding
+ * MLPs (lstm/gridbased_pooling.py:308-335).   C[M,N] = act(A[M,K] @ W[N,K]^T + bias)
+ * fp32-in / fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products.
+ *   variant: 0 = default tile selection; see DESIGN.md for the list
+ * ----------------------------------------------------------------------------------------- */
+TNP_API int tnp_linear_forward(const float *A, int lda, const float *W, int ldw, const float *bias, float *C,
+                       int ldc, int M, int N, int K, int relu, int variant, void *stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Model descriptor of trajnetbaselines.lstm.LSTM (lstm/lstm.py:45-89) with its
+ * GridBasedPooling (lstm/gridbased_pooling.py:15-92).  All pointers are device pointers to
+ * the parameters in PyTorch layout (may alias nn.Parameter storage; nothing is copied).
+ * ----------------------------------------------------------------------------------------- */
+typedef struct tnp_lstm_model {
+    int32_t E;            /* embedding_dim (64)                                   */
+    int32_t H;            /* hidden_dim (128), multiple of 32                     */
+    int32_t goal_flag;    /* lstm/lstm.py:73-76                                    */
+    int32_t goal_dim;
+    int32_t pool_type;    /* TNP_POOL_*                                           */
+    int32_t n;            /* grid cells per side                                  */
+    int32_t C;            /* pooling_dim: 1 / 2 / latent_dim                      */
+    int32_t P;            /* pool.out_dim                                         */
+    int32_t n_layers;     /* embedding MLP depth 1..3 (one_/two_/three_layer)     */
+    int32_t dims[4];      /* dims[0] = C*n*n ... dims[n_layers] = P               */
+    float cell;           /* float32(cell_side / pool_size)                       */
+    float half_x, half_y; /* n/2 ; front=True: half_y = 0                         */
+    float constant;       /* background value of the grid                         */
+    const float *We, *be; /* input_embedding.input_embeddings.0   [E-2,2], [E-2]  */
+    const float *Wg, *bg; /* goal_embedding.input_embeddings.0                    */
+    const float *enc_Wih, *enc_Whh, *enc_bih, *enc_bhh; /* encoder LSTMCell       */
+    const float *dec_Wih, *dec_Whh, *dec_bih, *dec_bhh; /* decoder LSTMCell       */
+    const float *Wn, *bn; /* hidden2normal.linear [5,H], [5]                      */
+    const float *Wh, *bh; /* pool.hidden_dim_encoding [C,H], [C] (social)         */
+    const float *Wp[3];   /* pool.embedding.{0,2,4}.weight                        */
+    const float *bp[3];   /* pool.embedding.{0,2,4}.bias                          */
+    int32_t variant;      /* kernel-variant selector (0 = default), see DESIGN.md  */
+} tnp_lstm_model;
+
+/* bytes of scratch HBM tnp_lstm_forward / tnp_lstm_step need for M tracks in B scenes */
+TNP_API size_t tnp_lstm_workspace_bytes(const tnp_lstm_model *model, int M, int B);
+
+/* -------------------------------------------------------------------------------------------
+ * LSTM.forward (lstm/lstm.py:170-264): T_obs-1 encoder steps + T_dec decoder steps.
+ *   observed    [T_obs,M,2]
+ *   goals       [M,2] (read only when model->goal_flag)
+ *   scene_start [B+1] int32, primary_flag [M] uint8 (tnp_mark_primaries), n_max
+ *   truth       [T_dec,M,2] teacher-forcing frames (prediction_truth) or NULL = n_predict
+ *               mode with T_dec = n_predict-1
+ *   rel_pred    [T_obs-1+T_dec, M, 5] out (mu_x, mu_y, sigma_x, sigma_y, rho), NaN = absent
+ *   pred        [npos, M, 2] out, npos = T_obs-1+T_dec (+1 if T_obs == 2, lstm/lstm.py:222)
+ *   workspace   tnp_lstm_workspace_bytes() bytes, 256-byte aligned
+ * ----------------------------------------------------------------------------------------- */
+TNP_API int tnp_lstm_forward(const tnp_lstm_model *model, const float *observed, int T_obs, int M,
+                     const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
+                     int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* -------------------------------------------------------------------------------------------
+ * LSTM.step (lstm/lstm.py:91-168) on dense state: one masked recurrent step.
+ *   decoder     0 = encoder cell, 1 = decoder cell
+ *   h_in, c_in  [M,H] state before the step;  h_out, c_out [M,H] after (rows of absent
+ *               tracks are copied through = frozen); in/out must not alias
+ *   normal      [M,5] out, NaN rows for absent tracks
+ * ----------------------------------------------------------------------------------------- */
+TNP_API int tnp_lstm_step(const tnp_lstm_model *model, int decoder, const float *h_in, const float *c_in,
+                  const float *obs1, const float *obs2, const float *goals, const int32_t *scene_start,
+                  int B, int M, int n_max, float *h_out, float *c_out, float *normal, void *workspace,
+                  size_t workspace_bytes, void *stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Kernel timing hook for bench.py's roofline leg: when enabled, every launch of the dominant
+ * kernel class (`which`: 0 = first pooling-embedding GEMM, 1 = all GEMM launches) on `stream`
+ * is bracketed by hipEvents; tnp_profile_read synchronises those events and returns the summed
+ * milliseconds and the launch count since tnp_profile_begin.
+ * ----------------------------------------------------------------------------------------- */
+TNP_API int tnp_profile_begin(int which);
+TNP_API int tnp_profile_read(double *total_ms, int *launches);
+TNP_API int tnp_profile_end(void);
+
+/* -------------------------------------------------------------------------------------------
+ * classical.constant_velocity.predict (classical/constant_velocity.py:4-20), batched:
+ *   last, prev [N,2] float64 -> out [n_predict,N,2] float64
+ * ----------------------------------------------------------------------------------------- */
+TNP_API int tnp_constant_velocity(const double *last, const double *prev, int N, int n_predict, double *out,
+                          void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAJNET_HIP_H */

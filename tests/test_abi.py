@@ -1,0 +1,85 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol the header
+declares, the host classes mirror the reference's constructor / state_dict contract, and the
+product path fails loudly without a GPU (no CPU fallback)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers
+from trajnetplusplusbaselines_amd import _lib
+from trajnetplusplusbaselines_amd import data as trajdata
+from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling, LSTMPredictor, drop_distant
+from trajnetplusplusbaselines_amd.lstm.modules import InputEmbedding
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = _lib.exported_symbols_in_header()
+    assert len(names) >= 12
+    for name in names:
+        assert hasattr(L, name), name
+    assert L.tnp_abi_version() == 1
+
+
+def test_struct_layout_matches_header_size():
+    # 13 int32 + 4 float + 22 pointers + 1 int32 (+ padding) -- guards against drift between header and ctypes
+    assert ctypes.sizeof(_lib.LstmModel) == 13 * 4 + 4 * 4 + 4 + 22 * 8 + 8
+
+
+@pytest.mark.parametrize('kind', ['vanilla', 'occupancy', 'directional', 'social', 'social_goals'])
+def test_state_dict_contract_matches_reference(kind):
+    sd, cfg, _ = helpers.load_lstm_case(kind)
+    model = helpers.build_amd_model(sd, cfg, device='cpu')
+    ours = model.state_dict()
+    assert list(ours.keys()) == list(sd.keys())
+    for k in sd:
+        assert tuple(ours[k].shape) == tuple(sd[k].shape), k
+        assert np.array_equal(ours[k].numpy(), sd[k]), k
+
+
+def test_no_cpu_fallback():
+    model = LSTM(pool=GridBasedPooling(type_='occupancy', n=4, out_dim=16))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        model(torch.zeros(9, 4, 2), torch.zeros(4, 2), torch.tensor([0, 4]), n_predict=12)
+    with pytest.raises(AssertionError):   # reference lstm/lstm.py:197 XOR contract
+        model(torch.zeros(9, 4, 2), torch.zeros(4, 2), torch.tensor([0, 4]))
+
+
+def test_unsupported_options_raise():
+    with pytest.raises(NotImplementedError):
+        GridBasedPooling(type_='dir_social')
+    with pytest.raises(NotImplementedError):
+        GridBasedPooling(embedding_arch='lstm_layer')
+
+
+def test_start_tags():
+    # reference tests/test_lstm_modules.py:5-14
+    emb = InputEmbedding(2, 4, 1.0)
+    assert emb.start_enc(torch.zeros(1, 2)).numpy().tolist() == [[0.0, 0.0, 1.0, 0.0]]
+    assert emb.start_dec(torch.zeros(1, 2)).numpy().tolist() == [[0.0, 0.0, 0.0, 1.0]]
+
+
+def test_drop_distant():
+    # reference tests/test_lstm_loss.py:46-60 adapted
+    xy = np.array([[[0.0, 0.0], [1.0, 1.0], [20.0, 20.0], [np.nan, np.nan]],
+                   [[0.0, 1.0], [1.5, 1.0], [20.0, 21.0], [3.0, 1.0]]])
+    kept, mask = drop_distant(xy, r=6.0)
+    assert mask.tolist() == [True, True, False, True]
+    assert kept.shape == (2, 3, 2)
+
+
+def test_paths_to_xy_and_center_scene_roundtrip():
+    rows = [[trajdata.TrackRow(f, 7, float(f), 2.0 * f) for f in range(0, 50, 10)],
+            [trajdata.TrackRow(f, 9, -float(f), 1.0) for f in range(10, 40, 10)]]
+    xy = trajdata.paths_to_xy(rows)
+    assert xy.shape == (5, 2, 2)
+    assert np.isnan(xy[0, 1]).all() and np.isnan(xy[4, 1]).all()
+    assert xy[2, 1].tolist() == [-20.0, 1.0]
+    full = np.random.RandomState(0).randn(12, 3, 2)
+    c, rot, center = trajdata.center_scene(full, obs_length=9)
+    assert np.allclose(c[8, 0], 0.0)
+    d = c[8, 0] - c[7, 0]
+    assert abs(d[0]) < 1e-12 and d[1] > 0
+    assert np.allclose(trajdata.inverse_scene(c, rot, center), full)

@@ -1,0 +1,115 @@
+"""GPU parity of the interaction-grid kernel (csrc/pool_grid.hip) through the GridBasedPooling API and the
+C ABI: bit-exact against the reference's golden grids (occupancy / directional; social to fp32 rounding of
+the hidden encoding) and against the oracle's integer cell ids."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from tests import helpers
+from trajnetplusplusbaselines_amd import _lib
+from trajnetplusplusbaselines_amd.lstm import GridBasedPooling
+
+pytestmark = pytest.mark.gpu
+
+GRID_CASES = helpers.load_grid_cases()
+FAST = [r for r in GRID_CASES if r['n'] * r['pool_size'] <= 64]
+
+
+def make_pool(rec):
+    pool = GridBasedPooling(cell_side=rec['cell_side'], n=rec['n'], hidden_dim=8, type_=rec['type'],
+                            pool_size=rec['pool_size'], blur_size=rec['blur_size'], front=bool(rec['front']),
+                            constant=rec['constant'], latent_dim=4, out_dim=8)
+    if rec['type'] == 'social':
+        with torch.no_grad():
+            pool.hidden_dim_encoding.weight.copy_(torch.tensor(rec['Wh']))
+            pool.hidden_dim_encoding.bias.copy_(torch.tensor(rec['bh']))
+    return pool.to('cuda')
+
+
+@pytest.mark.parametrize('rec', FAST, ids=[r['name'] for r in FAST])
+def test_grid_matches_reference_golden(rec):
+    pool = make_pool(rec)
+    o1 = torch.tensor(rec['obs1']).cuda()
+    o2 = torch.tensor(rec['obs2']).cuda()
+    if rec['type'] == 'occupancy':
+        g = pool.occupancies(o1, o2)
+    elif rec['type'] == 'directional':
+        g = pool.directional(o1, o2)
+    else:
+        g = pool.social(torch.tensor(rec['hidden']).cuda(), o1, o2)
+    g = g.cpu().numpy()
+    ref = rec['grid']
+    assert g.shape == ref.shape
+    if rec['type'] == 'social' or rec['blur_size'] != 1:
+        np.testing.assert_allclose(g, ref, rtol=0, atol=2e-6)
+    else:
+        assert np.array_equal(g, ref), float(np.abs(g - ref).max())
+
+
+@pytest.mark.parametrize('rec', [r for r in GRID_CASES if 'tag_grid' in r],
+                         ids=[r['name'] for r in GRID_CASES if 'tag_grid' in r])
+def test_tag_grid_and_winner_table(rec):
+    """occupancy() with per-pair tag values reproduces the reference's tag grid bit for bit, and the int16
+    winner table agrees with the oracle's integer cell ids (last writer wins, cell-0 clobber)."""
+    pool = make_pool(dict(rec, type='occupancy'))
+    o2 = torch.tensor(rec['obs2']).cuda()
+    B, N = o2.shape[:2]
+    tags = torch.arange(1, N, dtype=torch.float32).view(1, 1, N - 1, 1).repeat(B, N, 1, 1).cuda()
+    g = pool.occupancy(o2, tags, past_obs=torch.tensor(rec['obs1']).cuda()).cpu().numpy()
+    assert np.array_equal(g, rec['tag_grid'])
+    _, winners = pool._winner_grid(None, o2, _lib.POOL_OCCUPANCY, want_grid=False, want_winners=True)
+    winners = winners.cpu().numpy()
+    oi, inr = oracle.cell_ids(rec['obs2'], rec['n'], rec['cell_side'], front=bool(rec['front']))
+    n2 = rec['n'] ** 2
+    want = np.full((B * N, n2), -1, dtype=np.int16)
+    for r in range(B * N):
+        i = r % N
+        for jj in range(N - 1):
+            j = jj if jj < i else jj + 1
+            want[r, oi.reshape(B * N, N - 1)[r, jj]] = j if inr.reshape(B * N, N - 1)[r, jj] else -1
+    assert np.array_equal(winners, want)
+
+
+@pytest.mark.parametrize('type_,n,agents', [('occupancy', 16, 32), ('directional', 12, 64), ('social', 16, 32),
+                                            ('social', 16, 97), ('occupancy', 8, 130)])
+def test_grid_random_large_vs_oracle(type_, n, agents):
+    rng = np.random.RandomState(n * agents)
+    B = 5
+    obs2 = (rng.rand(B, agents, 2).astype(np.float32) * 8 - 4)
+    obs1 = obs2 - rng.randn(B, agents, 2).astype(np.float32) * 0.3
+    obs2[rng.rand(B, agents) < 0.15] = np.nan
+    obs1[rng.rand(B, agents) < 0.1] = np.nan
+    enc = rng.randn(B, agents, 16).astype(np.float32) if type_ == 'social' else None
+    want = oracle.grid(type_, obs1, obs2, enc, n=n, cell_side=0.6, C=None if type_ != 'social' else 16)
+    pool = GridBasedPooling(cell_side=0.6, n=n, type_=type_, latent_dim=16, out_dim=8).cuda()
+    tid = _lib.POOL_TYPES[type_]
+    vals = torch.tensor(enc).cuda() if enc is not None else None
+    got, _ = pool._winner_grid(torch.tensor(obs1).cuda(), torch.tensor(obs2).cuda(), tid, values=vals)
+    got = got.cpu().numpy().reshape(want.shape)
+    assert np.array_equal(got, want)
+
+
+def test_ragged_scenes_padded_slot_clobber():
+    """Flat ragged layout: scenes shorter than n_max get the reference's padded-slot cell-0 clobber."""
+    rng = np.random.RandomState(3)
+    sizes = [5, 2, 7, 1, 7]
+    n_max, n = max(sizes), 4
+    starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    M = int(starts[-1])
+    flat = (rng.rand(M, 2).astype(np.float32) * 2 - 1) * 2.0
+    flat[::3] = np.float32(-1.9)          # park agents in cell (0, 0) relative to others
+    padded = np.full((len(sizes), n_max, 2), np.nan, dtype=np.float32)
+    for s, ns in enumerate(sizes):
+        padded[s, :ns] = flat[starts[s]:starts[s + 1]]
+    want = oracle.grid('occupancy', padded, padded, n=n, cell_side=1.0).reshape(len(sizes), n_max, -1)
+    dev = torch.device('cuda')
+    grid = torch.empty(M, n * n, dtype=torch.float32, device=dev)
+    o = torch.tensor(flat).cuda()
+    st = torch.tensor(starts).cuda()
+    _lib.check(_lib.lib().tnp_pool_grid_forward(_lib.POOL_OCCUPANCY, _lib.ptr(o), _lib.ptr(o), None, 0, _lib.ptr(st),
+                                                len(sizes), n_max, n, 1, 1.0, n / 2, n / 2, 0.0, _lib.ptr(grid),
+                                                n * n, None, _lib.stream_ptr()), 'grid')
+    got = grid.cpu().numpy()
+    for s, ns in enumerate(sizes):
+        assert np.array_equal(got[starts[s]:starts[s + 1]], want[s, :ns]), s

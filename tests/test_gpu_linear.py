@@ -1,0 +1,56 @@
+"""GPU parity of the fp32 MFMA GEMM (csrc/gemm_f32_mfma.hip) against the oracle's sequential-k fp32 Linear."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from trajnetplusplusbaselines_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    (64, 64, 64), (128, 64, 32), (33, 70, 36), (1, 5, 128), (200, 130, 292), (257, 256, 288),
+    (96, 62, 2), (31, 17, 9),          # K not a multiple of 4 -> scalar loader
+    (2048, 256, 1024), (512, 1024, 4096),
+]
+
+
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize('M,N,K', SHAPES)
+def test_linear_matches_oracle(M, N, K, variant):
+    if variant != 0 and M * N * K > 2048 * 256 * 1024 and variant in (3, 7):
+        pytest.skip('slow small-tile variant on the big shape')
+    rng = np.random.RandomState(M + 7 * N + 13 * K)
+    x = rng.randn(M, K).astype(np.float32)
+    x[rng.rand(M, K) < 0.5] = 0.0
+    w = (rng.randn(N, K) / np.sqrt(K)).astype(np.float32)
+    b = rng.randn(N).astype(np.float32)
+    for relu in (False, True):
+        want = oracle.linear(x, w, b, relu=relu)
+        got = _lib.linear_forward(torch.tensor(x).cuda(), torch.tensor(w).cuda(), torch.tensor(b).cuda(), relu=relu,
+                                  variant=variant).cpu().numpy()
+        # fp32 products are exact fmas on both sides; only the summation order differs
+        tol = 2e-6 * np.sqrt(K) * max(1.0, float(np.abs(want).max()))
+        err = float(np.abs(got - want).max())
+        assert err <= tol, (err, tol)
+
+
+def test_linear_transpose_detecting():
+    """A = I with an asymmetric W: catches swapped rows / columns in the accumulator mapping."""
+    K = 64
+    x = np.eye(K, dtype=np.float32)
+    w = (np.arange(96 * K, dtype=np.float32).reshape(96, K) % 251) / 16.0
+    got = _lib.linear_forward(torch.tensor(x).cuda(), torch.tensor(w).cuda(), None).cpu().numpy()
+    assert np.array_equal(got, w.T)
+
+
+def test_linear_strided_output_slice():
+    """The last embedding layer writes into a column slice of the LSTM input buffer (ldc > N)."""
+    rng = np.random.RandomState(0)
+    x = rng.randn(70, 40).astype(np.float32)
+    w = rng.randn(24, 40).astype(np.float32)
+    buf = torch.full((70, 100), -7.0, device='cuda')
+    _lib.linear_forward(torch.tensor(x).cuda(), torch.tensor(w).cuda(), None, out=buf[:, 64:88])
+    got = buf.cpu().numpy()
+    assert np.all(got[:, :64] == -7.0) and np.all(got[:, 88:] == -7.0)
+    np.testing.assert_allclose(got[:, 64:88], x @ w.T, atol=2e-5)

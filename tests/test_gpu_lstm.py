@@ -1,0 +1,157 @@
+"""GPU parity of the recurrent path (tnp_lstm_forward / tnp_lstm_step) against the reference's golden outputs,
+against the CPU oracle at BASELINE config sizes, and through size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from tests import helpers
+from trajnetplusplusbaselines_amd import synth
+from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ['vanilla', 'occupancy', 'directional', 'social', 'social_goals']
+
+
+@pytest.mark.parametrize('kind', KINDS)
+@pytest.mark.parametrize('batch', ['lin', 'rag'])
+def test_forward_matches_reference_golden(kind, batch):
+    """FP32 tolerance 2e-5 on every predicted normal / position of the reference's own outputs."""
+    sd, cfg, d = helpers.load_lstm_case(kind)
+    model = helpers.build_amd_model(sd, cfg)
+    xy = torch.tensor(d[batch + '_xy'])
+    split = torch.tensor(d[batch + '_split'])
+    goals = torch.tensor(d[batch + '_goals'])
+    rel, pred = model(xy[:9], goals, split, n_predict=12)
+    helpers.assert_close_nan(rel.cpu().numpy(), d[batch + '_rel_npredict'], 2e-5, 'rel n_predict')
+    helpers.assert_close_nan(pred.cpu().numpy(), d[batch + '_pred_npredict'], 2e-5, 'pred n_predict')
+    rel, pred = model(xy[:9], goals, split, prediction_truth=xy[9:20].clone())
+    helpers.assert_close_nan(rel.cpu().numpy(), d[batch + '_rel_truth'], 2e-5, 'rel truth')
+    helpers.assert_close_nan(pred.cpu().numpy(), d[batch + '_pred_truth'], 2e-5, 'pred truth')
+
+
+@pytest.mark.parametrize('kind', ['directional', 'social'])
+def test_step_matches_oracle(kind):
+    """One masked step from a random state: state, normals and NaN pattern vs the oracle step."""
+    sd, cfg, d = helpers.load_lstm_case(kind)
+    model = helpers.build_amd_model(sd, cfg)
+    om = helpers.oracle_model(sd, cfg)
+    xy, split = d['rag_xy'], d['rag_split']
+    M = xy.shape[1]
+    rng = np.random.RandomState(1)
+    h = (rng.randn(M, 128) * 0.3).astype(np.float32)
+    c = (rng.randn(M, 128) * 0.3).astype(np.float32)
+    for decoder, (t1, t2) in ((0, (3, 4)), (1, (10, 11))):
+        h2, c2, normal, _ = om.step(decoder, h, c, xy[t1], xy[t2], None, split)
+        cell = model.decoder if decoder else model.encoder
+        (gh, gc), gn = model.step(cell, (torch.tensor(h).cuda(), torch.tensor(c).cuda()), torch.tensor(xy[t1]),
+                                  torch.tensor(xy[t2]), None, torch.tensor(split))
+        helpers.assert_close_nan(gn.cpu().numpy(), normal, 1e-5, 'normal')
+        np.testing.assert_allclose(gh.cpu().numpy(), h2, atol=1e-5)
+        np.testing.assert_allclose(gc.cpu().numpy(), c2, atol=1e-5)
+        # the reference's list-of-tensors state form is accepted too
+        hl = list(torch.tensor(h).cuda().unbind(0))
+        cl = list(torch.tensor(c).cuda().unbind(0))
+        (lh, lc), ln = model.step(cell, (hl, cl), torch.tensor(xy[t1]), torch.tensor(xy[t2]), None, torch.tensor(split))
+        assert isinstance(lh, list) and len(lh) == M
+        assert torch.equal(torch.stack(lh), gh)
+
+
+def _config2_model(seed=0):
+    torch.manual_seed(seed)
+    pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=16, out_dim=256,
+                            embedding_arch='two_layer', layer_dims=[1024], latent_dim=16)
+    return LSTM(pool=pool).eval()
+
+
+def _ade_fde(pred, truth, split):
+    prim = split[:-1]
+    d = np.linalg.norm(pred[:, prim].astype(np.float64) - truth[:, prim].astype(np.float64), axis=-1)
+    return d.mean(axis=0), d[-1]
+
+
+@pytest.mark.parametrize('scenes,agents', [(16, 32), (64, 32)])
+def test_config2_social_lstm_vs_oracle(scenes, agents):
+    """BASELINE config 2 (Social-LSTM n=16 two_layer 1024) at reduced and full size: per-scene ADE / FDE of the
+    primary within 1e-4 m of the oracle, all positions within 1e-3."""
+    model = _config2_model()
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    om = oracle.OracleModel(sd, pool_type='social', n=16, cell_side=0.6)
+    model = model.cuda()
+    xy, split = synth.linear_crowd(scenes, agents, seed=3)
+    rel, pred = model(xy[:9], torch.zeros(xy.shape[1], 2), split, n_predict=12)
+    orel, opred = om.forward(xy[:9].numpy(), None, split.numpy(), n_predict=12)
+    pred, rel = pred.cpu().numpy(), rel.cpu().numpy()
+    truth = xy[9:21].numpy()
+    ade_g, fde_g = _ade_fde(pred[-12:], truth, split.numpy())
+    ade_o, fde_o = _ade_fde(opred[-12:], truth, split.numpy())
+    print('max |dADE| %.2e max |dFDE| %.2e max |dpos| %.2e' % (np.abs(ade_g - ade_o).max(),
+          np.abs(fde_g - fde_o).max(), np.abs(pred - opred).max()))
+    assert np.abs(ade_g - ade_o).max() < 1e-4
+    assert np.abs(fde_g - fde_o).max() < 1e-4
+    helpers.assert_close_nan(pred, opred, 1e-3, 'positions')
+    helpers.assert_close_nan(rel, orel, 1e-3, 'normals')
+
+
+def test_config3_directional_vs_oracle():
+    """BASELINE config 3 per-GPU shard (D-LSTM n=12 one_layer; 32 scenes x 64 agents) with entering/leaving tracks."""
+    torch.manual_seed(1)
+    pool = GridBasedPooling(type_='directional', hidden_dim=128, cell_side=0.6, n=12, out_dim=256)
+    model = LSTM(pool=pool).eval()
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    om = oracle.OracleModel(sd, pool_type='directional', n=12, cell_side=0.6)
+    model = model.cuda()
+    xy, split = synth.ragged_crowd(32, 40, 64, seed=5)
+    M = xy.shape[1]
+    for kw in (dict(n_predict=12), dict(prediction_truth=xy[9:20].clone())):
+        rel, pred = model(xy[:9], torch.zeros(M, 2), split, **kw)
+        okw = {k: (v.numpy() if hasattr(v, 'numpy') else v) for k, v in kw.items()}
+        orel, opred = om.forward(xy[:9].numpy(), None, split.numpy(), **okw)
+        helpers.assert_close_nan(pred.cpu().numpy(), opred, 2e-4, 'positions')
+        helpers.assert_close_nan(rel.cpu().numpy(), orel, 2e-4, 'normals')
+
+
+def test_properties_full_size():
+    """Size-independent properties at BASELINE config 2 size: run-to-run bit reproducibility, scene-permutation
+    equivariance (bitwise) and equality of a joint batch with its two halves."""
+    model = _config2_model(seed=2).cuda()
+    xy, split = synth.linear_crowd(64, 32, seed=9)
+    M = xy.shape[1]
+    goals = torch.zeros(M, 2)
+    rel_a, pred_a = model(xy[:9], goals, split, n_predict=12)
+    rel_b, pred_b = model(xy[:9], goals, split, n_predict=12)
+    assert torch.equal(pred_a, pred_b) and torch.equal(rel_a, rel_b)
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(0))
+    idx = (perm.view(-1, 1) * 32 + torch.arange(32).view(1, -1)).reshape(-1)
+    rel_p, pred_p = model(xy[:9, idx], goals, split, n_predict=12)
+    assert torch.equal(pred_p, pred_a[:, idx.cuda()])
+    half = torch.arange(0, 32 * 32 + 1, 32)
+    _, p0 = model(xy[:9, :1024], goals[:1024], half, n_predict=12)
+    _, p1 = model(xy[:9, 1024:], goals[1024:], half, n_predict=12)
+    assert torch.equal(torch.cat([p0, p1], dim=1), pred_a)
+    assert not torch.isnan(pred_a).any()
+
+
+def test_edge_cases():
+    sd, cfg, d = helpers.load_lstm_case('occupancy')
+    model = helpers.build_amd_model(sd, cfg)
+    om = helpers.oracle_model(sd, cfg)
+    # (a) two observed frames only (reference lstm/lstm.py:222-223), (b) single-track scene, (c) all-NaN neighbour
+    xy = np.array(d['rag_xy'])
+    split = d['rag_split']
+    rel, pred = model(torch.tensor(xy[7:9]), None, torch.tensor(split), n_predict=4)
+    orel, opred = om.forward(xy[7:9], None, split, n_predict=4)
+    assert pred.shape[0] == orel.shape[0] + 1
+    helpers.assert_close_nan(pred.cpu().numpy(), opred, 2e-5, 'T_obs=2 positions')
+    one = np.cumsum(np.random.RandomState(0).randn(21, 1, 2).astype(np.float32) * 0.3, axis=0)
+    rel, pred = model(torch.tensor(one[:9]), None, torch.tensor([0, 1]), n_predict=12)
+    orel, opred = om.forward(one[:9], None, np.array([0, 1]), n_predict=12)
+    helpers.assert_close_nan(pred.cpu().numpy(), opred, 2e-5, 'single track')
+    xy2 = xy.copy()
+    xy2[:, 1] = np.nan
+    rel, pred = model(torch.tensor(xy2[:9]), None, torch.tensor(split), n_predict=12)
+    orel, opred = om.forward(xy2[:9], None, split, n_predict=12)
+    helpers.assert_close_nan(pred.cpu().numpy(), opred, 2e-5, 'all-NaN neighbour')
+    with pytest.raises(ValueError):
+        model(torch.tensor(xy[:9]), None, torch.tensor([0, 3]), n_predict=12)

@@ -1,0 +1,162 @@
+"""ctypes binding of libtrajnet_hip.so (include/trajnet_hip.h) -- the only way the Python host layer reaches
+the HIP kernels.  There is NO CPU fallback: if the library is missing the import of any op fails loudly.
+
+PyTorch is used only as plumbing here: device memory (tensor.data_ptr()), the current HIP stream and
+torch.distributed.  Every entry point enqueues on ``torch.cuda.current_stream()`` and returns immediately.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libtrajnet_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'trajnet_hip.h')
+
+POOL_NONE, POOL_OCCUPANCY, POOL_DIRECTIONAL, POOL_SOCIAL = -1, 0, 1, 2
+POOL_TYPES = {None: POOL_NONE, 'occupancy': POOL_OCCUPANCY, 'directional': POOL_DIRECTIONAL, 'social': POOL_SOCIAL}
+
+_fp = ctypes.c_void_p
+
+
+class LstmModel(ctypes.Structure):
+    """mirror of ``struct tnp_lstm_model`` (include/trajnet_hip.h)"""
+    _fields_ = [
+        ('E', ctypes.c_int32), ('H', ctypes.c_int32), ('goal_flag', ctypes.c_int32), ('goal_dim', ctypes.c_int32),
+        ('pool_type', ctypes.c_int32), ('n', ctypes.c_int32), ('C', ctypes.c_int32), ('P', ctypes.c_int32),
+        ('n_layers', ctypes.c_int32), ('dims', ctypes.c_int32 * 4),
+        ('cell', ctypes.c_float), ('half_x', ctypes.c_float), ('half_y', ctypes.c_float), ('constant', ctypes.c_float),
+        ('We', _fp), ('be', _fp), ('Wg', _fp), ('bg', _fp),
+        ('enc_Wih', _fp), ('enc_Whh', _fp), ('enc_bih', _fp), ('enc_bhh', _fp),
+        ('dec_Wih', _fp), ('dec_Whh', _fp), ('dec_bih', _fp), ('dec_bhh', _fp),
+        ('Wn', _fp), ('bn', _fp), ('Wh', _fp), ('bh', _fp),
+        ('Wp', _fp * 3), ('bp', _fp * 3),
+        ('variant', ctypes.c_int32),
+    ]
+
+
+_LIB = None
+
+
+def exported_symbols_in_header():
+    """Names of every entry point include/trajnet_hip.h declares (used by the ABI test)."""
+    import re
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    return sorted(set(re.findall(r'TNP_API\s+[\w\s\*]+?\b(tnp_\w+)\s*\(', text)))
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built -- there is no fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'libtrajnet_hip.so not found at %s: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950). The MI355X path has no CPU fallback.' % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    L.tnp_abi_version.restype = ctypes.c_int
+    L.tnp_last_error.restype = ctypes.c_char_p
+    L.tnp_lstm_workspace_bytes.restype = ctypes.c_size_t
+    L.tnp_lstm_workspace_bytes.argtypes = [ctypes.POINTER(LstmModel), ctypes.c_int, ctypes.c_int]
+    L.tnp_mark_primaries.argtypes = [_fp, ctypes.c_int, ctypes.c_int, _fp, _fp]
+    L.tnp_pool_grid_forward.argtypes = [ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                        ctypes.c_float, _fp, ctypes.c_int, _fp, _fp]
+    L.tnp_linear_forward.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]
+    L.tnp_lstm_forward.argtypes = [ctypes.POINTER(LstmModel), _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp,
+                                   ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t, _fp]
+    L.tnp_lstm_step.argtypes = [ctypes.POINTER(LstmModel), ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
+                                ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, ctypes.c_size_t, _fp]
+    L.tnp_profile_begin.argtypes = [ctypes.c_int]
+    L.tnp_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    L.tnp_constant_velocity.argtypes = [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp]
+    if L.tnp_abi_version() != 1:
+        raise RuntimeError('libtrajnet_hip.so ABI version mismatch')
+    _LIB = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().tnp_last_error().decode('utf-8', 'replace')
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, msg))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (or NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_device(t, what):
+    if not t.is_cuda:
+        raise RuntimeError('%s must live on a ROCm device (got %s): the MI355X path has no CPU fallback'
+                           % (what, t.device))
+
+
+def f32c(t, device=None):
+    """fp32, contiguous, on `device` (H2D copy if the caller handed a host tensor)."""
+    if device is not None and t.device != device:
+        t = t.to(device)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class SceneIndex(object):
+    """int32 scene starts + per-track primary flags + the reference's padded slot count (lstm/lstm.py:29)."""
+    _cache = {}
+
+    def __init__(self, batch_split, device):
+        split = batch_split.detach().to('cpu', torch.int64)
+        if split.numel() < 2:
+            raise ValueError('batch_split needs at least two entries')
+        sizes = split[1:] - split[:-1]
+        if int(sizes.min()) < 0:
+            raise ValueError('batch_split must be non-decreasing')
+        self.B = int(split.numel() - 1)
+        self.M = int(split[-1] - split[0])
+        if int(split[0]) != 0:
+            raise ValueError('batch_split must start at 0')
+        self.n_max = int(sizes.max()) if self.B > 0 else 0
+        self.starts = split.to(torch.int32).to(device)
+        self.primary = torch.empty(max(self.M, 1), dtype=torch.uint8, device=device)
+        check(lib().tnp_mark_primaries(ptr(self.starts), self.B, self.M, ptr(self.primary), stream_ptr()),
+              'tnp_mark_primaries')
+
+    @classmethod
+    def get(cls, batch_split, device):
+        if isinstance(batch_split, (list, tuple)):
+            batch_split = torch.tensor(batch_split, dtype=torch.int64)
+        host = batch_split.detach().to('cpu', torch.int64)
+        key = (str(device), host.numpy().tobytes())
+        idx = cls._cache.get(key)
+        if idx is None:
+            if len(cls._cache) > 64:
+                cls._cache.clear()
+            idx = cls(host, device)
+            cls._cache[key] = idx
+        return idx
+
+
+def linear_forward(x, weight, bias, relu=False, variant=0, out=None):
+    """act(x @ weight.T + bias) on the matrix cores (tnp_linear_forward). x [M,K] fp32, weight [N,K]."""
+    require_device(x, 'input')
+    x = f32c(x)
+    weight = f32c(weight, x.device)
+    bias_t = f32c(bias, x.device) if bias is not None else None
+    M, K = x.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    check(lib().tnp_linear_forward(ptr(x), x.stride(0), ptr(weight), weight.stride(0), ptr(bias_t), ptr(out),
+                                   out.stride(0), M, N, K, int(relu), int(variant), stream_ptr()), 'tnp_linear_forward')
+    return out

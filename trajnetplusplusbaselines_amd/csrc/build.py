@@ -1,0 +1,55 @@
+"""Build libtrajnet_hip.so (gfx950) in-tree with hipcc.  No torch dependency: the library is a plain
+C-ABI shared object (include/trajnet_hip.h); hipcc cross-compiles without a GPU."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT_DIR = os.path.join(PKG, 'lib')
+OUT = os.path.join(OUT_DIR, 'libtrajnet_hip.so')
+SOURCES = ['gemm_f32_mfma.hip', 'pool_grid.hip', 'lstm_seq.hip', 'classical.hip']
+HEADERS = ['tnp_internal.h', os.path.join('..', '..', 'include', 'trajnet_hip.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-fvisibility=hidden',
+         '-Wall', '-Wno-unused-function']
+
+
+def hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return 'hipcc'
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(HERE, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not (force or needs_build()):
+        return OUT
+    os.makedirs(OUT_DIR, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        path = os.path.join(HERE, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(OUT_DIR, os.path.splitext(src)[0] + '.o')
+        cmd = [hipcc()] + FLAGS + ['-c', path, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

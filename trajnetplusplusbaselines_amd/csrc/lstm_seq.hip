@@ -1,0 +1,489 @@
+// Sequence driver of trajnetbaselines.lstm.LSTM on MI355X (reference lstm/lstm.py:91-264), gfx950 only.
+//
+// The reference keeps per-track hidden state as Python lists and re-stacks them every step; here the state is
+// dense [M,H] fp32 in HBM with a per-step presence mask, and one recurrent step is four launches:
+//
+//   track_prepare   per track: finish step s-1 (Hidden2Normal of h, predicted position), select obs1/obs2 for
+//                   step s (observed / teacher-forced / own prediction, primary rows patched with the model's
+//                   prediction, lstm.py:240-250), presence mask, InputEmbedding (+goal embedding) into X[:,0:E],
+//                   and the social hidden-state encoding Linear(H->C) of the PREVIOUS-step hidden state.
+//   grid_build      pool_grid.hip
+//   linear x L      grid embedding MLP on the matrix cores (gemm_f32_mfma.hip), last layer writes X[:,E:]
+//   lstm_gates      [X | h] @ [W_ih | W_hh]^T + LSTMCell pointwise + masked state update (h ping-pong)
+//
+// All launches go to the caller's stream; nothing synchronises or allocates (graph capturable).
+#include "tnp_internal.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace tnp {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- profiling hook (bench.py roofline leg) -------------------------------------------------
+static int g_prof_cls = -1;
+static const int PROF_MAX = 4096;
+static hipEvent_t g_prof_ev[2 * PROF_MAX];
+static int g_prof_n = 0, g_prof_created = 0;
+void prof_before(int cls, hipStream_t s) {
+    if (g_prof_cls < 0 || (g_prof_cls != cls && g_prof_cls != PROF_ALL_GEMM) || g_prof_n >= PROF_MAX) return;
+    while (g_prof_created < 2 * (g_prof_n + 1)) (void)hipEventCreate(&g_prof_ev[g_prof_created++]);
+    (void)hipEventRecord(g_prof_ev[2 * g_prof_n], s);
+}
+void prof_after(int cls, hipStream_t s) {
+    if (g_prof_cls < 0 || (g_prof_cls != cls && g_prof_cls != PROF_ALL_GEMM) || g_prof_n >= PROF_MAX) return;
+    (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], s);
+    ++g_prof_n;
+}
+
+// ---- per-track prepare kernel -----------------------------------------------------------------
+struct PrepArgs {
+    int M, H, E, goal_flag, goal_dim, C, I;  // I = row stride of X
+    // finish previous step
+    int have_prev;
+    const float *h;              // [M,H] state after the previous step
+    const uint8_t *mask_prev;    // [M]
+    const float *obs2_prev;      // [M,2]
+    float *normal_out;           // [M,5]  rel_pred[s-1]
+    float *pos_out;              // [M,2]  pred[...]
+    const float *Wn, *bn;
+    // set up next step
+    int have_next;
+    const float *ext1, *ext2;    // [M,2] external frames or NULL
+    const float *pos1;           // positions[-2] ([M,2]) or NULL
+    int use_pos2;                // obs2 (all rows if ext2 == NULL, primary rows if patch2) <- the position just computed
+    int patch1, patch2;          // primary rows of an external frame are replaced by the prediction
+    const uint8_t *primary;      // [M]
+    const float *goals;          // [M,2]
+    float *obs1_buf, *obs2_buf;  // [M,2]
+    uint8_t *mask;               // [M]
+    float *X;                    // [M,I]
+    const float *We, *be, *Wg, *bg;
+    const float *Wh, *bh;        // social encoding [C,H]
+    float *enc;                  // [M,C]
+};
+
+#define PREP_TRACKS 8
+
+__device__ __forceinline__ float sigmoid_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// 256 threads = 8 tracks x 32 lanes.  Phase 1: the 5 + C dot products of length H per track (h row and the
+// weight rows staged in LDS, weight stride H+1 -> conflict free).  Phase 2: per-track scalar bookkeeping.
+// Phase 3: the E-2 (+ goal) embedding outputs, 32 lanes per track.
+__global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    const int H = a.H;
+    const int nout = (a.have_prev ? 5 : 0) + (a.have_next ? a.C : 0);  // rows of the stacked weight
+    float *hs = psm;                        // [8][H]
+    float *ws = hs + PREP_TRACKS * H;       // [nout][H+1]
+    float *outs = ws + nout * (H + 1);      // [8][nout]
+    float *ob = outs + PREP_TRACKS * (nout > 0 ? nout : 1);  // [8][8]: obs1.xy obs2.xy mask goal.xy
+    const int tid = threadIdx.x;
+    const int t_local = tid >> 5, l32 = tid & 31;
+    const int m0 = blockIdx.x * PREP_TRACKS;
+    const int m = m0 + t_local;
+    const bool valid = m < a.M;
+
+    if (nout > 0) {
+        for (int q = tid; q < PREP_TRACKS * H; q += 256) {
+            const int t = q / H, k = q - t * H;
+            hs[q] = (m0 + t < a.M) ? a.h[(size_t)(m0 + t) * H + k] : 0.0f;
+        }
+        for (int q = tid; q < nout * H; q += 256) {
+            const int o = q / H, k = q - o * H;
+            float w;
+            if (a.have_prev && o < 5) w = a.Wn[o * H + k];
+            else w = a.Wh[(o - (a.have_prev ? 5 : 0)) * H + k];
+            ws[o * (H + 1) + k] = w;
+        }
+    }
+    __syncthreads();
+    for (int o = l32; o < nout; o += 32) {
+        const float *hr = hs + t_local * H;
+        const float *wr = ws + o * (H + 1);
+        float acc;
+        if (a.have_prev && o < 5) acc = a.bn[o];
+        else acc = a.bh[o - (a.have_prev ? 5 : 0)];
+        for (int k = 0; k < H; ++k) acc = fmaf(hr[k], wr[k], acc);
+        outs[t_local * nout + o] = acc;
+    }
+    __syncthreads();
+
+    // ---- phase 2: one lane per track ----
+    if (l32 == 0 && valid) {
+        float px = NAN, py = NAN;  // position predicted by the previous step
+        if (a.have_prev) {
+            const float *o = outs + t_local * nout;
+            float n0 = NAN, n1 = NAN, n2 = NAN, n3 = NAN, n4 = NAN;
+            if (a.mask_prev[m]) {  // Hidden2Normal, lstm/modules.py:56-64
+                n0 = o[0]; n1 = o[1];
+                n2 = 0.01f + 0.2f * sigmoid_dev(o[2]);
+                n3 = 0.01f + 0.2f * sigmoid_dev(o[3]);
+                n4 = 0.7f * sigmoid_dev(o[4]);
+            }
+            float *no = a.normal_out + (size_t)m * 5;
+            no[0] = n0; no[1] = n1; no[2] = n2; no[3] = n3; no[4] = n4;
+            px = a.obs2_prev[2 * m] + n0;      // positions.append(obs2 + normal[:, :2]), lstm.py:232,255
+            py = a.obs2_prev[2 * m + 1] + n1;
+            a.pos_out[2 * m] = px; a.pos_out[2 * m + 1] = py;
+        }
+        if (a.have_next) {
+            const bool prim = a.primary[m] != 0;
+            float o1x, o1y, o2x, o2y;
+            if (a.ext1 && !(a.patch1 && prim)) { o1x = a.ext1[2 * m]; o1y = a.ext1[2 * m + 1]; }
+            else { o1x = a.pos1[2 * m]; o1y = a.pos1[2 * m + 1]; }
+            if (a.ext2 && !(a.patch2 && prim)) { o2x = a.ext2[2 * m]; o2y = a.ext2[2 * m + 1]; }
+            else { o2x = px; o2y = py; }
+            const bool present = (o1x == o1x) && (o2x == o2x);  // lstm.py:118
+            a.obs1_buf[2 * m] = o1x; a.obs1_buf[2 * m + 1] = o1y;
+            a.obs2_buf[2 * m] = o2x; a.obs2_buf[2 * m + 1] = o2y;
+            a.mask[m] = present ? 1 : 0;
+            float *b = ob + t_local * 8;
+            b[0] = o1x; b[1] = o1y; b[2] = o2x; b[3] = o2y;
+            if (a.goal_flag) {  // lstm.py:132-139
+                const float dx = o2x - a.goals[2 * m], dy = o2y - a.goals[2 * m + 1];
+                const float nf = sqrtf(dx * dx + dy * dy);
+                float gx = dx / nf, gy = dy / nf;
+                if (nf == 0.0f) { gx = 0.0f; gy = 0.0f; }
+                b[4] = gx; b[5] = gy;
+            }
+            if (a.enc) {
+                const float *o = outs + t_local * nout + (a.have_prev ? 5 : 0);
+                for (int c = 0; c < a.C; ++c) a.enc[(size_t)m * a.C + c] = o[c];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: InputEmbedding (lstm/modules.py:24-30): relu(W (4 v) + b) ++ 0,0 ----
+    if (a.have_next && valid) {
+        const float *b = ob + t_local * 8;
+        const float vx = (b[2] - b[0]) * 4.0f, vy = (b[3] - b[1]) * 4.0f;  // lstm.py:127
+        float *xr = a.X + (size_t)m * a.I;
+        for (int o = l32; o < a.E; o += 32) {
+            float v = 0.0f;
+            if (o < a.E - 2) {
+                v = fmaf(vy, a.We[2 * o + 1], fmaf(vx, a.We[2 * o], a.be[o]));
+                v = v > 0.0f ? v : 0.0f;  // absent track (NaN velocity) -> 0; the row is masked anyway
+            }
+            xr[o] = v;
+        }
+        if (a.goal_flag) {
+            const float gx = b[4] * 4.0f, gy = b[5] * 4.0f;
+            for (int o = l32; o < a.goal_dim; o += 32) {
+                float v = 0.0f;
+                if (o < a.goal_dim - 2) {
+                    v = fmaf(gy, a.Wg[2 * o + 1], fmaf(gx, a.Wg[2 * o], a.bg[o]));
+                    v = v > 0.0f ? v : 0.0f;
+                }
+                xr[a.E + o] = v;
+            }
+        }
+    }
+}
+
+static int launch_prepare(const PrepArgs &a, hipStream_t s) {
+    const int nout = (a.have_prev ? 5 : 0) + (a.have_next ? a.C : 0);
+    size_t smem = ((size_t)PREP_TRACKS * a.H + (size_t)nout * (a.H + 1) + (size_t)PREP_TRACKS * (nout > 0 ? nout : 1) +
+                   PREP_TRACKS * 8) * sizeof(float);
+    if (smem > 60000) TNP_FAIL(-1, "track_prepare: hidden_dim %d too large for the LDS staging", a.H);
+    const int blocks = (a.M + PREP_TRACKS - 1) / PREP_TRACKS;
+    hipLaunchKernelGGL(track_prepare_kernel, dim3(blocks), dim3(256), smem, s, a);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- workspace layout ---------------------------------------------------------------------------
+struct Workspace {
+    float *h[2];
+    float *c;
+    float *obs1, *obs2;
+    float *X;
+    float *enc;
+    float *grid;
+    float *y[2];
+    uint8_t *mask;
+    int I, Fin, ldg;
+    size_t bytes;
+};
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace &w) {
+    const int H = md->H, E = md->E;
+    const int GD = md->goal_flag ? md->goal_dim : 0;
+    const bool pool = md->pool_type != TNP_POOL_NONE;
+    const int P = pool ? md->P : 0;
+    w.I = E + GD + P;
+    w.Fin = pool ? md->C * md->n * md->n : 0;
+    w.ldg = (w.Fin + 3) & ~3;
+    size_t off = 0;
+    char *b = reinterpret_cast<char *>(base);
+    auto take = [&](size_t nbytes) { char *p = b ? b + off : nullptr; off += align256(nbytes); return p; };
+    w.h[0] = (float *)take((size_t)M * H * 4);
+    w.h[1] = (float *)take((size_t)M * H * 4);
+    w.c = (float *)take((size_t)M * H * 4);
+    w.obs1 = (float *)take((size_t)M * 2 * 4);
+    w.obs2 = (float *)take((size_t)M * 2 * 4);
+    w.X = (float *)take((size_t)M * w.I * 4);
+    w.enc = (float *)take((size_t)M * (md->C > 0 ? md->C : 1) * 4);
+    w.grid = (float *)take((size_t)M * (w.ldg > 0 ? w.ldg : 4) * 4);
+    int maxmid = 4;
+    for (int l = 1; l < md->n_layers; ++l) if (md->dims[l] > maxmid) maxmid = md->dims[l];
+    w.y[0] = (float *)take((size_t)M * maxmid * 4);
+    w.y[1] = (float *)take((size_t)M * maxmid * 4);
+    w.mask = (uint8_t *)take((size_t)M);
+    w.bytes = off;
+    return 0;
+}
+
+static int validate_model(const tnp_lstm_model *md) {
+    if (!md) TNP_FAIL(-1, "null model");
+    if (md->H <= 0 || md->H % 32 != 0) TNP_FAIL(-1, "hidden_dim must be a positive multiple of 32 (got %d)", md->H);
+    if (md->E < 4) TNP_FAIL(-1, "embedding_dim too small (%d)", md->E);
+    if (md->pool_type < TNP_POOL_NONE || md->pool_type > TNP_POOL_SOCIAL) TNP_FAIL(-1, "unknown pool_type %d", md->pool_type);
+    if (md->pool_type != TNP_POOL_NONE) {
+        if (md->n_layers < 1 || md->n_layers > 3) TNP_FAIL(-1, "embedding MLP depth %d not in 1..3", md->n_layers);
+        if (md->dims[0] != md->C * md->n * md->n) TNP_FAIL(-1, "dims[0]=%d != C*n*n=%d", md->dims[0], md->C * md->n * md->n);
+        if (md->dims[md->n_layers] != md->P) TNP_FAIL(-1, "dims[last] != P");
+        if (md->C > 64) TNP_FAIL(-1, "pooling_dim %d > 64 not supported", md->C);
+    }
+    return 0;
+}
+
+// pool + gates of one step; obs/mask/X[:,0:E+GD]/enc already prepared
+static int run_step_body(const tnp_lstm_model *md, int decoder, const Workspace &w, const float *h_in, float *h_out,
+                         const float *c_in, float *c_out, const int32_t *scene_start, int B, int M, int n_max,
+                         hipStream_t s) {
+    const int H = md->H;
+    if (md->pool_type != TNP_POOL_NONE) {
+        GridArgs ga;
+        ga.obs1 = w.obs1; ga.obs2 = w.obs2; ga.values = w.enc; ga.ldv = md->C; ga.scene_start = scene_start;
+        ga.B = B; ga.n_max = n_max; ga.type = md->pool_type; ga.n = md->n; ga.C = md->C;
+        ga.cell = md->cell; ga.half_x = md->half_x; ga.half_y = md->half_y; ga.constant = md->constant;
+        ga.grid = w.grid; ga.ldg = w.ldg; ga.winners = nullptr;
+        int rc = launch_grid(ga, s);
+        if (rc) return rc;
+        const float *src = w.grid;
+        int lds = w.ldg;
+        for (int l = 0; l < md->n_layers; ++l) {
+            const bool last = (l == md->n_layers - 1);
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.A1 = src; g.lda1 = lds; g.K1 = md->dims[l];
+            g.B1 = md->Wp[l]; g.ldb1 = md->dims[l];
+            g.bias1 = md->bp[l];
+            g.M = M; g.N = md->dims[l + 1];
+            g.relu = 1;
+            if (last) { g.C = w.X + (w.I - md->P); g.ldc = w.I; }
+            else { g.C = w.y[l & 1]; g.ldc = md->dims[l + 1]; }
+            const int cls = (l == 0) ? PROF_GEMM1 : PROF_ALL_GEMM;
+            prof_before(cls, s);
+            rc = launch_linear(g, (l == 0) ? (md->variant & 0xff) : 0, s);
+            prof_after(cls, s);
+            if (rc) return rc;
+            src = g.C; lds = g.ldc;
+        }
+    }
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A1 = w.X; g.lda1 = w.I; g.K1 = w.I;
+    g.A2 = h_in; g.lda2 = H; g.K2 = H;
+    g.B1 = decoder ? md->dec_Wih : md->enc_Wih; g.ldb1 = w.I;
+    g.B2 = decoder ? md->dec_Whh : md->enc_Whh; g.ldb2 = H;
+    g.bias1 = decoder ? md->dec_bih : md->enc_bih;
+    g.bias2 = decoder ? md->dec_bhh : md->enc_bhh;
+    g.M = M; g.N = 4 * H; g.H = H;
+    g.h_in = h_in; g.h_out = h_out; g.c_in = c_in; g.c_out = c_out; g.mask = w.mask;
+    prof_before(PROF_ALL_GEMM, s);
+    int rc = launch_lstm_gates(g, (md->variant >> 8) & 0xff, s);
+    prof_after(PROF_ALL_GEMM, s);
+    return rc;
+}
+
+static void fill_prep_common(PrepArgs &p, const tnp_lstm_model *md, const Workspace &w, int M) {
+    memset(&p, 0, sizeof(p));
+    p.M = M; p.H = md->H; p.E = md->E; p.goal_flag = md->goal_flag; p.goal_dim = md->goal_dim;
+    p.C = (md->pool_type == TNP_POOL_SOCIAL) ? md->C : 0;
+    p.I = w.I;
+    p.Wn = md->Wn; p.bn = md->bn; p.We = md->We; p.be = md->be; p.Wg = md->Wg; p.bg = md->bg;
+    p.Wh = md->Wh; p.bh = md->bh;
+    p.obs1_buf = w.obs1; p.obs2_buf = w.obs2; p.mask = w.mask; p.X = w.X;
+    p.enc = (md->pool_type == TNP_POOL_SOCIAL) ? w.enc : nullptr;
+}
+
+}  // namespace tnp
+
+using namespace tnp;
+
+extern "C" TNP_API int tnp_abi_version(void) { return TNP_ABI_VERSION; }
+extern "C" TNP_API const char *tnp_last_error(void) { return tnp::g_err; }
+
+extern "C" TNP_API size_t tnp_lstm_workspace_bytes(const tnp_lstm_model *model, int M, int B) {
+    (void)B;
+    if (validate_model(model)) return 0;
+    Workspace w;
+    plan_workspace(model, M > 0 ? M : 1, nullptr, w);
+    return w.bytes;
+}
+
+extern "C" TNP_API int tnp_lstm_forward(const tnp_lstm_model *md, const float *observed, int T_obs, int M,
+                                const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
+                                int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
+                                void *workspace, size_t workspace_bytes, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = validate_model(md);
+    if (rc) return rc;
+    if (T_obs < 2) TNP_FAIL(-1, "need at least 2 observed frames (got %d)", T_obs);
+    if (T_dec < 0) TNP_FAIL(-1, "negative decoder length");
+    if (M <= 0 || B <= 0) return 0;
+    if (md->goal_flag && !goals) TNP_FAIL(-1, "goal_flag set but goals == NULL");
+    Workspace w;
+    plan_workspace(md, M, workspace, w);
+    if (workspace == nullptr || workspace_bytes < w.bytes)
+        TNP_FAIL(-1, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    const size_t F = (size_t)M * 2;
+    const int H = md->H;
+    TNP_HIP(hipMemsetAsync(w.h[0], 0, (size_t)M * H * 4, s));  // lstm.py:207-210
+    TNP_HIP(hipMemsetAsync(w.c, 0, (size_t)M * H * 4, s));
+    int npos = 0, nnorm = 0, cur = 0;
+    if (T_obs == 2) {  // lstm.py:222-223
+        TNP_HIP(hipMemcpyAsync(pred, observed + F, F * 4, hipMemcpyDeviceToDevice, s));
+        npos = 1;
+    }
+    const int n_steps = (T_obs - 1) + T_dec;
+    for (int st = 0; st <= n_steps; ++st) {
+        PrepArgs p;
+        fill_prep_common(p, md, w, M);
+        p.h = w.h[cur];
+        p.primary = primary_flag;
+        p.goals = goals;
+        p.have_prev = st > 0;
+        if (p.have_prev) {
+            p.mask_prev = w.mask;       // read before this launch overwrites it: each thread owns one track
+            p.obs2_prev = w.obs2;
+            p.normal_out = rel_pred + (size_t)nnorm * M * 5;
+            p.pos_out = pred + (size_t)npos * F;
+            ++nnorm; ++npos;            // the entry being written is positions[-1] for the next step
+        }
+        p.have_next = st < n_steps;
+        int decoder = 0;
+        if (p.have_next) {
+            if (st < T_obs - 1) {       // encoder, lstm.py:226-232
+                p.ext1 = observed + (size_t)st * F;
+                p.ext2 = observed + (size_t)(st + 1) * F;
+            } else {                    // decoder step k, lstm.py:240-250
+                const int k = st - (T_obs - 1);
+                decoder = 1;
+                // positions[-2] at the time of this step = entry npos-2 (the one just written is npos-1)
+                p.pos1 = pred + (size_t)(npos - 2) * F;
+                if (k == 0) { p.ext1 = observed + (size_t)(T_obs - 1) * F; p.patch1 = 1; }
+                else if (truth) { p.ext1 = truth + (size_t)(k - 1) * F; p.patch1 = 1; }
+                else { p.ext1 = nullptr; }
+                if (truth) { p.ext2 = truth + (size_t)k * F; p.patch2 = 1; }
+                else { p.ext2 = nullptr; }
+                p.use_pos2 = 1;
+            }
+        }
+        rc = launch_prepare(p, s);
+        if (rc) return rc;
+        if (p.have_next) {
+            rc = run_step_body(md, decoder, w, w.h[cur], w.h[cur ^ 1], w.c, w.c, scene_start, B, M, n_max, s);
+            if (rc) return rc;
+            cur ^= 1;
+        }
+    }
+    return 0;
+}
+
+extern "C" TNP_API int tnp_lstm_step(const tnp_lstm_model *md, int decoder, const float *h_in, const float *c_in,
+                             const float *obs1, const float *obs2, const float *goals, const int32_t *scene_start,
+                             int B, int M, int n_max, float *h_out, float *c_out, float *normal, void *workspace,
+                             size_t workspace_bytes, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = validate_model(md);
+    if (rc) return rc;
+    if (M <= 0 || B <= 0) return 0;
+    if (h_in == h_out) TNP_FAIL(-1, "tnp_lstm_step: h_in and h_out must not alias");
+    Workspace w;
+    plan_workspace(md, M, workspace, w);
+    if (workspace == nullptr || workspace_bytes < w.bytes)
+        TNP_FAIL(-1, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    PrepArgs p;
+    fill_prep_common(p, md, w, M);
+    p.h = h_in; p.goals = goals;
+    p.have_prev = 0; p.have_next = 1;
+    p.ext1 = obs1; p.ext2 = obs2;
+    // primary flags are only consulted when patching; none here
+    p.primary = w.mask;  // any valid [M] byte buffer (unused: patch1 = patch2 = 0)
+    rc = launch_prepare(p, s);
+    if (rc) return rc;
+    rc = run_step_body(md, decoder, w, h_in, h_out, c_in, c_out, scene_start, B, M, n_max, s);
+    if (rc) return rc;
+    // Hidden2Normal of the new state; positions are the caller's business in step mode
+    PrepArgs q;
+    fill_prep_common(q, md, w, M);
+    q.h = h_out; q.have_prev = 1; q.have_next = 0;
+    q.mask_prev = w.mask; q.obs2_prev = w.obs2; q.normal_out = normal; q.pos_out = w.obs1;  // scratch
+    return launch_prepare(q, s);
+}
+
+extern "C" TNP_API int tnp_linear_forward(const float *A, int lda, const float *W, int ldw, const float *bias, float *C,
+                                  int ldc, int M, int N, int K, int relu, int variant, void *stream) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A1 = A; g.lda1 = lda; g.K1 = K; g.B1 = W; g.ldb1 = ldw; g.bias1 = bias;
+    g.M = M; g.N = N; g.C = C; g.ldc = ldc; g.relu = relu;
+    if (M <= 0 || N <= 0) return 0;
+    prof_before(PROF_GEMM1, (hipStream_t)stream);
+    int rc = launch_linear(g, variant, (hipStream_t)stream);
+    prof_after(PROF_GEMM1, (hipStream_t)stream);
+    return rc;
+}
+
+extern "C" TNP_API int tnp_profile_begin(int which) {
+    if (which != PROF_GEMM1 && which != PROF_ALL_GEMM) TNP_FAIL(-1, "tnp_profile_begin: which must be 0 or 1");
+    tnp::g_prof_cls = which;
+    tnp::g_prof_n = 0;
+    return 0;
+}
+extern "C" TNP_API int tnp_profile_read(double *total_ms, int *launches) {
+    double tot = 0.0;
+    for (int i = 0; i < tnp::g_prof_n; ++i) {
+        TNP_HIP(hipEventSynchronize(tnp::g_prof_ev[2 * i + 1]));
+        float ms = 0.f;
+        TNP_HIP(hipEventElapsedTime(&ms, tnp::g_prof_ev[2 * i], tnp::g_prof_ev[2 * i + 1]));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = tnp::g_prof_n;
+    tnp::g_prof_n = 0;
+    return 0;
+}
+extern "C" TNP_API int tnp_profile_end(void) { tnp::g_prof_cls = -1; tnp::g_prof_n = 0; return 0; }
+
+namespace tnp {
+__global__ void constant_velocity_kernel(const double *last, const double *prev, int N2, int n_predict, double *out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N2) return;
+    const double l = last[q], v = l - prev[q];
+    for (int t = 1; t <= n_predict; ++t) out[(size_t)(t - 1) * N2 + q] = l + (double)t * v;
+}
+}  // namespace tnp
+
+extern "C" TNP_API int tnp_constant_velocity(const double *last, const double *prev, int N, int n_predict, double *out,
+                                     void *stream) {
+    if (N <= 0 || n_predict <= 0) return 0;
+    const int N2 = 2 * N;
+    hipLaunchKernelGGL(tnp::constant_velocity_kernel, dim3((N2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, last,
+                       prev, N2, n_predict, out);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}

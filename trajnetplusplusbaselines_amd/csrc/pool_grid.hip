@@ -1,0 +1,165 @@
+// Interaction-grid build for GridBasedPooling (reference lstm/gridbased_pooling.py:112-170, 227-305), gfx950.
+//
+// One workgroup (4 waves) handles EGOS egos of one scene; the scene's positions / velocities / per-track
+// values are staged once in LDS (the O(N^2) relative-displacement work never touches HBM).  One wave owns one
+// ego at a time: its lanes walk the neighbours j, compute the cell with the reference's exact fp32 arithmetic
+//      oij = (pos_j - pos_i) / float32(cell_side) + n/2      (IEEE subtract, IEEE divide, IEEE add)
+// and resolve collisions with an LDS integer max on  key = 2*j + in_range : the reference's index_put keeps
+// the LAST writer in ascending j, and every out-of-range (or absent / padded) neighbour is redirected to
+// cell 0 carrying the background constant, so "largest j wins, and if it was out of range the cell holds the
+// constant" reproduces index_put exactly, including the cell-0 clobber.
+// Output: the dense grid row [C*n*n] (feature = c*n*n + cell) written with coalesced 256-byte wave stores,
+// and/or the compact int16 winner table [n*n] that a gather-GEMM can consume instead of the dense grid.
+#include "tnp_internal.h"
+
+namespace tnp {
+
+#define TNP_GRID_EGOS 8
+#define TNP_GRID_MAX_TRACKS 1024
+
+__device__ __forceinline__ float nan_to_num_dev(float v) {
+    if (v != v) return 0.0f;
+    if (__builtin_isinf(v)) return v > 0.0f ? 3.402823466e+38f : -3.402823466e+38f;
+    return v;
+}
+
+__global__ void __launch_bounds__(256) grid_build_kernel(const GridArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    const int s = blockIdx.y;
+    const int start = a.scene_start[s];
+    const int ns = a.scene_start[s + 1] - start;
+    const int ego0 = blockIdx.x * TNP_GRID_EGOS;
+    if (ego0 >= ns) return;  // uniform for the workgroup
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = a.n, ncell = G * G, C = a.C;
+    // LDS carve: pos[ns] (float2) | vel[ns] (float2) | vals[ns*C] | win[4][ncell] (int)
+    float2 *pos = reinterpret_cast<float2 *>(gsm);
+    float2 *vel = pos + ns;
+    float *vals = reinterpret_cast<float *>(vel + ns);
+    int *win_all = reinterpret_cast<int *>(vals + (a.type == TNP_POOL_SOCIAL ? ns * C : 0));
+    int *win = win_all + wave * ncell;
+
+    for (int j = tid; j < ns; j += 256) {
+        const float2 p2 = reinterpret_cast<const float2 *>(a.obs2)[start + j];
+        float2 p = p2;
+        if (p.x != p.x || p.y != p.y) { p.x = -500.0f; p.y = -500.0f; }  // :247-249 sentinel
+        pos[j] = p;
+        if (a.type == TNP_POOL_DIRECTIONAL) {
+            const float2 p1 = reinterpret_cast<const float2 *>(a.obs1)[start + j];
+            vel[j] = make_float2(__fsub_rn(p2.x, p1.x), __fsub_rn(p2.y, p1.y));  // :127 (NaN kept)
+        }
+    }
+    if (a.type == TNP_POOL_SOCIAL)
+        for (int q = tid; q < ns * C; q += 256) {
+            const int j = q / C, c = q - j * C;
+            vals[q] = a.values[(size_t)(start + j) * a.ldv + c];
+        }
+
+    const float fG = (float)G;
+    for (int e = 0; e < TNP_GRID_EGOS / 4; ++e) {
+        const int ki = ego0 + e * 4 + wave;
+        const bool active = ki < ns;
+        for (int c = lane; c < ncell; c += 64) win[c] = -1;
+        __syncthreads();
+        if (active) {
+            const float2 pi = pos[ki];
+            for (int j = lane; j < ns; j += 64) {
+                if (j == ki) continue;  // diagonal removed, :259-263
+                const float2 pj = pos[j];
+                const float ox = __fadd_rn(__fdiv_rn(__fsub_rn(pj.x, pi.x), a.cell), a.half_x);  // :276
+                const float oy = __fadd_rn(__fdiv_rn(__fsub_rn(pj.y, pi.y), a.cell), a.half_y);
+                const bool inr = !(ox < 0.0f) && !(ox >= fG) && !(oy < 0.0f) && !(oy >= fG);  // :278-279
+                const int cell = inr ? ((int)ox * G + (int)oy) : 0;                            // :281-287
+                atomicMax(&win[cell], 2 * j + (inr ? 1 : 0));
+            }
+            // slots the reference pads this scene with (lstm/lstm.py:29-40): absent, highest j, cell 0
+            if (ns < a.n_max && lane == 0) atomicMax(&win[0], 2 * (a.n_max - 1));
+        }
+        __syncthreads();
+        if (active) {
+            const size_t row = (size_t)(start + ki);
+            if (a.winners) {
+                for (int c = lane; c < ncell; c += 64) {
+                    const int w = win[c];
+                    a.winners[row * ncell + c] = (w >= 0 && (w & 1)) ? (int16_t)(w >> 1) : (int16_t)-1;
+                }
+            }
+            if (a.grid) {
+                float *out = a.grid + row * (size_t)a.ldg;
+                const int F = C * ncell;
+                const float2 vi = (a.type == TNP_POOL_DIRECTIONAL) ? vel[ki] : make_float2(0.f, 0.f);
+                for (int f = lane; f < F; f += 64) {
+                    const int c = f / ncell, cell = f - c * ncell;
+                    const int w = win[cell];
+                    float v = a.constant;
+                    if (w >= 0 && (w & 1)) {
+                        const int j = w >> 1;
+                        if (a.type == TNP_POOL_OCCUPANCY) v = 1.0f;                                  // :266-267
+                        else if (a.type == TNP_POOL_DIRECTIONAL) {
+                            const float2 vj = vel[j];
+                            v = nan_to_num_dev(c == 0 ? __fsub_rn(vj.x, vi.x) : __fsub_rn(vj.y, vi.y));  // :131-140
+                        } else v = vals[j * C + c];                                                   // :160-167
+                    }
+                    out[f] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int launch_grid(const GridArgs &a, hipStream_t s) {
+    if (a.B <= 0 || a.n_max <= 0) return 0;
+    if (a.n_max > TNP_GRID_MAX_TRACKS)
+        TNP_FAIL(-1, "grid pooling: %d tracks in one scene exceed the LDS-staged limit of %d", a.n_max,
+                 TNP_GRID_MAX_TRACKS);
+    if (a.n > 64) TNP_FAIL(-1, "grid pooling: n=%d cells per side not supported (max 64)", a.n);
+    if (a.n_max > 32767) TNP_FAIL(-1, "winner table is int16");
+    const int ncell = a.n * a.n;
+    size_t smem = (size_t)a.n_max * 16 + (a.type == TNP_POOL_SOCIAL ? (size_t)a.n_max * a.C * 4 : 0) +
+                  (size_t)4 * ncell * 4;
+    smem = (smem + 15) & ~(size_t)15;
+    static size_t attr = 0;
+    if (smem > attr) {
+        TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(grid_build_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = smem;
+    }
+    dim3 grid((a.n_max + TNP_GRID_EGOS - 1) / TNP_GRID_EGOS, a.B);
+    hipLaunchKernelGGL(grid_build_kernel, grid, dim3(256), smem, s, a);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void mark_primaries_kernel(const int32_t *scene_start, int B, uint8_t *flag) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < B && scene_start[s + 1] > scene_start[s]) flag[scene_start[s]] = 1;
+}
+
+}  // namespace tnp
+
+extern "C" TNP_API int tnp_mark_primaries(const int32_t *scene_start, int B, int M, uint8_t *primary_flag, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    TNP_HIP(hipMemsetAsync(primary_flag, 0, (size_t)M, s));
+    if (B > 0) {
+        hipLaunchKernelGGL(tnp::mark_primaries_kernel, dim3((B + 255) / 256), dim3(256), 0, s, scene_start, B,
+                           primary_flag);
+        TNP_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" TNP_API int tnp_pool_grid_forward(int type, const float *obs1, const float *obs2, const float *values, int ldv,
+                                     const int32_t *scene_start, int B, int n_max, int n, int C, float cell,
+                                     float half_x, float half_y, float constant, float *grid, int ldg,
+                                     int16_t *winners, void *stream) {
+    if (type < TNP_POOL_OCCUPANCY || type > TNP_POOL_SOCIAL) TNP_FAIL(-1, "unknown pooling type %d", type);
+    if (type == TNP_POOL_SOCIAL && values == nullptr) TNP_FAIL(-1, "social pooling needs per-track values");
+    tnp::GridArgs a;
+    a.obs1 = obs1; a.obs2 = obs2; a.values = values; a.ldv = ldv; a.scene_start = scene_start;
+    a.B = B; a.n_max = n_max; a.type = type; a.n = n; a.C = C;
+    a.cell = cell; a.half_x = half_x; a.half_y = half_y; a.constant = constant;
+    a.grid = grid; a.ldg = ldg; a.winners = winners;
+    return tnp::launch_grid(a, (hipStream_t)stream);
+}

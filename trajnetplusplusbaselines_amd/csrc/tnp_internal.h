@@ -1,0 +1,60 @@
+// Internal declarations shared by the HIP translation units of libtrajnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/trajnet_hip.h"
+
+namespace tnp {
+
+// ---- error handling -------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+#define TNP_FAIL(code, ...) do { ::tnp::set_error(__VA_ARGS__); return (code); } while (0)
+#define TNP_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    ::tnp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return -2; } } while (0)
+
+// ---- GEMM on the matrix cores ---------------------------------------------------------------
+enum { EPI_BIAS = 0, EPI_LSTM = 1 };
+
+struct GemmArgs {
+    // A = [A1 | A2] along K, row-major, K-contiguous
+    const float *A1; int lda1; int K1;
+    const float *A2; int lda2; int K2;
+    // W = [B1 | B2] along K, PyTorch layout [N, K]
+    const float *B1; int ldb1;
+    const float *B2; int ldb2;
+    const float *bias1; const float *bias2;
+    int M, N;
+    int vec_ok;           // all K / ld multiples of 4 and pointers 16-byte aligned
+    int tiles_m, tiles_n;
+    // EPI_BIAS
+    float *C; int ldc; int relu;
+    // EPI_LSTM: N == 4*H, tile columns = 4 gates x 32 hidden units
+    int H; const float *h_in; float *h_out; const float *c_in; float *c_out; const uint8_t *mask;
+};
+
+// generic dense layer (variant selects the tile configuration)
+int launch_linear(const GemmArgs &g, int variant, hipStream_t s);
+// fused LSTM gates GEMM + cell update
+int launch_lstm_gates(const GemmArgs &g, int variant, hipStream_t s);
+
+// ---- grid pooling ---------------------------------------------------------------------------
+struct GridArgs {
+    const float *obs1, *obs2;
+    const float *values; int ldv;
+    const int32_t *scene_start;
+    int B, n_max, type, n, C;
+    float cell, half_x, half_y, constant;
+    float *grid; int ldg;
+    int16_t *winners;
+};
+int launch_grid(const GridArgs &a, hipStream_t s);
+
+// ---- profiling hook -------------------------------------------------------------------------
+enum { PROF_GEMM1 = 0, PROF_ALL_GEMM = 1 };
+void prof_before(int cls, hipStream_t s);
+void prof_after(int cls, hipStream_t s);
+
+}  // namespace tnp

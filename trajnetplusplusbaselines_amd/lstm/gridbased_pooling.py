@@ -1,0 +1,212 @@
+"""GridBasedPooling on MI355X: same constructor, attributes, public methods and state_dict keys as the
+reference's lstm/gridbased_pooling.py:15-400; the grid build and the embedding MLP run in hand-written HIP
+(csrc/pool_grid.hip, csrc/gemm_f32_mfma.hip).  No CPU fallback."""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+
+class GridBasedPooling(torch.nn.Module):
+    def __init__(self, cell_side=2.0, n=4, hidden_dim=128, out_dim=None,
+                 type_='occupancy', pool_size=1, blur_size=1, front=False,
+                 embedding_arch='one_layer', pretrained_pool_encoder=None,
+                 constant=0, norm=0, layer_dims=None, latent_dim=16):
+        """Pools in a grid of size 'n * cell_side' centred at the ped location
+        (arguments as in reference lstm/gridbased_pooling.py:16-41)."""
+        super(GridBasedPooling, self).__init__()
+        self.cell_side = cell_side
+        self.n = n
+        self.type_ = type_
+        self.pool_size = pool_size
+        self.blur_size = blur_size
+        self.norm_pool = False
+        self.front = front
+        if self.front:
+            self.norm_pool = True
+        self.constant = constant
+        self.norm = norm
+        self.pool_scale = 1.0
+
+        if self.type_ not in ('occupancy', 'directional', 'social'):
+            # reference 'dir_social' concatenates along the neighbour axis (gridbased_pooling.py:209) and only
+            # runs for latent_dim == 2; it is not part of any BASELINE config
+            raise NotImplementedError("GridBasedPooling type_ %r is not supported on the MI355X path" % (type_,))
+        self.pooling_dim = 1
+        if self.type_ == 'directional':
+            self.pooling_dim = 2
+        if self.type_ == 'social':
+            self.hidden_dim_encoding = torch.nn.Linear(hidden_dim, latent_dim)
+            self.pooling_dim = latent_dim
+
+        if out_dim is None:
+            out_dim = hidden_dim
+        self.out_dim = out_dim
+
+        if pretrained_pool_encoder is not None:
+            raise NotImplementedError('pretrained_pool_encoder is not supported on the MI355X path')
+        self.pretrained_model = None
+
+        self.embedding = None
+        self.embedding_arch = embedding_arch
+        if self.embedding_arch == 'one_layer':
+            self.embedding = self.one_layer()
+        elif self.embedding_arch == 'two_layer':
+            self.embedding = self.two_layer(None, layer_dims)
+        elif self.embedding_arch == 'three_layer':
+            self.embedding = self.three_layer(None, layer_dims)
+        elif self.embedding_arch == 'lstm_layer':
+            raise NotImplementedError("embedding_arch 'lstm_layer' is not supported on the MI355X path")
+
+    # ---- embedding architectures (reference :308-335) --------------------------------------------
+    def one_layer(self, input_dim=None):
+        if input_dim is None:
+            input_dim = self.n * self.n * self.pooling_dim
+        return torch.nn.Sequential(
+            torch.nn.Linear(input_dim, self.out_dim),
+            torch.nn.ReLU(),)
+
+    def two_layer(self, input_dim=None, layer_dims=None):
+        if input_dim is None:
+            input_dim = self.n * self.n * self.pooling_dim
+        return torch.nn.Sequential(
+            torch.nn.Linear(input_dim, layer_dims[0]),
+            torch.nn.ReLU(),
+            torch.nn.Linear(layer_dims[0], self.out_dim),
+            torch.nn.ReLU(),)
+
+    def three_layer(self, input_dim=None, layer_dims=None):
+        if input_dim is None:
+            input_dim = self.n * self.n * self.pooling_dim
+        return torch.nn.Sequential(
+            torch.nn.Linear(input_dim, layer_dims[0]),
+            torch.nn.ReLU(),
+            torch.nn.Linear(layer_dims[0], layer_dims[1]),
+            torch.nn.ReLU(),
+            torch.nn.Linear(layer_dims[1], self.out_dim),
+            torch.nn.ReLU(),)
+
+    def reset(self, num_tracks, max_num_neigh, device):
+        """Called once per forward by the reference (lstm/lstm.py:213-216); nothing to reset here."""
+        self.track_mask = None
+
+    # ---- helpers -----------------------------------------------------------------------------------
+    def embedding_layers(self):
+        if self.embedding is None:
+            return []
+        return [m for m in self.embedding if isinstance(m, torch.nn.Linear)]
+
+    def _geometry(self):
+        G = self.n * self.pool_size
+        cell = float(torch.tensor(self.cell_side / self.pool_size, dtype=torch.float32))
+        half = float(G / 2)
+        return G, cell, half, (0.0 if self.front else half)
+
+    def _device(self, obs):
+        for p in self.parameters():
+            return p.device
+        return obs.device
+
+    def _winner_grid(self, obs1, obs2, type_id, values=None, want_grid=True, want_winners=False):
+        """obs1/obs2 [B,N,2] padded tensors -> dense grid [B*N, C*G*G] and/or winner table [B*N, G*G]."""
+        dev = obs2.device
+        _lib.require_device(obs2, 'obs2')
+        B, N = obs2.size(0), obs2.size(1)
+        G, cell, half_x, half_y = self._geometry()
+        C = {_lib.POOL_OCCUPANCY: 1, _lib.POOL_DIRECTIONAL: 2}.get(type_id, self.pooling_dim)
+        o1 = _lib.f32c(obs1 if obs1 is not None else obs2, dev).reshape(B * N, 2)
+        o2 = _lib.f32c(obs2, dev).reshape(B * N, 2)
+        starts = torch.arange(0, B * N + 1, N, dtype=torch.int32, device=dev)
+        grid = torch.empty(B * N, C * G * G, dtype=torch.float32, device=dev) if want_grid else None
+        winners = torch.empty(B * N, G * G, dtype=torch.int16, device=dev) if want_winners else None
+        vals = _lib.f32c(values, dev).reshape(B * N, -1) if values is not None else None
+        _lib.check(_lib.lib().tnp_pool_grid_forward(
+            type_id, _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(vals), vals.stride(0) if vals is not None else 0,
+            _lib.ptr(starts), B, N, G, C, cell, half_x, half_y, float(self.constant),
+            _lib.ptr(grid), C * G * G, _lib.ptr(winners), _lib.stream_ptr()), 'tnp_pool_grid_forward')
+        return grid, winners
+
+    def _finish(self, grid, rows, C):
+        """blur + pool_size reduction of the fine grid (reference :297-303).  The trainer never changes the
+        defaults pool_size = blur_size = 1, for which this is the identity."""
+        G = self.n * self.pool_size
+        occ = grid.view(rows, C, G, G)
+        if self.blur_size != 1:
+            occ = torch.nn.functional.avg_pool2d(occ, self.blur_size, 1, int(self.blur_size / 2),
+                                                 count_include_pad=True)
+        if self.pool_size != 1:
+            occ = torch.nn.functional.lp_pool2d(occ, 1, self.pool_size)
+        return occ
+
+    # ---- public grid builders (reference :112-170, 227-305) -----------------------------------------
+    def occupancies(self, obs1, obs2):
+        return self.occupancy(obs2, past_obs=obs1)
+
+    def occupancy(self, obs, other_values=None, past_obs=None):
+        """Occupancy map filled with `other_values` ([B,N,N-1,C], None = ones). Returns [B*N, C, n, n]."""
+        B, N = obs.size(0), obs.size(1)
+        if N == 1:  # reference :252-253
+            return self.constant * torch.ones(1, self.pooling_dim, self.n, self.n, device=obs.device)
+        if other_values is None:
+            grid, _ = self._winner_grid(past_obs, obs, _lib.POOL_OCCUPANCY)
+            return self._finish(grid, B * N, 1)
+        # arbitrary per-pair values: build the winner table on the GPU and gather the pair values
+        _, winners = self._winner_grid(past_obs, obs, _lib.POOL_OCCUPANCY, want_grid=False, want_winners=True)
+        C = other_values.size(-1)
+        vals = _lib.f32c(other_values, obs.device).reshape(B * N, N - 1, C)
+        w = winners.long()
+        ego = (torch.arange(B * N, device=obs.device) % N).unsqueeze(1)
+        jj = (w - (w > ego).long()).clamp(min=0)                                      # neighbour slot j -> j'
+        picked = torch.gather(vals, 1, jj.unsqueeze(-1).expand(-1, -1, C))            # [rows, G*G, C]
+        bg = torch.full_like(picked, float(self.constant))
+        grid = torch.where((w >= 0).unsqueeze(-1), picked, bg).transpose(1, 2).contiguous()
+        return self._finish(grid.view(B * N, -1), B * N, C)
+
+    def directional(self, obs1, obs2):
+        B, N = obs2.size(0), obs2.size(1)
+        if N == 1:
+            return self.occupancy(obs2, None, past_obs=obs1)
+        grid, _ = self._winner_grid(obs1, obs2, _lib.POOL_DIRECTIONAL)
+        return self._finish(grid, B * N, 2)
+
+    def social(self, hidden_state, obs1, obs2):
+        B, N = obs2.size(0), obs2.size(1)
+        if N == 1:
+            return self.occupancy(obs2, None, past_obs=obs1)
+        lin = self.hidden_dim_encoding
+        _lib.require_device(lin.weight, 'GridBasedPooling parameters')
+        h = torch.nan_to_num(_lib.f32c(hidden_state, lin.weight.device).reshape(B * N, -1))  # reference :166
+        enc = _lib.linear_forward(h, lin.weight.detach(), lin.bias.detach())
+        grid, _ = self._winner_grid(obs1, obs2, _lib.POOL_SOCIAL, values=enc)
+        return self._finish(grid, B * N, self.pooling_dim)
+
+    def forward(self, hidden_state, obs1, obs2):
+        """[B,N,H], [B,N,2], [B,N,2] -> [B*N, out_dim]  (reference :94-110)."""
+        batch_size, num_tracks = obs1.size(0), obs1.size(1)
+        if self.type_ == 'occupancy':
+            grid = self.occupancies(obs1, obs2)
+        elif self.type_ == 'directional':
+            grid = self.directional(obs1, obs2)
+        else:
+            grid = self.social(hidden_state, obs1, obs2)
+        grid = grid.reshape(batch_size * num_tracks, -1)
+        x = grid
+        for lin in self.embedding_layers():
+            x = _lib.linear_forward(x, lin.weight.detach(), lin.bias.detach(), relu=True)
+        return x
+
+    def make_grid(self, obs):
+        """Grids for all time-steps (occupancy / directional only), reference :381-400."""
+        if obs.ndim == 2:
+            obs = obs.unsqueeze(0)
+        grid = []
+        for i in range(1, obs.size(0)):
+            obs1, obs2 = obs[i - 1], obs[i]
+            track_mask = (torch.isnan(obs1[:, 0]) + torch.isnan(obs2[:, 0])) == 0
+            obs1, obs2 = obs1[track_mask], obs2[track_mask]
+            if self.type_ == 'occupancy':
+                grid.append(self.occupancies(obs1.unsqueeze(0), obs2.unsqueeze(0)))
+            elif self.type_ == 'directional':
+                grid.append(self.directional(obs1.unsqueeze(0), obs2.unsqueeze(0)))
+        return grid

@@ -1,0 +1,222 @@
+"""trajnetbaselines.lstm.LSTM / LSTMPredictor on MI355X.
+
+Same class names, constructor arguments, method signatures, return shapes and state_dict keys as the
+reference's lstm/lstm.py:45-313, so reference checkpoints load and the reference trainer / evaluator call
+sites keep working; the recurrent step runs in hand-written HIP (csrc/lstm_seq.hip and friends) on dense
+[M,H] state instead of the reference's Python lists of per-track tensors.  There is no CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .. import data as trajdata
+from .modules import Hidden2Normal, InputEmbedding
+
+NAN = float('nan')
+
+
+def drop_distant(xy, r=6.0):
+    """Drops pedestrians more than r meters away from primary ped (reference lstm/lstm.py:16-22; host side)."""
+    distance_2 = np.sum(np.square(xy - xy[:, 0:1]), axis=2)
+    mask = np.nanmin(distance_2, axis=0) < r**2
+    return xy[:, mask], mask
+
+
+class LSTM(torch.nn.Module):
+    def __init__(self, embedding_dim=64, hidden_dim=128, pool=None, pool_to_input=True, goal_dim=None,
+                 goal_flag=False):
+        """Arguments as in reference lstm/lstm.py:46-63."""
+        super(LSTM, self).__init__()
+        self.hidden_dim = hidden_dim
+        self.embedding_dim = embedding_dim
+        self.pool = pool
+        self.pool_to_input = pool_to_input
+        if pool is not None and not pool_to_input:
+            raise NotImplementedError('pool_to_input=False is not supported on the MI355X path')
+
+        scale = 4.0
+        self.input_embedding = InputEmbedding(2, self.embedding_dim, scale)
+
+        self.goal_flag = goal_flag
+        self.goal_dim = goal_dim or embedding_dim
+        self.goal_embedding = InputEmbedding(2, self.goal_dim, scale)
+        goal_rep_dim = self.goal_dim if self.goal_flag else 0
+
+        pooling_dim = 0
+        if pool is not None and self.pool_to_input:
+            pooling_dim = self.pool.out_dim
+
+        # parameter containers only (weight_ih [4H, I], weight_hh [4H, H], gate order i,f,g,o); the cell itself
+        # is the fused gates GEMM + pointwise epilogue of csrc/gemm_f32_mfma.hip
+        self.encoder = torch.nn.LSTMCell(self.embedding_dim + goal_rep_dim + pooling_dim, self.hidden_dim)
+        self.decoder = torch.nn.LSTMCell(self.embedding_dim + goal_rep_dim + pooling_dim, self.hidden_dim)
+
+        self.hidden2normal = Hidden2Normal(self.hidden_dim)
+
+        #: kernel-variant selector forwarded to the C ABI (0 = defaults), see DESIGN.md
+        self.kernel_variant = 0
+        self._ws = None
+
+    # ---- descriptor / workspace ---------------------------------------------------------------------
+    def _descriptor(self):
+        dev = self.hidden2normal.linear.weight.device
+        if dev.type != 'cuda':
+            raise RuntimeError('LSTM parameters live on %s: move the model to a ROCm device (model.to("cuda")); '
+                               'the MI355X path has no CPU fallback' % dev)
+        keep = []
+
+        def P(t):
+            t = t.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.float().contiguous()
+            keep.append(t)
+            return ctypes.c_void_p(t.data_ptr())
+
+        m = _lib.LstmModel()
+        m.E, m.H = self.embedding_dim, self.hidden_dim
+        m.goal_flag, m.goal_dim = int(self.goal_flag), self.goal_dim
+        ie, ge = self.input_embedding.input_embeddings[0], self.goal_embedding.input_embeddings[0]
+        m.We, m.be, m.Wg, m.bg = P(ie.weight), P(ie.bias), P(ge.weight), P(ge.bias)
+        for pre, cell in (('enc', self.encoder), ('dec', self.decoder)):
+            setattr(m, pre + '_Wih', P(cell.weight_ih))
+            setattr(m, pre + '_Whh', P(cell.weight_hh))
+            setattr(m, pre + '_bih', P(cell.bias_ih))
+            setattr(m, pre + '_bhh', P(cell.bias_hh))
+        m.Wn, m.bn = P(self.hidden2normal.linear.weight), P(self.hidden2normal.linear.bias)
+        m.pool_type = _lib.POOL_NONE
+        m.n, m.C, m.P, m.n_layers = 0, 0, 0, 0
+        pool = self.pool
+        if pool is not None:
+            if not hasattr(pool, 'embedding_layers'):
+                raise NotImplementedError('only GridBasedPooling interaction modules run on the MI355X path')
+            if pool.pool_size != 1 or pool.blur_size != 1:
+                raise NotImplementedError('the fused step supports pool_size = blur_size = 1 (the trainer defaults)')
+            m.pool_type = _lib.POOL_TYPES[pool.type_]
+            G, cell, half_x, half_y = pool._geometry()
+            m.n, m.C, m.P = pool.n, pool.pooling_dim, pool.out_dim
+            m.cell, m.half_x, m.half_y, m.constant = cell, half_x, half_y, float(pool.constant)
+            layers = pool.embedding_layers()
+            if not layers:
+                raise NotImplementedError("embedding_arch 'None' is not supported by the fused step")
+            m.n_layers = len(layers)
+            m.dims[0] = pool.pooling_dim * pool.n * pool.n
+            for li, lin in enumerate(layers):
+                m.dims[li + 1] = lin.weight.shape[0]
+                m.Wp[li] = P(lin.weight)
+                m.bp[li] = P(lin.bias)
+            if pool.type_ == 'social':
+                m.Wh, m.bh = P(pool.hidden_dim_encoding.weight), P(pool.hidden_dim_encoding.bias)
+        m.variant = int(self.kernel_variant)
+        return m, keep, dev
+
+    def _workspace(self, m, M, B, dev):
+        need = _lib.lib().tnp_lstm_workspace_bytes(ctypes.byref(m), M, B)
+        if need == 0:
+            _lib.check(-1, 'tnp_lstm_workspace_bytes')
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._ws, need
+
+    # ---- one recurrent step (reference lstm/lstm.py:91-168) -------------------------------------------
+    def step(self, lstm, hidden_cell_state, obs1, obs2, goals, batch_split):
+        """One masked step.  ``hidden_cell_state`` may be the reference's (list of [H] tensors, list of [H]
+        tensors) or a pair of dense [M,H] tensors; the same kind is returned, with ``normal`` [M,5]."""
+        m, keep, dev = self._descriptor()
+        was_list = isinstance(hidden_cell_state[0], (list, tuple))
+        if was_list:
+            h_in = torch.stack(list(hidden_cell_state[0]), dim=0)
+            c_in = torch.stack(list(hidden_cell_state[1]), dim=0)
+        else:
+            h_in, c_in = hidden_cell_state
+        h_in, c_in = _lib.f32c(h_in, dev), _lib.f32c(c_in, dev)
+        obs1, obs2 = _lib.f32c(obs1, dev), _lib.f32c(obs2, dev)
+        M = obs2.size(0)
+        idx = _lib.SceneIndex.get(batch_split, dev)
+        if idx.M != M:
+            raise ValueError('batch_split covers %d tracks, observations have %d' % (idx.M, M))
+        goals_t = _lib.f32c(goals, dev) if (goals is not None and self.goal_flag) else None
+        decoder = 1 if lstm is self.decoder else 0
+        ws, need = self._workspace(m, M, idx.B, dev)
+        h_out, c_out = torch.empty_like(h_in), torch.empty_like(c_in)
+        normal = torch.empty(M, 5, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().tnp_lstm_step(
+            ctypes.byref(m), decoder, _lib.ptr(h_in), _lib.ptr(c_in), _lib.ptr(obs1), _lib.ptr(obs2),
+            _lib.ptr(goals_t), _lib.ptr(idx.starts), idx.B, M, idx.n_max, _lib.ptr(h_out), _lib.ptr(c_out),
+            _lib.ptr(normal), _lib.ptr(ws), need, _lib.stream_ptr()), 'tnp_lstm_step')
+        if was_list:
+            return (list(h_out.unbind(0)), list(c_out.unbind(0))), normal
+        return (h_out, c_out), normal
+
+    # ---- whole sequence (reference lstm/lstm.py:170-264) ----------------------------------------------
+    def forward(self, observed, goals, batch_split, prediction_truth=None, n_predict=None):
+        """observed [T_obs,M,2], goals [M,2], batch_split [B+1] -> (rel_pred_scene [S,M,5], pred_scene [S,M,2])."""
+        assert ((prediction_truth is None) + (n_predict is None)) == 1
+        m, keep, dev = self._descriptor()
+        observed = _lib.f32c(observed, dev)
+        T_obs, M = observed.size(0), observed.size(1)
+        idx = _lib.SceneIndex.get(batch_split, dev)
+        if idx.M != M:
+            raise ValueError('batch_split covers %d tracks, observed has %d' % (idx.M, M))
+        if prediction_truth is not None:
+            if isinstance(prediction_truth, (list, tuple)):
+                prediction_truth = torch.stack(list(prediction_truth), dim=0)
+            truth = _lib.f32c(prediction_truth, dev)
+            T_dec = truth.size(0)
+        else:
+            truth, T_dec = None, n_predict - 1
+        goals_t = _lib.f32c(goals, dev) if (goals is not None and self.goal_flag) else None
+        n_steps = T_obs - 1 + T_dec
+        npos = n_steps + (1 if T_obs == 2 else 0)
+        rel_pred = torch.empty(n_steps, M, 5, dtype=torch.float32, device=dev)
+        pred = torch.empty(npos, M, 2, dtype=torch.float32, device=dev)
+        ws, need = self._workspace(m, M, idx.B, dev)
+        _lib.check(_lib.lib().tnp_lstm_forward(
+            ctypes.byref(m), _lib.ptr(observed), T_obs, M, _lib.ptr(goals_t), _lib.ptr(idx.starts),
+            _lib.ptr(idx.primary), idx.B, idx.n_max, _lib.ptr(truth), T_dec, _lib.ptr(rel_pred), _lib.ptr(pred),
+            _lib.ptr(ws), need, _lib.stream_ptr()), 'tnp_lstm_forward')
+        return rel_pred, pred
+
+
+class LSTMPredictor(object):
+    """Reference lstm/lstm.py:266-313: pickle-compatible wrapper used by the evaluator."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def save(self, state, filename):
+        with open(filename, 'wb') as f:
+            torch.save(self, f)
+        with open(filename + '.state', 'wb') as f:
+            torch.save(state, f)
+
+    @staticmethod
+    def load(filename):
+        with open(filename, 'rb') as f:
+            return torch.load(f, weights_only=False)
+
+    def __call__(self, paths, scene_goal, n_predict=12, modes=1, predict_all=True, obs_length=9, start_length=0,
+                 args=None):
+        self.model.eval()
+        with torch.no_grad():
+            xy = trajdata.paths_to_xy(paths)
+            batch_split = [0, xy.shape[1]]
+            normalize = bool(getattr(args, 'normalize_scene', False))
+            if normalize:
+                xy, rotation, center, scene_goal = trajdata.center_scene(xy, obs_length, goals=scene_goal)
+            xy = torch.tensor(np.asarray(xy), dtype=torch.float32)
+            scene_goal = torch.tensor(np.asarray(scene_goal), dtype=torch.float32)
+            batch_split = torch.tensor(batch_split, dtype=torch.int64)
+
+            multimodal_outputs = {}
+            for num_p in range(modes):
+                _, output_scenes = self.model(xy[start_length:obs_length], scene_goal, batch_split,
+                                              n_predict=n_predict)
+                output_scenes = output_scenes.cpu().numpy()
+                if normalize:
+                    output_scenes = trajdata.inverse_scene(output_scenes, rotation, center)
+                output_primary = output_scenes[-n_predict:, 0]
+                output_neighs = output_scenes[-n_predict:, 1:]
+                multimodal_outputs[num_p] = [output_primary, output_neighs]
+        return multimodal_outputs
