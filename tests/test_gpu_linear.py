@@ -15,11 +15,9 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize('variant', list(range(0, 15)))
 @pytest.mark.parametrize('M,N,K', SHAPES)
 def test_linear_matches_oracle(M, N, K, variant):
-    if variant != 0 and M * N * K > 2048 * 256 * 1024 and variant in (3, 7):
-        pytest.skip('slow small-tile variant on the big shape')
     rng = np.random.RandomState(M + 7 * N + 13 * K)
     x = rng.randn(M, K).astype(np.float32)
     x[rng.rand(M, K) < 0.5] = 0.0

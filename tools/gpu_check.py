@@ -36,9 +36,7 @@ def sweep_linear():
         w = torch.randn(N, K, device='cuda') / K ** 0.5
         b = torch.randn(N, device='cuda')
         out = torch.empty(M, N, device='cuda')
-        for v in range(0, 8):
-            if v in (3, 7) and M * N * K > 4e9:
-                continue
+        for v in range(0, 15):
             try:
                 us = time_fn(lambda: _lib.linear_forward(x, w, b, relu=True, variant=v, out=out))
             except RuntimeError as e:
@@ -61,8 +59,8 @@ def forward_timing():
         xy, split = synth.linear_crowd(scenes, agents, seed=1)
         obs = xy[:9].cuda()
         goals = torch.zeros(xy.shape[1], 2, device='cuda')
-        gate_variants = (0, 1, 2)
-        gemm_variants = (0, 1, 2, 6) if cfgname.startswith('social') else (0,)
+        gate_variants = (0, 1, 2, 3, 4, 5, 6)
+        gemm_variants = (0,)
         for gv in gate_variants:
             for lv in gemm_variants:
                 model.kernel_variant = lv | (gv << 8)

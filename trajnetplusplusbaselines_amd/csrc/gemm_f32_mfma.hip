@@ -73,7 +73,7 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
 
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int WM, int WN, int WK, int AN, int BK, int EPI, bool VEC>
+template <int WM, int WN, int WK, int AN, int BK, int PF, int EPI, bool VEC>
 __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_kernel(const GemmArgs g) {
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * WN * AN;
@@ -114,10 +114,14 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_kernel(const GemmAr
     const int K1 = g.K1, K2 = g.K2, gM = g.M, gN = g.N, gH = g.H;
 
     static_assert(CH * 4 <= 64, "ok bits");
-    f32x4 stage[CH];
-    unsigned long long okbits = 0ull;
+    static_assert(PF >= 1 && PF <= 4, "prefetch depth");
+    // PF register stage sets: the tile of K step t lives in set t % PF from the moment its loads are issued
+    // (PF steps before it is needed) until it is written to LDS, so global-load latency has PF-1 full
+    // compute phases (+ the current one) to hide under.
+    f32x4 stage[PF][CH];
+    unsigned long long okbits[PF];
 
-    auto load_stage = [&](int kt) {
+    auto load_stage = [&](int kt, f32x4 (&st)[CH], unsigned long long &okb) {
         unsigned lo = 0u, hi = 0u;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -141,16 +145,16 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_kernel(const GemmAr
                 ok = wr < gN;
             }
             const int m = m0 + row;
-            const bool row_ok = is_a ? (m < gM) : ok;
+            const bool row_ok = (is_a ? (m < gM) : ok) && (kt < KT);
             const size_t r = is_a ? (size_t)m : (size_t)wr;
             const float *r1 = (is_a ? gA1 : gB1) + r * (size_t)(is_a ? lda1 : ldb1);
             const float *r2 = (is_a ? gA2 : gB2) + r * (size_t)(is_a ? lda2 : ldb2);
-            if (c < 8) stage[c] = load4_dual<VEC>(r1, K1, r2, K2, k, row_ok, gA1, lo, (c & 7) * 4);
-            else stage[c] = load4_dual<VEC>(r1, K1, r2, K2, k, row_ok, gA1, hi, (c & 7) * 4);
+            if (c < 8) st[c] = load4_dual<VEC>(r1, K1, r2, K2, k, row_ok, gA1, lo, (c & 7) * 4);
+            else st[c] = load4_dual<VEC>(r1, K1, r2, K2, k, row_ok, gA1, hi, (c & 7) * 4);
         }
-        okbits = ((unsigned long long)hi << 32) | lo;
+        okb = ((unsigned long long)hi << 32) | lo;
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, const f32x4 (&st)[CH], unsigned long long okb) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int idx = tid + c * NT;
@@ -159,9 +163,9 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_kernel(const GemmAr
             const int row = rem / C4;
             const int c4 = rem - row * C4;
             float *dst = smem + (size_t)(buf * WK + grp) * GROUP_FLOATS + row * LDS_STRIDE + c4 * 4;
-            f32x4 v = stage[c];
+            f32x4 v = st[c];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = ((okbits >> (c * 4 + q)) & 1ull) ? v[q] : 0.0f;
+            for (int q = 0; q < 4; ++q) v[q] = ((okb >> (c * 4 + q)) & 1ull) ? v[q] : 0.0f;
             *reinterpret_cast<f32x4 *>(dst) = v;
         }
     };
@@ -172,16 +176,19 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_kernel(const GemmAr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[an][r] = 0.0f;
 
-    load_stage(0);
-    store_stage(0);
+    // prologue: tile 0 -> LDS buffer 0, tiles 1..PF in flight (tile t in set t % PF)
+    load_stage(0, stage[0], okbits[0]);
+#pragma unroll
+    for (int p = 1; p < PF; ++p) load_stage(p, stage[p], okbits[p]);
+    store_stage(0, stage[0], okbits[0]);
+    load_stage(PF, stage[0], okbits[0]);
     __syncthreads();
 
     const int a_off = (wm * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
     const int b_off = BM * LDS_STRIDE + (wn * AN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
 
-    for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) load_stage(kt + 1);
-        const float *base = smem + (size_t)((kt & 1) * WK + kg) * GROUP_FLOATS;
+    auto compute = [&](int buf) {
+        const float *base = smem + (size_t)(buf * WK + kg) * GROUP_FLOATS;
 #pragma unroll
         for (int k8 = 0; k8 < BK / 8; ++k8) {
             const f32x4 a4 = *reinterpret_cast<const f32x4 *>(base + a_off + k8 * 8);
@@ -195,8 +202,25 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_kernel(const GemmAr
                 for (int an = 0; an < AN; ++an)
                     acc[an] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[an][q], acc[an], 0, 0, 0);
         }
-        if (kt + 1 < KT) store_stage((kt + 1) & 1);
-        __syncthreads();
+    };
+
+    // main loop, unrolled by PF so that the register-set index is a compile-time constant.
+    // Iteration kt: tile kt+1 (issued PF steps ago) goes registers -> LDS buffer (kt+1)&1 (free since the
+    // barrier of iteration kt-1), its set is refilled with tile kt+1+PF, then the MFMAs of tile kt run.
+    for (int kt0 = 0; kt0 < KT; kt0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int kt = kt0 + p;
+            if (kt < KT) {
+                const int set = (p + 1) % PF;  // == (kt + 1) % PF because kt0 % PF == 0
+                if (kt + 1 < KT) {
+                    store_stage((kt + 1) & 1, stage[set], okbits[set]);
+                    load_stage(kt + 1 + PF, stage[set], okbits[set]);
+                }
+                compute(kt & 1);
+                __syncthreads();
+            }
+        }
     }
 
     // ---- reduce the k-groups through LDS (deterministic order) ----
@@ -271,13 +295,13 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_kernel(const GemmAr
     }
 }
 
-template <int WM, int WN, int WK, int AN, int BK, int EPI, bool VEC>
+template <int WM, int WN, int WK, int AN, int BK, int PF, int EPI, bool VEC>
 static int launch_cfg_v(GemmArgs g, hipStream_t s) {
     constexpr int BM = 32 * WM, BN = 32 * WN * AN, NT = 64 * WM * WN * WK;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (EPI == EPI_LSTM) ? (g.H + 31) / 32 : (g.N + BN - 1) / BN;
     const size_t smem = (size_t)2 * WK * (BM + BN) * (BK + 4) * sizeof(float);
-    auto kern = gemm_nt_kernel<WM, WN, WK, AN, BK, EPI, VEC>;
+    auto kern = gemm_nt_kernel<WM, WN, WK, AN, BK, PF, EPI, VEC>;
     static bool attr_set = false;  // one flag per template instantiation
     if (!attr_set) {
         TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -291,10 +315,11 @@ static int launch_cfg_v(GemmArgs g, hipStream_t s) {
     return 0;
 }
 
-template <int WM, int WN, int WK, int AN, int BK, int EPI>
+template <int WM, int WN, int WK, int AN, int BK, int PF, int EPI>
 static int launch_cfg(const GemmArgs &g, hipStream_t s) {
-    if (g.vec_ok) return launch_cfg_v<WM, WN, WK, AN, BK, EPI, true>(g, s);
-    return launch_cfg_v<WM, WN, WK, AN, BK, EPI, false>(g, s);
+    if (g.vec_ok) return launch_cfg_v<WM, WN, WK, AN, BK, PF, EPI, true>(g, s);
+    // rare fallback (K or a leading dimension not a multiple of 4): scalar loader, shallow prefetch
+    return launch_cfg_v<WM, WN, WK, AN, BK, 1, EPI, false>(g, s);
 }
 
 static int check_vec(GemmArgs &g) {
@@ -313,13 +338,21 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
         variant = (big_tiles >= 192) ? 1 : 3;
     }
     switch (variant) {
-        case 1: return launch_cfg<4, 2, 1, 1, 32, EPI_BIAS>(g, s);  // 128x64, 8 waves, 1 block/wave
-        case 2: return launch_cfg<4, 1, 1, 2, 32, EPI_BIAS>(g, s);  // 128x64, 4 waves, 2 blocks/wave
-        case 3: return launch_cfg<1, 2, 2, 1, 32, EPI_BIAS>(g, s);  // 32x64, split-K 2
-        case 4: return launch_cfg<2, 2, 1, 1, 32, EPI_BIAS>(g, s);  // 64x64, 4 waves
-        case 5: return launch_cfg<2, 2, 2, 1, 32, EPI_BIAS>(g, s);  // 64x64, 8 waves, split-K 2
-        case 6: return launch_cfg<2, 4, 1, 1, 32, EPI_BIAS>(g, s);  // 64x128, 8 waves
-        case 7: return launch_cfg<1, 1, 4, 1, 32, EPI_BIAS>(g, s);  // 32x32, split-K 4
+        //                         WM WN WK AN BK PF
+        case 1: return launch_cfg<4, 2, 1, 1, 32, 2, EPI_BIAS>(g, s);   // 128x64, 8 waves
+        case 2: return launch_cfg<2, 4, 1, 1, 32, 2, EPI_BIAS>(g, s);   // 64x128, 8 waves
+        case 3: return launch_cfg<1, 2, 2, 1, 32, 3, EPI_BIAS>(g, s);   // 32x64, split-K 2
+        case 4: return launch_cfg<4, 2, 1, 1, 32, 1, EPI_BIAS>(g, s);   // 128x64, prefetch 1 (round-1 baseline)
+        case 5: return launch_cfg<4, 2, 1, 1, 32, 3, EPI_BIAS>(g, s);   // 128x64, prefetch 3
+        case 6: return launch_cfg<2, 4, 1, 1, 32, 3, EPI_BIAS>(g, s);   // 64x128, prefetch 3
+        case 7: return launch_cfg<4, 2, 1, 1, 64, 2, EPI_BIAS>(g, s);   // 128x64, BK 64
+        case 8: return launch_cfg<2, 4, 1, 1, 64, 2, EPI_BIAS>(g, s);   // 64x128, BK 64
+        case 9: return launch_cfg<1, 2, 2, 1, 32, 1, EPI_BIAS>(g, s);   // 32x64 split-K 2, prefetch 1
+        case 10: return launch_cfg<1, 2, 2, 1, 32, 2, EPI_BIAS>(g, s);  // 32x64 split-K 2, prefetch 2
+        case 11: return launch_cfg<1, 2, 2, 1, 64, 2, EPI_BIAS>(g, s);  // 32x64 split-K 2, BK 64
+        case 12: return launch_cfg<1, 1, 4, 1, 32, 3, EPI_BIAS>(g, s);  // 32x32 split-K 4
+        case 13: return launch_cfg<2, 2, 2, 1, 32, 3, EPI_BIAS>(g, s);  // 64x64 split-K 2, 8 waves
+        case 14: return launch_cfg<4, 1, 1, 2, 32, 2, EPI_BIAS>(g, s);  // 128x64, 4 waves x 2 blocks
         default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d", variant);
     }
 }
@@ -330,8 +363,12 @@ int launch_lstm_gates(const GemmArgs &g_in, int variant, hipStream_t s) {
     if (g.H % 32 != 0) TNP_FAIL(-1, "LSTM hidden_dim must be a multiple of 32 (got %d)", g.H);
     if (variant == 0) variant = (g.M >= 4096) ? 1 : 2;
     switch (variant) {
-        case 1: return launch_cfg<2, 1, 2, 4, 32, EPI_LSTM>(g, s);  // 64 tracks x 32 units, split-K 2
-        case 2: return launch_cfg<1, 1, 4, 4, 16, EPI_LSTM>(g, s);  // 32 tracks x 32 units, split-K 4
+        case 1: return launch_cfg<2, 1, 2, 4, 32, 2, EPI_LSTM>(g, s);  // 64 tracks x 32 units, split-K 2
+        case 2: return launch_cfg<1, 1, 4, 4, 16, 3, EPI_LSTM>(g, s);  // 32 tracks x 32 units, split-K 4
+        case 3: return launch_cfg<1, 1, 4, 4, 16, 1, EPI_LSTM>(g, s);  // same, prefetch 1 (round-1 baseline)
+        case 4: return launch_cfg<1, 1, 4, 4, 16, 2, EPI_LSTM>(g, s);  // same, prefetch 2
+        case 5: return launch_cfg<2, 1, 2, 4, 32, 1, EPI_LSTM>(g, s);  // 64 tracks, prefetch 1
+        case 6: return launch_cfg<2, 1, 2, 4, 16, 3, EPI_LSTM>(g, s);  // 64 tracks, BK 16, prefetch 3
         default: TNP_FAIL(-1, "lstm gates: unknown variant %d", variant);
     }
 }

@@ -14,7 +14,7 @@
 
 namespace tnp {
 
-#define TNP_GRID_EGOS 8
+#define TNP_GRID_EGOS 4
 #define TNP_GRID_MAX_TRACKS 1024
 
 __device__ __forceinline__ float nan_to_num_dev(float v) {
@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) grid_build_kernel(const GridArgs a) {
     float2 *pos = reinterpret_cast<float2 *>(gsm);
     float2 *vel = pos + ns;
     float *vals = reinterpret_cast<float *>(vel + ns);
-    int *win_all = reinterpret_cast<int *>(vals + (a.type == TNP_POOL_SOCIAL ? ns * C : 0));
+    int *win_all = reinterpret_cast<int *>(vals + (a.type == TNP_POOL_SOCIAL ? ((ns * C + 3) & ~3) : 0));
     int *win = win_all + wave * ncell;
 
     for (int j = tid; j < ns; j += 256) {
@@ -89,19 +89,29 @@ __global__ void __launch_bounds__(256) grid_build_kernel(const GridArgs a) {
                 float *out = a.grid + row * (size_t)a.ldg;
                 const int F = C * ncell;
                 const float2 vi = (a.type == TNP_POOL_DIRECTIONAL) ? vel[ki] : make_float2(0.f, 0.f);
-                for (int f = lane; f < F; f += 64) {
-                    const int c = f / ncell, cell = f - c * ncell;
-                    const int w = win[cell];
-                    float v = a.constant;
-                    if (w >= 0 && (w & 1)) {
-                        const int j = w >> 1;
-                        if (a.type == TNP_POOL_OCCUPANCY) v = 1.0f;                                  // :266-267
-                        else if (a.type == TNP_POOL_DIRECTIONAL) {
-                            const float2 vj = vel[j];
-                            v = nan_to_num_dev(c == 0 ? __fsub_rn(vj.x, vi.x) : __fsub_rn(vj.y, vi.y));  // :131-140
-                        } else v = vals[j * C + c];                                                   // :160-167
+                auto value_of = [&](int w, int c) -> float {
+                    if (!(w >= 0 && (w & 1))) return a.constant;
+                    const int j = w >> 1;
+                    if (a.type == TNP_POOL_OCCUPANCY) return 1.0f;                                    // :266-267
+                    if (a.type == TNP_POOL_DIRECTIONAL) {
+                        const float2 vj = vel[j];
+                        return nan_to_num_dev(c == 0 ? __fsub_rn(vj.x, vi.x) : __fsub_rn(vj.y, vi.y));  // :131-140
                     }
-                    out[f] = v;
+                    return vals[j * C + c];                                                            // :160-167
+                };
+                if (a.vec4) {  // 4 consecutive cells of one channel per lane: 1 KiB coalesced wave stores
+                    for (int f = lane * 4; f < F; f += 256) {
+                        const int c = f / ncell, cell = f - c * ncell;
+                        const int4 w4 = *reinterpret_cast<const int4 *>(win + cell);
+                        float4 v;
+                        v.x = value_of(w4.x, c); v.y = value_of(w4.y, c); v.z = value_of(w4.z, c); v.w = value_of(w4.w, c);
+                        *reinterpret_cast<float4 *>(out + f) = v;
+                    }
+                } else {
+                    for (int f = lane; f < F; f += 64) {
+                        const int c = f / ncell, cell = f - c * ncell;
+                        out[f] = value_of(win[cell], c);
+                    }
                 }
             }
         }
@@ -117,9 +127,11 @@ int launch_grid(const GridArgs &a, hipStream_t s) {
     if (a.n > 64) TNP_FAIL(-1, "grid pooling: n=%d cells per side not supported (max 64)", a.n);
     if (a.n_max > 32767) TNP_FAIL(-1, "winner table is int16");
     const int ncell = a.n * a.n;
-    size_t smem = (size_t)a.n_max * 16 + (a.type == TNP_POOL_SOCIAL ? (size_t)a.n_max * a.C * 4 : 0) +
+    size_t smem = (size_t)a.n_max * 16 + (a.type == TNP_POOL_SOCIAL ? (((size_t)a.n_max * a.C + 3) & ~(size_t)3) * 4 : 0) +
                   (size_t)4 * ncell * 4;
     smem = (smem + 15) & ~(size_t)15;
+    GridArgs b = a;
+    b.vec4 = (ncell % 4 == 0) && (a.ldg % 4 == 0) && a.grid && ((reinterpret_cast<uintptr_t>(a.grid) & 15) == 0);
     static size_t attr = 0;
     if (smem > attr) {
         TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(grid_build_kernel),
@@ -127,7 +139,7 @@ int launch_grid(const GridArgs &a, hipStream_t s) {
         attr = smem;
     }
     dim3 grid((a.n_max + TNP_GRID_EGOS - 1) / TNP_GRID_EGOS, a.B);
-    hipLaunchKernelGGL(grid_build_kernel, grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL(grid_build_kernel, grid, dim3(256), smem, s, b);
     TNP_HIP(hipGetLastError());
     return 0;
 }

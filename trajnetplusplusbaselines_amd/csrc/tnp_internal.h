@@ -49,6 +49,7 @@ struct GridArgs {
     float cell, half_x, half_y, constant;
     float *grid; int ldg;
     int16_t *winners;
+    int vec4;  // set by launch_grid
 };
 int launch_grid(const GridArgs &a, hipStream_t s);
 
