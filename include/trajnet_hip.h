@@ -152,6 +152,14 @@ TNP_API int tnp_profile_end(void);
 TNP_API int tnp_constant_velocity(const double *last, const double *prev, int N, int n_predict, double *out,
                           void *stream);
 
+/* -------------------------------------------------------------------------------------------
+ * Calibration probe (measurement only): launches `blocks` workgroups of `waves_per_wg` waves,
+ * each issuing iters*8*n_acc v_mfma_f32_32x32x2_f32 (4096 FLOP each) with no memory traffic.
+ * scratch: >= 4 bytes of device memory (never written in practice).
+ * ----------------------------------------------------------------------------------------- */
+TNP_API int tnp_mfma_ablate(int mode, int iters, int blocks, const float *src, float *scratch, void *stream);
+TNP_API int tnp_mfma_probe(int waves_per_wg, int n_acc, int iters, int blocks, float *scratch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize('variant', list(range(0, 15)))
+@pytest.mark.parametrize('variant', list(range(0, 16)) + list(range(20, 29)) + [30, 31, 33, 100, 101])
 @pytest.mark.parametrize('M,N,K', SHAPES)
 def test_linear_matches_oracle(M, N, K, variant):
     rng = np.random.RandomState(M + 7 * N + 13 * K)

@@ -36,7 +36,7 @@ def sweep_linear():
         w = torch.randn(N, K, device='cuda') / K ** 0.5
         b = torch.randn(N, device='cuda')
         out = torch.empty(M, N, device='cuda')
-        for v in range(0, 15):
+        for v in [0, 4, 5, 12, 20, 21, 22, 23, 24, 28]:
             try:
                 us = time_fn(lambda: _lib.linear_forward(x, w, b, relu=True, variant=v, out=out))
             except RuntimeError as e:
@@ -59,7 +59,7 @@ def forward_timing():
         xy, split = synth.linear_crowd(scenes, agents, seed=1)
         obs = xy[:9].cuda()
         goals = torch.zeros(xy.shape[1], 2, device='cuda')
-        gate_variants = (0, 1, 2, 3, 4, 5, 6)
+        gate_variants = (0, 2, 5, 20, 22)
         gemm_variants = (0,)
         for gv in gate_variants:
             for lv in gemm_variants:

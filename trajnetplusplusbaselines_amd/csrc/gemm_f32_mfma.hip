@@ -73,180 +73,10 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
 
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int WM, int WN, int WK, int AN, int BK, int PF, int EPI, bool VEC>
-__global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_kernel(const GemmArgs g) {
-    constexpr int BM = 32 * WM;
-    constexpr int BN = 32 * WN * AN;
-    constexpr int NT = 64 * WM * WN * WK;
-    constexpr int WMN = WM * WN;
-    constexpr int LDS_STRIDE = BK + 4;
-    constexpr int ROWS = BM + BN;
-    constexpr int GROUP_FLOATS = ROWS * LDS_STRIDE;
-    constexpr int C4 = BK / 4;
-    constexpr int CHUNKS = WK * ROWS * C4;
-    static_assert(CHUNKS % NT == 0, "loader must tile evenly");
-    constexpr int CH = CHUNKS / NT;
-    static_assert(EPI != EPI_LSTM || (WN == 1 && AN == 4), "LSTM epilogue: 4 gate blocks per wave");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][WK][GROUP_FLOATS]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int kg = wave / WMN;
-    const int wq = wave - kg * WMN;
-    const int wm = wq / WN;
-    const int wn = wq - wm * WN;
-
-    int tm, tn;
-    tile_coords(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
-    const int m0 = tm * BM;
-    const int n0 = tn * BN;  // EPI_LSTM: tn indexes a block of 32 hidden units
-
-    const int K = g.K1 + g.K2;
-    const int Kg = (((K + WK - 1) / WK) + BK - 1) / BK * BK;  // K span of one k-group
-    const int KT = Kg / BK;
-
-    // kernel arguments into scalars once (selecting between struct fields per lane would otherwise turn
-    // into per-lane loads of the argument block)
-    const float *const gA1 = g.A1, *const gA2 = g.A2, *const gB1 = g.B1, *const gB2 = g.B2;
-    const int lda1 = g.lda1, lda2 = g.lda2, ldb1 = g.ldb1, ldb2 = g.ldb2;
-    const int K1 = g.K1, K2 = g.K2, gM = g.M, gN = g.N, gH = g.H;
-
-    static_assert(CH * 4 <= 64, "ok bits");
-    static_assert(PF >= 1 && PF <= 4, "prefetch depth");
-    // PF register stage sets: the tile of K step t lives in set t % PF from the moment its loads are issued
-    // (PF steps before it is needed) until it is written to LDS, so global-load latency has PF-1 full
-    // compute phases (+ the current one) to hide under.
-    f32x4 stage[PF][CH];
-    unsigned long long okbits[PF];
-
-    auto load_stage = [&](int kt, f32x4 (&st)[CH], unsigned long long &okb) {
-        unsigned lo = 0u, hi = 0u;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int idx = tid + c * NT;
-            const int grp = idx / (ROWS * C4);
-            const int rem = idx - grp * (ROWS * C4);
-            const int row = rem / C4;
-            const int c4 = rem - row * C4;
-            const int k = grp * Kg + kt * BK + c4 * 4;
-            const bool is_a = row < BM;
-            // source row: a track of A, or a weight row of W
-            int wr;
-            bool ok;
-            if (EPI == EPI_LSTM) {
-                const int cc = row - BM;
-                const int unit = tn * 32 + (cc & 31);
-                wr = (cc >> 5) * gH + unit;
-                ok = unit < gH;
-            } else {
-                wr = n0 + (row - BM);
-                ok = wr < gN;
-            }
-            const int m = m0 + row;
-            const bool row_ok = (is_a ? (m < gM) : ok) && (kt < KT);
-            const size_t r = is_a ? (size_t)m : (size_t)wr;
-            const float *r1 = (is_a ? gA1 : gB1) + r * (size_t)(is_a ? lda1 : ldb1);
-            const float *r2 = (is_a ? gA2 : gB2) + r * (size_t)(is_a ? lda2 : ldb2);
-            if (c < 8) st[c] = load4_dual<VEC>(r1, K1, r2, K2, k, row_ok, gA1, lo, (c & 7) * 4);
-            else st[c] = load4_dual<VEC>(r1, K1, r2, K2, k, row_ok, gA1, hi, (c & 7) * 4);
-        }
-        okb = ((unsigned long long)hi << 32) | lo;
-    };
-    auto store_stage = [&](int buf, const f32x4 (&st)[CH], unsigned long long okb) {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int idx = tid + c * NT;
-            const int grp = idx / (ROWS * C4);
-            const int rem = idx - grp * (ROWS * C4);
-            const int row = rem / C4;
-            const int c4 = rem - row * C4;
-            float *dst = smem + (size_t)(buf * WK + grp) * GROUP_FLOATS + row * LDS_STRIDE + c4 * 4;
-            f32x4 v = st[c];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = ((okb >> (c * 4 + q)) & 1ull) ? v[q] : 0.0f;
-            *reinterpret_cast<f32x4 *>(dst) = v;
-        }
-    };
-
-    f32x16 acc[AN];
-#pragma unroll
-    for (int an = 0; an < AN; ++an)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[an][r] = 0.0f;
-
-    // prologue: tile 0 -> LDS buffer 0, tiles 1..PF in flight (tile t in set t % PF)
-    load_stage(0, stage[0], okbits[0]);
-#pragma unroll
-    for (int p = 1; p < PF; ++p) load_stage(p, stage[p], okbits[p]);
-    store_stage(0, stage[0], okbits[0]);
-    load_stage(PF, stage[0], okbits[0]);
-    __syncthreads();
-
-    const int a_off = (wm * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
-    const int b_off = BM * LDS_STRIDE + (wn * AN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
-
-    auto compute = [&](int buf) {
-        const float *base = smem + (size_t)(buf * WK + kg) * GROUP_FLOATS;
-#pragma unroll
-        for (int k8 = 0; k8 < BK / 8; ++k8) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4 *>(base + a_off + k8 * 8);
-            f32x4 b4[AN];
-#pragma unroll
-            for (int an = 0; an < AN; ++an)
-                b4[an] = *reinterpret_cast<const f32x4 *>(base + b_off + an * 32 * LDS_STRIDE + k8 * 8);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int an = 0; an < AN; ++an)
-                    acc[an] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[an][q], acc[an], 0, 0, 0);
-        }
-    };
-
-    // main loop, unrolled by PF so that the register-set index is a compile-time constant.
-    // Iteration kt: tile kt+1 (issued PF steps ago) goes registers -> LDS buffer (kt+1)&1 (free since the
-    // barrier of iteration kt-1), its set is refilled with tile kt+1+PF, then the MFMAs of tile kt run.
-    for (int kt0 = 0; kt0 < KT; kt0 += PF) {
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const int kt = kt0 + p;
-            if (kt < KT) {
-                const int set = (p + 1) % PF;  // == (kt + 1) % PF because kt0 % PF == 0
-                if (kt + 1 < KT) {
-                    store_stage((kt + 1) & 1, stage[set], okbits[set]);
-                    load_stage(kt + 1 + PF, stage[set], okbits[set]);
-                }
-                compute(kt & 1);
-                __syncthreads();
-            }
-        }
-    }
-
-    // ---- reduce the k-groups through LDS (deterministic order) ----
-    if (WK > 1) {
-        float *red = smem;
-        if (kg > 0) {
-#pragma unroll
-            for (int an = 0; an < AN; ++an)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    red[(((kg - 1) * WMN + wq) * AN * 16 + an * 16 + r) * 64 + lane] = acc[an][r];
-        }
-        __syncthreads();
-        if (kg == 0) {
-            for (int gk = 1; gk < WK; ++gk)
-#pragma unroll
-                for (int an = 0; an < AN; ++an)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc[an][r] += red[(((gk - 1) * WMN + wq) * AN * 16 + an * 16 + r) * 64 + lane];
-        }
-    }
-    if (kg != 0) return;
-
+template <int AN, int EPI>
+__device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[AN], int rbase, int n0, int wn, int tn,
+                                         int lane) {
     // ---- epilogue: accumulator (lane, reg r) <-> row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31 ----
-    const int rbase = m0 + wm * 32 + 4 * (lane >> 5);
     if (EPI == EPI_BIAS) {
 #pragma unroll
         for (int an = 0; an < AN; ++an) {
@@ -295,14 +125,490 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_kernel(const GemmAr
     }
 }
 
-template <int WM, int WN, int WK, int AN, int BK, int PF, int EPI, bool VEC>
-static int launch_cfg_v(GemmArgs g, hipStream_t s) {
-    constexpr int BM = 32 * WM, BN = 32 * WN * AN, NT = 64 * WM * WN * WK;
+template <int WM, int WN, int WK, int AN, int BK, int EPI, bool VEC>
+__global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_general(const GemmArgs g) {
+    constexpr int BM = 32 * WM;
+    constexpr int BN = 32 * WN * AN;
+    constexpr int NT = 64 * WM * WN * WK;
+    constexpr int WMN = WM * WN;
+    constexpr int LDS_STRIDE = BK + 4;
+    constexpr int ROWS = BM + BN;
+    constexpr int GROUP_FLOATS = ROWS * LDS_STRIDE;
+    constexpr int C4 = BK / 4;
+    constexpr int CHUNKS = WK * ROWS * C4;
+    static_assert(CHUNKS % NT == 0, "loader must tile evenly");
+    constexpr int CH = CHUNKS / NT;
+    static_assert(EPI != EPI_LSTM || (WN == 1 && AN == 4), "LSTM epilogue: 4 gate blocks per wave");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][WK][GROUP_FLOATS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int kg = wave / WMN;
+    const int wq = wave - kg * WMN;
+    const int wm = wq / WN;
+    const int wn = wq - wm * WN;
+
+    int tm, tn;
+    tile_coords(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;  // EPI_LSTM: tn indexes a block of 32 hidden units
+
+    const int K = g.K1 + g.K2;
+    const int Kg = (((K + WK - 1) / WK) + BK - 1) / BK * BK;  // K span of one k-group
+    const int KT = Kg / BK;
+
+    // kernel arguments into scalars once (selecting between struct fields per lane would otherwise turn
+    // into per-lane loads of the argument block)
+    const float *const gA1 = g.A1, *const gA2 = g.A2, *const gB1 = g.B1, *const gB2 = g.B2;
+    const int lda1 = g.lda1, lda2 = g.lda2, ldb1 = g.ldb1, ldb2 = g.ldb2;
+    const int K1 = g.K1, K2 = g.K2, gM = g.M, gN = g.N, gH = g.H;
+
+    static_assert(CH * 4 <= 64, "ok bits");
+    f32x4 stage[CH];
+    unsigned long long okbits = 0ull;
+
+    auto load_stage = [&](int kt) {
+        unsigned lo = 0u, hi = 0u;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int idx = tid + c * NT;
+            const int grp = idx / (ROWS * C4);
+            const int rem = idx - grp * (ROWS * C4);
+            const int row = rem / C4;
+            const int c4 = rem - row * C4;
+            const int k = grp * Kg + kt * BK + c4 * 4;
+            const bool is_a = row < BM;
+            // source row: a track of A, or a weight row of W
+            int wr;
+            bool ok;
+            if (EPI == EPI_LSTM) {
+                const int cc = row - BM;
+                const int unit = tn * 32 + (cc & 31);
+                wr = (cc >> 5) * gH + unit;
+                ok = unit < gH;
+            } else {
+                wr = n0 + (row - BM);
+                ok = wr < gN;
+            }
+            const int m = m0 + row;
+            const bool row_ok = is_a ? (m < gM) : ok;
+            const size_t r = is_a ? (size_t)m : (size_t)wr;
+            const float *r1 = (is_a ? gA1 : gB1) + r * (size_t)(is_a ? lda1 : ldb1);
+            const float *r2 = (is_a ? gA2 : gB2) + r * (size_t)(is_a ? lda2 : ldb2);
+            if (c < 8) stage[c] = load4_dual<VEC>(r1, K1, r2, K2, k, row_ok, gA1, lo, (c & 7) * 4);
+            else stage[c] = load4_dual<VEC>(r1, K1, r2, K2, k, row_ok, gA1, hi, (c & 7) * 4);
+        }
+        okbits = ((unsigned long long)hi << 32) | lo;
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int idx = tid + c * NT;
+            const int grp = idx / (ROWS * C4);
+            const int rem = idx - grp * (ROWS * C4);
+            const int row = rem / C4;
+            const int c4 = rem - row * C4;
+            float *dst = smem + (size_t)(buf * WK + grp) * GROUP_FLOATS + row * LDS_STRIDE + c4 * 4;
+            f32x4 v = stage[c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = ((okbits >> (c * 4 + q)) & 1ull) ? v[q] : 0.0f;
+            *reinterpret_cast<f32x4 *>(dst) = v;
+        }
+    };
+
+    f32x16 acc[AN];
+#pragma unroll
+    for (int an = 0; an < AN; ++an)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[an][r] = 0.0f;
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+
+    const int a_off = (wm * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+    const int b_off = BM * LDS_STRIDE + (wn * AN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+
+    // Fragment reads are software-pipelined one k8 step ahead: the ds_read_b128 of step k8+1 are issued before the
+    // four MFMAs of step k8, so LDS latency hides under the matrix pipe instead of idling both waves of a SIMD.
+    auto read_frags = [&](const float *base, int k8, f32x4 &a4, f32x4 (&b4)[AN]) {
+        a4 = *reinterpret_cast<const f32x4 *>(base + a_off + k8 * 8);
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+            b4[an] = *reinterpret_cast<const f32x4 *>(base + b_off + an * 32 * LDS_STRIDE + k8 * 8);
+    };
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) load_stage(kt + 1);
+        const float *base = smem + (size_t)((kt & 1) * WK + kg) * GROUP_FLOATS;
+        f32x4 a4[2];
+        f32x4 b4[2][AN];
+        read_frags(base, 0, a4[0], b4[0]);
+#pragma unroll
+        for (int k8 = 0; k8 < BK / 8; ++k8) {
+            if (k8 + 1 < BK / 8) read_frags(base, k8 + 1, a4[(k8 + 1) & 1], b4[(k8 + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);  // keep the next step's ds_reads ahead of this step's MFMAs
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int an = 0; an < AN; ++an)
+                    acc[an] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[k8 & 1][q], b4[k8 & 1][an][q], acc[an], 0, 0, 0);
+        }
+        if (kt + 1 < KT) store_stage((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- reduce the k-groups through LDS (deterministic order) ----
+    if (WK > 1) {
+        float *red = smem;
+        if (kg > 0) {
+#pragma unroll
+            for (int an = 0; an < AN; ++an)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    red[(((kg - 1) * WMN + wq) * AN * 16 + an * 16 + r) * 64 + lane] = acc[an][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+            for (int gk = 1; gk < WK; ++gk)
+#pragma unroll
+                for (int an = 0; an < AN; ++an)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[an][r] += red[(((gk - 1) * WMN + wq) * AN * 16 + an * 16 + r) * 64 + lane];
+        }
+    }
+    if (kg != 0) return;
+    epilogue<AN, EPI>(g, acc, m0 + wm * 32 + 4 * (lane >> 5), n0, wn, tn, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fast path: K1, K2 multiples of BK, K multiple of WK*BK, 16-byte aligned rows.  Per K step a lane issues CH
+// global_load_dwordx4 through running pointers (one 64-bit add each, no masks: out-of-range rows are clamped to
+// the last valid row and their results are never stored), so the non-MFMA part of a K step is a few dozen
+// instructions instead of a few hundred -- the barrier re-aligns all waves every K step, which serialises
+// whatever VALU work precedes the MFMA chain with the matrix pipe.
+// ---------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int WK, int AN, int BK, int EPI, bool DUAL>
+__global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_fast(const GemmArgs g) {
+    constexpr int BM = 32 * WM;
+    constexpr int BN = 32 * WN * AN;
+    constexpr int NT = 64 * WM * WN * WK;
+    constexpr int WMN = WM * WN;
+    constexpr int LDS_STRIDE = BK + 4;
+    constexpr int ROWS = BM + BN;
+    constexpr int GROUP_FLOATS = ROWS * LDS_STRIDE;
+    constexpr int C4 = BK / 4;
+    constexpr int CHUNKS = WK * ROWS * C4;
+    static_assert(CHUNKS % NT == 0, "loader must tile evenly");
+    constexpr int CH = CHUNKS / NT;
+    static_assert(EPI != EPI_LSTM || (WN == 1 && AN == 4), "LSTM epilogue: 4 gate blocks per wave");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][WK][GROUP_FLOATS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int kg = wave / WMN;
+    const int wq = wave - kg * WMN;
+    const int wm = wq / WN;
+    const int wn = wq - wm * WN;
+
+    int tm, tn;
+    tile_coords(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+
+    const int K1 = g.K1;
+    const int Kg = (g.K1 + g.K2) / WK;  // multiple of BK
+    const int KT = Kg / BK;
+
+    const float *cur[CH];   // running source pointer (source 1)
+    const float *alt[CH];   // DUAL: source-2 pointer such that alt + k addresses column k - K1 of source 2
+    int kbeg[CH];           // DUAL: first k of this chunk
+    int ldsoff[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int idx = tid + c * NT;
+        const int grp = idx / (ROWS * C4);
+        const int rem = idx - grp * (ROWS * C4);
+        const int row = rem / C4;
+        const int c4 = rem - row * C4;
+        const bool is_a = row < BM;
+        int wr;
+        if (EPI == EPI_LSTM) {
+            const int cc = row - BM;
+            wr = (cc >> 5) * g.H + tn * 32 + (cc & 31);
+        } else {
+            wr = min(n0 + (row - BM), g.N - 1);
+        }
+        const size_t r = is_a ? (size_t)min(m0 + row, g.M - 1) : (size_t)wr;
+        const int k0 = grp * Kg + c4 * 4;
+        cur[c] = (is_a ? g.A1 : g.B1) + r * (size_t)(is_a ? g.lda1 : g.ldb1) + k0;
+        if (DUAL) {
+            alt[c] = (is_a ? g.A2 : g.B2) + r * (size_t)(is_a ? g.lda2 : g.ldb2) + (k0 - K1);
+            kbeg[c] = k0;
+        }
+        ldsoff[c] = grp * GROUP_FLOATS + row * LDS_STRIDE + c4 * 4;
+    }
+
+    f32x4 stage[CH];
+    auto load_stage = [&](int kt) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const float *p = cur[c] + kt * BK;
+            if (DUAL) p = (kbeg[c] + kt * BK < K1) ? p : (alt[c] + kt * BK);
+            stage[c] = *reinterpret_cast<const f32x4 *>(p);
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            *reinterpret_cast<f32x4 *>(smem + (size_t)buf * WK * GROUP_FLOATS + ldsoff[c]) = stage[c];
+    };
+
+    f32x16 acc[AN];
+#pragma unroll
+    for (int an = 0; an < AN; ++an)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[an][r] = 0.0f;
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+
+    const int a_off = (wm * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+    const int b_off = BM * LDS_STRIDE + (wn * AN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+
+    // Fragment reads are software-pipelined one k8 step ahead: the ds_read_b128 of step k8+1 are issued before the
+    // four MFMAs of step k8, so LDS latency hides under the matrix pipe instead of idling both waves of a SIMD.
+    auto read_frags = [&](const float *base, int k8, f32x4 &a4, f32x4 (&b4)[AN]) {
+        a4 = *reinterpret_cast<const f32x4 *>(base + a_off + k8 * 8);
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+            b4[an] = *reinterpret_cast<const f32x4 *>(base + b_off + an * 32 * LDS_STRIDE + k8 * 8);
+    };
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) load_stage(kt + 1);
+        const float *base = smem + (size_t)((kt & 1) * WK + kg) * GROUP_FLOATS;
+        f32x4 a4[2];
+        f32x4 b4[2][AN];
+        read_frags(base, 0, a4[0], b4[0]);
+#pragma unroll
+        for (int k8 = 0; k8 < BK / 8; ++k8) {
+            if (k8 + 1 < BK / 8) read_frags(base, k8 + 1, a4[(k8 + 1) & 1], b4[(k8 + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);  // keep the next step's ds_reads ahead of this step's MFMAs
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int an = 0; an < AN; ++an)
+                    acc[an] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[k8 & 1][q], b4[k8 & 1][an][q], acc[an], 0, 0, 0);
+        }
+        if (kt + 1 < KT) store_stage((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    if (WK > 1) {
+        float *red = smem;
+        if (kg > 0) {
+#pragma unroll
+            for (int an = 0; an < AN; ++an)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    red[(((kg - 1) * WMN + wq) * AN * 16 + an * 16 + r) * 64 + lane] = acc[an][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+            for (int gk = 1; gk < WK; ++gk)
+#pragma unroll
+                for (int an = 0; an < AN; ++an)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[an][r] += red[(((gk - 1) * WMN + wq) * AN * 16 + an * 16 + r) * 64 + lane];
+        }
+    }
+    if (kg != 0) return;
+    epilogue<AN, EPI>(g, acc, m0 + wm * 32 + 4 * (lane >> 5), n0, wn, tn, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pipelined fast path ("mid-stream barrier").  PMC on the kernel above shows the matrix pipe busy only ~67 %:
+// the end-of-step barrier aligns all waves, so their non-MFMA work (vmcnt wait, ds_write, barrier, first ds_read)
+// coincides and the pipe drains once per K step.  Here the LDS ring is three tiles deep and the single barrier of
+// a K step sits in the MIDDLE of the step's MFMA stream:
+//     first half : MFMAs of tile t   | registers -> LDS of tile t+1 (its loads were issued half a step earlier)
+//     barrier    : tile t+1 visible; everybody is past tile t-1, whose buffer tile t+2 will reuse
+//     second half: MFMAs of tile t   | global loads of tile t+2 -> registers | first fragments of tile t+1
+// so there is no barrier at the step boundary, fragments are always one k8 step ahead of the MFMAs that use
+// them, and a wave that waits at the barrier still has its last MFMA in the pipe while its SIMD partner issues.
+// ---------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int WK, int AN, int BK, int EPI, bool DUAL>
+__global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_pipe(const GemmArgs g) {
+    constexpr int BM = 32 * WM;
+    constexpr int BN = 32 * WN * AN;
+    constexpr int NT = 64 * WM * WN * WK;
+    constexpr int WMN = WM * WN;
+    constexpr int LDS_STRIDE = BK + 4;
+    constexpr int ROWS = BM + BN;
+    constexpr int GROUP_FLOATS = ROWS * LDS_STRIDE;
+    constexpr int BUF_FLOATS = WK * GROUP_FLOATS;
+    constexpr int C4 = BK / 4;
+    constexpr int CHUNKS = WK * ROWS * C4;
+    static_assert(CHUNKS % NT == 0, "loader must tile evenly");
+    constexpr int CH = CHUNKS / NT;
+    constexpr int NK8 = BK / 8;
+    static_assert(NK8 >= 2 && NK8 % 2 == 0, "BK must be a multiple of 16");
+    constexpr int WRITE_AT = NK8 / 2 - 1;
+    static_assert(EPI != EPI_LSTM || (WN == 1 && AN == 4), "LSTM epilogue: 4 gate blocks per wave");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][WK][GROUP_FLOATS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int kg = wave / WMN;
+    const int wq = wave - kg * WMN;
+    const int wm = wq / WN;
+    const int wn = wq - wm * WN;
+
+    int tm, tn;
+    tile_coords(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+
+    const int K1 = g.K1;
+    const int Kg = (g.K1 + g.K2) / WK;  // multiple of BK
+    const int KT = Kg / BK;
+
+    const float *cur[CH];
+    const float *alt[CH];
+    int kbeg[CH];
+    int ldsoff[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int idx = tid + c * NT;
+        const int grp = idx / (ROWS * C4);
+        const int rem = idx - grp * (ROWS * C4);
+        const int row = rem / C4;
+        const int c4 = rem - row * C4;
+        const bool is_a = row < BM;
+        int wr;
+        if (EPI == EPI_LSTM) {
+            const int cc = row - BM;
+            wr = (cc >> 5) * g.H + tn * 32 + (cc & 31);
+        } else {
+            wr = min(n0 + (row - BM), g.N - 1);
+        }
+        const size_t r = is_a ? (size_t)min(m0 + row, g.M - 1) : (size_t)wr;
+        const int k0 = grp * Kg + c4 * 4;
+        cur[c] = (is_a ? g.A1 : g.B1) + r * (size_t)(is_a ? g.lda1 : g.ldb1) + k0;
+        if (DUAL) {
+            alt[c] = (is_a ? g.A2 : g.B2) + r * (size_t)(is_a ? g.lda2 : g.ldb2) + (k0 - K1);
+            kbeg[c] = k0;
+        }
+        ldsoff[c] = grp * GROUP_FLOATS + row * LDS_STRIDE + c4 * 4;
+    }
+
+    f32x4 stage[CH];
+    auto load_stage = [&](int kt) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const float *p = cur[c] + kt * BK;
+            if (DUAL) p = (kbeg[c] + kt * BK < K1) ? p : (alt[c] + kt * BK);
+            stage[c] = *reinterpret_cast<const f32x4 *>(p);
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            *reinterpret_cast<f32x4 *>(smem + (size_t)buf * BUF_FLOATS + ldsoff[c]) = stage[c];
+    };
+
+    f32x16 acc[AN];
+#pragma unroll
+    for (int an = 0; an < AN; ++an)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[an][r] = 0.0f;
+
+    const int a_off = kg * GROUP_FLOATS + (wm * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+    const int b_off = kg * GROUP_FLOATS + BM * LDS_STRIDE + (wn * AN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+    auto read_frags = [&](int buf, int k8, f32x4 &a4, f32x4 (&b4)[AN]) {
+        const float *base = smem + (size_t)buf * BUF_FLOATS;
+        a4 = *reinterpret_cast<const f32x4 *>(base + a_off + k8 * 8);
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+            b4[an] = *reinterpret_cast<const f32x4 *>(base + b_off + an * 32 * LDS_STRIDE + k8 * 8);
+    };
+
+    // optional static priority for the second-dispatched half of the waves (they share SIMDs with the first
+    // half): breaks the phase lock in which both waves of a SIMD do their non-MFMA work at the same time
+    if (g.prio && __builtin_amdgcn_readfirstlane(wave) >= (WM * WN * WK) / 2) __builtin_amdgcn_s_setprio(1);
+
+    // prologue: tile 0 in LDS buffer 0, tile 1 in registers, first fragments of tile 0 in flight
+    load_stage(0);
+    store_stage(0);
+    if (KT > 1) load_stage(1);
+    __syncthreads();
+    f32x4 a4[2];
+    f32x4 b4[2][AN];
+    read_frags(0, 0, a4[0], b4[0]);
+
+    int buf_cur = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf_nxt = (buf_cur == 2) ? 0 : buf_cur + 1;
+        const bool has_next = kt + 1 < KT;
+#pragma unroll
+        for (int k8 = 0; k8 < NK8; ++k8) {
+            // fragments one k8 step ahead (the first ones of the next tile once its buffer is published)
+            if (k8 + 1 < NK8) read_frags(buf_cur, k8 + 1, a4[(k8 + 1) & 1], b4[(k8 + 1) & 1]);
+            else if (has_next) read_frags(buf_nxt, 0, a4[(k8 + 1) & 1], b4[(k8 + 1) & 1]);
+            if (k8 == WRITE_AT && has_next) store_stage(buf_nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int an = 0; an < AN; ++an)
+                    acc[an] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[k8 & 1][q], b4[k8 & 1][an][q], acc[an], 0, 0, 0);
+            if (k8 == WRITE_AT) {
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                if (kt + 2 < KT) load_stage(kt + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        buf_cur = buf_nxt;
+    }
+
+    if (WK > 1) {
+        __syncthreads();  // everybody is done with the tile ring before it is reused for the reduction
+        float *red = smem;
+        if (kg > 0) {
+#pragma unroll
+            for (int an = 0; an < AN; ++an)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    red[(((kg - 1) * WMN + wq) * AN * 16 + an * 16 + r) * 64 + lane] = acc[an][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+            for (int gk = 1; gk < WK; ++gk)
+#pragma unroll
+                for (int an = 0; an < AN; ++an)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[an][r] += red[(((gk - 1) * WMN + wq) * AN * 16 + an * 16 + r) * 64 + lane];
+        }
+    }
+    if (kg != 0) return;
+    epilogue<AN, EPI>(g, acc, m0 + wm * 32 + 4 * (lane >> 5), n0, wn, tn, lane);
+}
+
+template <typename KernT>
+static int launch_kernel(KernT kern, GemmArgs &g, int BM, int BN, int NT, size_t smem, bool lstm, hipStream_t s,
+                         bool &attr_set) {
     g.tiles_m = (g.M + BM - 1) / BM;
-    g.tiles_n = (EPI == EPI_LSTM) ? (g.H + 31) / 32 : (g.N + BN - 1) / BN;
-    const size_t smem = (size_t)2 * WK * (BM + BN) * (BK + 4) * sizeof(float);
-    auto kern = gemm_nt_kernel<WM, WN, WK, AN, BK, PF, EPI, VEC>;
-    static bool attr_set = false;  // one flag per template instantiation
+    g.tiles_n = lstm ? (g.H + 31) / 32 : (g.N + BN - 1) / BN;
     if (!attr_set) {
         TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -315,11 +621,34 @@ static int launch_cfg_v(GemmArgs g, hipStream_t s) {
     return 0;
 }
 
-template <int WM, int WN, int WK, int AN, int BK, int PF, int EPI>
-static int launch_cfg(const GemmArgs &g, hipStream_t s) {
-    if (g.vec_ok) return launch_cfg_v<WM, WN, WK, AN, BK, PF, EPI, true>(g, s);
-    // rare fallback (K or a leading dimension not a multiple of 4): scalar loader, shallow prefetch
-    return launch_cfg_v<WM, WN, WK, AN, BK, 1, EPI, false>(g, s);
+// general (masked) kernel: any M, N, K
+template <int WM, int WN, int WK, int AN, int BK, int EPI>
+static int launch_general(GemmArgs g, hipStream_t s) {
+    constexpr int BM = 32 * WM, BN = 32 * WN * AN, NT = 64 * WM * WN * WK;
+    const size_t smem = (size_t)2 * WK * (BM + BN) * (BK + 4) * sizeof(float);
+    static bool attr_v = false, attr_s = false;
+    if (g.vec_ok) return launch_kernel(gemm_nt_general<WM, WN, WK, AN, BK, EPI, true>, g, BM, BN, NT, smem,
+                                       EPI == EPI_LSTM, s, attr_v);
+    return launch_kernel(gemm_nt_general<WM, WN, WK, AN, BK, EPI, false>, g, BM, BN, NT, smem, EPI == EPI_LSTM, s,
+                         attr_s);
+}
+
+static bool fast_ok(const GemmArgs &g, int WK, int BK) {
+    if (!g.vec_ok) return false;
+    if (g.K1 <= 0 || g.K1 % BK != 0 || g.K2 % BK != 0) return false;
+    return ((g.K1 + g.K2) % (WK * BK)) == 0;
+}
+
+// fast kernel when the shape allows it, otherwise the general kernel of a fallback tile configuration
+template <int WM, int WN, int WK, int AN, int BK, int EPI>
+static int launch_fast(GemmArgs g, hipStream_t s) {
+    constexpr int BM = 32 * WM, BN = 32 * WN * AN, NT = 64 * WM * WN * WK;
+    const size_t smem = (size_t)2 * WK * (BM + BN) * (BK + 4) * sizeof(float);
+    static bool attr_1 = false, attr_2 = false;
+    if (g.K2 > 0) return launch_kernel(gemm_nt_fast<WM, WN, WK, AN, BK, EPI, true>, g, BM, BN, NT, smem,
+                                       EPI == EPI_LSTM, s, attr_2);
+    return launch_kernel(gemm_nt_fast<WM, WN, WK, AN, BK, EPI, false>, g, BM, BN, NT, smem, EPI == EPI_LSTM, s,
+                         attr_1);
 }
 
 static int check_vec(GemmArgs &g) {
@@ -330,47 +659,192 @@ static int check_vec(GemmArgs &g) {
     return 0;
 }
 
+template <int WM, int WN, int WK, int AN, int BK, int EPI>
+static int launch_pipe(GemmArgs g, hipStream_t s) {
+    constexpr int BM = 32 * WM, BN = 32 * WN * AN, NT = 64 * WM * WN * WK;
+    constexpr size_t smem = (size_t)3 * WK * (BM + BN) * (BK + 4) * sizeof(float);
+    static_assert(smem <= 163840, "LDS ring does not fit");
+    static bool attr_1 = false, attr_2 = false;
+    if (g.K2 > 0) return launch_kernel(gemm_nt_pipe<WM, WN, WK, AN, BK, EPI, true>, g, BM, BN, NT, smem,
+                                       EPI == EPI_LSTM, s, attr_2);
+    return launch_kernel(gemm_nt_pipe<WM, WN, WK, AN, BK, EPI, false>, g, BM, BN, NT, smem, EPI == EPI_LSTM, s,
+                         attr_1);
+}
+
+#define TNP_TRY_FAST(WM, WN, WK, AN, BK, EPI) \
+    if (fast_ok(g, WK, BK)) return launch_fast<WM, WN, WK, AN, BK, EPI>(g, s)
+#define TNP_TRY_PIPE(WM, WN, WK, AN, BK, EPI) \
+    if (fast_ok(g, WK, BK)) return launch_pipe<WM, WN, WK, AN, BK, EPI>(g, s)
+
 int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
     GemmArgs g = g_in;
     check_vec(g);
-    if (variant == 0) {
-        const long big_tiles = (long)((g.M + 127) / 128) * ((g.N + 63) / 64);
-        variant = (big_tiles >= 192) ? 1 : 3;
-    }
+    const long big_tiles = (long)((g.M + 127) / 128) * ((g.N + 63) / 64);
+    if (variant == 0) variant = (big_tiles >= 192) ? 12 : 24;  // measured best on MI355X (tools/gpu_check.py)
     switch (variant) {
-        //                         WM WN WK AN BK PF
-        case 1: return launch_cfg<4, 2, 1, 1, 32, 2, EPI_BIAS>(g, s);   // 128x64, 8 waves
-        case 2: return launch_cfg<2, 4, 1, 1, 32, 2, EPI_BIAS>(g, s);   // 64x128, 8 waves
-        case 3: return launch_cfg<1, 2, 2, 1, 32, 3, EPI_BIAS>(g, s);   // 32x64, split-K 2
-        case 4: return launch_cfg<4, 2, 1, 1, 32, 1, EPI_BIAS>(g, s);   // 128x64, prefetch 1 (round-1 baseline)
-        case 5: return launch_cfg<4, 2, 1, 1, 32, 3, EPI_BIAS>(g, s);   // 128x64, prefetch 3
-        case 6: return launch_cfg<2, 4, 1, 1, 32, 3, EPI_BIAS>(g, s);   // 64x128, prefetch 3
-        case 7: return launch_cfg<4, 2, 1, 1, 64, 2, EPI_BIAS>(g, s);   // 128x64, BK 64
-        case 8: return launch_cfg<2, 4, 1, 1, 64, 2, EPI_BIAS>(g, s);   // 64x128, BK 64
-        case 9: return launch_cfg<1, 2, 2, 1, 32, 1, EPI_BIAS>(g, s);   // 32x64 split-K 2, prefetch 1
-        case 10: return launch_cfg<1, 2, 2, 1, 32, 2, EPI_BIAS>(g, s);  // 32x64 split-K 2, prefetch 2
-        case 11: return launch_cfg<1, 2, 2, 1, 64, 2, EPI_BIAS>(g, s);  // 32x64 split-K 2, BK 64
-        case 12: return launch_cfg<1, 1, 4, 1, 32, 3, EPI_BIAS>(g, s);  // 32x32 split-K 4
-        case 13: return launch_cfg<2, 2, 2, 1, 32, 3, EPI_BIAS>(g, s);  // 64x64 split-K 2, 8 waves
-        case 14: return launch_cfg<4, 1, 1, 2, 32, 2, EPI_BIAS>(g, s);  // 128x64, 4 waves x 2 blocks
+        //                  WM WN WK AN BK
+        case 1: TNP_TRY_FAST(4, 2, 1, 1, 32, EPI_BIAS); break;   // 128x64, 8 waves
+        case 2: TNP_TRY_FAST(2, 4, 1, 1, 64, EPI_BIAS); break;   // 64x128, 8 waves, BK 64
+        case 3: TNP_TRY_FAST(4, 2, 1, 1, 64, EPI_BIAS); break;   // 128x64, 8 waves, BK 64
+        case 4: TNP_TRY_FAST(2, 4, 1, 1, 32, EPI_BIAS); break;   // 64x128, 8 waves
+        case 5: TNP_TRY_FAST(1, 2, 2, 1, 32, EPI_BIAS); break;   // 32x64, split-K 2
+        case 6: TNP_TRY_FAST(1, 2, 2, 1, 64, EPI_BIAS); break;   // 32x64, split-K 2, BK 64
+        case 7: TNP_TRY_FAST(1, 1, 4, 1, 32, EPI_BIAS); break;   // 32x32, split-K 4 (512 workgroups at M=2048,N=256)
+        case 8: TNP_TRY_FAST(1, 1, 4, 1, 64, EPI_BIAS); break;   // 32x32, split-K 4, BK 64
+        case 9: TNP_TRY_FAST(2, 2, 2, 1, 32, EPI_BIAS); break;   // 64x64, split-K 2, 8 waves
+        case 10: TNP_TRY_FAST(4, 1, 1, 2, 32, EPI_BIAS); break;  // 128x64, 4 waves x 2 blocks
+        case 11: TNP_TRY_FAST(2, 2, 1, 1, 64, EPI_BIAS); break;  // 64x64, 4 waves, BK 64 (2 workgroups / CU)
+        case 12: TNP_TRY_FAST(2, 2, 1, 1, 32, EPI_BIAS); break;  // 64x64, 4 waves
+        case 13: TNP_TRY_FAST(2, 1, 1, 2, 64, EPI_BIAS); break;  // 64x64, 2 waves x 2 blocks, BK 64
+        case 14: TNP_TRY_FAST(4, 1, 1, 2, 64, EPI_BIAS); break;  // 128x64, 4 waves x 2 blocks, BK 64
+        case 15: TNP_TRY_FAST(2, 2, 1, 2, 32, EPI_BIAS); break;  // 64x128, 4 waves x 2 blocks
+        case 20: TNP_TRY_PIPE(2, 4, 1, 1, 32, EPI_BIAS); break;  // pipelined: 64x128, 8 waves
+        case 21: TNP_TRY_PIPE(4, 2, 1, 1, 32, EPI_BIAS); break;  // pipelined: 128x64, 8 waves
+        case 22: TNP_TRY_PIPE(2, 2, 1, 1, 32, EPI_BIAS); break;  // pipelined: 64x64, 4 waves
+        case 23: TNP_TRY_PIPE(2, 4, 1, 1, 64, EPI_BIAS); break;  // pipelined: 64x128, BK 64
+        case 24: TNP_TRY_PIPE(1, 2, 2, 1, 32, EPI_BIAS); break;  // pipelined: 32x64, split-K 2
+        case 25: TNP_TRY_PIPE(1, 1, 4, 1, 32, EPI_BIAS); break;  // pipelined: 32x32, split-K 4
+        case 26: TNP_TRY_PIPE(2, 2, 1, 2, 32, EPI_BIAS); break;  // pipelined: 64x128, 4 waves x 2 blocks
+        case 27: TNP_TRY_PIPE(4, 1, 1, 2, 32, EPI_BIAS); break;  // pipelined: 128x64, 4 waves x 2 blocks
+        case 28: TNP_TRY_PIPE(1, 2, 2, 1, 16, EPI_BIAS); break;  // pipelined: 32x64, split-K 2, BK 16
+        case 30: g.prio = 1; TNP_TRY_PIPE(2, 4, 1, 1, 32, EPI_BIAS); break;  // variant 20 + static wave priority
+        case 31: g.prio = 1; TNP_TRY_PIPE(4, 2, 1, 1, 32, EPI_BIAS); break;
+        case 33: g.prio = 1; TNP_TRY_PIPE(2, 4, 1, 1, 64, EPI_BIAS); break;
+        case 100: return launch_general<4, 2, 1, 1, 32, EPI_BIAS>(g, s);  // round-1a kernels, kept for A/B
+        case 101: return launch_general<1, 2, 2, 1, 32, EPI_BIAS>(g, s);
         default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d", variant);
     }
+    // shape not eligible for the fast path: masked general kernel
+    if (big_tiles >= 192) return launch_general<4, 2, 1, 1, 32, EPI_BIAS>(g, s);
+    return launch_general<1, 2, 2, 1, 32, EPI_BIAS>(g, s);
 }
 
 int launch_lstm_gates(const GemmArgs &g_in, int variant, hipStream_t s) {
     GemmArgs g = g_in;
     check_vec(g);
     if (g.H % 32 != 0) TNP_FAIL(-1, "LSTM hidden_dim must be a multiple of 32 (got %d)", g.H);
-    if (variant == 0) variant = (g.M >= 4096) ? 1 : 2;
+    if (variant == 0) variant = (g.M >= 4096) ? 5 : 20;  // measured best on MI355X (tools/gpu_check.py)
     switch (variant) {
-        case 1: return launch_cfg<2, 1, 2, 4, 32, 2, EPI_LSTM>(g, s);  // 64 tracks x 32 units, split-K 2
-        case 2: return launch_cfg<1, 1, 4, 4, 16, 3, EPI_LSTM>(g, s);  // 32 tracks x 32 units, split-K 4
-        case 3: return launch_cfg<1, 1, 4, 4, 16, 1, EPI_LSTM>(g, s);  // same, prefetch 1 (round-1 baseline)
-        case 4: return launch_cfg<1, 1, 4, 4, 16, 2, EPI_LSTM>(g, s);  // same, prefetch 2
-        case 5: return launch_cfg<2, 1, 2, 4, 32, 1, EPI_LSTM>(g, s);  // 64 tracks, prefetch 1
-        case 6: return launch_cfg<2, 1, 2, 4, 16, 3, EPI_LSTM>(g, s);  // 64 tracks, BK 16, prefetch 3
+        case 1: TNP_TRY_FAST(2, 1, 2, 4, 32, EPI_LSTM); break;  // 64 tracks x 32 units, split-K 2
+        case 2: TNP_TRY_FAST(1, 1, 4, 4, 16, EPI_LSTM); break;  // 32 tracks x 32 units, split-K 4
+        case 3: TNP_TRY_FAST(2, 1, 2, 4, 16, EPI_LSTM); break;  // 64 tracks, BK 16
+        case 4: TNP_TRY_FAST(1, 1, 2, 4, 32, EPI_LSTM); break;  // 32 tracks, split-K 2, 2 waves
+        case 5: TNP_TRY_FAST(4, 1, 2, 4, 16, EPI_LSTM); break;  // 128 tracks x 32 units, 8 waves
+        case 20: TNP_TRY_PIPE(1, 1, 4, 4, 16, EPI_LSTM); break;  // pipelined: 32 tracks x 32 units, split-K 4
+        case 21: TNP_TRY_PIPE(2, 1, 2, 4, 16, EPI_LSTM); break;  // pipelined: 64 tracks, split-K 2
+        case 22: TNP_TRY_PIPE(4, 1, 2, 4, 16, EPI_LSTM); break;  // pipelined: 128 tracks, 8 waves
+        case 23: TNP_TRY_PIPE(1, 1, 2, 4, 16, EPI_LSTM); break;  // pipelined: 32 tracks, split-K 2, 2 waves
+        case 100: return launch_general<2, 1, 2, 4, 32, EPI_LSTM>(g, s);
+        case 101: return launch_general<1, 1, 4, 4, 16, EPI_LSTM>(g, s);
         default: TNP_FAIL(-1, "lstm gates: unknown variant %d", variant);
     }
+    if (g.M >= 4096) return launch_general<2, 1, 2, 4, 32, EPI_LSTM>(g, s);
+    return launch_general<1, 1, 4, 4, 16, EPI_LSTM>(g, s);
 }
 
 }  // namespace tnp
+
+// ---------------------------------------------------------------------------------------------------------
+// Calibration probe: a pure v_mfma_f32_32x32x2_f32 stream (no memory traffic) on every SIMD of the chip.
+// bench.py / tools use it to report what the matrix pipe sustains on THIS box (clock, power state) next to
+// the datasheet peak, so that roofline fractions can be read against both.
+// ---------------------------------------------------------------------------------------------------------
+namespace tnp {
+typedef float pf32x16 __attribute__((ext_vector_type(16)));
+template <int NACC>
+__global__ void __launch_bounds__(512) mfma_probe_kernel(float *out, int iters) {
+    pf32x16 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+    float x = (float)(threadIdx.x & 7) * 0.25f, y = (float)(threadIdx.x & 3) * 0.5f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[a], 0, 0, 0);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[a][r];
+    if (s == 12345.678f) out[0] = s;  // keep the chain alive
+}
+}  // namespace tnp
+
+extern "C" TNP_API int tnp_mfma_probe(int waves_per_wg, int n_acc, int iters, int blocks, float *scratch, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (waves_per_wg < 1 || waves_per_wg > 8) TNP_FAIL(-1, "waves_per_wg must be 1..8");
+    dim3 grid(blocks), block(64 * waves_per_wg);
+    if (n_acc == 1) hipLaunchKernelGGL(tnp::mfma_probe_kernel<1>, grid, block, 0, s, scratch, iters);
+    else if (n_acc == 2) hipLaunchKernelGGL(tnp::mfma_probe_kernel<2>, grid, block, 0, s, scratch, iters);
+    else if (n_acc == 4) hipLaunchKernelGGL(tnp::mfma_probe_kernel<4>, grid, block, 0, s, scratch, iters);
+    else TNP_FAIL(-1, "n_acc must be 1, 2 or 4");
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Ablation probe: the same MFMA stream with the GEMM's side traffic added one ingredient at a time
+// (bit 0: fragments via ds_read_b128, bit 1: a barrier every 16 MFMAs, bit 2: global loads + ds_write per 16).
+// ---------------------------------------------------------------------------------------------------------
+namespace tnp {
+typedef float af32x4 __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ void __launch_bounds__(512) mfma_ablate_kernel(const float *src, float *out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float asm_[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 16384; i += blockDim.x) asm_[i] = (iters < 0) ? src[(blockIdx.x * 16384 + i) & 0xFFFFF] : (float)(i & 15) * 0.125f;
+    if (iters < 0) iters = -iters;
+    __syncthreads();
+    pf32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    af32x4 a4 = {0.5f, 0.25f, 0.125f, 1.0f}, b4 = {1.0f, 0.5f, 0.25f, 0.125f};
+    const float *lbase = asm_ + ((tid >> 6) * 1024) + (lane & 31) * 36 + (lane >> 5) * 4;
+    const float *gp = src + (size_t)blockIdx.x * 8192 + tid * 4;
+    af32x4 st[3];
+    for (int i = 0; i < iters; ++i) {
+        if (MODE & 4) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) st[c] = *reinterpret_cast<const af32x4 *>(gp + ((i * 3 + c) & 3) * 2048);
+        }
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {
+            if (MODE & 1) {
+                a4 = *reinterpret_cast<const af32x4 *>(lbase + k8 * 8);
+                b4 = *reinterpret_cast<const af32x4 *>(lbase + 4608 + k8 * 8);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[q], acc, 0, 0, 0);
+        }
+        if (MODE & 4) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                *reinterpret_cast<af32x4 *>(asm_ + 8192 + ((i & 1) * 4096) + (tid * 4 + c * 2048) % 4096) = st[c];
+        }
+        if (MODE & 2) __syncthreads();
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[r];
+    if (s == 12345.678f) out[0] = s;
+}
+}  // namespace tnp
+
+extern "C" TNP_API int tnp_mfma_ablate(int mode, int iters, int blocks, const float *src, float *scratch, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(blocks), block(512);
+    const size_t smem = 16384 * sizeof(float);
+    static bool set = false;
+#define TNP_ABL(M) case M: { if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(tnp::mfma_ablate_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); } \
+        hipLaunchKernelGGL(tnp::mfma_ablate_kernel<M>, grid, block, smem, s, src, scratch, iters); break; }
+    switch (mode) {
+        TNP_ABL(0) TNP_ABL(1) TNP_ABL(2) TNP_ABL(3) TNP_ABL(4) TNP_ABL(5) TNP_ABL(6) TNP_ABL(7)
+        default: TNP_FAIL(-1, "mode 0..7");
+    }
+    TNP_HIP(hipGetLastError());
+    return 0;
+}

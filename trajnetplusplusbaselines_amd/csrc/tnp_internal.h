@@ -28,6 +28,7 @@ struct GemmArgs {
     const float *bias1; const float *bias2;
     int M, N;
     int vec_ok;           // all K / ld multiples of 4 and pointers 16-byte aligned
+    int prio;             // pipelined kernel: static s_setprio for the second half of the waves
     int tiles_m, tiles_n;
     // EPI_BIAS
     float *C; int ldc; int relu;
