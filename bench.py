@@ -85,6 +85,7 @@ def main():
     ap.add_argument('--config', default='social', choices=sorted(CONFIGS))
     ap.add_argument('--variant', type=int, default=0, help='kernel variant selector (DESIGN.md)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dense', action='store_true', help='dense MFMA first embedding layer instead of the sparse one')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -104,6 +105,7 @@ def main():
     cfg = CONFIGS[args.config]
     model = build_model(cfg, device)
     model.kernel_variant = args.variant
+    model.sparse_embedding = not args.dense
     # every rank gets its own shard of scenes (different seed): weak scaling, no data-path collective
     xy, split = synth.linear_crowd(cfg['scenes'], cfg['agents'], seed=100 + rank)
     M = xy.shape[1]
@@ -147,14 +149,30 @@ def main():
             L.tnp_profile_end()
             K0 = cfg['n'] * cfg['n'] * model.pool.pooling_dim
             N0 = model.pool.embedding_layers()[0].weight.shape[0]
-            flops = 2.0 * M * N0 * K0                      # dense algorithmic FLOPs of one launch
+            dense_flops = 2.0 * M * N0 * K0                # dense Linear(C*n*n -> N0) on the grid
+            sparse = bool(model.sparse_embedding and cfg['type_'] == 'social')
+            if sparse:
+                # gather formulation: at most A-1 occupied cells per ego, C values each (SURVEY 8d "sparse lower
+                # bound for the first embedding layer"); the kernel runs on the fp32 VALU, whose peak equals the
+                # fp32 MFMA peak on CDNA4 (157.3 TFLOP/s)
+                flops = 2.0 * M * (cfg['agents'] - 1) * model.pool.pooling_dim * N0
+                kname = ('pool_embed_sparse_kernel + sparse_reduce_kernel (pool.embedding.0 on the winner table: '
+                         '%d egos x <=%d occupied cells x %d values -> %d)' % (M, cfg['agents'] - 1,
+                                                                              model.pool.pooling_dim, N0))
+            else:
+                flops = dense_flops
+                kname = 'gemm_nt_* (pool.embedding.0: [%d,%d]x[%d,%d]^T on v_mfma_f32_32x32x2_f32)' % (M, K0, N0, K0)
             if n.value > 0 and ms.value > 0:
                 avg_s = ms.value / n.value * 1e-3
                 achieved = flops / avg_s / 1e12
                 roof = dict(bound='mfma', achieved=achieved, peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                            frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=None,
-                            kernel='gemm_nt_kernel (pool.embedding.0: [%d,%d]x[%d,%d]^T)' % (M, K0, N0, K0),
+                            frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=None, kernel=kname,
+                            engine=('fp32 VALU FMA (same 157.3 TFLOP/s peak as the fp32 matrix cores)' if sparse
+                                    else 'fp32 MFMA'),
+                            formulation=('sparse gather (algorithmic FLOPs = 2*M*(A-1)*C*N1)' if sparse
+                                         else 'dense GEMM (algorithmic FLOPs = 2*M*N1*C*n*n)'),
                             launches=n.value, avg_launch_us=avg_s * 1e6, flops_per_launch=flops,
+                            dense_equivalent_tflops=dense_flops / avg_s / 1e12,
                             share_of_step=ms.value * 1e-3 / elapsed)
 
     if rank == 0:
@@ -177,7 +195,8 @@ def main():
                                    '(LSTM.forward, n_predict=12)' % (cfg['name'], cfg['scenes'], cfg['agents']),
                        'scenes_per_gpu': cfg['scenes'], 'agents_per_scene': cfg['agents'],
                        'recurrent_steps_per_forward': 19, 'parallelism': 'dp%d (scene sharding)' % world,
-                       'kernel_variant': args.variant},
+                       'kernel_variant': args.variant,
+                       'first_embedding_layer': 'dense mfma' if args.dense else 'sparse gather (social) / dense mfma'},
             'recurrent_scene_steps_per_s': scenes_total * 19 * args.steps / elapsed,
             'roofline': roof,
         }

@@ -75,6 +75,21 @@ TNP_API int tnp_linear_forward(const float *A, int lda, const float *W, int ldw,
                        int ldc, int M, int N, int K, int relu, int variant, void *stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Sparse first layer of the grid-embedding MLP on the winner table (social pooling, constant 0):
+ *   out[i,o] = act(bias[o] + sum over occupied cells c of sum_ch W_cell_major[c][ch][o] * values[j(i,c)][ch])
+ * == torch.nn.Linear on the dense grid (lstm/gridbased_pooling.py:107-109), 8x fewer multiply-adds.
+ *   winners   [M, ncell] int16 from tnp_pool_grid_forward; values [M, ldv]; row_base [M] int32 =
+ *   first row of the row's scene (tnp_row_base); W_cell_major [ncell][C][N1]; C in {4,8,16,32}
+ *   workspace: tnp_pool_embed_sparse_workspace_bytes(M, N1, ncell) bytes (partial sums)
+ * ----------------------------------------------------------------------------------------- */
+TNP_API size_t tnp_pool_embed_sparse_workspace_bytes(int M, int N1, int ncell);
+TNP_API int tnp_row_base(const int32_t *scene_start, int B, int32_t *row_base, void *stream);
+TNP_API int tnp_pool_embed_sparse_forward(const int16_t *winners, const float *values, int ldv,
+                                  const int32_t *row_base, const float *W_cell_major, const float *bias,
+                                  int M, int ncell, int C, int N1, int relu, float *out, int ldo,
+                                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* -------------------------------------------------------------------------------------------
  * Model descriptor of trajnetbaselines.lstm.LSTM (lstm/lstm.py:45-89) with its
  * GridBasedPooling (lstm/gridbased_pooling.py:15-92).  All pointers are device pointers to
  * the parameters in PyTorch layout (may alias nn.Parameter storage; nothing is copied).
@@ -101,6 +116,9 @@ typedef struct tnp_lstm_model {
     const float *Wh, *bh; /* pool.hidden_dim_encoding [C,H], [C] (social)         */
     const float *Wp[3];   /* pool.embedding.{0,2,4}.weight                        */
     const float *bp[3];   /* pool.embedding.{0,2,4}.bias                          */
+    const float *Wp0_cell_major; /* optional [n*n][C][dims[1]] copy of Wp[0] (W'[c][ch][o] =
+                                    Wp[0][o][ch*n*n + c]); enables the sparse first layer
+                                    for social pooling with constant == 0; NULL = dense   */
     int32_t variant;      /* kernel-variant selector (0 = default), see DESIGN.md  */
 } tnp_lstm_model;
 

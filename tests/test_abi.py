@@ -24,8 +24,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layout_matches_header_size():
-    # 13 int32 + 4 float + 22 pointers + 1 int32 (+ padding) -- guards against drift between header and ctypes
-    assert ctypes.sizeof(_lib.LstmModel) == 13 * 4 + 4 * 4 + 4 + 22 * 8 + 8
+    # 13 int32 + 4 float + 23 pointers + 1 int32 (+ padding) -- guards against drift between header and ctypes
+    assert ctypes.sizeof(_lib.LstmModel) == 13 * 4 + 4 * 4 + 4 + 23 * 8 + 8
 
 
 @pytest.mark.parametrize('kind', ['vanilla', 'occupancy', 'directional', 'social', 'social_goals'])

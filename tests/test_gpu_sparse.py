@@ -1,0 +1,100 @@
+"""GPU parity of the sparse first embedding layer (csrc/pool_embed_sparse.hip): winner table + per-track values
+-> Linear on the (never materialised) social grid, against the oracle's dense grid + Linear, and against the dense
+MFMA path of the same library."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from trajnetplusplusbaselines_amd import _lib, synth
+from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling
+
+pytestmark = pytest.mark.gpu
+
+
+def run_sparse(obs1, obs2, enc, starts, n_max, n, cell_side, W, b, relu=True):
+    dev = torch.device('cuda')
+    M, C = enc.shape
+    N1 = W.shape[0]
+    ncell = n * n
+    o1, o2 = torch.tensor(obs1).to(dev), torch.tensor(obs2).to(dev)
+    e = torch.tensor(enc).to(dev)
+    st = torch.tensor(starts, dtype=torch.int32).to(dev)
+    B = len(starts) - 1
+    winners = torch.empty(M, ncell, dtype=torch.int16, device=dev)
+    L = _lib.lib()
+    _lib.check(L.tnp_pool_grid_forward(_lib.POOL_SOCIAL, _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(e), C, _lib.ptr(st), B,
+                                       n_max, n, C, float(np.float32(cell_side)), n / 2, n / 2, 0.0, None, 0,
+                                       _lib.ptr(winners), _lib.stream_ptr()), 'grid')
+    row_base = torch.empty(M, dtype=torch.int32, device=dev)
+    _lib.check(L.tnp_row_base(_lib.ptr(st), B, _lib.ptr(row_base), _lib.stream_ptr()), 'row_base')
+    Wt = torch.tensor(W).to(dev)
+    Wcm = Wt.view(N1, C, ncell).permute(2, 1, 0).contiguous()
+    bt = torch.tensor(b).to(dev)
+    need = L.tnp_pool_embed_sparse_workspace_bytes(M, N1, ncell)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    out = torch.empty(M, N1, dtype=torch.float32, device=dev)
+    _lib.check(L.tnp_pool_embed_sparse_forward(_lib.ptr(winners), _lib.ptr(e), C, _lib.ptr(row_base), _lib.ptr(Wcm),
+                                               _lib.ptr(bt), M, ncell, C, N1, int(relu), _lib.ptr(out), N1,
+                                               _lib.ptr(ws), need, _lib.stream_ptr()), 'sparse')
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize('scenes,agents,n,C,N1', [(3, 7, 8, 8, 64), (64, 32, 16, 16, 1024), (5, 40, 16, 16, 260),
+                                                   (20, 13, 12, 4, 128), (2, 130, 16, 32, 256)])
+def test_sparse_embedding_matches_dense_oracle(scenes, agents, n, C, N1):
+    rng = np.random.RandomState(scenes * 31 + agents)
+    B, N = scenes, agents
+    obs2 = (rng.rand(B, N, 2).astype(np.float32) * 8 - 4)
+    obs2[rng.rand(B, N) < 0.15] = np.nan
+    obs1 = obs2 - np.float32(0.1)
+    enc = rng.randn(B, N, C).astype(np.float32)
+    W = (rng.randn(N1, C * n * n) / np.sqrt(C * 30)).astype(np.float32)
+    b = rng.randn(N1).astype(np.float32)
+    grid = oracle.grid('social', obs1, obs2, enc, n=n, cell_side=0.6, C=C).reshape(B * N, -1)
+    want = oracle.linear(grid, W, b, relu=True)
+    starts = np.arange(0, B * N + 1, N)
+    got = run_sparse(obs1.reshape(-1, 2), obs2.reshape(-1, 2), enc.reshape(-1, C), starts, N, n, 0.6, W, b)
+    err = float(np.abs(got - want).max())
+    assert err < 2e-5 * max(1.0, float(np.abs(want).max())), err
+
+
+def test_sparse_ragged_scenes():
+    rng = np.random.RandomState(7)
+    sizes = [5, 1, 9, 3, 9, 2]
+    n_max, n, C, N1 = max(sizes), 8, 8, 96
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    M = int(starts[-1])
+    flat = (rng.rand(M, 2).astype(np.float32) * 4 - 2)
+    enc = rng.randn(M, C).astype(np.float32)
+    W = rng.randn(N1, C * n * n).astype(np.float32) / 8
+    b = rng.randn(N1).astype(np.float32)
+    padded = np.full((len(sizes), n_max, 2), np.nan, dtype=np.float32)
+    pe = np.zeros((len(sizes), n_max, C), dtype=np.float32)
+    for s, ns in enumerate(sizes):
+        padded[s, :ns] = flat[starts[s]:starts[s + 1]]
+        pe[s, :ns] = enc[starts[s]:starts[s + 1]]
+    grid = oracle.grid('social', padded, padded, pe, n=n, cell_side=0.6, C=C).reshape(len(sizes), n_max, -1)
+    got = run_sparse(flat, flat, enc, starts, n_max, n, 0.6, W, b)
+    for s, ns in enumerate(sizes):
+        want = oracle.linear(grid[s, :ns], W, b, relu=True)
+        np.testing.assert_allclose(got[starts[s]:starts[s + 1]], want, atol=3e-5)
+
+
+def test_forward_sparse_equals_dense_path():
+    """Whole Social-LSTM forward: the sparse first layer and the dense MFMA first layer agree to fp32 rounding."""
+    torch.manual_seed(3)
+    pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=16, out_dim=256,
+                            embedding_arch='two_layer', layer_dims=[1024], latent_dim=16)
+    model = LSTM(pool=pool).eval().cuda()
+    xy, split = synth.ragged_crowd(24, 3, 40, seed=4)
+    goals = torch.zeros(xy.shape[1], 2)
+    model.sparse_embedding = True
+    rel_s, pred_s = model(xy[:9], goals, split, n_predict=12)
+    model.sparse_embedding = False
+    rel_d, pred_d = model(xy[:9], goals, split, n_predict=12)
+    assert torch.equal(torch.isnan(pred_s), torch.isnan(pred_d))
+    assert (torch.nan_to_num(pred_s) - torch.nan_to_num(pred_d)).abs().max().item() < 2e-5
+    assert (torch.nan_to_num(rel_s) - torch.nan_to_num(rel_d)).abs().max().item() < 2e-5

@@ -59,11 +59,11 @@ def forward_timing():
         xy, split = synth.linear_crowd(scenes, agents, seed=1)
         obs = xy[:9].cuda()
         goals = torch.zeros(xy.shape[1], 2, device='cuda')
-        gate_variants = (0, 2, 5, 20, 22)
-        gemm_variants = (0,)
+        gate_variants = (0, 5, 20)
+        gemm_variants = (0, 1 << 16) if cfgname.startswith('social') else (0,)
         for gv in gate_variants:
             for lv in gemm_variants:
-                model.kernel_variant = lv | (gv << 8)
+                model.kernel_variant = (lv & 0xff) | (gv << 8) | (lv & (1 << 16))
                 try:
                     with torch.no_grad():
                         us = time_fn(lambda: model(obs, goals, split, n_predict=12), iters=10, warmup=2)

@@ -31,6 +31,7 @@ class LstmModel(ctypes.Structure):
         ('dec_Wih', _fp), ('dec_Whh', _fp), ('dec_bih', _fp), ('dec_bhh', _fp),
         ('Wn', _fp), ('bn', _fp), ('Wh', _fp), ('bh', _fp),
         ('Wp', _fp * 3), ('bp', _fp * 3),
+        ('Wp0_cell_major', _fp),
         ('variant', ctypes.c_int32),
     ]
 
@@ -73,6 +74,12 @@ def lib():
     L.tnp_profile_begin.argtypes = [ctypes.c_int]
     L.tnp_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     L.tnp_constant_velocity.argtypes = [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp]
+    L.tnp_pool_embed_sparse_workspace_bytes.restype = ctypes.c_size_t
+    L.tnp_pool_embed_sparse_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.tnp_row_base.argtypes = [_fp, ctypes.c_int, _fp, _fp]
+    L.tnp_pool_embed_sparse_forward.argtypes = [_fp, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp,
+                                                ctypes.c_size_t, _fp]
     L.tnp_mfma_probe.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]
     if L.tnp_abi_version() != 1:
         raise RuntimeError('libtrajnet_hip.so ABI version mismatch')

@@ -210,6 +210,10 @@ struct Workspace {
     float *grid;
     float *y[2];
     uint8_t *mask;
+    int16_t *winners;
+    int32_t *row_base;
+    float *partial;
+    int sparse;   // first embedding layer runs on the winner table (pool_embed_sparse.hip)
     int I, Fin, ldg;
     size_t bytes;
 };
@@ -240,6 +244,15 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     w.y[0] = (float *)take((size_t)M * maxmid * 4);
     w.y[1] = (float *)take((size_t)M * maxmid * 4);
     w.mask = (uint8_t *)take((size_t)M);
+    w.sparse = pool && md->pool_type == TNP_POOL_SOCIAL && md->Wp0_cell_major != nullptr && md->constant == 0.0f &&
+               ((md->variant >> 16) & 1) == 0 && sparse_supported(md->C, md->dims[1], md->n * md->n) && (w.I % 4 == 0);
+    w.winners = nullptr; w.row_base = nullptr; w.partial = nullptr;
+    if (w.sparse) {
+        w.winners = (int16_t *)take((size_t)M * md->n * md->n * sizeof(int16_t));
+        w.row_base = (int32_t *)take((size_t)M * sizeof(int32_t));
+        const size_t pb = sparse_partial_bytes(M, md->dims[1], md->n * md->n);
+        if (pb) w.partial = (float *)take(pb);
+    }
     w.bytes = off;
     return 0;
 }
@@ -268,12 +281,24 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, const Workspace 
         ga.obs1 = w.obs1; ga.obs2 = w.obs2; ga.values = w.enc; ga.ldv = md->C; ga.scene_start = scene_start;
         ga.B = B; ga.n_max = n_max; ga.type = md->pool_type; ga.n = md->n; ga.C = md->C;
         ga.cell = md->cell; ga.half_x = md->half_x; ga.half_y = md->half_y; ga.constant = md->constant;
-        ga.grid = w.grid; ga.ldg = w.ldg; ga.winners = nullptr;
+        ga.grid = w.sparse ? nullptr : w.grid; ga.ldg = w.ldg; ga.winners = w.sparse ? w.winners : nullptr;
         int rc = launch_grid(ga, s);
         if (rc) return rc;
         const float *src = w.grid;
         int lds = w.ldg;
-        for (int l = 0; l < md->n_layers; ++l) {
+        int l0 = 0;
+        if (w.sparse) {  // first layer straight from the winner table
+            const bool last = (md->n_layers == 1);
+            float *dst = last ? (w.X + (w.I - md->P)) : w.y[0];
+            const int ldo = last ? w.I : md->dims[1];
+            prof_before(PROF_GEMM1, s);
+            rc = launch_pool_embed_sparse(w.winners, w.enc, md->C, w.row_base, md->Wp0_cell_major, md->bp[0], M,
+                                          md->n * md->n, md->C, md->dims[1], 1, dst, ldo, w.partial, s);
+            prof_after(PROF_GEMM1, s);
+            if (rc) return rc;
+            src = dst; lds = ldo; l0 = 1;
+        }
+        for (int l = l0; l < md->n_layers; ++l) {
             const bool last = (l == md->n_layers - 1);
             GemmArgs g;
             memset(&g, 0, sizeof(g));
@@ -351,6 +376,7 @@ extern "C" TNP_API int tnp_lstm_forward(const tnp_lstm_model *md, const float *o
         TNP_FAIL(-1, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
     const size_t F = (size_t)M * 2;
     const int H = md->H;
+    if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s); if (rc) return rc; }
     TNP_HIP(hipMemsetAsync(w.h[0], 0, (size_t)M * H * 4, s));  // lstm.py:207-210
     TNP_HIP(hipMemsetAsync(w.c, 0, (size_t)M * H * 4, s));
     int npos = 0, nnorm = 0, cur = 0;
@@ -416,6 +442,7 @@ extern "C" TNP_API int tnp_lstm_step(const tnp_lstm_model *md, int decoder, cons
     plan_workspace(md, M, workspace, w);
     if (workspace == nullptr || workspace_bytes < w.bytes)
         TNP_FAIL(-1, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s); if (rc) return rc; }
     PrepArgs p;
     fill_prep_common(p, md, w, M);
     p.h = h_in; p.goals = goals;

@@ -54,6 +54,14 @@ struct GridArgs {
 };
 int launch_grid(const GridArgs &a, hipStream_t s);
 
+// ---- sparse pooling embedding (first MLP layer on the winner table) ---------------------------
+bool sparse_supported(int C, int N1, int ncell);
+size_t sparse_partial_bytes(int M, int N1, int ncell);
+int launch_row_base(const int32_t *scene_start, int B, int32_t *row_base, hipStream_t s);
+int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, const int32_t *row_base,
+                             const float *Wp, const float *bias, int M, int ncell, int C, int N1, int relu,
+                             float *out, int ldo, float *partial, hipStream_t s);
+
 // ---- profiling hook -------------------------------------------------------------------------
 enum { PROF_GEMM1 = 0, PROF_ALL_GEMM = 1 };
 void prof_before(int cls, hipStream_t s);

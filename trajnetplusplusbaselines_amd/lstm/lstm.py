@@ -57,7 +57,10 @@ class LSTM(torch.nn.Module):
 
         #: kernel-variant selector forwarded to the C ABI (0 = defaults), see DESIGN.md
         self.kernel_variant = 0
+        #: run the first grid-embedding layer on the sparse winner table when the configuration allows it
+        self.sparse_embedding = True
         self._ws = None
+        self._cell_major = None  # (key, tensor): cell-major copy of pool.embedding[0].weight
 
     # ---- descriptor / workspace ---------------------------------------------------------------------
     def _descriptor(self):
@@ -108,8 +111,21 @@ class LSTM(torch.nn.Module):
                 m.bp[li] = P(lin.bias)
             if pool.type_ == 'social':
                 m.Wh, m.bh = P(pool.hidden_dim_encoding.weight), P(pool.hidden_dim_encoding.bias)
+                if self.sparse_embedding and float(pool.constant) == 0.0 and pool.pooling_dim in (4, 8, 16, 32) \
+                        and layers[0].weight.shape[0] % 4 == 0:
+                    m.Wp0_cell_major = P(self._cell_major_weight(layers[0].weight, pool))
         m.variant = int(self.kernel_variant)
         return m, keep, dev
+
+    def _cell_major_weight(self, weight, pool):
+        """W'[c][ch][o] = W[o][ch*n*n + c]: cell-major copy of the first embedding layer for the sparse kernel
+        (pool_embed_sparse.hip); rebuilt only when the parameter changes (data_ptr / in-place version)."""
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device))
+        if self._cell_major is None or self._cell_major[0] != key:
+            n1 = weight.shape[0]
+            w = weight.detach().float().view(n1, pool.pooling_dim, pool.n * pool.n).permute(2, 1, 0).contiguous()
+            self._cell_major = (key, w)
+        return self._cell_major[1]
 
     def _workspace(self, m, M, B, dev):
         need = _lib.lib().tnp_lstm_workspace_bytes(ctypes.byref(m), M, B)
