@@ -154,6 +154,21 @@ TNP_API int tnp_lstm_step(const tnp_lstm_model *model, int decoder, const float 
                   size_t workspace_bytes, void *stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Losses on the primaries (rows scene_start[s]) of a batch, lstm/loss.py:
+ *   mode 0  PredictionLoss.forward (:52-91): -log(0.01 + bg*N(x;mu,3,3,0) + (0.99-bg)*N(x;mu,sigma,rho))
+ *   mode 1  L2Loss.forward (:107-135): squared error of (mu_x, mu_y); scale carries the x100 (and the 1/2 of the
+ *           mean over the two coordinates)
+ *   inputs [T,M,5], targets [T,M,2]; out: [1] mean (keep_batch_dim = 0) or [B] per-scene mean over time;
+ *   values_ws: T*B floats of scratch.
+ * tnp_collision_loss_forward = CollisionLoss (:138-162) over predictions [T,M,ld] (first two columns), out [1].
+ * ----------------------------------------------------------------------------------------- */
+TNP_API int tnp_primary_loss_forward(int mode, const float *inputs, const float *targets, const int32_t *scene_start,
+                             int B, int T, int M, float background_rate, int keep_batch_dim, float scale,
+                             float *values_ws, float *out, void *stream);
+TNP_API int tnp_collision_loss_forward(const float *predictions, int ld, const int32_t *scene_start, int B, int T,
+                               int M, float col_wt, float col_distance, float *partial_ws, float *out, void *stream);
+
+/* -------------------------------------------------------------------------------------------
  * Kernel timing hook for bench.py's roofline leg: when enabled, every launch of the dominant
  * kernel class (`which`: 0 = first pooling-embedding GEMM, 1 = all GEMM launches) on `stream`
  * is bracketed by hipEvents; tnp_profile_read synchronises those events and returns the summed

@@ -164,9 +164,45 @@ def lstm_case(ref, kind):
     print('lstm_%s.npz' % kind)
 
 
+def loss_cases(ref):
+    """PredictionLoss / L2Loss / CollisionLoss values of the reference on random normals (lstm/loss.py)."""
+    import trajnetbaselines.lstm.loss as ref_loss
+    rng = np.random.RandomState(77)
+    out = {}
+    for k, (T, sizes) in enumerate(((12, [5, 3, 8, 1, 6]), (11, [32] * 8))):
+        split = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        M = int(split[-1])
+        normals = rng.randn(T, M, 5).astype(np.float32) * 0.3
+        normals[:, :, 2:4] = 0.01 + 0.2 / (1 + np.exp(-normals[:, :, 2:4]))
+        normals[:, :, 4] = 0.7 / (1 + np.exp(-normals[:, :, 4]))
+        targets = (normals[:, :, :2] + rng.randn(T, M, 2).astype(np.float32) * 0.1).astype(np.float32)
+        positions = np.cumsum(rng.randn(T, M, 2).astype(np.float32) * 0.3, axis=0)
+        positions[:, 1::3] = positions[:, 0:1] + np.float32(0.05)          # some neighbours collide with a primary
+        positions[2:, 2] = np.nan
+        tsplit = torch.tensor(split)
+        pre = 'l%d_' % k
+        out.update({pre + 'normals': normals, pre + 'targets': targets, pre + 'positions': positions, pre + 'split': split})
+        for bg in (0.2, 0.0):
+            for keep in (False, True):
+                crit = ref.PredictionLoss(keep_batch_dim=keep, background_rate=bg)
+                out[pre + 'nll_bg%g_keep%d' % (bg, keep)] = np.atleast_1d(
+                    crit(torch.tensor(normals), torch.tensor(targets), tsplit).numpy())
+        for keep in (False, True):
+            crit = ref.L2Loss(keep_batch_dim=keep)
+            out[pre + 'l2_keep%d' % keep] = np.atleast_1d(crit(torch.tensor(normals), torch.tensor(targets), tsplit).numpy())
+        for cw, cd in ((2.0, 0.2), (10.0, 0.5)):
+            val = ref_loss.CollisionLoss(torch.tensor(positions.copy()), tsplit, col_wt=cw, col_distance=cd)
+            out[pre + 'col_%g_%g' % (cw, cd)] = np.atleast_1d(np.float32(float(val)))
+    np.savez_compressed(os.path.join(OUT, 'loss_cases.npz'), **out)
+    print('loss_cases.npz')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.import_reference()
+    loss_cases(ref)
+    if '--only-new' in sys.argv:
+        return
     grid_cases(ref)
     for kind in ('vanilla', 'occupancy', 'directional', 'social', 'social_goals'):
         lstm_case(ref, kind)

@@ -202,3 +202,26 @@ def ade_fde(pred, gt):
     """pred, gt [T, 2] -> (ADE, FDE) in metres."""
     d = np.linalg.norm(np.asarray(pred, dtype=np.float64) - np.asarray(gt, dtype=np.float64), axis=-1)
     return float(np.mean(d)), float(d[-1])
+
+
+# --------------------------------------------------------------------------
+# losses (lstm/loss.py)
+# --------------------------------------------------------------------------
+def primary_loss(mode, inputs, targets, batch_split, background_rate=0.2, keep_batch_dim=False, multiplier=1.0):
+    inputs, targets = _c32(inputs), _c32(targets)
+    split = np.ascontiguousarray(np.asarray(batch_split, dtype=np.int64))
+    B, T, M = len(split) - 1, inputs.shape[0], inputs.shape[1]
+    out = np.empty(B if keep_batch_dim else 1, dtype=np.float32)
+    lib().orc_primary_loss(int(mode), _p(inputs), _p(targets), split.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), B, T,
+                           M, ctypes.c_float(background_rate), int(keep_batch_dim), ctypes.c_float(multiplier), _p(out))
+    return out if keep_batch_dim else float(out[0])
+
+
+def collision_loss(predictions, batch_split, col_wt=10.0, col_distance=0.2):
+    pred = _c32(predictions)
+    split = np.ascontiguousarray(np.asarray(batch_split, dtype=np.int64))
+    L = lib()
+    L.orc_collision_loss.restype = ctypes.c_float
+    return float(L.orc_collision_loss(_p(pred), pred.shape[2], split.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                      len(split) - 1, pred.shape[0], pred.shape[1], ctypes.c_float(col_wt),
+                                      ctypes.c_float(col_distance)))

@@ -527,3 +527,67 @@ ORC_API void orc_constant_velocity(const double *xy, int T, int N, int n_predict
 }
 
 ORC_API int orc_abi_version(void) { return 1; }
+
+/* ------------------------------------------------------------------------- *
+ * Losses, lstm/loss.py.  inputs [T,M,5], targets [T,M,2]; primaries = rows split[s].
+ * ------------------------------------------------------------------------- */
+static float gaussian_2d_f(const float *p, float s1, float s2, float rho, const float *x) {
+    /* lstm/loss.py:23-50 */
+    float norm1 = x[0] - p[0], norm2 = x[1] - p[1];
+    float s1s2 = s1 * s2;
+    float q1 = norm1 / s1, q2 = norm2 / s2;
+    float z = q1 * q1 + q2 * q2 - 2.0f * rho * norm1 * norm2 / s1s2;
+    float omr = 1.0f - rho * rho;
+    float num = expf(-z / (2.0f * omr));
+    float den = 6.283185307179586f * s1s2 * sqrtf(omr);
+    return num / den;
+}
+
+/* mode 0: PredictionLoss.forward (:52-91); mode 1: L2Loss.forward (:107-135).
+ * keep_batch_dim: out [B] (mean over time; L2 also over the 2 coordinates), else out [1] (mean over everything).
+ * The result is multiplied by `multiplier` (1 / 100). */
+ORC_API void orc_primary_loss(int mode, const float *inputs, const float *targets, const int64_t *split, int B, int T,
+                              int M, float bg, int keep_batch_dim, float multiplier, float *out) {
+    double tot = 0.0;
+    for (int s = 0; s < B; ++s) {
+        double acc = 0.0;
+        for (int t = 0; t < T; ++t) {
+            const float *in = inputs + ((size_t)t * M + split[s]) * 5;
+            const float *tg = targets + ((size_t)t * M + split[s]) * 2;
+            float v;
+            if (mode == 0) {
+                float g_bg = gaussian_2d_f(in, 3.0f, 3.0f, 0.0f, tg);          /* :73-76 */
+                float g = gaussian_2d_f(in, in[2], in[3], in[4], tg);
+                v = -logf(0.01f + bg * g_bg + (0.99f - bg) * g);              /* :78-82 */
+            } else {
+                float d0 = in[0] - tg[0], d1 = in[1] - tg[1];
+                v = 0.5f * (d0 * d0 + d1 * d1);                              /* mean over the 2 coordinates */
+            }
+            acc += v;
+        }
+        if (keep_batch_dim) out[s] = (float)(acc / T) * multiplier;
+        tot += acc;
+    }
+    if (!keep_batch_dim) out[0] = (float)(tot / ((double)T * B)) * multiplier;
+}
+
+/* CollisionLoss, lstm/loss.py:138-162 (predictions [T,M,ld], first two columns) */
+ORC_API float orc_collision_loss(const float *pred, int ld, const int64_t *split, int B, int T, int M, float col_wt,
+                                 float col_distance) {
+    double loss = 0.0;
+    for (int s = 0; s < B; ++s) {
+        int lo = (int)split[s], hi = (int)split[s + 1];
+        double a = 0.0;
+        for (int t = 0; t < T; ++t)
+            for (int j = lo + 1; j < hi; ++j) {
+                const float *pp = pred + ((size_t)t * M + lo) * ld, *pn = pred + ((size_t)t * M + j) * ld;
+                float px = pp[0] != pp[0] ? -1000.0f : pp[0], py = pp[1] != pp[1] ? -1000.0f : pp[1];
+                float nx = pn[0] != pn[0] ? -1000.0f : pn[0], ny = pn[1] != pn[1] ? -1000.0f : pn[1];
+                float dx = px - nx, dy = py - ny;
+                float d = sqrtf(dx * dx + dy * dy);
+                if (d <= col_distance) a += 1.0f - d / col_distance;
+            }
+        loss += col_wt * a;
+    }
+    return (float)loss;
+}

@@ -1,0 +1,87 @@
+"""Losses (reference lstm/loss.py): oracle vs the reference's golden values and adapted known-answer vectors
+(reference tests/test_lstm_loss.py:12-43, 63-83) on CPU; HIP kernels vs both on the GPU."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'loss_cases.npz'))
+CASES = [0, 1]
+
+
+def _collision_known_answer():
+    predictions = np.array([[[0, 0], [1, 0], [2, 0], [3, 0]],
+                            [[0, 4], [1, 3], [2, 2], [3, 1]],
+                            [[0, -3], [1, -2], [2, -1], [3, -1]],
+                            [[0, -8], [1, -8], [2, -8], [3, -8]]], dtype=np.float32).transpose(1, 0, 2)
+    return np.ascontiguousarray(predictions), np.array([0, 4])
+
+
+def test_oracle_known_answers():
+    params = np.array([[[0, 0, 1, 1, 0], [0, 0, 1, 1, 0]]], dtype=np.float32)
+    coords = np.zeros((1, 2, 2), dtype=np.float32)
+    got = oracle.primary_loss(0, params, coords, [0, 1, 2], background_rate=0.0, keep_batch_dim=True)
+    want = -math.log(0.01 + 0.99 / (2 * math.pi))
+    assert got.tolist() == pytest.approx([want, want], rel=1e-4)
+    pred, split = _collision_known_answer()
+    assert oracle.collision_loss(pred, split, 2.0, 2.0) == 3.0
+    assert oracle.collision_loss(pred, split, 4.0, 2.0) == 6.0
+    assert oracle.collision_loss(pred, split, 2.0, 4.0) == 7.5
+
+
+@pytest.mark.parametrize('k', CASES)
+def test_oracle_losses_match_reference(k):
+    pre = 'l%d_' % k
+    n, t, p, split = GOLD[pre + 'normals'], GOLD[pre + 'targets'], GOLD[pre + 'positions'], GOLD[pre + 'split']
+    for bg in (0.2, 0.0):
+        for keep in (False, True):
+            got = np.atleast_1d(oracle.primary_loss(0, n, t, split, bg, keep))
+            np.testing.assert_allclose(got, GOLD[pre + 'nll_bg%g_keep%d' % (bg, keep)], rtol=2e-5, atol=1e-6)
+    for keep in (False, True):
+        got = np.atleast_1d(oracle.primary_loss(1, n, t, split, 0.0, keep, multiplier=100.0))
+        np.testing.assert_allclose(got, GOLD[pre + 'l2_keep%d' % keep], rtol=2e-5)
+    for cw, cd in ((2.0, 0.2), (10.0, 0.5)):
+        np.testing.assert_allclose(oracle.collision_loss(p, split, cw, cd), GOLD[pre + 'col_%g_%g' % (cw, cd)][0], rtol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k', CASES)
+def test_gpu_losses_match_reference(k):
+    from trajnetplusplusbaselines_amd.lstm import PredictionLoss, L2Loss, CollisionLoss
+    pre = 'l%d_' % k
+    n, t = torch.tensor(GOLD[pre + 'normals']).cuda(), torch.tensor(GOLD[pre + 'targets']).cuda()
+    p, split = torch.tensor(GOLD[pre + 'positions']).cuda(), torch.tensor(GOLD[pre + 'split'])
+    for bg in (0.2, 0.0):
+        for keep in (False, True):
+            got = np.atleast_1d(PredictionLoss(keep_batch_dim=keep, background_rate=bg)(n, t, split).cpu().numpy())
+            np.testing.assert_allclose(got, GOLD[pre + 'nll_bg%g_keep%d' % (bg, keep)], rtol=2e-5, atol=1e-6)
+    for keep in (False, True):
+        got = np.atleast_1d(L2Loss(keep_batch_dim=keep)(n, t, split).cpu().numpy())
+        np.testing.assert_allclose(got, GOLD[pre + 'l2_keep%d' % keep], rtol=2e-5)
+    for cw, cd in ((2.0, 0.2), (10.0, 0.5)):
+        got = float(CollisionLoss(p, split, cw, cd).cpu())
+        np.testing.assert_allclose(got, GOLD[pre + 'col_%g_%g' % (cw, cd)][0], rtol=2e-5)
+    # with the auxiliary collision term (lstm/loss.py:89-90)
+    crit = PredictionLoss(col_wt=2.0, col_distance=0.2)
+    got = float(crit(n, t, split, positions=p).cpu())
+    want = GOLD[pre + 'nll_bg0.2_keep0'][0] + GOLD[pre + 'col_2_0.2'][0]
+    np.testing.assert_allclose(got, want, rtol=2e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_known_answers():
+    from trajnetplusplusbaselines_amd.lstm import PredictionLoss, CollisionLoss
+    params = torch.tensor([[[0, 0, 1, 1, 0], [0, 0, 1, 1, 0]]], dtype=torch.float32).cuda()
+    coords = torch.zeros(1, 2, 2).cuda()
+    got = PredictionLoss(keep_batch_dim=True, background_rate=0.0)(params, coords, torch.tensor([0, 1, 2])).cpu().tolist()
+    want = -math.log(0.01 + 0.99 / (2 * math.pi))
+    assert got == pytest.approx([want, want], rel=1e-4)
+    pred, split = _collision_known_answer()
+    pt = torch.tensor(pred).cuda()
+    assert float(CollisionLoss(pt, torch.tensor(split), 2.0, 2.0)) == 3.0
+    assert float(CollisionLoss(pt, torch.tensor(split), 4.0, 2.0)) == 6.0
+    assert float(CollisionLoss(pt, torch.tensor(split), 2.0, 4.0)) == 7.5

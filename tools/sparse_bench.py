@@ -6,7 +6,8 @@ dev = torch.device('cuda')
 B, N, n, C, N1 = 64, 32, 16, 16, 1024
 M, ncell = B * N, n * n
 g = torch.Generator().manual_seed(0)
-obs2 = (torch.rand(M, 2, generator=g) * 8 - 4).to(dev); obs1 = obs2 - 0.1
+SPREAD = float(os.environ.get('SPREAD', '8'))
+obs2 = (torch.rand(M, 2, generator=g) * SPREAD - SPREAD / 2).to(dev); obs1 = obs2 - 0.1
 enc = torch.randn(M, C, generator=g).to(dev)
 st = torch.arange(0, M + 1, N, dtype=torch.int32, device=dev)
 W = (torch.randn(N1, C * ncell, generator=g) / 20).to(dev); b = torch.randn(N1, generator=g).to(dev)

@@ -80,6 +80,10 @@ def lib():
     L.tnp_pool_embed_sparse_forward.argtypes = [_fp, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp,
                                                 ctypes.c_size_t, _fp]
+    L.tnp_primary_loss_forward.argtypes = [ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_float, ctypes.c_int, ctypes.c_float, _fp, _fp, _fp]
+    L.tnp_collision_loss_forward.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_float, ctypes.c_float, _fp, _fp, _fp]
     L.tnp_mfma_probe.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]
     if L.tnp_abi_version() != 1:
         raise RuntimeError('libtrajnet_hip.so ABI version mismatch')

@@ -1,0 +1,131 @@
+// Losses of the reference's lstm/loss.py on the primaries of a batch (gfx950): PredictionLoss (2-D Gaussian NLL with
+// a flat background, :6-91), L2Loss (:93-135) and CollisionLoss (:138-162).  One lane per (time step, scene);
+// reductions are two-stage, fixed order (deterministic).
+#include "tnp_internal.h"
+
+namespace tnp {
+
+__device__ __forceinline__ float gaussian_2d_dev(float mu1, float mu2, float s1, float s2, float rho, float x1, float x2) {
+    // lstm/loss.py:23-50, same operation order
+    const float norm1 = x1 - mu1, norm2 = x2 - mu2;
+    const float s1s2 = s1 * s2;
+    const float q1 = norm1 / s1, q2 = norm2 / s2;
+    const float z = q1 * q1 + q2 * q2 - 2.0f * rho * norm1 * norm2 / s1s2;
+    const float omr = 1.0f - rho * rho;
+    const float num = expf(-z / (2.0f * omr));
+    const float den = 6.283185307179586f * s1s2 * sqrtf(omr);
+    return num / den;
+}
+
+// values[t*B + s] = per-element loss of primary s at step t;  mode 0 = PredictionLoss, 1 = L2 (sum of the 2 squared errors)
+__global__ void loss_values_kernel(int mode, const float *inputs, const float *targets, const int32_t *scene_start,
+                                   int B, int T, int M, float bg, float *values) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * B) return;
+    const int t = idx / B, s = idx - t * B;
+    const int m = scene_start[s];
+    const float *in = inputs + ((size_t)t * M + m) * 5;
+    const float *tg = targets + ((size_t)t * M + m) * 2;
+    float v;
+    if (mode == 0) {
+        const float g_bg = gaussian_2d_dev(in[0], in[1], 3.0f, 3.0f, 0.0f, tg[0], tg[1]);   // :73-76
+        const float g = gaussian_2d_dev(in[0], in[1], in[2], in[3], in[4], tg[0], tg[1]);
+        v = -logf(0.01f + bg * g_bg + (0.99f - bg) * g);                                       // :78-82
+    } else {
+        const float d0 = in[0] - tg[0], d1 = in[1] - tg[1];
+        v = d0 * d0 + d1 * d1;
+    }
+    values[idx] = v;
+}
+
+// out[s] = scale * mean_t values[t*B+s]   (keep_batch_dim)   or   out[0] = scale * mean over everything
+__global__ void __launch_bounds__(256) loss_reduce_kernel(const float *values, int B, int T, int per_scene, float scale,
+                                                          float *out) {
+    __shared__ float sh[256];
+    const int tid = threadIdx.x;
+    if (per_scene) {
+        const int s = blockIdx.x;
+        float a = 0.0f;
+        for (int t = tid; t < T; t += 256) a += values[(size_t)t * B + s];
+        sh[tid] = a;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) { if (tid < w) sh[tid] += sh[tid + w]; __syncthreads(); }
+        if (tid == 0) out[s] = scale * (sh[0] / (float)T);
+    } else {
+        float a = 0.0f;
+        for (int q = tid; q < T * B; q += 256) a += values[q];
+        sh[tid] = a;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) { if (tid < w) sh[tid] += sh[tid + w]; __syncthreads(); }
+        if (tid == 0) out[0] = scale * (sh[0] / (float)(T * B));
+    }
+}
+
+// CollisionLoss, lstm/loss.py:138-162: one workgroup per scene, partial[s] = col_wt * sum (1 - d/col_distance)
+__global__ void __launch_bounds__(256) collision_scene_kernel(const float *pred, int ld, const int32_t *scene_start, int T,
+                                                              int M, float col_wt, float col_distance, float *partial) {
+    __shared__ float sh[256];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int lo = scene_start[s], hi = scene_start[s + 1];
+    const int nn = hi - lo - 1;
+    float a = 0.0f;
+    for (int q = tid; q < T * nn; q += 256) {
+        const int t = q / nn, j = lo + 1 + (q - t * nn);
+        const float *pp = pred + ((size_t)t * M + lo) * ld, *pn = pred + ((size_t)t * M + j) * ld;
+        float px = pp[0], py = pp[1], nx = pn[0], ny = pn[1];
+        if (px != px) px = -1000.0f;   // :148 NaN -> -1000 (elementwise)
+        if (py != py) py = -1000.0f;
+        if (nx != nx) nx = -1000.0f;
+        if (ny != ny) ny = -1000.0f;
+        const float dx = px - nx, dy = py - ny;
+        const float d = sqrtf(dx * dx + dy * dy);
+        if (d <= col_distance) a += 1.0f - d / col_distance;
+    }
+    sh[tid] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (tid < w) sh[tid] += sh[tid + w]; __syncthreads(); }
+    if (tid == 0) partial[s] = col_wt * sh[0];
+}
+
+__global__ void __launch_bounds__(256) sum_kernel(const float *x, int n, float *out) {
+    __shared__ float sh[256];
+    const int tid = threadIdx.x;
+    float a = 0.0f;
+    for (int q = tid; q < n; q += 256) a += x[q];
+    sh[tid] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (tid < w) sh[tid] += sh[tid + w]; __syncthreads(); }
+    if (tid == 0) out[0] = sh[0];
+}
+
+}  // namespace tnp
+
+extern "C" TNP_API int tnp_primary_loss_forward(int mode, const float *inputs, const float *targets,
+                                                const int32_t *scene_start, int B, int T, int M, float background_rate,
+                                                int keep_batch_dim, float scale, float *values_ws, float *out,
+                                                void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (mode != 0 && mode != 1) TNP_FAIL(-1, "tnp_primary_loss_forward: mode must be 0 (NLL) or 1 (L2)");
+    if (B <= 0 || T <= 0) return 0;
+    const int n = T * B;
+    hipLaunchKernelGGL(tnp::loss_values_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mode, inputs, targets, scene_start,
+                       B, T, M, background_rate, values_ws);
+    TNP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(tnp::loss_reduce_kernel, dim3(keep_batch_dim ? B : 1), dim3(256), 0, s, values_ws, B, T,
+                       keep_batch_dim, scale, out);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" TNP_API int tnp_collision_loss_forward(const float *predictions, int ld, const int32_t *scene_start, int B,
+                                                  int T, int M, float col_wt, float col_distance, float *partial_ws,
+                                                  float *out, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(tnp::collision_scene_kernel, dim3(B), dim3(256), 0, s, predictions, ld, scene_start, T, M, col_wt,
+                       col_distance, partial_ws);
+    TNP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(tnp::sum_kernel, dim3(1), dim3(256), 0, s, partial_ws, B, out);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}

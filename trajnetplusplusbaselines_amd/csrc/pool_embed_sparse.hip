@@ -465,6 +465,144 @@ __global__ void __launch_bounds__(256 * EQ) pool_embed_sparse_list_kernel(const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Register-accumulator variant.  Wave (q, cs) keeps the accumulators of its 32 egos x 64 columns in 32 VGPRs
+// (lane <-> column): the ego of a hit is wave-uniform, so "acc[ego] += c" is a scalar jump into a 32-way switch
+// of single v_add instructions -- no LDS traffic for the accumulators at all.  LDS only holds the compact
+// per-(cell, ego group) hit lists (neighbour row << 8 | ego).  Per hit: one s_load_dwordx16 of the neighbour's
+// values (SGPR FMA operands), C FMAs, one add.
+// ---------------------------------------------------------------------------------------------------------
+#define SP_ACC_CASE(i) case i: acc[i] += c; break;
+#define SP_ACC_SWITCH(el, c) switch (el) { \
+    SP_ACC_CASE(0) SP_ACC_CASE(1) SP_ACC_CASE(2) SP_ACC_CASE(3) SP_ACC_CASE(4) SP_ACC_CASE(5) SP_ACC_CASE(6) SP_ACC_CASE(7) \
+    SP_ACC_CASE(8) SP_ACC_CASE(9) SP_ACC_CASE(10) SP_ACC_CASE(11) SP_ACC_CASE(12) SP_ACC_CASE(13) SP_ACC_CASE(14) SP_ACC_CASE(15) \
+    SP_ACC_CASE(16) SP_ACC_CASE(17) SP_ACC_CASE(18) SP_ACC_CASE(19) SP_ACC_CASE(20) SP_ACC_CASE(21) SP_ACC_CASE(22) SP_ACC_CASE(23) \
+    SP_ACC_CASE(24) SP_ACC_CASE(25) SP_ACC_CASE(26) SP_ACC_CASE(27) SP_ACC_CASE(28) SP_ACC_CASE(29) SP_ACC_CASE(30) SP_ACC_CASE(31) \
+    default: break; }
+
+template <int C>
+__global__ void __launch_bounds__(1024) pool_embed_sparse_reg_kernel(const SparseArgs a, int hcap) {
+    extern __shared__ __attribute__((aligned(16))) float ssm[];
+    constexpr int EQ = 4, NTH = 1024, EPG = 32;
+    constexpr int TAB = 128 * EQ + 4;
+    int *hits = reinterpret_cast<int *>(ssm);                // [hcap]
+    int *cstart = hits + hcap;                               // [TAB]
+    int *cursor = cstart + TAB;                              // [TAB]
+    int *cnt = cursor + TAB;                                 // [TAB]
+    int *ctl = cnt + TAB;                                    // [4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cs = wave & 3, eq = wave >> 2;
+    const int ncombo = a.out_blocks * a.S;
+    int combo, et;
+    if ((ncombo & 7) == 0) {
+        const int cpx = ncombo >> 3, xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+        combo = xcd * cpx + (l % cpx);
+        et = l / cpx;
+    } else {
+        combo = blockIdx.x % ncombo;
+        et = blockIdx.x / ncombo;
+    }
+    const int ob = combo % a.out_blocks, sp = combo / a.out_blocks;
+    const int row0 = et * SP_TE;
+    const int c0 = sp * a.cps;
+    const int ncl = min(a.cps, a.ncell - c0);
+    const int o = ob * SP_OB + cs * 64 + lane;
+    const bool o_ok = o < a.N1;
+    const int oc = o_ok ? o : (a.N1 - 1);
+
+    for (int q = tid; q < TAB; q += NTH) cnt[q] = 0;
+    __syncthreads();
+    for (int q = tid; q < SP_TE * ncl; q += NTH) {
+        const int e = q / ncl, cc = q - e * ncl;
+        const int row = row0 + e;
+        if (row < a.M && a.winners[(size_t)row * a.ncell + c0 + cc] >= 0) atomicAdd(&cnt[cc * EQ + e / EPG], 1);
+    }
+    __syncthreads();
+
+    float acc[EPG];
+#pragma unroll
+    for (int i = 0; i < EPG; ++i) acc[i] = 0.0f;
+    const float *wcol = a.Wp + oc;
+    const float *encp = a.enc;
+    const int ldv = a.ldv;
+    auto load_w = [&](float (&w)[C], int cc) {
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) w[ch] = wcol[((size_t)(c0 + cc) * C + ch) * a.N1];
+    };
+    auto process = [&](const float (&w)[C], int cc) {
+        int k = cstart[cc * EQ + eq];
+        const int k1 = cstart[cc * EQ + eq + 1];
+        for (; k < k1; ++k) {
+            const int h0 = __builtin_amdgcn_readfirstlane(hits[k]);
+            const float *e0 = encp + (size_t)(h0 >> 8) * ldv;
+            float c = 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) c = fmaf(w[ch], e0[ch], c);
+            const int el = (h0 & 255) - eq * EPG;
+            SP_ACC_SWITCH(el, c)
+        }
+    };
+
+    int pass_lo = 0;
+    while (pass_lo < ncl) {
+        if (tid == 0) {
+            int tot = 0, c = pass_lo;
+            while (c < ncl) {
+                int cell_tot = 0;
+                for (int gq = 0; gq < EQ; ++gq) cell_tot += cnt[c * EQ + gq];
+                if (c > pass_lo && tot + cell_tot > hcap) break;
+                for (int gq = 0; gq < EQ; ++gq) { cstart[(c - pass_lo) * EQ + gq] = tot; tot += cnt[c * EQ + gq]; }
+                ++c;
+            }
+            cstart[(c - pass_lo) * EQ] = tot;
+            ctl[0] = c;
+        }
+        for (int q = tid; q < TAB; q += NTH) cursor[q] = 0;
+        __syncthreads();
+        const int pass_hi = ctl[0];
+        const int npc = pass_hi - pass_lo;
+        for (int q = tid; q < SP_TE * npc; q += NTH) {
+            const int e = q / npc, cc = q - e * npc;
+            const int row = row0 + e;
+            if (row >= a.M) continue;
+            const int wv = a.winners[(size_t)row * a.ncell + c0 + pass_lo + cc];
+            if (wv < 0) continue;
+            const int li = cc * EQ + e / EPG;
+            const int slot = cstart[li] + atomicAdd(&cursor[li], 1);
+            if (slot < hcap) hits[slot] = ((a.row_base[row] + wv) << 8) | e;
+        }
+        __syncthreads();
+        float wA[C], wB[C];
+        load_w(wA, pass_lo);
+        for (int cc = 0; cc < npc; cc += 2) {
+            if (cc + 1 < npc) load_w(wB, pass_lo + cc + 1);
+            process(wA, cc);
+            if (cc + 1 < npc) {
+                if (cc + 2 < npc) load_w(wA, pass_lo + cc + 2);
+                process(wB, cc + 1);
+            }
+        }
+        __syncthreads();
+        pass_lo = pass_hi;
+    }
+
+    if (o_ok) {
+        const float b = (a.S == 1 && a.bias) ? a.bias[o] : 0.0f;
+        float *pp = (a.S == 1) ? a.out : a.out + (size_t)sp * a.M * a.N1;
+        const int ld = (a.S == 1) ? a.ldo : a.N1;
+#pragma unroll
+        for (int i = 0; i < EPG; ++i) {
+            const int row = row0 + eq * EPG + i;
+            if (row < a.M) {
+                float v = acc[i] + b;
+                if (a.S == 1 && a.relu) v = v > 0.0f ? v : 0.0f;
+                pp[(size_t)row * ld + o] = v;
+            }
+        }
+    }
+}
+
 // Y[m][o] = act(bias[o] + sum_s partial[s][m][o]), fixed summation order
 __global__ void __launch_bounds__(256) sparse_reduce_kernel(const float *partial, int S, int M, int N1, const float *bias,
                                                             int relu, float *out, int ldo) {
@@ -549,7 +687,13 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
         static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
         pool_embed_sparse_list_kernel<CC, EQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
         hipLaunchKernelGGL((pool_embed_sparse_list_kernel<CC, EQ>), dim3(blocks), dim3(256 * EQ), sm, s, a, hc); }
+#define SP_LAUNCH6(CC) { const int tab = 128 * 4 + 4; const int hc = 16384; \
+        const size_t sm = (size_t)hc * 4 + (size_t)3 * tab * 4 + 64; \
+        static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
+        pool_embed_sparse_reg_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((pool_embed_sparse_reg_kernel<CC>), dim3(blocks), dim3(1024), sm, s, a, hc); }
 #define SP_LAUNCH(CC) { switch (sp_variant) { \
+        case 30: SP_LAUNCH6(CC) break; \
         case 20: SP_LAUNCH5(CC, 1) break; case 21: SP_LAUNCH5(CC, 2) break; case 22: SP_LAUNCH5(CC, 4) break; \
         case 10: SP_LAUNCH3(CC, 1) break; case 11: SP_LAUNCH3(CC, 2) break; case 12: SP_LAUNCH3(CC, 4) break; \
         case 1: SP_LAUNCH2(CC, 1, true) break; case 2: SP_LAUNCH2(CC, 2, false) break; case 3: SP_LAUNCH2(CC, 2, true) break; \
