@@ -186,6 +186,28 @@ TNP_API int tnp_constant_velocity(const double *last, const double *prev, int N,
                           void *stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Batched classical rollouts (one workgroup per scene).  The reference wrappers simulate one scene per call through
+ * un-vendored CPU libraries (socialforce, rvo2, pykalman); initial states are built on the host exactly as the
+ * wrappers do (classical/socialforce.py:15-72, classical/orca.py:14-79) and handed over flat with scene_start.
+ *   tnp_sf_rollout      socialforce.Simulator(...).step() x n_steps, state after every sample_every-th step
+ *                       (classical/socialforce.py:84-95).  state0 [M,6] f64 = x,y,vx,vy,goal_x,goal_y -> out [n_out,M,2]
+ *   tnp_orca_rollout    rvo2 doStep() x n_iter with the wrapper's preferred-velocity update (classical/orca.py:90-119),
+ *                       float32 simulator state, float64 goals / speeds -> out [n_out,M,2] f32;
+ *                       nbr_dbg (optional) [M,16] int32: neighbour indices of the first step (index parity checks)
+ *   tnp_kalman_predict  pykalman KalmanFilter(CV model).em(n_iter) -> smooth -> mean of n_samples sampled observation
+ *                       sequences (classical/kalman.py:40-60); obs [n_tracks,T,2] f64, z standard normal draws
+ *                       [n_tracks,n_samples,n_steps,6] f64 -> out [n_tracks,n_steps,2] (row 0 = last smoothed state)
+ * ----------------------------------------------------------------------------------------- */
+TNP_API int tnp_sf_rollout(const double *state0, const int32_t *scene_start, int B, int M, int n_max, int n_steps,
+                   int sample_every, double tau, double v0, double sigma, double delta_t, double *out, void *stream);
+TNP_API int tnp_orca_rollout(const float *pos0, const float *vel0, const double *goals, const double *speed,
+                     const float *max_speed, const int32_t *scene_start, int B, int M, int n_max, int n_iter,
+                     int sample_every, float time_step, float neighbor_dist, int max_neighbors, float time_horizon,
+                     float radius, float *out, int *nbr_dbg, void *stream);
+TNP_API int tnp_kalman_predict(const double *obs, int n_tracks, int T, int n_iter, int n_steps, int n_samples,
+                       const double *z, double transition_var, double observation_var, double *out, void *stream);
+
+/* -------------------------------------------------------------------------------------------
  * Calibration probe (measurement only): launches `blocks` workgroups of `waves_per_wg` waves,
  * each issuing iters*8*n_acc v_mfma_f32_32x32x2_f32 (4096 FLOP each) with no memory traffic.
  * scratch: >= 4 bytes of device memory (never written in practice).

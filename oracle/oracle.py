@@ -225,3 +225,54 @@ def collision_loss(predictions, batch_split, col_wt=10.0, col_distance=0.2):
     return float(L.orc_collision_loss(_p(pred), pred.shape[2], split.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
                                       len(split) - 1, pred.shape[0], pred.shape[1], ctypes.c_float(col_wt),
                                       ctypes.c_float(col_distance)))
+
+
+# --------------------------------------------------------------------------
+# classical predictors (oracle/classical_oracle.c; parity unpinned, see its header)
+# --------------------------------------------------------------------------
+_d = ctypes.POINTER(ctypes.c_double)
+_i32 = ctypes.POINTER(ctypes.c_int32)
+
+
+def _pd(a):
+    return a.ctypes.data_as(_d) if a is not None else ctypes.cast(None, _d)
+
+
+def sf_rollout(state0, scene_start, n_steps=96, sample_every=8, tau=0.5, v0=2.1, sigma=0.3, delta_t=0.05):
+    state0 = np.ascontiguousarray(state0, dtype=np.float64)
+    st = np.ascontiguousarray(scene_start, dtype=np.int32)
+    M, B = state0.shape[0], len(st) - 1
+    n_out = (n_steps + sample_every - 1) // sample_every
+    out = np.empty((n_out, M, 2), dtype=np.float64)
+    lib().orc_sf_rollout(_pd(state0), st.ctypes.data_as(_i32), B, M, n_steps, sample_every, ctypes.c_double(tau),
+                         ctypes.c_double(v0), ctypes.c_double(sigma), ctypes.c_double(delta_t), _pd(out))
+    return out
+
+
+def orca_rollout(pos0, vel0, goals, speed, max_speed, scene_start, n_iter=97, sample_every=8, time_step=0.05,
+                 neighbor_dist=1.5, max_neighbors=10, time_horizon=1.5, radius=0.4, want_neighbors=False):
+    pos0, vel0 = _c32(pos0), _c32(vel0)
+    goals = np.ascontiguousarray(goals, dtype=np.float64)
+    speed = np.ascontiguousarray(speed, dtype=np.float64)
+    max_speed = _c32(max_speed)
+    st = np.ascontiguousarray(scene_start, dtype=np.int32)
+    M, B = pos0.shape[0], len(st) - 1
+    n_out = n_iter // sample_every
+    out = np.empty((n_out, M, 2), dtype=np.float32)
+    nbr = np.full((M, 16), -1, dtype=np.int32) if want_neighbors else None
+    lib().orc_orca_rollout(_p(pos0), _p(vel0), _pd(goals), _pd(speed), _p(max_speed), st.ctypes.data_as(_i32), B, M, n_iter,
+                           sample_every, ctypes.c_float(time_step), ctypes.c_float(neighbor_dist), max_neighbors,
+                           ctypes.c_float(time_horizon), ctypes.c_float(radius), _p(out),
+                           nbr.ctypes.data_as(_i32) if nbr is not None else ctypes.cast(None, _i32))
+    return (out, nbr) if want_neighbors else out
+
+
+def kalman_predict(obs, z, n_iter=10, transition_var=1e-5, observation_var=0.05 ** 2):
+    obs = np.ascontiguousarray(obs, dtype=np.float64)
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    n_tracks, T = obs.shape[0], obs.shape[1]
+    n_samples, n_steps = z.shape[1], z.shape[2]
+    out = np.empty((n_tracks, n_steps, 2), dtype=np.float64)
+    lib().orc_kalman_predict(_pd(obs), n_tracks, T, n_iter, n_steps, n_samples, _pd(z), ctypes.c_double(transition_var),
+                             ctypes.c_double(observation_var), _pd(out))
+    return out

@@ -9,7 +9,7 @@ PKG = os.path.dirname(HERE)
 OUT_DIR = os.path.join(PKG, 'lib')
 OUT = os.path.join(OUT_DIR, 'libtrajnet_hip.so')
 SOURCES = ['gemm_f32_mfma.hip', 'pool_grid.hip', 'pool_embed_sparse.hip', 'lstm_seq.hip', 'loss.hip', 'classical.hip']
-HEADERS = ['tnp_internal.h', os.path.join('..', '..', 'include', 'trajnet_hip.h')]
+HEADERS = ['tnp_internal.h', 'classical_core.h', os.path.join('..', '..', 'include', 'trajnet_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-fvisibility=hidden',
          '-Wall', '-Wno-unused-function']
 
@@ -39,7 +39,9 @@ def build(force=False, verbose=False):
         if not os.path.exists(path):
             continue
         obj = os.path.join(OUT_DIR, os.path.splitext(src)[0] + '.o')
-        cmd = [hipcc()] + FLAGS + ['-c', path, '-o', obj]
+        # exact-arithmetic units (cell indexing, float64 / float32 simulators): no fma contraction
+        extra = ['-ffp-contract=off'] if src in ('classical.hip', 'pool_grid.hip') else []
+        cmd = [hipcc()] + FLAGS + extra + ['-c', path, '-o', obj]
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)

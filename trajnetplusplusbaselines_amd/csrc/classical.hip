@@ -1,0 +1,197 @@
+// Batched classical predictors on MI355X: social force, ORCA and constant-velocity Kalman rollouts for many scenes
+// at once (reference wrappers classical/socialforce.py:10-111, classical/orca.py:10-134, classical/kalman.py:6-73,
+// which simulate ONE scene per call through third-party CPU libraries).  The arithmetic lives in classical_core.h
+// (shared with the host oracle); this file is the GPU execution: one workgroup per scene, one lane per agent, the
+// scene's state staged in LDS for the all-pairs force / neighbour search, synchronous (Jacobi) state updates
+// separated by workgroup barriers, the 8 simulator sub-steps per output frame fused in one launch.
+// Compiled with -ffp-contract=off so that the float32 ORCA arithmetic is bit-identical to the host restatement.
+#include "tnp_internal.h"
+#include "classical_core.h"
+
+namespace tnp {
+
+// ---- social force: state0 [M][6] = x, y, vx, vy, gx, gy (float64); out [n_out][M][2] --------------------------------
+__global__ void __launch_bounds__(256) sf_rollout_kernel(const double *state0, const int32_t *scene_start, int M,
+                                                         int n_steps, int sample_every, double tau, sf_params prm,
+                                                         double max_speed_mult, double *out) {
+    extern __shared__ __attribute__((aligned(16))) double sfs[];
+    const int s = blockIdx.x;
+    const int lo = scene_start[s], ns = scene_start[s + 1] - lo;
+    double *st = sfs;                    // [ns][7]
+    double *nv = st + (size_t)ns * 7;    // [ns][2]
+    double *isp = nv + (size_t)ns * 2;   // [ns] initial speeds
+    for (int a = threadIdx.x; a < ns; a += blockDim.x) {
+        const double *src = state0 + (size_t)(lo + a) * 6;
+        for (int k = 0; k < 6; ++k) st[a * 7 + k] = src[k];
+        st[a * 7 + 6] = tau;
+        isp[a] = sqrt(src[2] * src[2] + src[3] * src[3]);
+    }
+    __syncthreads();
+    int n_out = 0;
+    for (int step = 0; step < n_steps; ++step) {
+        for (int a = threadIdx.x; a < ns; a += blockDim.x)
+            sf_agent_step(a, ns, st, isp[a], max_speed_mult * isp[a], &prm, &nv[2 * a], &nv[2 * a + 1]);
+        __syncthreads();
+        for (int a = threadIdx.x; a < ns; a += blockDim.x) {
+            st[a * 7 + 0] += nv[2 * a] * prm.delta_t;
+            st[a * 7 + 1] += nv[2 * a + 1] * prm.delta_t;
+            st[a * 7 + 2] = nv[2 * a];
+            st[a * 7 + 3] = nv[2 * a + 1];
+            if (step % sample_every == 0) {   // reference keeps the states after steps 0, 8, 16, ... (socialforce.py:95)
+                out[((size_t)n_out * M + lo + a) * 2 + 0] = st[a * 7 + 0];
+                out[((size_t)n_out * M + lo + a) * 2 + 1] = st[a * 7 + 1];
+            }
+        }
+        if (step % sample_every == 0) ++n_out;
+        __syncthreads();
+    }
+}
+
+// ---- ORCA: pos0/vel0 [M][2] float32, goals [M][2] and speed [M] float64 (the wrapper's numpy side) --------------------
+__global__ void __launch_bounds__(256) orca_rollout_kernel(const float *pos0, const float *vel0, const double *goals,
+                                                           const double *speed, const float *max_speed,
+                                                           const int32_t *scene_start, int M, int n_iter, int sample_every,
+                                                           orca_params prm, float *out, int *nbr_dbg) {
+    extern __shared__ __attribute__((aligned(16))) float ors[];
+    const int s = blockIdx.x;
+    const int lo = scene_start[s], ns = scene_start[s + 1] - lo;
+    float *pos = ors;                   // [ns][2]
+    float *vel = pos + (size_t)ns * 2;  // [ns][2]
+    float *nvl = vel + (size_t)ns * 2;  // [ns][2]
+    float *prf = nvl + (size_t)ns * 2;  // [ns][2] preferred velocity (0 before the first step, orca.py:99-119)
+    for (int a = threadIdx.x; a < ns; a += blockDim.x) {
+        pos[2 * a] = pos0[2 * (lo + a)]; pos[2 * a + 1] = pos0[2 * (lo + a) + 1];
+        vel[2 * a] = vel0[2 * (lo + a)]; vel[2 * a + 1] = vel0[2 * (lo + a) + 1];
+        prf[2 * a] = 0.0f; prf[2 * a + 1] = 0.0f;
+    }
+    __syncthreads();
+    int n_out = 0;
+    for (int count = 1; count <= n_iter; ++count) {
+        for (int a = threadIdx.x; a < ns; a += blockDim.x) {
+            int *dbg = (nbr_dbg && count == 1) ? nbr_dbg + (size_t)(lo + a) * ORCA_MAX_NEIGHBORS : nullptr;
+            orca_agent_new_velocity(a, ns, pos, vel, prf[2 * a], prf[2 * a + 1], max_speed[lo + a], &prm, &nvl[2 * a],
+                                    &nvl[2 * a + 1], dbg);
+        }
+        __syncthreads();
+        for (int a = threadIdx.x; a < ns; a += blockDim.x) {
+            vel[2 * a] = nvl[2 * a]; vel[2 * a + 1] = nvl[2 * a + 1];          // Agent::update
+            pos[2 * a] += vel[2 * a] * prm.time_step; pos[2 * a + 1] += vel[2 * a + 1] * prm.time_step;
+            if (count % sample_every == 0) {                                    // orca.py:107
+                out[((size_t)n_out * M + lo + a) * 2 + 0] = pos[2 * a];
+                out[((size_t)n_out * M + lo + a) * 2 + 1] = pos[2 * a + 1];
+            }
+            // preferred velocity towards the goal, capped at the initial speed (orca.py:111-119), in float64
+            const double px = (double)pos[2 * a], py = (double)pos[2 * a + 1];
+            const double gx = goals[2 * (lo + a)], gy = goals[2 * (lo + a) + 1];
+            const double dx = gx - px, dy = gy - py;
+            const double dist = sqrt(dx * dx + dy * dy);
+            float pvx, pvy;
+            if (dist < 0.05) { pvx = 0.0f; pvy = 0.0f; }
+            else {
+                const double sp = speed[lo + a];
+                if (dist > sp) { pvx = (float)(sp * dx / dist); pvy = (float)(sp * dy / dist); }
+                else { pvx = (float)dx; pvy = (float)dy; }
+            }
+            prf[2 * a] = pvx; prf[2 * a + 1] = pvy;
+        }
+        if (count % sample_every == 0) ++n_out;
+        __syncthreads();
+    }
+}
+
+// ---- Kalman: one lane per track; obs [n_tracks][T][2] float64, z [n_tracks][n_samples][n_steps][6] ---------------------
+__global__ void __launch_bounds__(64) kalman_kernel(const double *obs, int n_tracks, int T, int n_iter, int n_steps,
+                                                    int n_samples, const double *z, double q0, double r0, double *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tracks) return;
+    const double *o = obs + (size_t)i * T * 2;
+    kf_model md;
+    for (int k = 0; k < 16; ++k) { md.Q[k] = (k % 5 == 0) ? q0 : 0.0; md.P0[k] = (k % 5 == 0) ? 1.0 : 0.0; }
+    md.R[0] = r0; md.R[1] = 0.0; md.R[2] = 0.0; md.R[3] = r0;
+    md.m0[0] = o[0]; md.m0[1] = 0.0; md.m0[2] = o[1]; md.m0[3] = 0.0;     // kalman.py:31
+    double x_last[4];
+    kf_em_smooth(o, T, n_iter, &md, x_last);
+    kf_sample_mean(&md, x_last, n_steps, n_samples, z + (size_t)i * n_samples * n_steps * 6, out + (size_t)i * n_steps * 2);
+}
+
+}  // namespace tnp
+
+extern "C" TNP_API int tnp_sf_rollout(const double *state0, const int32_t *scene_start, int B, int M, int n_max,
+                                      int n_steps, int sample_every, double tau, double v0, double sigma, double delta_t,
+                                      double *out, void *stream) {
+    if (B <= 0 || M <= 0) return 0;
+    sf_params p;
+    p.delta_t = delta_t; p.v0 = v0; p.sigma = sigma;
+    p.cosphi = cos(200.0 / 2.0 / 180.0 * M_PI);      // FieldOfView(twophi = 200 degrees)
+    p.out_of_view = 0.5;
+    const size_t smem = (size_t)n_max * 10 * sizeof(double);
+    if (smem > 160 * 1024) TNP_FAIL(-1, "tnp_sf_rollout: %d agents in one scene exceed the LDS-staged limit", n_max);
+    static size_t attr = 0;
+    if (smem > attr) {
+        TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tnp::sf_rollout_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = smem;
+    }
+    const int threads = n_max <= 64 ? 64 : (n_max <= 128 ? 128 : 256);
+    hipLaunchKernelGGL(tnp::sf_rollout_kernel, dim3(B), dim3(threads), smem, (hipStream_t)stream, state0, scene_start, M,
+                       n_steps, sample_every, tau, p, 1.3, out);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" TNP_API int tnp_orca_rollout(const float *pos0, const float *vel0, const double *goals, const double *speed,
+                                        const float *max_speed, const int32_t *scene_start, int B, int M, int n_max,
+                                        int n_iter, int sample_every, float time_step, float neighbor_dist,
+                                        int max_neighbors, float time_horizon, float radius, float *out, int *nbr_dbg,
+                                        void *stream) {
+    if (B <= 0 || M <= 0) return 0;
+    if (max_neighbors > ORCA_MAX_NEIGHBORS) TNP_FAIL(-1, "tnp_orca_rollout: max_neighbors %d > %d", max_neighbors, ORCA_MAX_NEIGHBORS);
+    orca_params p;
+    p.time_step = time_step; p.neighbor_dist = neighbor_dist; p.time_horizon = time_horizon; p.radius = radius;
+    p.max_neighbors = max_neighbors;
+    const size_t smem = (size_t)n_max * 8 * sizeof(float);
+    if (smem > 160 * 1024) TNP_FAIL(-1, "tnp_orca_rollout: %d agents in one scene exceed the LDS-staged limit", n_max);
+    static size_t attr = 0;
+    if (smem > attr) {
+        TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tnp::orca_rollout_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = smem;
+    }
+    const int threads = n_max <= 64 ? 64 : (n_max <= 128 ? 128 : 256);
+    hipLaunchKernelGGL(tnp::orca_rollout_kernel, dim3(B), dim3(threads), smem, (hipStream_t)stream, pos0, vel0, goals, speed,
+                       max_speed, scene_start, M, n_iter, sample_every, p, out, nbr_dbg);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" TNP_API int tnp_kalman_predict(const double *obs, int n_tracks, int T, int n_iter, int n_steps, int n_samples,
+                                          const double *z, double transition_var, double observation_var, double *out,
+                                          void *stream) {
+    if (n_tracks <= 0) return 0;
+    if (T < 2 || T > KF_MAX_T) TNP_FAIL(-1, "tnp_kalman_predict: observation length %d not in 2..%d", T, KF_MAX_T);
+    hipLaunchKernelGGL(tnp::kalman_kernel, dim3((n_tracks + 63) / 64), dim3(64), 0, (hipStream_t)stream, obs, n_tracks, T,
+                       n_iter, n_steps, n_samples, z, transition_var, observation_var, out);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- classical.constant_velocity.predict (classical/constant_velocity.py:4-20) ---------------------------------------
+namespace tnp {
+__global__ void constant_velocity_kernel(const double *last, const double *prev, int N2, int n_predict, double *out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N2) return;
+    const double l = last[q], v = l - prev[q];
+    // this file is built with -ffp-contract=off: last + t * v keeps numpy's two roundings (bit-exact float64)
+    for (int t = 1; t <= n_predict; ++t) out[(size_t)(t - 1) * N2 + q] = l + (double)t * v;
+}
+}  // namespace tnp
+
+extern "C" TNP_API int tnp_constant_velocity(const double *last, const double *prev, int N, int n_predict, double *out,
+                                     void *stream) {
+    if (N <= 0 || n_predict <= 0) return 0;
+    const int N2 = 2 * N;
+    hipLaunchKernelGGL(tnp::constant_velocity_kernel, dim3((N2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, last,
+                       prev, N2, n_predict, out);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}

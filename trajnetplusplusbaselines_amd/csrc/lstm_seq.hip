@@ -496,21 +496,3 @@ extern "C" TNP_API int tnp_profile_read(double *total_ms, int *launches) {
 }
 extern "C" TNP_API int tnp_profile_end(void) { tnp::g_prof_cls = -1; tnp::g_prof_n = 0; return 0; }
 
-namespace tnp {
-__global__ void constant_velocity_kernel(const double *last, const double *prev, int N2, int n_predict, double *out) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= N2) return;
-    const double l = last[q], v = l - prev[q];
-    for (int t = 1; t <= n_predict; ++t) out[(size_t)(t - 1) * N2 + q] = l + (double)t * v;
-}
-}  // namespace tnp
-
-extern "C" TNP_API int tnp_constant_velocity(const double *last, const double *prev, int N, int n_predict, double *out,
-                                     void *stream) {
-    if (N <= 0 || n_predict <= 0) return 0;
-    const int N2 = 2 * N;
-    hipLaunchKernelGGL(tnp::constant_velocity_kernel, dim3((N2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, last,
-                       prev, N2, n_predict, out);
-    TNP_HIP(hipGetLastError());
-    return 0;
-}
