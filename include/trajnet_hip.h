@@ -142,6 +142,24 @@ TNP_API int tnp_lstm_forward(const tnp_lstm_model *model, const float *observed,
                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Same sequence with the S-GAN hooks (sgan/sgan.py):
+ *   noise interface of LSTMGenerator (adding_noise, :200-221): after the encoder,
+ *       h <- [relu(W_ctx h + b_ctx) | noise]  for every track  (W_ctx [H-noise_dim, H], noise [noise_dim]);
+ *   h_final [M,H]: hidden state after the last step (LSTMDiscriminator scores the primaries' rows, :564-576;
+ *       run with truth = NULL, T_dec = 0 over the concatenated observed + predicted frames).
+ * ----------------------------------------------------------------------------------------- */
+typedef struct tnp_lstm_extras {
+    const float *W_ctx, *b_ctx;   /* mlp_decoder_context.0 */
+    const float *noise;           /* [noise_dim], one vector shared by all tracks */
+    int32_t noise_dim;            /* 0 = no noise interface */
+    float *h_final;               /* optional out [M,H] */
+} tnp_lstm_extras;
+TNP_API int tnp_lstm_forward_ex(const tnp_lstm_model *model, const float *observed, int T_obs, int M,
+                        const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
+                        int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
+                        void *workspace, size_t workspace_bytes, const tnp_lstm_extras *extras, void *stream);
+
+/* -------------------------------------------------------------------------------------------
  * LSTM.step (lstm/lstm.py:91-168) on dense state: one masked recurrent step.
  *   decoder     0 = encoder cell, 1 = decoder cell
  *   h_in, c_in  [M,H] state before the step;  h_out, c_out [M,H] after (rows of absent

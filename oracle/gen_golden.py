@@ -197,9 +197,48 @@ def loss_cases(ref):
     print('loss_cases.npz')
 
 
+def sgan_case(ref):
+    """SGAN (directional generator with noise, discriminator) forward of the reference with seeded noise."""
+    import trajnetbaselines.sgan.sgan as ref_sgan
+    torch.manual_seed(21)
+    gpool = ref.GridBasedPooling(type_='directional', hidden_dim=128, cell_side=0.6, n=12, out_dim=64,
+                                 embedding_arch='one_layer')
+    dpool = ref.GridBasedPooling(type_='directional', hidden_dim=128, cell_side=0.6, n=12, out_dim=64,
+                                 embedding_arch='one_layer')
+    gen = ref_sgan.LSTMGenerator(pool=gpool, noise_dim=16)
+    disc = ref_sgan.LSTMDiscriminator(pool=dpool)
+    model = ref_sgan.SGAN(generator=gen, discriminator=disc, k=3, d_steps=1, g_steps=1).eval()
+    out = {}
+    for k, v in model.state_dict().items():
+        out['sd_' + k] = v.numpy().copy()
+    xy, split = synth.ragged_crowd(4, 2, 7, seed=31)
+    M = xy.shape[1]
+    goals = torch.zeros(M, 2)
+    out.update(xy=xy.numpy(), split=split.numpy())
+    with torch.no_grad():
+        torch.manual_seed(5)
+        rel, pred, s_real, s_fake = model(xy[:9].clone(), goals, split, prediction_truth=xy[9:21].clone(), step_type='g',
+                                          pred_length=12)
+        for i in range(3):
+            out['truth_rel%d' % i] = rel[i].numpy()
+            out['truth_pred%d' % i] = pred[i].numpy()
+        out['scores_real'] = s_real.numpy()
+        out['scores_fake'] = s_fake.numpy()
+        torch.manual_seed(6)
+        rel, pred, _, _ = model(xy[:9].clone(), goals, split, n_predict=12)
+        for i in range(3):
+            out['npred_rel%d' % i] = rel[i].numpy()
+            out['npred_pred%d' % i] = pred[i].numpy()
+    np.savez_compressed(os.path.join(OUT, 'sgan_case.npz'), **out)
+    print('sgan_case.npz')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.import_reference()
+    sgan_case(ref)
+    if '--only-sgan' in sys.argv:
+        return
     loss_cases(ref)
     if '--only-new' in sys.argv:
         return

@@ -36,6 +36,11 @@ class LstmModel(ctypes.Structure):
     ]
 
 
+class LstmExtras(ctypes.Structure):
+    """mirror of ``struct tnp_lstm_extras``"""
+    _fields_ = [('W_ctx', _fp), ('b_ctx', _fp), ('noise', _fp), ('noise_dim', ctypes.c_int32), ('h_final', _fp)]
+
+
 _LIB = None
 
 
@@ -69,6 +74,9 @@ def lib():
                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]
     L.tnp_lstm_forward.argtypes = [ctypes.POINTER(LstmModel), _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp,
                                    ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t, _fp]
+    L.tnp_lstm_forward_ex.argtypes = [ctypes.POINTER(LstmModel), _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp,
+                                      ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t,
+                                      ctypes.POINTER(LstmExtras), _fp]
     L.tnp_lstm_step.argtypes = [ctypes.POINTER(LstmModel), ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
                                 ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, ctypes.c_size_t, _fp]
     L.tnp_profile_begin.argtypes = [ctypes.c_int]

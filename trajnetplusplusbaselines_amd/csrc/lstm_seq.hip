@@ -58,6 +58,7 @@ struct PrepArgs {
     int have_next;
     const float *ext1, *ext2;    // [M,2] external frames or NULL
     const float *pos1;           // positions[-2] ([M,2]) or NULL
+    const float *pos2;           // positions[-1] ([M,2]) when this launch does not compute it itself (have_prev == 0)
     int use_pos2;                // obs2 (all rows if ext2 == NULL, primary rows if patch2) <- the position just computed
     int patch1, patch2;          // primary rows of an external frame are replaced by the prediction
     const uint8_t *primary;      // [M]
@@ -119,6 +120,7 @@ __global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
     // ---- phase 2: one lane per track ----
     if (l32 == 0 && valid) {
         float px = NAN, py = NAN;  // position predicted by the previous step
+        if (!a.have_prev && a.pos2) { px = a.pos2[2 * m]; py = a.pos2[2 * m + 1]; }
         if (a.have_prev) {
             const float *o = outs + t_local * nout;
             float n0 = NAN, n1 = NAN, n2 = NAN, n3 = NAN, n4 = NAN;
@@ -344,6 +346,14 @@ static void fill_prep_common(PrepArgs &p, const tnp_lstm_model *md, const Worksp
     p.enc = (md->pool_type == TNP_POOL_SOCIAL) ? w.enc : nullptr;
 }
 
+// h[:, H-nd:H] = z (one noise vector shared by all tracks, sgan/sgan.py:213-216)
+__global__ void noise_broadcast_kernel(float *h, int M, int H, int nd, const float *z) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= M * nd) return;
+    const int m = q / nd, k = q - m * nd;
+    h[(size_t)m * H + (H - nd) + k] = z[k];
+}
+
 }  // namespace tnp
 
 using namespace tnp;
@@ -359,10 +369,10 @@ extern "C" TNP_API size_t tnp_lstm_workspace_bytes(const tnp_lstm_model *model, 
     return w.bytes;
 }
 
-extern "C" TNP_API int tnp_lstm_forward(const tnp_lstm_model *md, const float *observed, int T_obs, int M,
-                                const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
-                                int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
-                                void *workspace, size_t workspace_bytes, void *stream) {
+static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, int T_obs, int M,
+                             const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
+                             int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
+                             void *workspace, size_t workspace_bytes, const tnp_lstm_extras *ex, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc = validate_model(md);
     if (rc) return rc;
@@ -370,6 +380,9 @@ extern "C" TNP_API int tnp_lstm_forward(const tnp_lstm_model *md, const float *o
     if (T_dec < 0) TNP_FAIL(-1, "negative decoder length");
     if (M <= 0 || B <= 0) return 0;
     if (md->goal_flag && !goals) TNP_FAIL(-1, "goal_flag set but goals == NULL");
+    const bool noisy = ex && ex->noise_dim > 0;
+    if (noisy && (ex->noise_dim >= md->H || !ex->W_ctx || !ex->b_ctx || !ex->noise))
+        TNP_FAIL(-1, "tnp_lstm_forward_ex: bad noise interface (noise_dim %d)", ex->noise_dim);
     Workspace w;
     plan_workspace(md, M, workspace, w);
     if (workspace == nullptr || workspace_bytes < w.bytes)
@@ -418,6 +431,29 @@ extern "C" TNP_API int tnp_lstm_forward(const tnp_lstm_model *md, const float *o
                 p.use_pos2 = 1;
             }
         }
+        if (noisy && p.have_next && st == T_obs - 1) {
+            // S-GAN generator (sgan/sgan.py:200-221, 366): the last encoder step is finished on the clean hidden state,
+            // then h <- [relu(W_ctx h + b_ctx) | z] for every track, then the first decoder step is prepared
+            PrepArgs pa = p;
+            pa.have_next = 0;
+            rc = launch_prepare(pa, s);
+            if (rc) return rc;
+            GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.A1 = w.h[cur]; g.lda1 = H; g.K1 = H;
+            g.B1 = ex->W_ctx; g.ldb1 = H; g.bias1 = ex->b_ctx;
+            g.M = M; g.N = H - ex->noise_dim; g.C = w.h[cur ^ 1]; g.ldc = H; g.relu = 1;
+            rc = launch_linear(g, 0, s);
+            if (rc) return rc;
+            const int tot = M * ex->noise_dim;
+            hipLaunchKernelGGL(noise_broadcast_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, w.h[cur ^ 1], M, H,
+                               ex->noise_dim, ex->noise);
+            TNP_HIP(hipGetLastError());
+            cur ^= 1;
+            p.h = w.h[cur];
+            p.have_prev = 0;
+            p.pos2 = pred + (size_t)(npos - 1) * F;
+        }
         rc = launch_prepare(p, s);
         if (rc) return rc;
         if (p.have_next) {
@@ -426,7 +462,25 @@ extern "C" TNP_API int tnp_lstm_forward(const tnp_lstm_model *md, const float *o
             cur ^= 1;
         }
     }
+    if (ex && ex->h_final) TNP_HIP(hipMemcpyAsync(ex->h_final, w.h[cur], (size_t)M * H * 4, hipMemcpyDeviceToDevice, s));
     return 0;
+}
+
+extern "C" TNP_API int tnp_lstm_forward(const tnp_lstm_model *md, const float *observed, int T_obs, int M,
+                                const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
+                                int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
+                                void *workspace, size_t workspace_bytes, void *stream) {
+    return lstm_forward_impl(md, observed, T_obs, M, goals, scene_start, primary_flag, B, n_max, truth, T_dec, rel_pred,
+                             pred, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" TNP_API int tnp_lstm_forward_ex(const tnp_lstm_model *md, const float *observed, int T_obs, int M,
+                                   const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
+                                   int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
+                                   void *workspace, size_t workspace_bytes, const tnp_lstm_extras *extras,
+                                   void *stream) {
+    return lstm_forward_impl(md, observed, T_obs, M, goals, scene_start, primary_flag, B, n_max, truth, T_dec, rel_pred,
+                             pred, workspace, workspace_bytes, extras, stream);
 }
 
 extern "C" TNP_API int tnp_lstm_step(const tnp_lstm_model *md, int decoder, const float *h_in, const float *c_in,

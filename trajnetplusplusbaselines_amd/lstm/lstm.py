@@ -63,8 +63,14 @@ class LSTM(torch.nn.Module):
         self._cell_major = None  # (key, tensor): cell-major copy of pool.embedding[0].weight
 
     # ---- descriptor / workspace ---------------------------------------------------------------------
+    def _decoder_cell(self):
+        return self.decoder
+
+    def _normal_head(self):
+        return self.hidden2normal.linear.weight, self.hidden2normal.linear.bias
+
     def _descriptor(self):
-        dev = self.hidden2normal.linear.weight.device
+        dev = self.encoder.weight_ih.device
         if dev.type != 'cuda':
             raise RuntimeError('LSTM parameters live on %s: move the model to a ROCm device (model.to("cuda")); '
                                'the MI355X path has no CPU fallback' % dev)
@@ -82,12 +88,13 @@ class LSTM(torch.nn.Module):
         m.goal_flag, m.goal_dim = int(self.goal_flag), self.goal_dim
         ie, ge = self.input_embedding.input_embeddings[0], self.goal_embedding.input_embeddings[0]
         m.We, m.be, m.Wg, m.bg = P(ie.weight), P(ie.bias), P(ge.weight), P(ge.bias)
-        for pre, cell in (('enc', self.encoder), ('dec', self.decoder)):
+        for pre, cell in (('enc', self.encoder), ('dec', self._decoder_cell())):
             setattr(m, pre + '_Wih', P(cell.weight_ih))
             setattr(m, pre + '_Whh', P(cell.weight_hh))
             setattr(m, pre + '_bih', P(cell.bias_ih))
             setattr(m, pre + '_bhh', P(cell.bias_hh))
-        m.Wn, m.bn = P(self.hidden2normal.linear.weight), P(self.hidden2normal.linear.bias)
+        wn, bn = self._normal_head()
+        m.Wn, m.bn = P(wn), P(bn)
         m.pool_type = _lib.POOL_NONE
         m.n, m.C, m.P, m.n_layers = 0, 0, 0, 0
         pool = self.pool
@@ -169,30 +176,42 @@ class LSTM(torch.nn.Module):
     def forward(self, observed, goals, batch_split, prediction_truth=None, n_predict=None):
         """observed [T_obs,M,2], goals [M,2], batch_split [B+1] -> (rel_pred_scene [S,M,5], pred_scene [S,M,2])."""
         assert ((prediction_truth is None) + (n_predict is None)) == 1
+        if prediction_truth is not None and isinstance(prediction_truth, (list, tuple)):
+            prediction_truth = torch.stack(list(prediction_truth), dim=0)
+        T_dec = prediction_truth.size(0) if prediction_truth is not None else n_predict - 1
+        rel_pred, pred, _ = self._run_sequence(observed, goals, batch_split, prediction_truth, T_dec)
+        return rel_pred, pred
+
+    def _run_sequence(self, observed, goals, batch_split, truth, T_dec, w_ctx=None, b_ctx=None, noise=None,
+                      want_h_final=False):
+        """tnp_lstm_forward(_ex): T_obs-1 encoder steps + T_dec decoder steps; optional S-GAN hooks."""
         m, keep, dev = self._descriptor()
         observed = _lib.f32c(observed, dev)
         T_obs, M = observed.size(0), observed.size(1)
         idx = _lib.SceneIndex.get(batch_split, dev)
         if idx.M != M:
             raise ValueError('batch_split covers %d tracks, observed has %d' % (idx.M, M))
-        if prediction_truth is not None:
-            if isinstance(prediction_truth, (list, tuple)):
-                prediction_truth = torch.stack(list(prediction_truth), dim=0)
-            truth = _lib.f32c(prediction_truth, dev)
-            T_dec = truth.size(0)
-        else:
-            truth, T_dec = None, n_predict - 1
+        truth = _lib.f32c(truth, dev) if truth is not None else None
         goals_t = _lib.f32c(goals, dev) if (goals is not None and self.goal_flag) else None
         n_steps = T_obs - 1 + T_dec
         npos = n_steps + (1 if T_obs == 2 else 0)
         rel_pred = torch.empty(n_steps, M, 5, dtype=torch.float32, device=dev)
         pred = torch.empty(npos, M, 2, dtype=torch.float32, device=dev)
         ws, need = self._workspace(m, M, idx.B, dev)
-        _lib.check(_lib.lib().tnp_lstm_forward(
+        ex = _lib.LstmExtras()
+        h_final = None
+        if noise is not None:
+            w_ctx, b_ctx, noise = _lib.f32c(w_ctx.detach(), dev), _lib.f32c(b_ctx.detach(), dev), _lib.f32c(noise, dev)
+            ex.W_ctx, ex.b_ctx, ex.noise = _lib.ptr(w_ctx), _lib.ptr(b_ctx), _lib.ptr(noise)
+            ex.noise_dim = int(noise.numel())
+        if want_h_final:
+            h_final = torch.empty(M, self.hidden_dim, dtype=torch.float32, device=dev)
+            ex.h_final = _lib.ptr(h_final)
+        _lib.check(_lib.lib().tnp_lstm_forward_ex(
             ctypes.byref(m), _lib.ptr(observed), T_obs, M, _lib.ptr(goals_t), _lib.ptr(idx.starts),
             _lib.ptr(idx.primary), idx.B, idx.n_max, _lib.ptr(truth), T_dec, _lib.ptr(rel_pred), _lib.ptr(pred),
-            _lib.ptr(ws), need, _lib.stream_ptr()), 'tnp_lstm_forward')
-        return rel_pred, pred
+            _lib.ptr(ws), need, ctypes.byref(ex), _lib.stream_ptr()), 'tnp_lstm_forward')
+        return rel_pred, pred, h_final
 
 
 class LSTMPredictor(object):

@@ -1,0 +1,173 @@
+"""S-GAN on MI355X (reference sgan/sgan.py:46-630): the generator is the LSTM forecaster of lstm/lstm.py with a noise
+interface between encoder and decoder, the discriminator an encoder LSTM over observed + predicted frames followed
+by a small MLP on the primaries' hidden state.  Both run on the same HIP sequence driver (tnp_lstm_forward_ex);
+class names, constructor arguments, state_dict keys and return values mirror the reference.  Forward only."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .. import data as trajdata
+from ..lstm.lstm import LSTM, drop_distant  # noqa: F401  (drop_distant is re-exported like the reference does)
+
+
+def get_noise(shape, noise_type, device):
+    """reference sgan/sgan.py:27-32"""
+    if noise_type == 'gaussian':
+        return torch.randn(*shape, device=device)
+    if noise_type == 'uniform':
+        return torch.rand(*shape, device=device).sub_(0.5).mul_(2.0)
+    raise ValueError('Unrecognized noise type "%s"' % noise_type)
+
+
+def make_mlp(dim_list, activation='relu', batch_norm=True, dropout=0):
+    """reference sgan/sgan.py:34-44 (a ReLU follows EVERY Linear, including the last one)"""
+    layers = []
+    for dim_in, dim_out in zip(dim_list[:-1], dim_list[1:]):
+        layers.append(nn.Linear(dim_in, dim_out))
+        if activation == 'relu':
+            layers.append(nn.ReLU())
+        elif activation == 'leakyrelu':
+            layers.append(nn.LeakyReLU())
+        if dropout > 0:
+            layers.append(nn.Dropout(p=dropout))
+    return nn.Sequential(*layers)
+
+
+class LSTMGenerator(LSTM):
+    def __init__(self, embedding_dim=64, hidden_dim=128, pool=None, pool_to_input=True, goal_dim=None, goal_flag=False,
+                 noise_dim=8, no_noise=False, noise_type='gaussian'):
+        """Arguments as in reference sgan/sgan.py:135-153."""
+        super(LSTMGenerator, self).__init__(embedding_dim=embedding_dim, hidden_dim=hidden_dim, pool=pool,
+                                            pool_to_input=pool_to_input, goal_dim=goal_dim, goal_flag=goal_flag)
+        self.noise_dim = noise_dim
+        self.no_noise = no_noise
+        self.noise_type = noise_type
+        self.mlp_decoder_context = make_mlp([self.hidden_dim, self.hidden_dim - self.noise_dim])
+
+    def forward(self, observed, goals, batch_split, prediction_truth=None, n_predict=None, noise=None):
+        """reference sgan/sgan.py:302-399.  `noise` ([noise_dim]) may be given explicitly; by default it is drawn with
+        get_noise() on the host exactly where the reference draws it."""
+        assert ((prediction_truth is None) + (n_predict is None)) == 1
+        if prediction_truth is not None:
+            if isinstance(prediction_truth, (list, tuple)):
+                prediction_truth = torch.stack(list(prediction_truth), dim=0)
+            truth = prediction_truth[:-1]            # the reference feeds prediction_truth[:-1] (:362-364)
+            T_dec = truth.size(0)
+        else:
+            truth, T_dec = None, n_predict - 1
+        if self.no_noise:
+            rel, pred, _ = self._run_sequence(observed, goals, batch_split, truth, T_dec)
+            return rel, pred
+        if noise is None:
+            noise = get_noise((self.noise_dim,), self.noise_type, device='cpu')
+        lin = self.mlp_decoder_context[0]
+        rel, pred, _ = self._run_sequence(observed, goals, batch_split, truth, T_dec, w_ctx=lin.weight, b_ctx=lin.bias,
+                                          noise=noise)
+        return rel, pred
+
+
+class LSTMDiscriminator(LSTM):
+    def __init__(self, embedding_dim=64, hidden_dim=128, pool=None, pool_to_input=True, goal_dim=None, goal_flag=False):
+        """Arguments as in reference sgan/sgan.py:402-446.  Only `encoder` is used; the unused decoder / hidden2normal
+        parameters of the base class are removed so that the state_dict matches the reference."""
+        super(LSTMDiscriminator, self).__init__(embedding_dim=embedding_dim, hidden_dim=hidden_dim, pool=pool,
+                                                pool_to_input=pool_to_input, goal_dim=goal_dim, goal_flag=goal_flag)
+        del self.decoder
+        del self.hidden2normal
+        self.real_classifier = make_mlp([self.hidden_dim, int(self.hidden_dim / 2), int(self.hidden_dim / 4), 1])
+        self._dummy_head = None
+
+    # the C descriptor wants a decoder cell and a Hidden2Normal head; an encoder-only run never uses the first and
+    # discards the output of the second, so hand it the encoder and a zero head
+    def _decoder_cell(self):
+        return self.encoder
+
+    def _normal_head(self):
+        dev = self.encoder.weight_ih.device
+        if self._dummy_head is None or self._dummy_head[0].device != dev:
+            self._dummy_head = (torch.zeros(5, self.hidden_dim, device=dev), torch.zeros(5, device=dev))
+        return self._dummy_head
+
+    def forward(self, observed, prediction, goals, batch_split):
+        """[T_obs,M,2], [T_pred,M,2] -> scores [B,1] of the primaries (reference sgan/sgan.py:512-576)."""
+        dev = self.encoder.weight_ih.device
+        frames = torch.cat([_lib.f32c(observed, dev), _lib.f32c(prediction, dev)], dim=0)
+        _, _, h = self._run_sequence(frames, goals, batch_split, None, 0, want_h_final=True)
+        split = torch.as_tensor(batch_split, dtype=torch.int64).to(dev)
+        x = h[split[:-1]]
+        for layer in self.real_classifier:
+            if isinstance(layer, nn.Linear):
+                x = _lib.linear_forward(x, layer.weight.detach(), layer.bias.detach(), relu=True)
+        return x
+
+
+class SGAN(torch.nn.Module):
+    def __init__(self, generator=None, discriminator=None, k=1, d_steps=1, g_steps=1):
+        """reference sgan/sgan.py:46-76"""
+        super(SGAN, self).__init__()
+        self.generator = generator if generator is not None else LSTMGenerator()
+        self.g_steps = g_steps
+        self.discriminator = discriminator if discriminator is not None else LSTMDiscriminator()
+        self.d_steps = d_steps
+        self.k = k
+
+    def forward(self, observed, goals, batch_split, prediction_truth=None, n_predict=None, step_type='g',
+                pred_length=12):
+        """reference sgan/sgan.py:78-132: k generator samples, then real / fake discriminator scores."""
+        rel_pred_list, pred_list = [], []
+        for _ in range(self.k):
+            rel_pred_scene, pred_scene = self.generator(observed, goals, batch_split, prediction_truth, n_predict)
+            rel_pred_list.append(rel_pred_scene)
+            pred_list.append(pred_scene)
+            if step_type == 'd':
+                break
+        if self.d_steps and (prediction_truth is not None):
+            scores_real = self.discriminator(observed, prediction_truth, goals, batch_split)
+            scores_fake = self.discriminator(observed, pred_scene[-pred_length:], goals, batch_split)
+            return rel_pred_list, pred_list, scores_real, scores_fake
+        return rel_pred_list, pred_list, None, None
+
+
+class SGANPredictor(object):
+    """reference sgan/sgan.py:578-630"""
+
+    def __init__(self, model):
+        self.model = model
+
+    def save(self, state, filename):
+        with open(filename, 'wb') as f:
+            torch.save(self, f)
+        with open(filename + '.state', 'wb') as f:
+            torch.save(state, f)
+
+    @staticmethod
+    def load(filename):
+        with open(filename, 'rb') as f:
+            return torch.load(f, weights_only=False)
+
+    def __call__(self, paths, scene_goal, n_predict=12, modes=1, predict_all=True, obs_length=9, start_length=0,
+                 args=None):
+        self.model.eval()
+        self.model.d_steps = 0
+        if modes is not None:
+            self.model.k = modes
+        with torch.no_grad():
+            xy = trajdata.paths_to_xy(paths)
+            batch_split = [0, xy.shape[1]]
+            normalize = bool(getattr(args, 'normalize_scene', False))
+            if normalize:
+                xy, rotation, center, scene_goal = trajdata.center_scene(xy, obs_length, goals=scene_goal)
+            xy = torch.tensor(np.asarray(xy), dtype=torch.float32)
+            scene_goal = torch.tensor(np.asarray(scene_goal), dtype=torch.float32)
+            batch_split = torch.tensor(batch_split, dtype=torch.int64)
+            multimodal_outputs = {}
+            _, output_scenes_list, _, _ = self.model(xy[:obs_length], scene_goal, batch_split, n_predict=n_predict)
+            for num_p, output_scenes in enumerate(output_scenes_list):
+                output_scenes = output_scenes.cpu().numpy()
+                if normalize:
+                    output_scenes = trajdata.inverse_scene(output_scenes, rotation, center)
+                output_primary = output_scenes[-n_predict:, 0]
+                output_neighs = output_scenes[-n_predict:, 1:]
+                multimodal_outputs[num_p] = [output_primary, output_neighs if num_p == 0 else []]
+        return multimodal_outputs
