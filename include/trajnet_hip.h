@@ -65,6 +65,12 @@ TNP_API int tnp_pool_grid_forward(int type, const float *obs1, const float *obs2
                           float half_x, float half_y, float constant, float *grid, int ldg,
                           int16_t *winners, void *stream);
 
+/* Cells of all ordered (ego, neighbour) pairs, for the backward pass of the grid scatter (autograd of
+ * `occ[arange, oi] = other_values`, lstm/gridbased_pooling.py:293: every in-range neighbour receives the gradient of
+ * its cell).  row_base / row_count [M]: first row and size of the row's scene; out [M, n_max] int32, -1 = no cell. */
+TNP_API int tnp_pool_pair_cells(const float *obs2, const int32_t *row_base, const int32_t *row_count, int M, int n_max,
+                        int n, float cell, float half_x, float half_y, int32_t *out, void *stream);
+
 /* -------------------------------------------------------------------------------------------
  * Dense layer on the matrix cores: torch.nn.Linear (+ReLU) as used by the grid embedding
  * MLPs (lstm/gridbased_pooling.py:308-335).   C[M,N] = act(A[M,K] @ W[N,K]^T + bias)

@@ -233,9 +233,44 @@ def sgan_case(ref):
     print('sgan_case.npz')
 
 
+def grad_case(ref):
+    """Parameter gradients of the reference (loss.backward()) for small models: the trainer's loss
+    PredictionLoss(rel[-12:], targets) * batch_size (lstm/trainer.py:252-265) plus a term on the predicted positions."""
+    out = {}
+    for kind in ('social', 'directional', 'vanilla'):
+        torch.manual_seed({'social': 41, 'directional': 42, 'vanilla': 43}[kind])
+        pool = None
+        if kind == 'social':
+            pool = ref.GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=8, out_dim=64,
+                                        embedding_arch='two_layer', layer_dims=[128], latent_dim=8)
+        elif kind == 'directional':
+            pool = ref.GridBasedPooling(type_='directional', hidden_dim=128, cell_side=0.6, n=12, out_dim=64)
+        model = ref.LSTM(pool=pool).train()
+        xy, split = synth.ragged_crowd(4, 2, 8, seed=51)
+        M = xy.shape[1]
+        observed, truth = xy[:9].clone(), xy[9:20].clone()
+        targets = xy[9:21] - xy[8:20]
+        rel, pred = model(observed, torch.zeros(M, 2), split, truth)
+        crit = ref.PredictionLoss()
+        loss = crit(rel[-12:], targets, split) * 8 + 0.1 * torch.nan_to_num(pred[-12:, split[:-1]]).pow(2).mean()
+        loss.backward()
+        pre = kind + '_'
+        out[pre + 'xy'], out[pre + 'split'] = xy.numpy(), split.numpy()
+        out[pre + 'loss'] = np.float32(loss.item())
+        for k, v in model.state_dict().items():
+            out[pre + 'sd_' + k] = v.numpy().copy()
+        for k, p in model.named_parameters():
+            out[pre + 'grad_' + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'grad_cases.npz'), **out)
+    print('grad_cases.npz')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.import_reference()
+    if '--only-grad' in sys.argv:
+        return grad_case(ref)
+    grad_case(ref)
     sgan_case(ref)
     if '--only-sgan' in sys.argv:
         return

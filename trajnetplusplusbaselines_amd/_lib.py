@@ -99,6 +99,8 @@ def lib():
                                    ctypes.c_float, _fp, _fp, _fp]
     L.tnp_kalman_predict.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
                                      ctypes.c_double, ctypes.c_double, _fp, _fp]
+    L.tnp_pool_pair_cells.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                      ctypes.c_float, ctypes.c_float, _fp, _fp]
     L.tnp_mfma_probe.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]
     if L.tnp_abi_version() != 1:
         raise RuntimeError('libtrajnet_hip.so ABI version mismatch')

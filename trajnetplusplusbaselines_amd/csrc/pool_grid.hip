@@ -144,6 +144,28 @@ int launch_grid(const GridArgs &a, hipStream_t s) {
     return 0;
 }
 
+// Cell of every ordered pair (ego, neighbour slot) for the scatter's backward pass: the reference's autograd gives
+// EVERY in-range neighbour the gradient of its cell, overwritten duplicates included.
+// out[row][j] = cell id of neighbour j of the row's scene as seen from the ego, -1 if j is the ego itself, absent,
+// out of range or beyond the scene.  One thread per (row, j).
+__global__ void pair_cells_kernel(const float *obs2, const int32_t *row_base, const int32_t *row_count, int M, int n_max,
+                                  int G, float cell, float half_x, float half_y, int32_t *out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= M * n_max) return;
+    const int row = q / n_max, j = q - row * n_max;
+    const int base = row_base[row], ns = row_count[row];
+    int res = -1;
+    if (j < ns && base + j != row) {
+        float2 pi = reinterpret_cast<const float2 *>(obs2)[row], pj = reinterpret_cast<const float2 *>(obs2)[base + j];
+        if (pi.x != pi.x || pi.y != pi.y) { pi.x = -500.0f; pi.y = -500.0f; }
+        if (pj.x != pj.x || pj.y != pj.y) { pj.x = -500.0f; pj.y = -500.0f; }
+        const float ox = (pj.x - pi.x) / cell + half_x, oy = (pj.y - pi.y) / cell + half_y;
+        const float fG = (float)G;
+        if (!(ox < 0.0f) && !(ox >= fG) && !(oy < 0.0f) && !(oy >= fG)) res = (int)ox * G + (int)oy;
+    }
+    out[q] = res;
+}
+
 __global__ void mark_primaries_kernel(const int32_t *scene_start, int B, uint8_t *flag) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s < B && scene_start[s + 1] > scene_start[s]) flag[scene_start[s]] = 1;
@@ -159,6 +181,17 @@ extern "C" TNP_API int tnp_mark_primaries(const int32_t *scene_start, int B, int
                            primary_flag);
         TNP_HIP(hipGetLastError());
     }
+    return 0;
+}
+
+extern "C" TNP_API int tnp_pool_pair_cells(const float *obs2, const int32_t *row_base, const int32_t *row_count, int M,
+                                           int n_max, int n, float cell, float half_x, float half_y, int32_t *out,
+                                           void *stream) {
+    if (M <= 0 || n_max <= 0) return 0;
+    const int tot = M * n_max;
+    hipLaunchKernelGGL(tnp::pair_cells_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, obs2, row_base,
+                       row_count, M, n_max, n, cell, half_x, half_y, out);
+    TNP_HIP(hipGetLastError());
     return 0;
 }
 

@@ -1,12 +1,43 @@
 """Losses of the reference's lstm/loss.py (same class names and call signatures), evaluated on the primaries of a
 batch by csrc/loss.hip.  Forward values only in this round (the backward arrives with the training kernels)."""
+import math
+
 import torch
 
 from .. import _lib
 
 
+def _gaussian_2d(p, x):
+    """differentiable restatement of lstm/loss.py:23-50 on device tensors (training path only)"""
+    norm1, norm2 = x[:, 0] - p[:, 0], x[:, 1] - p[:, 1]
+    s1, s2, rho = p[:, 2], p[:, 3], p[:, 4]
+    s1s2 = s1 * s2
+    z = (norm1 / s1) ** 2 + (norm2 / s2) ** 2 - 2 * rho * norm1 * norm2 / s1s2
+    return torch.exp(-z / (2 * (1 - rho ** 2))) / (2 * math.pi * s1s2 * torch.sqrt(1 - rho ** 2))
+
+
+def _primary_loss_autograd(mode, inputs, targets, batch_split, background_rate, keep_batch_dim, scale):
+    """Loss on the [T, B] primaries with autograd (tiny tensors; the heavy part of the backward is lstm/training.py)."""
+    dev = inputs.device
+    split = torch.as_tensor(batch_split, dtype=torch.int64).to(dev)
+    prim = split[:-1]
+    T, B = inputs.size(0), prim.numel()
+    inp = inputs[:, prim].reshape(-1, 5)
+    tgt = _lib.f32c(targets.detach(), dev)[:, prim].reshape(-1, 2)
+    if mode == 0:
+        bg = inp.clone()
+        bg[:, 2], bg[:, 3], bg[:, 4] = 3.0, 3.0, 0.0
+        values = -torch.log(0.01 + background_rate * _gaussian_2d(bg, tgt) + (0.99 - background_rate) * _gaussian_2d(inp, tgt))
+        values = values.reshape(T, B)
+        return (values.mean(dim=0) if keep_batch_dim else values.mean()) * scale
+    sq = ((inp[:, :2] - tgt) ** 2).reshape(T, B, 2)
+    return (sq.mean(dim=0).mean(dim=1) if keep_batch_dim else sq.mean()) * (scale * 2.0)
+
+
 def _primary_loss(mode, inputs, targets, batch_split, background_rate, keep_batch_dim, scale):
     _lib.require_device(inputs, 'inputs')
+    if inputs.requires_grad and torch.is_grad_enabled():
+        return _primary_loss_autograd(mode, inputs, targets, batch_split, background_rate, keep_batch_dim, scale)
     dev = inputs.device
     inputs = _lib.f32c(inputs.detach())
     targets = _lib.f32c(targets.detach(), dev)

@@ -179,6 +179,10 @@ class LSTM(torch.nn.Module):
         if prediction_truth is not None and isinstance(prediction_truth, (list, tuple)):
             prediction_truth = torch.stack(list(prediction_truth), dim=0)
         T_dec = prediction_truth.size(0) if prediction_truth is not None else n_predict - 1
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training: same kernels step by step + an explicit backward sweep (lstm/training.py)
+            from .training import run_sequence_with_grad
+            return run_sequence_with_grad(self, observed, goals, batch_split, prediction_truth, T_dec)
         rel_pred, pred, _ = self._run_sequence(observed, goals, batch_split, prediction_truth, T_dec)
         return rel_pred, pred
 
