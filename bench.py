@@ -85,6 +85,7 @@ def main():
     ap.add_argument('--config', default='social', choices=sorted(CONFIGS))
     ap.add_argument('--variant', type=int, default=0, help='kernel variant selector (DESIGN.md)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--train', action='store_true', help='time one optimisation step (forward + backward + Adam + gradient all-reduce) instead of the inference forward')
     ap.add_argument('--dense', action='store_true', help='dense MFMA first embedding layer instead of the sparse one')
     args = ap.parse_args()
 
@@ -112,15 +113,26 @@ def main():
     observed = xy[:9].to(device)
     goals = torch.zeros(M, 2, device=device)
 
-    def step():
-        return model(observed, goals, split, n_predict=12)
+    if args.train:
+        from trajnetplusplusbaselines_amd.lstm import PredictionLoss
+        from trajnetplusplusbaselines_amd.lstm.train_step import train_batch
+        optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)   # lstm/trainer.py:497
+        criterion = PredictionLoss()
+        scene_dev = xy.to(device)
+
+        def step():
+            return train_batch(model, optimizer, criterion, scene_dev, goals, split, 9, 12, batch_size=cfg['scenes'] * world,
+                               n_global_scenes=cfg['scenes'] * world)
+    else:
+        def step():
+            return model(observed, goals, split, n_predict=12)
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
+    with torch.set_grad_enabled(args.train):
         for _ in range(args.warmup):
             step()
         barrier()
@@ -137,7 +149,7 @@ def main():
         # ---- roofline leg: same region again with HIP events around every launch of the dominant kernel ----
         L = _lib.lib()
         roof = None
-        if rank == 0:
+        if rank == 0 and not args.train:
             import ctypes
             _lib.check(L.tnp_profile_begin(0), 'tnp_profile_begin')
             torch.cuda.synchronize()
@@ -191,9 +203,12 @@ def main():
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': '%s, %d scenes x %d agents x (9 obs + 12 pred) per GPU, inference forward '
-                                   '(LSTM.forward, n_predict=12)' % (cfg['name'], cfg['scenes'], cfg['agents']),
+            'config': {'workload': '%s, %d scenes x %d agents x (9 obs + 12 pred) per GPU, %s' % (
+                           cfg['name'], cfg['scenes'], cfg['agents'],
+                           'training step (Trainer.train_batch: teacher-forced forward, NLL loss, backward, Adam)'
+                           if args.train else 'inference forward (LSTM.forward, n_predict=12)'),
                        'scenes_per_gpu': cfg['scenes'], 'agents_per_scene': cfg['agents'],
+                       'mode': 'training step (fwd + bwd + Adam%s)' % (' + gradient all-reduce' if world > 1 else '') if args.train else 'inference forward',
                        'recurrent_steps_per_forward': 19, 'parallelism': 'dp%d (scene sharding)' % world,
                        'kernel_variant': args.variant,
                        'first_embedding_layer': 'dense mfma' if args.dense else 'sparse gather (social) / dense mfma'},
