@@ -32,6 +32,9 @@ class SequenceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, observed, goals, batch_split, truth, T_dec, *params):
         dev = params[0].device
+        if dev.type != 'cuda':
+            raise RuntimeError('LSTM parameters live on %s: move the model to a ROCm device (model.to("cuda")); '
+                               'the MI355X path has no CPU fallback' % dev)
         observed = _lib.f32c(observed.detach(), dev)
         truth = _lib.f32c(truth.detach(), dev) if truth is not None else None
         goals_t = _lib.f32c(goals.detach(), dev) if (goals is not None and model.goal_flag) else None
