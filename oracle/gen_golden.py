@@ -265,9 +265,58 @@ def grad_case(ref):
     print('grad_cases.npz')
 
 
+REAL_SEED = 123
+
+
+def real_model(mod_pool, mod_lstm):
+    """The headline (config 2) Social-LSTM, default torch init under a fixed seed; our module and the
+    reference's construct their parameters in the same order, so the same seed gives the same weights."""
+    torch.manual_seed(REAL_SEED)
+    pool = mod_pool(type_='social', hidden_dim=128, cell_side=0.6, n=16, out_dim=256,
+                    embedding_arch='two_layer', layer_dims=[1024], latent_dim=16)
+    return mod_lstm(pool=pool)
+
+
+def real_cases(ref):
+    """Reference LSTM.forward on REAL TrajNet++ scenes (DATA_BLOCK/trajdata/train/*.ndjson of the reference
+    checkout) with the full-size config-2 model: pins ADE/FDE parity on real crowds."""
+    import trajnetbaselines.lstm.utils as ref_utils
+    import trajnetbaselines.lstm.lstm as ref_lstm
+    from trajnetplusplusbaselines_amd import data
+    model = real_model(ref.GridBasedPooling, ref.LSTM).eval()
+    out = {'seed': np.asarray(REAL_SEED)}
+    for k, v in model.state_dict().items():
+        out['wsum_' + k] = np.asarray(v.double().sum().item())
+    root = os.path.join(ref_import.REFERENCE_ROOT, 'DATA_BLOCK', 'trajdata', 'train')
+    for tag, fname, count, stride in (('hotel', 'biwi_hotel.ndjson', 16, 3), ('students', 'crowds_students001.ndjson', 8, 11)):
+        scenes = data.read_ndjson_scenes(os.path.join(root, fname), limit=count * stride)[::stride][:count]
+        xs, centered = [], []
+        for _, paths in scenes:
+            xy = data.paths_to_xy(paths)
+            xy, _ = ref_lstm.drop_distant(xy)
+            xs.append(xy)
+            c, rot, center = ref_utils.center_scene(xy.copy(), 9)
+            centered.append(c)
+        xy, split = data.batch_scenes(xs)
+        cxy, _ = data.batch_scenes(centered)
+        for name, arr in (('raw', xy), ('centered', cxy)):
+            t = torch.tensor(arr, dtype=torch.float32)
+            with torch.no_grad():
+                rel, pred = model(t[:9].clone(), torch.zeros(t.shape[1], 2), torch.tensor(split), n_predict=12)
+            out.update({'%s_%s_xy' % (tag, name): arr, '%s_%s_rel' % (tag, name): rel.numpy(),
+                        '%s_%s_pred' % (tag, name): pred.numpy()})
+        out[tag + '_split'] = split
+        print(tag, xy.shape, split)
+    np.savez_compressed(os.path.join(OUT, 'real_cases.npz'), **out)
+    print('real_cases.npz')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.import_reference()
+    if '--only-real' in sys.argv:
+        return real_cases(ref)
+    real_cases(ref)
     if '--only-grad' in sys.argv:
         return grad_case(ref)
     grad_case(ref)

@@ -73,3 +73,25 @@ def build_amd_model(sd, cfg, device='cuda'):
                  hidden_dim=sd['encoder.weight_hh'].shape[1], pool=pool, goal_flag=cfg['goal_flag'])
     model.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
     return model.to(device).eval()
+
+
+def real_model(device='cpu'):
+    """The seeded config-2 Social-LSTM of oracle/gen_golden.py:real_model, built from OUR modules (same
+    parameter construction order => same weights as the reference under the same seed; the fixture's per-tensor
+    checksums verify that)."""
+    import torch
+    from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling
+    z = np.load(os.path.join(GOLDEN, 'real_cases.npz'), allow_pickle=False)
+    torch.manual_seed(int(z['seed']))
+    pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=16, out_dim=256,
+                            embedding_arch='two_layer', layer_dims=[1024], latent_dim=16)
+    model = LSTM(pool=pool)
+    for k, v in model.state_dict().items():
+        assert abs(v.double().sum().item() - float(z['wsum_' + k])) < 1e-9, 'seeded weight differs: ' + k
+    return model.to(device).eval(), z
+
+
+def ade_fde(pred, truth):
+    """Average / final displacement error of the primaries' predicted path [T, B, 2] (metres)."""
+    d = np.linalg.norm(np.asarray(pred, dtype=np.float64) - np.asarray(truth, dtype=np.float64), axis=-1)
+    return d.mean(axis=0), d[-1]

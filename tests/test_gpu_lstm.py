@@ -156,3 +156,23 @@ def test_edge_cases():
     helpers.assert_close_nan(pred.cpu().numpy(), opred, 2e-5, 'all-NaN neighbour')
     with pytest.raises(ValueError):
         model(torch.tensor(xy[:9]), None, torch.tensor([0, 3]), n_predict=12)
+
+
+@pytest.mark.parametrize('tag', ['hotel', 'students'])
+def test_real_scenes_match_reference(tag):
+    """Headline model (Social-LSTM n=16, two_layer 1024) on real TrajNet++ scenes against the reference's own
+    outputs (tests/golden/real_cases.npz): every normal within 5e-5, primaries' ADE/FDE within 1e-4 m."""
+    model, z = helpers.real_model('cuda')
+    split = z[tag + '_split']
+    for name in ('raw', 'centered'):
+        xy = z['%s_%s_xy' % (tag, name)].astype(np.float32)
+        for dense in (False, True):
+            model.sparse_embedding = not dense
+            rel, pred = model(torch.tensor(xy[:9]), torch.zeros(xy.shape[1], 2), torch.tensor(split), n_predict=12)
+            rel, pred = rel.cpu().numpy(), pred.cpu().numpy()
+            helpers.assert_close_nan(rel, z['%s_%s_rel' % (tag, name)], 5e-5, 'rel')
+            helpers.assert_close_nan(pred, z['%s_%s_pred' % (tag, name)], 5e-5, 'pred')
+            prim = split[:-1]
+            a0, f0 = helpers.ade_fde(z['%s_%s_pred' % (tag, name)][-12:, prim], xy[9:21, prim])
+            a1, f1 = helpers.ade_fde(pred[-12:, prim], xy[9:21, prim])
+            assert np.abs(a0 - a1).max() < 1e-4 and np.abs(f0 - f1).max() < 1e-4

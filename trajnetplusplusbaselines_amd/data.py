@@ -55,3 +55,53 @@ def center_scene(xy, obs_length=9, ped_id=0, goals=None):
 def inverse_scene(xy, rotation, center):
     """Undo center_scene (reference augmentation.py:65-68)."""
     return rotate_path(xy, -rotation) + center[np.newaxis, np.newaxis, :]
+
+
+def read_ndjson_scenes(path, limit=None, scene_ids=None):
+    """Read a TrajNet++ ``.ndjson`` file into ``[(scene_id, paths)]`` with ``paths`` = list of tracks (primary
+    first, the others in order of first appearance), each a list of ``TrackRow`` within the scene's frame range.
+
+    Stands in for ``trajnetplusplustools.Reader(path, scene_type='paths').scenes()`` as the reference calls it
+    (lstm/data_load_utils.py:33-44, evaluator/trajnet_evaluator.py:25-36); the package itself is not vendored
+    (SURVEY.md 8c), so the record layout is taken from the data files: ``{"scene": {id, p, s, e, fps, tag}}`` and
+    ``{"track": {f, p, x, y[, prediction_number, scene_id]}}``.
+    """
+    import json
+    by_frame = {}
+    scenes = []
+    with open(path, 'r') as f:
+        for line in f:
+            rec = json.loads(line)
+            if 'track' in rec:
+                t = rec['track']
+                if t.get('prediction_number') is not None:
+                    continue
+                by_frame.setdefault(t['f'], []).append(TrackRow(t['f'], t['p'], t['x'], t['y']))
+            elif 'scene' in rec:
+                s = rec['scene']
+                scenes.append(SceneRow(s['id'], s['p'], s['s'], s['e'], s.get('fps'), s.get('tag')))
+    frames = sorted(by_frame)
+    out = []
+    for sc in scenes:
+        if scene_ids is not None and sc.scene not in scene_ids:
+            continue
+        tracks = {}
+        for fr in frames:
+            if fr < sc.start or fr > sc.end:
+                continue
+            for row in by_frame[fr]:
+                tracks.setdefault(row.pedestrian, []).append(row)
+        if sc.pedestrian not in tracks:
+            continue
+        paths = [tracks[sc.pedestrian]] + [p for ped, p in tracks.items() if ped != sc.pedestrian]
+        out.append((sc.scene, paths))
+        if limit is not None and len(out) >= limit:
+            break
+    return out
+
+
+def batch_scenes(scenes_xy):
+    """Concatenate per-scene ``[T, N_s, 2]`` arrays along the track axis -> (``[T, M, 2]``, ``batch_split [B+1]``);
+    the batch assembly of reference lstm/trainer.py:120-131."""
+    split = np.cumsum([0] + [int(s.shape[1]) for s in scenes_xy])
+    return np.concatenate(scenes_xy, axis=1), split
