@@ -86,7 +86,8 @@ TNP_API int tnp_linear_forward(const float *A, int lda, const float *W, int ldw,
  * == torch.nn.Linear on the dense grid (lstm/gridbased_pooling.py:107-109), 8x fewer multiply-adds.
  *   winners   [M, ncell] int16 from tnp_pool_grid_forward; values [M, ldv]; row_base [M] int32 =
  *   first row of the row's scene (tnp_row_base); W_cell_major [ncell][C][N1]; C in {4,8,16,32}
- *   workspace: tnp_pool_embed_sparse_workspace_bytes(M, N1, ncell) bytes (partial sums)
+ *   workspace: tnp_pool_embed_sparse_workspace_bytes(M, N1, ncell) bytes (0 for grids of up to 440 cells;
+ *   partial sums of the cell-range fallback beyond that)
  * ----------------------------------------------------------------------------------------- */
 TNP_API size_t tnp_pool_embed_sparse_workspace_bytes(int M, int N1, int ncell);
 TNP_API int tnp_row_base(const int32_t *scene_start, int B, int32_t *row_base, void *stream);

@@ -43,7 +43,8 @@ def run_sparse(obs1, obs2, enc, starts, n_max, n, cell_side, W, b, relu=True):
 
 
 @pytest.mark.parametrize('scenes,agents,n,C,N1', [(3, 7, 8, 8, 64), (64, 32, 16, 16, 1024), (5, 40, 16, 16, 260),
-                                                   (20, 13, 12, 4, 128), (2, 130, 16, 32, 256)])
+                                                   (20, 13, 12, 4, 128), (2, 130, 16, 32, 256),
+                                                   (4, 20, 24, 8, 128)])  # 576 cells: cell-range fallback kernel
 def test_sparse_embedding_matches_dense_oracle(scenes, agents, n, C, N1):
     rng = np.random.RandomState(scenes * 31 + agents)
     B, N = scenes, agents

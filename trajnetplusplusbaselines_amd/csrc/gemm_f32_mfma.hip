@@ -73,6 +73,73 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
 
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// One (track, unit) of torch.nn.LSTMCell from the four gate pre-activations (bias included).
+__device__ __forceinline__ void lstm_cell_store(const GemmArgs &g, int row, int unit, float pi, float pf, float pg,
+                                                float po) {
+    if (row >= g.M) return;
+    const size_t o = (size_t)row * g.H + unit;
+    if (g.mask[row]) {
+        const float ig = sigmoidf_acc(pi);
+        const float fg = sigmoidf_acc(pf);
+        const float gg = tanhf(pg);
+        const float og = sigmoidf_acc(po);
+        const float cn = fg * g.c_in[o] + ig * gg;
+        g.c_out[o] = cn;
+        g.h_out[o] = og * tanhf(cn);
+    } else {  // absent track: state frozen (reference lstm/lstm.py:118-124,158-166)
+        g.c_out[o] = g.c_in[o];
+        g.h_out[o] = g.h_in[o];
+    }
+}
+
+// Split-K reduction fused with the LSTM epilogue, spread over ALL WK k-group waves: wave kg owns accumulator
+// registers [kg*16/WK, (kg+1)*16/WK) of the 32x32 block (x 4 gates), receives the other waves' partials for those
+// through LDS, and runs the transcendental epilogue for its rows only.  Partials are added in k-group order, so the
+// result is bit-identical to the single-wave reduction it replaces.  LDS: (WK-1)*WMN*4*16*64 floats.
+template <int WK, int WMN>
+__device__ __forceinline__ void lstm_reduce_epilogue(const GemmArgs &g, f32x16 (&acc)[4], float *red, int kg, int wq,
+                                                     int lane, int rbase, int tn) {
+    constexpr int RN = 16 / WK;
+#pragma unroll
+    for (int o = 0; o < WK; ++o) {
+        if (o == kg) continue;
+        const int slot = kg - (kg > o ? 1 : 0);
+#pragma unroll
+        for (int an = 0; an < 4; ++an)
+#pragma unroll
+            for (int rr = 0; rr < RN; ++rr)
+                red[((((o * (WK - 1) + slot) * WMN + wq) * 4 + an) * RN + rr) * 64 + lane] = acc[an][o * RN + rr];
+    }
+    __syncthreads();
+    const int H = g.H;
+    const int unit = tn * 32 + (lane & 31);
+    if (unit >= H) return;
+    float bias[4];
+#pragma unroll
+    for (int an = 0; an < 4; ++an) bias[an] = g.bias1[an * H + unit] + g.bias2[an * H + unit];
+#pragma unroll
+    for (int o = 0; o < WK; ++o) {
+        if (o != kg) continue;
+#pragma unroll
+        for (int rr = 0; rr < RN; ++rr) {
+            float pre[4];
+#pragma unroll
+            for (int an = 0; an < 4; ++an) {
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < WK; ++k) {
+                    const float v = (k == o) ? acc[an][o * RN + rr]
+                                             : red[((((o * (WK - 1) + (k - (k > o ? 1 : 0))) * WMN + wq) * 4 + an) * RN + rr) * 64 + lane];
+                    s = (k == 0) ? v : s + v;
+                }
+                pre[an] = s + bias[an];
+            }
+            const int r = o * RN + rr;
+            lstm_cell_store(g, rbase + (r & 3) + 8 * (r >> 2), unit, pre[0], pre[1], pre[2], pre[3]);
+        }
+    }
+}
+
 template <int AN, int EPI>
 __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[AN], int rbase, int n0, int wn, int tn,
                                          int lane) {
@@ -104,22 +171,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[AN], i
             float bo = g.bias1[3 * H + unit] + g.bias2[3 * H + unit];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < g.M) {
-                    const size_t o = (size_t)row * H + unit;
-                    if (g.mask[row]) {
-                        const float ig = sigmoidf_acc(acc[0][r] + bi);
-                        const float fg = sigmoidf_acc(acc[1][r] + bf);
-                        const float gg = tanhf(acc[2][r] + bg);
-                        const float og = sigmoidf_acc(acc[3][r] + bo);
-                        const float cn = fg * g.c_in[o] + ig * gg;
-                        g.c_out[o] = cn;
-                        g.h_out[o] = og * tanhf(cn);
-                    } else {  // absent track: state frozen (reference lstm/lstm.py:118-124,158-166)
-                        g.c_out[o] = g.c_in[o];
-                        g.h_out[o] = g.h_in[o];
-                    }
-                }
+                lstm_cell_store(g, rbase + (r & 3) + 8 * (r >> 2), unit, acc[0][r] + bi, acc[1][r] + bf,
+                                acc[2][r] + bg, acc[3][r] + bo);
             }
         }
     }
@@ -409,7 +462,10 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_fast(const GemmArgs
         __syncthreads();
     }
 
-    if (WK > 1) {
+    if constexpr (WK > 1 && EPI == EPI_LSTM) {
+        lstm_reduce_epilogue<WK, WMN>(g, acc, smem, kg, wq, lane, m0 + wm * 32 + 4 * (lane >> 5), tn);
+        return;
+    } else if (WK > 1) {
         float *red = smem;
         if (kg > 0) {
 #pragma unroll
@@ -580,7 +636,11 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_pipe(const GemmArgs
         buf_cur = buf_nxt;
     }
 
-    if (WK > 1) {
+    if constexpr (WK > 1 && EPI == EPI_LSTM) {
+        __syncthreads();  // everybody is done with the tile ring before it is reused for the reduction
+        lstm_reduce_epilogue<WK, WMN>(g, acc, smem, kg, wq, lane, m0 + wm * 32 + 4 * (lane >> 5), tn);
+        return;
+    } else if (WK > 1) {
         __syncthreads();  // everybody is done with the tile ring before it is reused for the reduction
         float *red = smem;
         if (kg > 0) {

@@ -92,6 +92,18 @@ __global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
     const int m = m0 + t_local;
     const bool valid = m < a.M;
 
+    // phase-2 operands of lane 0 are fetched now so their latency hides behind phase 1
+    float pf_o2x = NAN, pf_o2y = NAN, pf_e1x = NAN, pf_e1y = NAN, pf_e2x = NAN, pf_e2y = NAN, pf_p1x = NAN, pf_p1y = NAN;
+    int pf_maskprev = 0, pf_prim = 0;
+    if (l32 == 0 && valid) {
+        if (a.have_prev) { pf_o2x = a.obs2_prev[2 * m]; pf_o2y = a.obs2_prev[2 * m + 1]; pf_maskprev = a.mask_prev[m]; }
+        if (a.have_next) {
+            pf_prim = a.primary[m];
+            if (a.ext1) { pf_e1x = a.ext1[2 * m]; pf_e1y = a.ext1[2 * m + 1]; }
+            if (a.ext2) { pf_e2x = a.ext2[2 * m]; pf_e2y = a.ext2[2 * m + 1]; }
+            if (a.pos1) { pf_p1x = a.pos1[2 * m]; pf_p1y = a.pos1[2 * m + 1]; }
+        }
+    }
     if (nout > 0) {
         for (int q = tid; q < PREP_TRACKS * H; q += 256) {
             const int t = q / H, k = q - t * H;
@@ -112,8 +124,15 @@ __global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
         float acc;
         if (a.have_prev && o < 5) acc = a.bn[o];
         else acc = a.bh[o - (a.have_prev ? 5 : 0)];
-        for (int k = 0; k < H; ++k) acc = fmaf(hr[k], wr[k], acc);
-        outs[t_local * nout + o] = acc;
+        // four interleaved partial sums (H % 4 == 0): breaks the 128-long dependent FMA chain
+        float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        for (int k = 0; k < H; k += 4) {
+            acc = fmaf(hr[k], wr[k], acc);
+            s1 = fmaf(hr[k + 1], wr[k + 1], s1);
+            s2 = fmaf(hr[k + 2], wr[k + 2], s2);
+            s3 = fmaf(hr[k + 3], wr[k + 3], s3);
+        }
+        outs[t_local * nout + o] = (acc + s1) + (s2 + s3);
     }
     __syncthreads();
 
@@ -124,7 +143,7 @@ __global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
         if (a.have_prev) {
             const float *o = outs + t_local * nout;
             float n0 = NAN, n1 = NAN, n2 = NAN, n3 = NAN, n4 = NAN;
-            if (a.mask_prev[m]) {  // Hidden2Normal, lstm/modules.py:56-64
+            if (pf_maskprev) {  // Hidden2Normal, lstm/modules.py:56-64
                 n0 = o[0]; n1 = o[1];
                 n2 = 0.01f + 0.2f * sigmoid_dev(o[2]);
                 n3 = 0.01f + 0.2f * sigmoid_dev(o[3]);
@@ -132,16 +151,16 @@ __global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
             }
             float *no = a.normal_out + (size_t)m * 5;
             no[0] = n0; no[1] = n1; no[2] = n2; no[3] = n3; no[4] = n4;
-            px = a.obs2_prev[2 * m] + n0;      // positions.append(obs2 + normal[:, :2]), lstm.py:232,255
-            py = a.obs2_prev[2 * m + 1] + n1;
+            px = pf_o2x + n0;      // positions.append(obs2 + normal[:, :2]), lstm.py:232,255
+            py = pf_o2y + n1;
             a.pos_out[2 * m] = px; a.pos_out[2 * m + 1] = py;
         }
         if (a.have_next) {
-            const bool prim = a.primary[m] != 0;
+            const bool prim = pf_prim != 0;
             float o1x, o1y, o2x, o2y;
-            if (a.ext1 && !(a.patch1 && prim)) { o1x = a.ext1[2 * m]; o1y = a.ext1[2 * m + 1]; }
-            else { o1x = a.pos1[2 * m]; o1y = a.pos1[2 * m + 1]; }
-            if (a.ext2 && !(a.patch2 && prim)) { o2x = a.ext2[2 * m]; o2y = a.ext2[2 * m + 1]; }
+            if (a.ext1 && !(a.patch1 && prim)) { o1x = pf_e1x; o1y = pf_e1y; }
+            else { o1x = pf_p1x; o1y = pf_p1y; }
+            if (a.ext2 && !(a.patch2 && prim)) { o2x = pf_e2x; o2y = pf_e2y; }
             else { o2x = px; o2y = py; }
             const bool present = (o1x == o1x) && (o2x == o2x);  // lstm.py:118
             a.obs1_buf[2 * m] = o1x; a.obs1_buf[2 * m + 1] = o1y;

@@ -5,20 +5,24 @@
 // neighbour, so   Linear(C*n*n -> N1)(grid)[i, o] = b[o] + sum_{occupied cells c} sum_ch W[o, ch*n*n + c] * enc[j(i,c), ch].
 // At BASELINE config 2 (n = 16, C = 16, 31 neighbours) that is 8.3x fewer multiply-adds than the dense GEMM,
 // but the non-zeros are unstructured inside any 32-wide block, so the matrix cores cannot skip them.  The fp32
-// VECTOR rate of CDNA4 equals its fp32 MFMA rate (157.3 TFLOP/s), so the sparse sum runs on the VALU:
+// VECTOR rate of CDNA4 equals its fp32 MFMA rate (157.3 TFLOP/s), so the sparse sum runs on the VALU.
 //
-//   * one workgroup = 128 egos x 256 outputs x a range of cells; lane <-> output column, 4 waves = 256 columns;
-//   * the [128 x 256] fp32 accumulator tile lives in LDS (128 KiB of the CU's 160 KiB) because the ego of a
-//     (cell, ego) hit is data dependent; a hit is  acc[ego][lane] += sum_ch w[ch] * enc[j][ch]  with the cell's
-//     C weights w[ch] = W'[c][ch][o] held in VGPRs (W' = cell-major copy of the weight, o contiguous -> 256-byte
-//     coalesced wave loads) and reused by every ego of the tile that has cell c occupied (~15 per cell);
-//   * enc[j] is wave-uniform (scalar loads / broadcast), hits of one cell touch distinct egos, so they are
-//     processed 4 at a time to overlap the LDS read-modify-write latencies;
-//   * the int16 winner table of the tile's cell range is staged transposed in LDS and scanned with ballots;
-//   * workgroup -> (output block, cell range) is XCD aware: the weight slice an XCD streams (2 MiB at config 2)
-//     stays in its 4 MiB L2, so the 16.8 MiB weight is read from HBM / Infinity Cache once per launch.
-// Cell ranges (split S) give enough workgroups for 256 CUs; their partial tiles are summed in fixed order by
-// a small reduce kernel that also applies bias + ReLU (deterministic, no atomics).
+// Default kernel (pool_embed_cellsplit_kernel), one workgroup = 32 egos x 256 output columns, 16 waves:
+//   * wave (q, cs): cells c with c % 4 == q, columns cs*64 + lane.  The C weights of the current cell
+//     W'[c][ch][o] (cell-major copy of the weight, o contiguous -> 256-byte coalesced wave loads) sit in VGPRs,
+//     prefetched one cell ahead, and are reused by every ego of the tile that has cell c occupied;
+//   * the int16 winner table of the tile is staged transposed in LDS; a cell's hits are found with one ballot
+//     (lane <-> ego), and a hit costs: s_ff1 + bit clear, one v_readlane (32-bit byte offset of the neighbour's
+//     row, computed per cell for all lanes at once), one SMEM load of the C-float row (inline asm, so that two
+//     hits are in flight before the single s_waitcnt), one LDS read-modify-write of acc[q][ego][column] and
+//     C/2 v_pk_fma_f32 (even / odd channels in the two halves of a packed register);
+//   * every wave group q owns a private 32 x 256 accumulator copy (4 x 32 KiB of LDS): (ego, column) has one
+//     writer wave, adds happen in program order (deterministic), and the four copies are summed in the epilogue
+//     with bias + ReLU fused -- no partial sums in HBM, no reduce kernel, no atomics;
+//   * blocks b, b+8, ... share an XCD and the same output block, so the 4 MiB weight slice of an output block
+//     stays in that XCD's L2.
+// Grids above 440 cells (winner tile does not fit beside the accumulators) fall back to pool_embed_sparse_kernel:
+// 128 egos x 256 columns x a RANGE of cells per workgroup, partial tiles summed by sparse_reduce_kernel.
 #include "tnp_internal.h"
 #include <stdlib.h>
 
@@ -48,7 +52,9 @@ struct SparseArgs {
 // (egos of group q) x (columns of set cs): every (ego, column) address has exactly one writer wave, so the LDS
 // float adds are race free and their order is program order (deterministic), while SP_EQ waves per SIMD hide the
 // scalar-load and LDS latencies of each other.
-template <int C, int EQ, bool ATOMIC>
+// ABL (measurement only, tools/sparse_sweep.sh): 1 = no neighbour-row loads, 2 = no accumulator read-modify-write,
+// 4 = no weight loads, 8 = no hits at all.  ABL != 0 computes garbage; it isolates where the time goes.
+template <int C, int EQ, bool ATOMIC, int PF = 2, int ABL = 0>
 __global__ void __launch_bounds__(256 * EQ) pool_embed_sparse_kernel(const SparseArgs a) {
     extern __shared__ __attribute__((aligned(16))) float ssm[];
     float *acc = ssm;                                                  // [SP_TE][SP_OB]
@@ -95,19 +101,27 @@ __global__ void __launch_bounds__(256 * EQ) pool_embed_sparse_kernel(const Spars
     __syncthreads();
 
     float *accl = acc + cs * 64 + lane;                                // this lane's column of the tile
-    const float *wcol = a.Wp + oc;
 
+    // uniform (SGPR) row base + 32-bit lane offset -> saddr-form global loads, no 64-bit per-lane address chains
+    const unsigned ocu = (unsigned)oc;
     auto load_w = [&](float (&w)[C], int cc) {
+        const float *wb = a.Wp + (size_t)(c0 + cc) * C * a.N1;
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) w[ch] = wcol[((size_t)(c0 + cc) * C + ch) * a.N1];
+        for (int ch = 0; ch < C; ++ch) w[ch] = (ABL & 4) ? (float)(cc + ch) : (wb + (size_t)ch * a.N1)[ocu];
     };
-    auto process = [&](const float (&w)[C], int cc) {
+    float abl_sum = 0.0f;
+    auto process = [&](float (&w)[C], int cc) {
+        // pin the wait for THIS cell's weights here (straight-line code, so the compiler emits vmcnt(#younger
+        // loads) and the prefetched sets stay in flight); inside the hit loop it would fall back to vmcnt(0)
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) asm("" : "+v"(w[ch]));
 #pragma unroll
       for (int hh = 0; hh < NH; ++hh) {
         const int lego = hh * 64 + lane;                               // ego index inside the group
         const int wv = (lego < EPG) ? (int)wl[cc * WLS + eq * EPG + lego] : -1;
         const int rb = rbv[hh];
         unsigned long long mask = __ballot(wv >= 0);
+        if (ABL & 8) mask = 0ull;
         while (mask) {
             int eg[SP_U];
             const float *ep[SP_U];
@@ -123,7 +137,18 @@ __global__ void __launch_bounds__(256 * EQ) pool_embed_sparse_kernel(const Spars
                 eg[u] = eq * EPG + hh * 64 + b;
                 ep[u] = a.enc + (size_t)j * a.ldv;
             }
-            if (ATOMIC) {
+            if (ABL & 3) {
+                // ablations: neighbour values from the row index instead of memory and / or a private sum
+                // instead of the LDS tile
+#pragma unroll
+                for (int u = 0; u < SP_U; ++u) {
+                    float v = (ABL & 2) ? 0.0f : accl[eg[u] * SP_OB];
+#pragma unroll
+                    for (int ch = 0; ch < C; ++ch)
+                        v = fmaf(w[ch], (ABL & 1) ? (float)((int)(ep[u] - a.enc) + ch) : ep[u][ch], v);
+                    if (ABL & 2) { abl_sum += v; } else if (ok[u]) accl[eg[u] * SP_OB] = v;
+                }
+            } else if (ATOMIC) {
 #pragma unroll
                 for (int u = 0; u < SP_U; ++u) {
                     float c = 0.0f;
@@ -147,17 +172,22 @@ __global__ void __launch_bounds__(256 * EQ) pool_embed_sparse_kernel(const Spars
         }
       }
     };
-    // the C weights of the next cell are in flight while the hits of the current cell are processed
-    float wA[C], wB[C];
-    if (ncl > 0) load_w(wA, 0);
-    for (int cc = 0; cc < ncl; cc += 2) {
-        if (cc + 1 < ncl) load_w(wB, cc + 1);
-        process(wA, cc);
-        if (cc + 1 < ncl) {
-            if (cc + 2 < ncl) load_w(wA, cc + 2);
-            process(wB, cc + 1);
+    // the C weights of the next PF-1 cells are in flight while the hits of the current cell are processed
+    float w[PF][C];
+#pragma unroll
+    for (int p = 0; p < PF - 1; ++p)
+        if (p < ncl) load_w(w[p], p);
+    for (int cc = 0; cc < ncl; cc += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int cur = cc + p;
+            if (cur < ncl) {
+                if (cur + PF - 1 < ncl) load_w(w[(p + PF - 1) % PF], cur + PF - 1);
+                process(w[p], cur);
+            }
         }
     }
+    if (ABL & 2) accl[eq * EPG * SP_OB] = abl_sum;
     __syncthreads();   // all adds of the tile have landed before it is read back
 
     // epilogue: wave (q, cs) writes its egos' rows of its columns
@@ -177,427 +207,6 @@ __global__ void __launch_bounds__(256 * EQ) pool_embed_sparse_kernel(const Spars
                 const int row = row0 + e;
                 if (row >= a.M) break;
                 pp[(size_t)row * a.N1 + o] = accl[e * SP_OB];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Staged variant: per pass over a range of cells, the workgroup first builds a compact hit list in LDS --
-// (ego, the neighbour's C values) for every occupied (ego, cell) of the tile, grouped by cell -- with all
-// lanes gathering in parallel (lane <-> (ego, cell) entry of the winner table).  The accumulation loop then
-// touches only LDS (broadcast reads of the staged values, read-modify-write of the accumulator tile) plus the
-// double-buffered weight loads, and needs almost no scalar bookkeeping per hit.
-// ---------------------------------------------------------------------------------------------------------
-template <int C, int EQ>
-__global__ void __launch_bounds__(256 * EQ) pool_embed_sparse_staged_kernel(const SparseArgs a, int hcap) {
-    extern __shared__ __attribute__((aligned(16))) float ssm[];
-    constexpr int NTH = 256 * EQ;
-    constexpr int EPG = SP_TE / EQ;
-    float *acc = ssm;                                        // [SP_TE][SP_OB]
-    float *henc = acc + SP_TE * SP_OB;                       // [hcap][C]
-    int *hego = reinterpret_cast<int *>(henc + (size_t)hcap * C);   // [hcap]
-    int *cstart = hego + hcap;                               // [cps + 1]  start of each cell's hits in the pass
-    int *cursor = cstart + 132;                              // [cps]
-    int *cnt = cursor + 132;                                 // [cps]  hits per cell (whole split)
-    int *ctl = cnt + 132;                                    // [4]    pass bounds
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cs = wave & 3, eq = wave >> 2;
-    const int ncombo = a.out_blocks * a.S;
-    int combo, et;
-    if ((ncombo & 7) == 0) {
-        const int cpx = ncombo >> 3, xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
-        combo = xcd * cpx + (l % cpx);
-        et = l / cpx;
-    } else {
-        combo = blockIdx.x % ncombo;
-        et = blockIdx.x / ncombo;
-    }
-    const int ob = combo % a.out_blocks, sp = combo / a.out_blocks;
-    const int row0 = et * SP_TE;
-    const int c0 = sp * a.cps;
-    const int ncl = min(a.cps, a.ncell - c0);
-    const int o = ob * SP_OB + cs * 64 + lane;
-    const bool o_ok = o < a.N1;
-    const int oc = o_ok ? o : (a.N1 - 1);
-
-    for (int q = tid; q < SP_TE * SP_OB; q += NTH) acc[q] = 0.0f;
-    for (int q = tid; q < 132; q += NTH) cnt[q] = 0;
-    __syncthreads();
-    // hits per cell of this tile / split
-    for (int q = tid; q < SP_TE * ncl; q += NTH) {
-        const int e = q / ncl, cc = q - e * ncl;
-        const int row = row0 + e;
-        if (row < a.M && a.winners[(size_t)row * a.ncell + c0 + cc] >= 0) atomicAdd(&cnt[cc], 1);
-    }
-    __syncthreads();
-
-    float *accl = acc + cs * 64 + lane;
-    const float *wcol = a.Wp + oc;
-    auto load_w = [&](float (&w)[C], int cc) {
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) w[ch] = wcol[((size_t)(c0 + cc) * C + ch) * a.N1];
-    };
-    auto process = [&](const float (&w)[C], int cc) {
-        const int k0 = cstart[cc], k1 = cstart[cc + 1];
-        for (int k = k0; k < k1; ++k) {
-            const int ego = __builtin_amdgcn_readfirstlane(hego[k]);
-            if (ego / EPG != eq) continue;                    // single writer per (ego, column)
-            const float *ev = henc + (size_t)k * C;
-            float av = accl[ego * SP_OB];
-#pragma unroll
-            for (int ch = 0; ch < C; ch += 4) {
-                const float4 e4 = *reinterpret_cast<const float4 *>(ev + ch);
-                av = fmaf(w[ch], e4.x, av); av = fmaf(w[ch + 1], e4.y, av);
-                av = fmaf(w[ch + 2], e4.z, av); av = fmaf(w[ch + 3], e4.w, av);
-            }
-            accl[ego * SP_OB] = av;
-        }
-    };
-
-    int pass_lo = 0;
-    while (pass_lo < ncl) {
-        // pass bounds: as many cells as fit the staging buffer (at least one)
-        if (tid == 0) {
-            int tot = 0, c = pass_lo;
-            while (c < ncl && (c == pass_lo || tot + cnt[c] <= hcap)) { cstart[c - pass_lo] = tot; tot += cnt[c]; ++c; }
-            cstart[c - pass_lo] = tot;
-            ctl[0] = c;
-        }
-        for (int q = tid; q < 132; q += NTH) cursor[q] = 0;
-        __syncthreads();
-        const int pass_hi = ctl[0];
-        const int npc = pass_hi - pass_lo;
-        // fill: lane <-> (ego, cell) entry; gather the neighbour's values next to the ego id
-        for (int q = tid; q < SP_TE * npc; q += NTH) {
-            const int e = q / npc, cc = q - e * npc;
-            const int row = row0 + e;
-            if (row >= a.M) continue;
-            const int wv = a.winners[(size_t)row * a.ncell + c0 + pass_lo + cc];
-            if (wv < 0) continue;
-            const int slot = cstart[cc] + atomicAdd(&cursor[cc], 1);
-            if (slot >= hcap) continue;                       // a single over-full cell: cannot happen (<= SP_TE hits)
-            hego[slot] = e;
-            const float *src = a.enc + (size_t)(a.row_base[row] + wv) * a.ldv;
-#pragma unroll
-            for (int ch = 0; ch < C; ch += 4)
-                *reinterpret_cast<float4 *>(henc + (size_t)slot * C + ch) = *reinterpret_cast<const float4 *>(src + ch);
-        }
-        __syncthreads();
-        float wA[C], wB[C];
-        load_w(wA, pass_lo);
-        for (int cc = 0; cc < npc; cc += 2) {
-            if (cc + 1 < npc) load_w(wB, pass_lo + cc + 1);
-            process(wA, cc);
-            if (cc + 1 < npc) {
-                if (cc + 2 < npc) load_w(wA, pass_lo + cc + 2);
-                process(wB, cc + 1);
-            }
-        }
-        __syncthreads();
-        pass_lo = pass_hi;
-    }
-
-    if (o_ok) {
-        if (a.S == 1) {
-            const float b = a.bias ? a.bias[o] : 0.0f;
-            for (int e = eq * EPG; e < (eq + 1) * EPG; ++e) {
-                const int row = row0 + e;
-                if (row >= a.M) break;
-                float v = accl[e * SP_OB] + b;
-                if (a.relu) v = v > 0.0f ? v : 0.0f;
-                a.out[(size_t)row * a.ldo + o] = v;
-            }
-        } else {
-            float *pp = a.out + (size_t)sp * a.M * a.N1;
-            for (int e = eq * EPG; e < (eq + 1) * EPG; ++e) {
-                const int row = row0 + e;
-                if (row >= a.M) break;
-                pp[(size_t)row * a.N1 + o] = accl[e * SP_OB];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// List variant: a compact per-(cell, ego group) hit list  (neighbour row j << 8 | ego)  is built in LDS first
-// (lane <-> winner-table entry, integer LDS atomics for the slots), so the accumulation loop carries almost no
-// scalar bookkeeping: per hit one broadcast LDS read, one s_load_dwordx16 of the neighbour's values, C FMAs with
-// SGPR operands and the LDS read-modify-write of the accumulator entry.  EQ ego groups x 4 column sets of waves
-// keep 4 waves per SIMD in flight; a wave only walks the hits of its own ego group (single writer per entry).
-// ---------------------------------------------------------------------------------------------------------
-template <int C, int EQ>
-__global__ void __launch_bounds__(256 * EQ) pool_embed_sparse_list_kernel(const SparseArgs a, int hcap) {
-    extern __shared__ __attribute__((aligned(16))) float ssm[];
-    constexpr int NTH = 256 * EQ;
-    constexpr int EPG = SP_TE / EQ;
-    constexpr int TAB = 128 * EQ + 4;                        // >= cps * EQ + 1
-    float *acc = ssm;                                        // [SP_TE][SP_OB]
-    int *hits = reinterpret_cast<int *>(acc + SP_TE * SP_OB);   // [hcap]
-    int *cstart = hits + hcap;                               // [TAB] start of (cell, group) lists
-    int *cursor = cstart + TAB;                              // [TAB]
-    int *cnt = cursor + TAB;                                 // [TAB]
-    int *ctl = cnt + TAB;                                    // [4]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cs = wave & 3, eq = wave >> 2;
-    const int ncombo = a.out_blocks * a.S;
-    int combo, et;
-    if ((ncombo & 7) == 0) {
-        const int cpx = ncombo >> 3, xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
-        combo = xcd * cpx + (l % cpx);
-        et = l / cpx;
-    } else {
-        combo = blockIdx.x % ncombo;
-        et = blockIdx.x / ncombo;
-    }
-    const int ob = combo % a.out_blocks, sp = combo / a.out_blocks;
-    const int row0 = et * SP_TE;
-    const int c0 = sp * a.cps;
-    const int ncl = min(a.cps, a.ncell - c0);
-    const int o = ob * SP_OB + cs * 64 + lane;
-    const bool o_ok = o < a.N1;
-    const int oc = o_ok ? o : (a.N1 - 1);
-
-    for (int q = tid; q < SP_TE * SP_OB; q += NTH) acc[q] = 0.0f;
-    for (int q = tid; q < TAB; q += NTH) cnt[q] = 0;
-    __syncthreads();
-    for (int q = tid; q < SP_TE * ncl; q += NTH) {
-        const int e = q / ncl, cc = q - e * ncl;
-        const int row = row0 + e;
-        if (row < a.M && a.winners[(size_t)row * a.ncell + c0 + cc] >= 0) atomicAdd(&cnt[cc * EQ + e / EPG], 1);
-    }
-    __syncthreads();
-
-    float *accl = acc + cs * 64 + lane;
-    const float *wcol = a.Wp + oc;
-    const float *encp = a.enc;
-    const int ldv = a.ldv;
-    auto load_w = [&](float (&w)[C], int cc) {
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) w[ch] = wcol[((size_t)(c0 + cc) * C + ch) * a.N1];
-    };
-    auto process = [&](const float (&w)[C], int cc) {
-        int k = cstart[cc * EQ + eq];
-        const int k1 = cstart[cc * EQ + eq + 1];
-        for (; k + 1 < k1; k += 2) {                          // two hits (distinct egos) in flight
-            const int h0 = __builtin_amdgcn_readfirstlane(hits[k]), h1 = __builtin_amdgcn_readfirstlane(hits[k + 1]);
-            const float *e0 = encp + (size_t)(h0 >> 8) * ldv, *e1 = encp + (size_t)(h1 >> 8) * ldv;
-            const int g0 = (h0 & 255) * SP_OB, g1 = (h1 & 255) * SP_OB;
-            float a0 = accl[g0], a1 = accl[g1];
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) { a0 = fmaf(w[ch], e0[ch], a0); a1 = fmaf(w[ch], e1[ch], a1); }
-            accl[g0] = a0; accl[g1] = a1;
-        }
-        if (k < k1) {
-            const int h0 = __builtin_amdgcn_readfirstlane(hits[k]);
-            const float *e0 = encp + (size_t)(h0 >> 8) * ldv;
-            const int g0 = (h0 & 255) * SP_OB;
-            float a0 = accl[g0];
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) a0 = fmaf(w[ch], e0[ch], a0);
-            accl[g0] = a0;
-        }
-    };
-
-    int pass_lo = 0;
-    while (pass_lo < ncl) {
-        if (tid == 0) {   // pass bounds: as many cells as fit the hit list (at least one)
-            int tot = 0, c = pass_lo;
-            while (c < ncl) {
-                int cell_tot = 0;
-                for (int gq = 0; gq < EQ; ++gq) cell_tot += cnt[c * EQ + gq];
-                if (c > pass_lo && tot + cell_tot > hcap) break;
-                for (int gq = 0; gq < EQ; ++gq) { cstart[(c - pass_lo) * EQ + gq] = tot; tot += cnt[c * EQ + gq]; }
-                ++c;
-            }
-            cstart[(c - pass_lo) * EQ] = tot;
-            ctl[0] = c;
-        }
-        for (int q = tid; q < TAB; q += NTH) cursor[q] = 0;
-        __syncthreads();
-        const int pass_hi = ctl[0];
-        const int npc = pass_hi - pass_lo;
-        for (int q = tid; q < SP_TE * npc; q += NTH) {
-            const int e = q / npc, cc = q - e * npc;
-            const int row = row0 + e;
-            if (row >= a.M) continue;
-            const int wv = a.winners[(size_t)row * a.ncell + c0 + pass_lo + cc];
-            if (wv < 0) continue;
-            const int li = cc * EQ + e / EPG;
-            const int slot = cstart[li] + atomicAdd(&cursor[li], 1);
-            if (slot < hcap) hits[slot] = ((a.row_base[row] + wv) << 8) | e;
-        }
-        __syncthreads();
-        float wA[C], wB[C];
-        load_w(wA, pass_lo);
-        for (int cc = 0; cc < npc; cc += 2) {
-            if (cc + 1 < npc) load_w(wB, pass_lo + cc + 1);
-            process(wA, cc);
-            if (cc + 1 < npc) {
-                if (cc + 2 < npc) load_w(wA, pass_lo + cc + 2);
-                process(wB, cc + 1);
-            }
-        }
-        __syncthreads();
-        pass_lo = pass_hi;
-    }
-
-    if (o_ok) {
-        if (a.S == 1) {
-            const float b = a.bias ? a.bias[o] : 0.0f;
-            for (int e = eq * EPG; e < (eq + 1) * EPG; ++e) {
-                const int row = row0 + e;
-                if (row >= a.M) break;
-                float v = accl[e * SP_OB] + b;
-                if (a.relu) v = v > 0.0f ? v : 0.0f;
-                a.out[(size_t)row * a.ldo + o] = v;
-            }
-        } else {
-            float *pp = a.out + (size_t)sp * a.M * a.N1;
-            for (int e = eq * EPG; e < (eq + 1) * EPG; ++e) {
-                const int row = row0 + e;
-                if (row >= a.M) break;
-                pp[(size_t)row * a.N1 + o] = accl[e * SP_OB];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Register-accumulator variant.  Wave (q, cs) keeps the accumulators of its 32 egos x 64 columns in 32 VGPRs
-// (lane <-> column): the ego of a hit is wave-uniform, so "acc[ego] += c" is a scalar jump into a 32-way switch
-// of single v_add instructions -- no LDS traffic for the accumulators at all.  LDS only holds the compact
-// per-(cell, ego group) hit lists (neighbour row << 8 | ego).  Per hit: one s_load_dwordx16 of the neighbour's
-// values (SGPR FMA operands), C FMAs, one add.
-// ---------------------------------------------------------------------------------------------------------
-#define SP_ACC_CASE(i) case i: acc[i] += c; break;
-#define SP_ACC_SWITCH(el, c) switch (el) { \
-    SP_ACC_CASE(0) SP_ACC_CASE(1) SP_ACC_CASE(2) SP_ACC_CASE(3) SP_ACC_CASE(4) SP_ACC_CASE(5) SP_ACC_CASE(6) SP_ACC_CASE(7) \
-    SP_ACC_CASE(8) SP_ACC_CASE(9) SP_ACC_CASE(10) SP_ACC_CASE(11) SP_ACC_CASE(12) SP_ACC_CASE(13) SP_ACC_CASE(14) SP_ACC_CASE(15) \
-    SP_ACC_CASE(16) SP_ACC_CASE(17) SP_ACC_CASE(18) SP_ACC_CASE(19) SP_ACC_CASE(20) SP_ACC_CASE(21) SP_ACC_CASE(22) SP_ACC_CASE(23) \
-    SP_ACC_CASE(24) SP_ACC_CASE(25) SP_ACC_CASE(26) SP_ACC_CASE(27) SP_ACC_CASE(28) SP_ACC_CASE(29) SP_ACC_CASE(30) SP_ACC_CASE(31) \
-    default: break; }
-
-template <int C>
-__global__ void __launch_bounds__(1024) pool_embed_sparse_reg_kernel(const SparseArgs a, int hcap) {
-    extern __shared__ __attribute__((aligned(16))) float ssm[];
-    constexpr int EQ = 4, NTH = 1024, EPG = 32;
-    constexpr int TAB = 128 * EQ + 4;
-    int *hits = reinterpret_cast<int *>(ssm);                // [hcap]
-    int *cstart = hits + hcap;                               // [TAB]
-    int *cursor = cstart + TAB;                              // [TAB]
-    int *cnt = cursor + TAB;                                 // [TAB]
-    int *ctl = cnt + TAB;                                    // [4]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cs = wave & 3, eq = wave >> 2;
-    const int ncombo = a.out_blocks * a.S;
-    int combo, et;
-    if ((ncombo & 7) == 0) {
-        const int cpx = ncombo >> 3, xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
-        combo = xcd * cpx + (l % cpx);
-        et = l / cpx;
-    } else {
-        combo = blockIdx.x % ncombo;
-        et = blockIdx.x / ncombo;
-    }
-    const int ob = combo % a.out_blocks, sp = combo / a.out_blocks;
-    const int row0 = et * SP_TE;
-    const int c0 = sp * a.cps;
-    const int ncl = min(a.cps, a.ncell - c0);
-    const int o = ob * SP_OB + cs * 64 + lane;
-    const bool o_ok = o < a.N1;
-    const int oc = o_ok ? o : (a.N1 - 1);
-
-    for (int q = tid; q < TAB; q += NTH) cnt[q] = 0;
-    __syncthreads();
-    for (int q = tid; q < SP_TE * ncl; q += NTH) {
-        const int e = q / ncl, cc = q - e * ncl;
-        const int row = row0 + e;
-        if (row < a.M && a.winners[(size_t)row * a.ncell + c0 + cc] >= 0) atomicAdd(&cnt[cc * EQ + e / EPG], 1);
-    }
-    __syncthreads();
-
-    float acc[EPG];
-#pragma unroll
-    for (int i = 0; i < EPG; ++i) acc[i] = 0.0f;
-    const float *wcol = a.Wp + oc;
-    const float *encp = a.enc;
-    const int ldv = a.ldv;
-    auto load_w = [&](float (&w)[C], int cc) {
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) w[ch] = wcol[((size_t)(c0 + cc) * C + ch) * a.N1];
-    };
-    auto process = [&](const float (&w)[C], int cc) {
-        int k = cstart[cc * EQ + eq];
-        const int k1 = cstart[cc * EQ + eq + 1];
-        for (; k < k1; ++k) {
-            const int h0 = __builtin_amdgcn_readfirstlane(hits[k]);
-            const float *e0 = encp + (size_t)(h0 >> 8) * ldv;
-            float c = 0.0f;
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) c = fmaf(w[ch], e0[ch], c);
-            const int el = (h0 & 255) - eq * EPG;
-            SP_ACC_SWITCH(el, c)
-        }
-    };
-
-    int pass_lo = 0;
-    while (pass_lo < ncl) {
-        if (tid == 0) {
-            int tot = 0, c = pass_lo;
-            while (c < ncl) {
-                int cell_tot = 0;
-                for (int gq = 0; gq < EQ; ++gq) cell_tot += cnt[c * EQ + gq];
-                if (c > pass_lo && tot + cell_tot > hcap) break;
-                for (int gq = 0; gq < EQ; ++gq) { cstart[(c - pass_lo) * EQ + gq] = tot; tot += cnt[c * EQ + gq]; }
-                ++c;
-            }
-            cstart[(c - pass_lo) * EQ] = tot;
-            ctl[0] = c;
-        }
-        for (int q = tid; q < TAB; q += NTH) cursor[q] = 0;
-        __syncthreads();
-        const int pass_hi = ctl[0];
-        const int npc = pass_hi - pass_lo;
-        for (int q = tid; q < SP_TE * npc; q += NTH) {
-            const int e = q / npc, cc = q - e * npc;
-            const int row = row0 + e;
-            if (row >= a.M) continue;
-            const int wv = a.winners[(size_t)row * a.ncell + c0 + pass_lo + cc];
-            if (wv < 0) continue;
-            const int li = cc * EQ + e / EPG;
-            const int slot = cstart[li] + atomicAdd(&cursor[li], 1);
-            if (slot < hcap) hits[slot] = ((a.row_base[row] + wv) << 8) | e;
-        }
-        __syncthreads();
-        float wA[C], wB[C];
-        load_w(wA, pass_lo);
-        for (int cc = 0; cc < npc; cc += 2) {
-            if (cc + 1 < npc) load_w(wB, pass_lo + cc + 1);
-            process(wA, cc);
-            if (cc + 1 < npc) {
-                if (cc + 2 < npc) load_w(wA, pass_lo + cc + 2);
-                process(wB, cc + 1);
-            }
-        }
-        __syncthreads();
-        pass_lo = pass_hi;
-    }
-
-    if (o_ok) {
-        const float b = (a.S == 1 && a.bias) ? a.bias[o] : 0.0f;
-        float *pp = (a.S == 1) ? a.out : a.out + (size_t)sp * a.M * a.N1;
-        const int ld = (a.S == 1) ? a.ldo : a.N1;
-#pragma unroll
-        for (int i = 0; i < EPG; ++i) {
-            const int row = row0 + eq * EPG + i;
-            if (row < a.M) {
-                float v = acc[i] + b;
-                if (a.S == 1 && a.relu) v = v > 0.0f ? v : 0.0f;
-                pp[(size_t)row * ld + o] = v;
             }
         }
     }
@@ -636,10 +245,185 @@ int launch_row_base(const int32_t *scene_start, int B, int32_t *row_base, hipStr
     return 0;
 }
 
+
+constexpr int TL_TE = 32;    // egos per tile
+constexpr int TL_OB = 256;   // output columns per workgroup
+constexpr int TL_NQ = 4;     // cell groups of one workgroup (cell c belongs to group c % 4)
+constexpr int TL_MAXCELL_LDS = 440;   // the int16 winner tile [ncell][34] must fit beside the 128 KiB accumulators
+
+// ---------------------------------------------------------------------------------------------------------
+// Cell-split kernel: the hit discovery of pool_embed_sparse_kernel (winner tile in LDS, ballot, scalar loads of
+// the neighbour rows straight from `enc`, which stays hot in the scalar cache) on a tile of 32 egos x 256
+// columns, with the CELLS split over the 4 wave groups of one workgroup (cell c -> group c % 4, each with its own
+// accumulator copy).  The copies are summed in the epilogue with bias + ReLU fused: no partial sums in HBM, no
+// reduce kernel, and the fixed per-workgroup work (zeroing, winner staging, epilogue) shrinks 4x.
+// ---------------------------------------------------------------------------------------------------------
+
+// Scalar (SMEM) load of one C-float neighbour row, issued as inline asm so that the U loads of a hit group are all
+// in flight before the single s_waitcnt (the compiler otherwise sinks each load next to its use, exposing one
+// scalar-load latency per hit).
+template <int C> struct SRow;
+template <> struct SRow<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct SRow<8> { typedef float type __attribute__((ext_vector_type(8))); };
+template <> struct SRow<16> { typedef float type __attribute__((ext_vector_type(16))); };
+template <int C>
+__device__ __forceinline__ void sload_row(typename SRow<C>::type &v, const float *base, unsigned byte_off) {
+    if constexpr (C == 4) asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(v) : "s"(base), "s"(byte_off));
+    else if constexpr (C == 8) asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(base), "s"(byte_off));
+    else asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(base), "s"(byte_off));
+}
+
+// ABL: measurement only (4 = no weight loads, 8 = no hits).
+template <int C, int PF, int U, bool SASM, int ABL = 0>
+__global__ void __launch_bounds__(1024) pool_embed_cellsplit_kernel(const SparseArgs a) {
+    typedef int16_t WT;
+    constexpr int TE = TL_TE, OB = TL_OB, NCS = OB / 64;
+    constexpr int NQ = TL_NQ, WLS = TE + 2, NTH = 64 * NQ * NCS;
+    extern __shared__ __attribute__((aligned(16))) float csm[];
+    float *acc = csm;                                                        // [NQ][TE][OB]
+    WT *wl = reinterpret_cast<WT *>(csm + NQ * TE * OB);    // [ncell][WLS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cs = wave % NCS, q = wave / NCS;
+    const int ob = blockIdx.x % a.out_blocks, tile = blockIdx.x / a.out_blocks;   // blocks b, b+8, .. share an XCD
+    const int row0 = tile * TE;
+    const int o = ob * OB + cs * 64 + lane;
+    const unsigned ocu = (unsigned)(o < a.N1 ? o : a.N1 - 1);
+
+    float *accl = acc + (size_t)q * TE * OB + cs * 64 + lane;
+#pragma unroll
+    for (int e = 0; e < TE; ++e) accl[e * OB] = 0.0f;
+    for (int idx = tid; idx < TE * a.ncell; idx += NTH) {
+        const int e = idx / a.ncell, c = idx - e * a.ncell;
+        const int row = row0 + e;
+        wl[c * WLS + e] = row < a.M ? (WT)a.winners[(size_t)row * a.ncell + c] : (WT)-1;
+    }
+    const int rb = a.row_base[min(row0 + (lane & (TE - 1)), a.M - 1)];
+    __syncthreads();
+
+    auto load_w = [&](float (&w)[C], int c) {
+        const float *wb = a.Wp + (size_t)c * C * a.N1;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) w[ch] = (ABL & 4) ? (float)(c + ch) : (wb + (size_t)ch * a.N1)[ocu];
+    };
+    auto process = [&](float (&w)[C], int c) {
+        const int wv = lane < TE ? (int)wl[c * WLS + lane] : -1;
+        unsigned long long mask = __ballot(wv >= 0);
+        if (mask == 0ull || (ABL & 8)) return;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) asm("" : "+v"(w[ch]));
+        if constexpr (SASM && C <= 16) {
+            // lean path: the byte offset of every lane's neighbour row is one VALU op per cell; a hit then costs
+            // ff1 + bit clear + one readlane + one SMEM load (SGPR offset) + LDS read-modify-write + C FMAs
+            const unsigned off = (unsigned)(rb + wv) * (unsigned)(a.ldv * 4);
+            auto one = [&](int b, typename SRow<C>::type &ev, float &av) {
+                sload_row<C>(ev, a.enc, (unsigned)__builtin_amdgcn_readlane((int)off, b));
+                av = accl[b * OB];
+            };
+            // even / odd channels accumulate in the two halves of one packed register: C/2 v_pk_fma_f32 with the
+            // weight pair (w[2k], w[2k+1]) and the SGPR pair (e[2k], e[2k+1]) instead of C v_fmac_f32
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            auto fin = [&](int b, const typename SRow<C>::type &ev, float av) {
+                f2 p = {av, 0.0f};
+#pragma unroll
+                for (int k = 0; k < C / 2; ++k) {
+                    const f2 wk = {w[2 * k], w[2 * k + 1]};
+                    const f2 ek = {ev[2 * k], ev[2 * k + 1]};
+                    p = __builtin_elementwise_fma(wk, ek, p);
+                }
+                accl[b * OB] = p.x + p.y;
+            };
+            if constexpr (U >= 2) {
+                while (mask & (mask - 1ull)) {                      // at least two hits left
+                    const int b0 = __ffsll((long long)mask) - 1; mask &= mask - 1ull;
+                    const int b1 = __ffsll((long long)mask) - 1; mask &= mask - 1ull;
+                    typename SRow<C>::type e0, e1;
+                    float a0, a1;
+                    one(b0, e0, a0);
+                    one(b1, e1, a1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e0), "+s"(e1));
+                    fin(b0, e0, a0);
+                    fin(b1, e1, a1);
+                }
+            }
+            while (mask) {
+                const int b0 = __ffsll((long long)mask) - 1; mask &= mask - 1ull;
+                typename SRow<C>::type e0;
+                float a0;
+                one(b0, e0, a0);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e0));
+                fin(b0, e0, a0);
+            }
+            return;
+        }
+        while (mask) {
+            int eg[U];
+            const float *ep[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ok[u] = mask != 0ull;
+                const int b = ok[u] ? (__ffsll((long long)mask) - 1) : 0;
+                if (ok[u]) mask &= mask - 1ull;
+                const int wj = __builtin_amdgcn_readlane(wv, b);
+                const int base = __builtin_amdgcn_readlane(rb, b);
+                const int j = ok[u] ? (base + wj) : 0;
+                eg[u] = b;
+                ep[u] = a.enc + (size_t)j * a.ldv;
+            }
+            float av[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) av[u] = accl[eg[u] * OB];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) av[u] = fmaf(w[ch], ep[u][ch], av[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (ok[u]) accl[eg[u] * OB] = av[u];
+        }
+    };
+    float w[PF][C];
+    const int nk = (a.ncell - q + NQ - 1) / NQ;
+#pragma unroll
+    for (int p = 0; p < PF - 1; ++p)
+        if (p < nk) load_w(w[p], q + NQ * p);
+    for (int k0 = 0; k0 < nk; k0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int k = k0 + p;
+            if (k < nk) {
+                if (k + PF - 1 < nk) load_w(w[(p + PF - 1) % PF], q + NQ * (k + PF - 1));
+                process(w[p], q + NQ * k);
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int g = tid; g < TE * OB / 4; g += NTH) {
+        const int e = g / (OB / 4), c4 = (g - e * (OB / 4)) * 4;
+        const int row = row0 + e, oo = ob * OB + c4;
+        if (row >= a.M || oo >= a.N1) continue;
+        float4 v = *reinterpret_cast<const float4 *>(acc + (size_t)e * OB + c4);
+#pragma unroll
+        for (int qq = 1; qq < NQ; ++qq) {
+            const float4 t = *reinterpret_cast<const float4 *>(acc + ((size_t)qq * TE + e) * OB + c4);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (a.bias) {
+            const float4 b = *reinterpret_cast<const float4 *>(a.bias + oo);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (a.relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+        *reinterpret_cast<float4 *>(a.out + (size_t)row * a.ldo + oo) = v;
+    }
+}
+
 bool sparse_supported(int C, int N1, int ncell) {
     return (C == 4 || C == 8 || C == 16 || C == 32) && N1 >= 4 && (N1 % 4 == 0) && ncell >= 1;
 }
 
+// fallback plan (pool_embed_sparse_kernel): cell ranges across workgroups
 void sparse_plan(int M, int N1, int ncell, int &S, int &cps, int &ego_tiles, int &out_blocks) {
     ego_tiles = (M + SP_TE - 1) / SP_TE;
     out_blocks = (N1 + SP_OB - 1) / SP_OB;
@@ -648,7 +432,9 @@ void sparse_plan(int M, int N1, int ncell, int &S, int &cps, int &ego_tiles, int
     cps = (ncell + S - 1) / S;
 }
 
+// the cell-split kernel needs no workspace; the fallback needs its partial sums
 size_t sparse_partial_bytes(int M, int N1, int ncell) {
+    if (ncell <= TL_MAXCELL_LDS) return 0;
     int S, cps, et, obk;
     sparse_plan(M, N1, ncell, S, cps, et, obk);
     return S > 1 ? (size_t)S * M * N1 * sizeof(float) : 0;
@@ -659,9 +445,30 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
                              float *out, int ldo, float *partial, hipStream_t s) {
     if (M <= 0) return 0;
     if (!sparse_supported(C, N1, ncell)) TNP_FAIL(-1, "sparse pooling embedding: unsupported C=%d N1=%d", C, N1);
+    // TNP_SPARSE_VARIANT (measurement, tools/sparse_sweep.sh): 0 default; 1 = one hit in flight; 2 = compiler-
+    // scheduled scalar loads; 8 / 9 = ablations (no hits / no weight loads: WRONG results, timing only)
+    static int sp_variant = -1;
+    if (sp_variant < 0) { const char *e = getenv("TNP_SPARSE_VARIANT"); sp_variant = e ? atoi(e) : 0; }
     SparseArgs a;
     a.winners = winners; a.enc = enc; a.ldv = ldv; a.row_base = row_base; a.Wp = Wp; a.bias = bias;
     a.M = M; a.ncell = ncell; a.C = C; a.N1 = N1; a.relu = relu; a.ldo = ldo;
+    if (ncell <= TL_MAXCELL_LDS) {
+        a.out = out;
+        a.S = 1; a.cps = ncell; a.ego_tiles = (M + TL_TE - 1) / TL_TE; a.out_blocks = (N1 + TL_OB - 1) / TL_OB;
+        const size_t csmem = (size_t)TL_NQ * TL_TE * TL_OB * 4 + (((size_t)ncell * (TL_TE + 2) * 2 + 15) & ~(size_t)15);
+        const int cblocks = a.ego_tiles * a.out_blocks;
+        // the lean path addresses neighbour rows with a 32-bit byte offset
+        const bool lean = (size_t)M * ldv * sizeof(float) < ((size_t)1 << 32) && sp_variant != 2;
+#define CS_LAUNCH(CC, UU, SA, ABLM) { static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
+        pool_embed_cellsplit_kernel<CC, 2, UU, SA, ABLM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((pool_embed_cellsplit_kernel<CC, 2, UU, SA, ABLM>), dim3(cblocks), dim3(1024), csmem, s, a); }
+#define CS_SWITCH(CC) { if (!lean) CS_LAUNCH(CC, 2, false, 0) else switch (sp_variant) { case 1: CS_LAUNCH(CC, 1, true, 0) break; \
+        case 8: CS_LAUNCH(CC, 2, true, 8) break; case 9: CS_LAUNCH(CC, 2, true, 4) break; default: CS_LAUNCH(CC, 2, true, 0) break; } }
+        if (C == 4) CS_SWITCH(4) else if (C == 8) CS_SWITCH(8) else if (C == 16) CS_SWITCH(16) else CS_SWITCH(32)
+        TNP_HIP(hipGetLastError());
+        return 0;
+    }
+    // ---- fallback for grids too large for the LDS winner tile: cell ranges across workgroups + reduce ----
     sparse_plan(M, N1, ncell, a.S, a.cps, a.ego_tiles, a.out_blocks);
     if (a.cps > 120) TNP_FAIL(-1, "sparse pooling embedding: %d cells per split exceed the LDS winner tile", a.cps);
     if (a.S > 1 && !partial) TNP_FAIL(-1, "sparse pooling embedding: partial workspace missing");
@@ -669,35 +476,9 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
     if (a.S > 1) a.ldo = N1;
     const size_t smem = (size_t)SP_TE * SP_OB * 4 + (((size_t)a.cps * (SP_TE + 2) * 2 + 15) & ~(size_t)15);
     const int blocks = a.ego_tiles * a.out_blocks * a.S;
-    static int sp_variant = -1;
-    if (sp_variant < 0) { const char *e = getenv("TNP_SPARSE_VARIANT"); sp_variant = e ? atoi(e) : 4; }  // 4 = 16 waves, read-modify-write accumulators (measured best)
-#define SP_LAUNCH2(CC, EQ, AT) { static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
-        pool_embed_sparse_kernel<CC, EQ, AT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        hipLaunchKernelGGL((pool_embed_sparse_kernel<CC, EQ, AT>), dim3(blocks), dim3(256 * EQ), smem, s, a); }
-    // staged kernel: LDS = accumulator tile + hit list (hcap hits x (C values + ego id)) + per-cell tables
-    const int hcap = (int)((163840 - (size_t)SP_TE * SP_OB * 4 - 4 * 132 * 4 - 64) / ((size_t)C * 4 + 4)) & ~3;
-    const size_t smem_st = (size_t)SP_TE * SP_OB * 4 + (size_t)hcap * (C * 4 + 4) + 4 * 132 * 4;
-#define SP_LAUNCH3(CC, EQ) { static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
-        pool_embed_sparse_staged_kernel<CC, EQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        hipLaunchKernelGGL((pool_embed_sparse_staged_kernel<CC, EQ>), dim3(blocks), dim3(256 * EQ), smem_st, s, a, hcap); }
-    // list kernel: LDS = accumulator tile + hit list + 3 tables of 128*EQ+4 ints + ctl
-#define SP_LAUNCH5(CC, EQ) { const int tab = 128 * EQ + 4; \
-        const int hc = (int)((163840 - (size_t)SP_TE * SP_OB * 4 - (size_t)3 * tab * 4 - 64) / 4) & ~3; \
-        const size_t sm = (size_t)SP_TE * SP_OB * 4 + (size_t)hc * 4 + (size_t)3 * tab * 4 + 64; \
-        static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
-        pool_embed_sparse_list_kernel<CC, EQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        hipLaunchKernelGGL((pool_embed_sparse_list_kernel<CC, EQ>), dim3(blocks), dim3(256 * EQ), sm, s, a, hc); }
-#define SP_LAUNCH6(CC) { const int tab = 128 * 4 + 4; const int hc = 16384; \
-        const size_t sm = (size_t)hc * 4 + (size_t)3 * tab * 4 + 64; \
-        static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
-        pool_embed_sparse_reg_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        hipLaunchKernelGGL((pool_embed_sparse_reg_kernel<CC>), dim3(blocks), dim3(1024), sm, s, a, hc); }
-#define SP_LAUNCH(CC) { switch (sp_variant) { \
-        case 30: SP_LAUNCH6(CC) break; \
-        case 20: SP_LAUNCH5(CC, 1) break; case 21: SP_LAUNCH5(CC, 2) break; case 22: SP_LAUNCH5(CC, 4) break; \
-        case 10: SP_LAUNCH3(CC, 1) break; case 11: SP_LAUNCH3(CC, 2) break; case 12: SP_LAUNCH3(CC, 4) break; \
-        case 1: SP_LAUNCH2(CC, 1, true) break; case 2: SP_LAUNCH2(CC, 2, false) break; case 3: SP_LAUNCH2(CC, 2, true) break; \
-        case 4: SP_LAUNCH2(CC, 4, false) break; case 5: SP_LAUNCH2(CC, 4, true) break; default: SP_LAUNCH2(CC, 1, false) break; } }
+#define SP_LAUNCH(CC) { static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
+        pool_embed_sparse_kernel<CC, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((pool_embed_sparse_kernel<CC, 4, false>), dim3(blocks), dim3(1024), smem, s, a); }
     if (C == 4) SP_LAUNCH(4) else if (C == 8) SP_LAUNCH(8) else if (C == 16) SP_LAUNCH(16) else SP_LAUNCH(32)
     TNP_HIP(hipGetLastError());
     if (a.S > 1) {

@@ -259,3 +259,41 @@ class LSTMPredictor(object):
                 output_neighs = output_scenes[-n_predict:, 1:]
                 multimodal_outputs[num_p] = [output_primary, output_neighs]
         return multimodal_outputs
+
+    def predict_batch(self, scenes, n_predict=12, modes=1, obs_length=9, start_length=0, args=None):
+        """Batched form of ``__call__`` for the evaluator: ``scenes`` is a list of
+        ``(paths, scene_goal)``; all scenes go through ONE ``LSTM.forward`` (tracks concatenated, ``batch_split``
+        marking the primaries) instead of one call per scene per joblib worker (reference
+        evaluator/trajnet_evaluator.py:61-75).  Returns a list (scene order) of the ``multimodal_outputs`` dicts
+        ``__call__`` returns.  Scene preprocessing (paths_to_xy, center_scene) is per scene on the host, as in
+        the reference; scenes never interact (lstm/lstm.py:243-250), so the result equals the per-scene calls."""
+        self.model.eval()
+        normalize = bool(getattr(args, 'normalize_scene', False))
+        xys, goals, frames = [], [], []
+        for paths, scene_goal in scenes:
+            xy = trajdata.paths_to_xy(paths)
+            if xy.shape[0] < obs_length:
+                raise ValueError('scene has %d frames, need at least obs_length=%d' % (xy.shape[0], obs_length))
+            scene_goal = np.zeros((xy.shape[1], 2)) if scene_goal is None else np.asarray(scene_goal)
+            if normalize:
+                xy, rotation, center, scene_goal = trajdata.center_scene(xy, obs_length, goals=scene_goal)
+                frames.append((rotation, center))
+            xys.append(np.asarray(xy)[start_length:obs_length])
+            goals.append(scene_goal)
+        if not xys:
+            return []
+        xy, split = trajdata.batch_scenes(xys)
+        results = [dict() for _ in xys]
+        with torch.no_grad():
+            obs = torch.tensor(xy, dtype=torch.float32)
+            goal = torch.tensor(np.concatenate(goals, axis=0), dtype=torch.float32)
+            batch_split = torch.tensor(split, dtype=torch.int64)
+            for num_p in range(modes):
+                _, output = self.model(obs, goal, batch_split, n_predict=n_predict)
+                output = output.cpu().numpy()
+                for s in range(len(xys)):
+                    out = output[:, split[s]:split[s + 1]]
+                    if normalize:
+                        out = trajdata.inverse_scene(out, *frames[s])
+                    results[s][num_p] = [out[-n_predict:, 0], out[-n_predict:, 1:]]
+        return results
