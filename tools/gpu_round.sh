@@ -11,4 +11,4 @@ timeout 600 python tools/gpu_check.py ${GPU_CHECK_ARGS:-} > gpurun_out/gpu_check
 timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.log 2>&1; echo "bench rc=$?" | tee -a gpurun_out/summary.log
 tail -2 gpurun_out/bench.log
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/rocprof.log" 2>&1); echo "rocprof rc=$?" | tee -a gpurun_out/summary.log
-find gpurun_out/prof -name "*stats*" | head
+python tools/rocprof_summary.py gpurun_out/prof/*.db > gpurun_out/kernel_stats.md 2>&1; head -14 gpurun_out/kernel_stats.md | cut -c1-170

@@ -282,7 +282,8 @@ __global__ void __launch_bounds__(1024) pool_embed_cellsplit_kernel(const Sparse
     extern __shared__ __attribute__((aligned(16))) float csm[];
     float *acc = csm;                                                        // [NQ][TE][OB]
     WT *wl = reinterpret_cast<WT *>(csm + NQ * TE * OB);    // [ncell][WLS]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the cell loop and its addresses stay scalar
     const int cs = wave % NCS, q = wave / NCS;
     const int ob = blockIdx.x % a.out_blocks, tile = blockIdx.x / a.out_blocks;   // blocks b, b+8, .. share an XCD
     const int row0 = tile * TE;
@@ -308,7 +309,7 @@ __global__ void __launch_bounds__(1024) pool_embed_cellsplit_kernel(const Sparse
     auto process = [&](float (&w)[C], int c) {
         const int wv = lane < TE ? (int)wl[c * WLS + lane] : -1;
         unsigned long long mask = __ballot(wv >= 0);
-        if (mask == 0ull || (ABL & 8)) return;
+        if (mask == 0ull) return;
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) asm("" : "+v"(w[ch]));
         if constexpr (SASM && C <= 16) {
@@ -383,20 +384,37 @@ __global__ void __launch_bounds__(1024) pool_embed_cellsplit_kernel(const Sparse
                 if (ok[u]) accl[eg[u] * OB] = av[u];
         }
     };
-    float w[PF][C];
-    const int nk = (a.ncell - q + NQ - 1) / NQ;
+    // Occupancy of this wave group's cells (cell q + NQ*k <-> bit k; lane k and lane k + 64 scan the 32 egos of
+    // their cell): only cells with at least one hit in the tile are visited, and only their weights are loaded.
+    const int nk = (a.ncell - q + NQ - 1) / NQ;                      // <= 128 (ncell <= 440 + NQ)
+    unsigned long long occ[2];
 #pragma unroll
-    for (int p = 0; p < PF - 1; ++p)
-        if (p < nk) load_w(w[p], q + NQ * p);
-    for (int k0 = 0; k0 < nk; k0 += PF) {
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const int k = k0 + p;
-            if (k < nk) {
-                if (k + PF - 1 < nk) load_w(w[(p + PF - 1) % PF], q + NQ * (k + PF - 1));
-                process(w[p], q + NQ * k);
-            }
+    for (int hh = 0; hh < 2; ++hh) {
+        const int k = hh * 64 + lane;
+        bool any = false;
+        if (k < nk) {
+            const WT *col = wl + (q + NQ * k) * WLS;
+            for (int e = 0; e < TE; ++e) any |= col[e] >= 0;
         }
+        occ[hh] = __ballot(any);
+    }
+    auto pop = [&]() -> int {                                         // next occupied cell of the group, or -1
+        if (occ[0]) { const int k = __ffsll((long long)occ[0]) - 1; occ[0] &= occ[0] - 1ull; return q + NQ * k; }
+        if (occ[1]) { const int k = __ffsll((long long)occ[1]) - 1; occ[1] &= occ[1] - 1ull; return q + NQ * (64 + k); }
+        return -1;
+    };
+    static_assert(PF == 2, "double-buffered weights");
+    float wA[C], wB[C];
+    int ca = (ABL & 8) ? -1 : pop();
+    if (ca >= 0) load_w(wA, ca);
+    while (ca >= 0) {
+        const int cb = pop();
+        if (cb >= 0) load_w(wB, cb);
+        process(wA, ca);
+        if (cb < 0) break;
+        ca = pop();
+        if (ca >= 0) load_w(wA, ca);
+        process(wB, cb);
     }
     __syncthreads();
 
