@@ -168,7 +168,7 @@ def main():
                 # bound for the first embedding layer"); the kernel runs on the fp32 VALU, whose peak equals the
                 # fp32 MFMA peak on CDNA4 (157.3 TFLOP/s)
                 flops = 2.0 * M * (cfg['agents'] - 1) * model.pool.pooling_dim * N0
-                kname = ('pool_embed_sparse_kernel + sparse_reduce_kernel (pool.embedding.0 on the winner table: '
+                kname = ('pool_embed_cellsplit_kernel (pool.embedding.0 on the winner table: '
                          '%d egos x <=%d occupied cells x %d values -> %d)' % (M, cfg['agents'] - 1,
                                                                               model.pool.pooling_dim, N0))
             else:
@@ -221,6 +221,7 @@ def main():
             out['cpu_baseline'] = None
         print(json.dumps(out))
     if distributed:
+        dist.barrier()   # rank 0 ran the roofline / cpu_baseline legs; leave together
         dist.destroy_process_group()
 
 
