@@ -265,6 +265,45 @@ def grad_case(ref):
     print('grad_cases.npz')
 
 
+def train_curve_case(ref):
+    """Loss trajectory of the reference over 6 optimisation steps of Trainer.train_batch's arithmetic
+    (lstm/trainer.py:229-269: teacher-forced forward, PredictionLoss * batch_size, backward, Adam lr 1e-3 wd 1e-4
+    as in lstm/trainer.py:497) on two alternating batches, and the free-running ADE/FDE of the trained model."""
+    torch.manual_seed(61)
+    pool = ref.GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=8, out_dim=64,
+                                embedding_arch='two_layer', layer_dims=[128], latent_dim=8)
+    model = ref.LSTM(pool=pool).train()
+    out = {}
+    for k, v in model.state_dict().items():
+        out['sd_' + k] = v.numpy().copy()
+    batches = [synth.ragged_crowd(6, 2, 8, seed=71), synth.linear_crowd(5, 7, seed=72)]
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    crit = ref.PredictionLoss()
+    losses = []
+    for it in range(6):
+        xy, split = batches[it % 2]
+        observed, truth = xy[:9].clone(), xy[9:20].clone()
+        targets = xy[9:21] - xy[8:20]
+        rel, _ = model(observed, torch.zeros(xy.shape[1], 2), split, truth)
+        loss = crit(rel[-12:], targets, split) * (split.numel() - 1)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    for i, (xy, split) in enumerate(batches):
+        out['b%d_xy' % i], out['b%d_split' % i] = xy.numpy(), split.numpy()
+    model.eval()
+    with torch.no_grad():
+        xy, split = batches[0]
+        _, pred = model(xy[:9].clone(), torch.zeros(xy.shape[1], 2), split, n_predict=12)
+    out['losses'] = np.asarray(losses, dtype=np.float64)
+    out['final_pred'] = pred.numpy()
+    for k, v in model.state_dict().items():
+        out['final_sd_' + k] = v.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'train_curve.npz'), **out)
+    print('train_curve.npz', losses)
+
+
 REAL_SEED = 123
 
 
@@ -314,6 +353,9 @@ def real_cases(ref):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.import_reference()
+    if '--only-curve' in sys.argv:
+        return train_curve_case(ref)
+    train_curve_case(ref)
     if '--only-real' in sys.argv:
         return real_cases(ref)
     real_cases(ref)

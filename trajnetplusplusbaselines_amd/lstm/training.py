@@ -213,9 +213,15 @@ class SequenceFn(torch.autograd.Function):
                     dh_prev = dh_prev + _mm(denc, P['pool.hidden_dim_encoding.weight'].t())
             dh, dc = dh_prev, dc_prev
 
+        # parameters the forward never touches get no gradient (None, as autograd does for the reference), so that
+        # optimizers skip them: a zero gradient would still let Adam + weight decay move them
+        def unused(n):
+            if n.startswith('goal_embedding.') and not model.goal_flag:
+                return True
+            return n.startswith('pool.hidden_dim_encoding.') and (pool is None or pool.type_ != 'social')
         out = [None] * 6
         for n in ctx.param_names:
-            out.append(grads[n])
+            out.append(None if unused(n) else grads[n])
         return tuple(out)
 
 
