@@ -224,6 +224,27 @@ def sgan_case(ref):
             out['truth_pred%d' % i] = pred[i].numpy()
         out['scores_real'] = s_real.numpy()
         out['scores_fake'] = s_fake.numpy()
+        # S-GAN trainer losses of the reference on these outputs (sgan/trainer.py:330-400, lstm/loss.py:165-208)
+        import random
+        import types
+        import trajnetbaselines.sgan.trainer as ref_tr
+        import trajnetbaselines.lstm.loss as ref_loss
+        fake_self = types.SimpleNamespace(criterion=ref_loss.PredictionLoss(keep_batch_dim=True), pred_length=12)
+        targets = xy[9:21] - xy[8:20]
+        out['variety_loss'] = np.float64(ref_tr.Trainer.variety_loss(fake_self, rel, targets, split).item())
+        random.seed(9)
+        out['gan_g_loss'] = np.float64(ref_loss.gan_g_loss(s_fake).item())
+        random.seed(9)
+        out['gan_d_loss'] = np.float64(ref_loss.gan_d_loss(s_real, s_fake).item())
+        # the discriminator's last ReLU makes these scores 0 here; pin the formulas on non-trivial scores too
+        g = torch.Generator().manual_seed(17)
+        sr, sf = torch.randn(9, generator=g) * 3, torch.randn(9, generator=g) * 3
+        out['rand_scores_real'], out['rand_scores_fake'] = sr.numpy(), sf.numpy()
+        out['rand_bce'] = np.float64(ref_loss.bce_loss(sr, (sf > 0).float()).item())
+        random.seed(10)
+        out['rand_gan_g_loss'] = np.float64(ref_loss.gan_g_loss(sf).item())
+        random.seed(10)
+        out['rand_gan_d_loss'] = np.float64(ref_loss.gan_d_loss(sr, sf).item())
         torch.manual_seed(6)
         rel, pred, _, _ = model(xy[:9].clone(), goals, split, n_predict=12)
         for i in range(3):

@@ -108,3 +108,34 @@ class L2Loss(torch.nn.Module):
             assert positions is not None, "Prediction positions required to calculate collision loss"
             return loss + CollisionLoss(positions, batch_split, self.col_wt, self.col_distance) * self.loss_multiplier
         return loss
+
+
+# ---- S-GAN trainer losses (reference lstm/loss.py:165-208, sgan/trainer.py:371-400) ---------------------------
+def bce_loss(input_, target):
+    """Numerically stable binary cross-entropy on logits, mean over the batch (reference lstm/loss.py:165-181)."""
+    neg_abs = -input_.abs()
+    loss = input_.clamp(min=0) - input_ * target + (1 + neg_abs.exp()).log()
+    return loss.mean()
+
+
+def gan_g_loss(scores_fake):
+    """Generator loss with the reference's noisy label drawn from Python's `random` (lstm/loss.py:183-192)."""
+    import random
+    y_fake = torch.ones_like(scores_fake) * random.uniform(0.7, 1.2)
+    return bce_loss(scores_fake, y_fake)
+
+
+def gan_d_loss(scores_real, scores_fake):
+    """Discriminator loss; the fake label is zeros * uniform = 0, the draw is kept for RNG-stream parity
+    (lstm/loss.py:195-208)."""
+    import random
+    y_real = torch.ones_like(scores_real) * random.uniform(0.7, 1.2)
+    y_fake = torch.zeros_like(scores_fake) * random.uniform(0, 0.3)
+    return bce_loss(scores_real, y_real) + bce_loss(scores_fake, y_fake)
+
+
+def variety_loss(criterion, inputs, target, batch_split, pred_length=12):
+    """Top-k ("variety") loss of S-GAN: per scene the minimum over the k samples of the per-scene loss, summed over
+    scenes (reference sgan/trainer.py:371-400).  `criterion` must keep the batch dimension."""
+    per_sample = torch.stack([criterion(sample[-pred_length:], target, batch_split) for sample in inputs])
+    return torch.min(per_sample, dim=0)[0].sum()
