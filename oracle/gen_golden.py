@@ -325,6 +325,46 @@ def train_curve_case(ref):
     print('train_curve.npz', losses)
 
 
+def nongrid_cases(ref):
+    """Non-grid interaction modules of the reference (lstm/non_gridbased_pooling.py): stand-alone module outputs on
+    padded [B,N,*] tensors with NaN slots, and LSTM.forward with the module as `pool` (both decoder modes)."""
+    import trajnetbaselines.lstm.non_gridbased_pooling as ng
+    out = {}
+    for kind in ('nn', 'hiddenstatemlp'):
+        torch.manual_seed({'nn': 81, 'hiddenstatemlp': 82}[kind])
+        pool = ng.NearestNeighborMLP(n=4, out_dim=32) if kind == 'nn' else ng.HiddenStateMLPPooling(hidden_dim=128, out_dim=48)
+        model = ref.LSTM(pool=pool).eval()
+        pre = kind + '_'
+        for k, v in model.state_dict().items():
+            out[pre + 'sd_' + k] = v.numpy().copy()
+        # module level: 3 scenes x 6 slots, some slots absent (NaN), one scene with 2 padded slots, NaN hidden there
+        g = torch.Generator().manual_seed(83)
+        obs2 = torch.rand(3, 6, 2, generator=g) * 6 - 3
+        obs1 = obs2 - torch.randn(3, 6, 2, generator=g) * 0.2
+        hidden = torch.randn(3, 6, 128, generator=g)
+        obs2[0, 2] = NAN; obs1[0, 2] = NAN              # absent track with a valid (frozen) hidden state
+        obs1[1, 4] = NAN                                # position known, velocity unknown
+        obs2[2, 4:] = NAN; obs1[2, 4:] = NAN; hidden[2, 4:] = NAN   # padded slots
+        with torch.no_grad():
+            y = pool(hidden.clone(), obs1.clone(), obs2.clone())
+        out.update({pre + 'm_obs1': obs1.numpy(), pre + 'm_obs2': obs2.numpy(), pre + 'm_hidden': hidden.numpy(),
+                    pre + 'm_out': y.numpy()})
+        # a 3-slot scene for the "fewer than n neighbours" branch of NearestNeighborMLP (:134-137)
+        with torch.no_grad():
+            y3 = pool(hidden[:1, :3].clone(), obs1[:1, :3].clone(), obs2[:1, :3].clone())
+        out[pre + 'm3_out'] = y3.numpy()
+        for tag, (xy, split) in (('lin', synth.linear_crowd(3, 6, seed=84)), ('rag', synth.ragged_crowd(5, 1, 9, seed=85))):
+            M = xy.shape[1]
+            with torch.no_grad():
+                rel_n, pred_n = model(xy[:9].clone(), torch.zeros(M, 2), split, n_predict=12)
+                rel_t, pred_t = model(xy[:9].clone(), torch.zeros(M, 2), split, prediction_truth=xy[9:20].clone())
+            out.update({pre + tag + '_xy': xy.numpy(), pre + tag + '_split': split.numpy(),
+                        pre + tag + '_rel_npredict': rel_n.numpy(), pre + tag + '_pred_npredict': pred_n.numpy(),
+                        pre + tag + '_rel_truth': rel_t.numpy(), pre + tag + '_pred_truth': pred_t.numpy()})
+    np.savez_compressed(os.path.join(OUT, 'nongrid_cases.npz'), **out)
+    print('nongrid_cases.npz')
+
+
 REAL_SEED = 123
 
 
@@ -374,6 +414,9 @@ def real_cases(ref):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.import_reference()
+    if '--only-nongrid' in sys.argv:
+        return nongrid_cases(ref)
+    nongrid_cases(ref)
     if '--only-curve' in sys.argv:
         return train_curve_case(ref)
     train_curve_case(ref)

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-POOL_TYPES = {'occupancy': 0, 'directional': 1, 'social': 2, None: -1}
+POOL_TYPES = {'occupancy': 0, 'directional': 1, 'social': 2, None: -1, 'nn': 4, 'hiddenstatemlp': 5}
 
 _f = ctypes.POINTER(ctypes.c_float)
 
@@ -88,7 +88,24 @@ class OracleModel(object):
             setattr(m, pre + '_bhh', _p(sd[full + '.bias_hh']))
         m.Wn, m.bn = _p(sd['hidden2normal.linear.weight']), _p(sd['hidden2normal.linear.bias'])
         m.C, m.P, m.n_layers = 1, 0, 0
-        if pool_type is not None:
+        if pool_type == 'nn':            # NearestNeighborMLP (lstm/non_gridbased_pooling.py:64-147); n = neighbours kept
+            w = sd['pool.embedding.0.weight']
+            m.C, m.P = w.shape[1], w.shape[0] * n
+            m.Wp[0], m.bp[0] = _p(w), _p(sd['pool.embedding.0.bias'])
+        elif pool_type == 'hiddenstatemlp':   # HiddenStateMLPPooling (lstm/non_gridbased_pooling.py:150-239)
+            ws = sd['pool.spatial_embedding.0.weight']
+            m.dims[0] = ws.shape[0]
+            m.Wp[0], m.bp[0] = _p(ws), _p(sd['pool.spatial_embedding.0.bias'])
+            if 'pool.vel_embedding.0.weight' in sd:
+                m.dims[1] = sd['pool.vel_embedding.0.weight'].shape[0]
+                m.Wp[1], m.bp[1] = _p(sd['pool.vel_embedding.0.weight']), _p(sd['pool.vel_embedding.0.bias'])
+            if 'pool.hidden_embedding.0.weight' in sd:
+                m.dims[2] = sd['pool.hidden_embedding.0.weight'].shape[0]
+                m.Wh, m.bh = _p(sd['pool.hidden_embedding.0.weight']), _p(sd['pool.hidden_embedding.0.bias'])
+            m.C = m.dims[2]
+            m.Wp[2], m.bp[2] = _p(sd['pool.out_projection.weight']), _p(sd['pool.out_projection.bias'])
+            m.P = sd['pool.out_projection.weight'].shape[0]
+        elif pool_type is not None:
             if pool_type == 'directional':
                 m.C = 2
             elif pool_type == 'social':
@@ -145,6 +162,16 @@ class OracleModel(object):
         lib().orc_lstm_step(ctypes.byref(self.c), int(decoder), _p(h), _p(c), _p(obs1), _p(obs2), _p(goals),
                             split.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), B, M, _p(normal), _p(grid))
         return h, c, normal, grid
+
+
+def pool_module(model, hidden, obs1, obs2):
+    """Stand-alone NearestNeighborMLP / HiddenStateMLPPooling forward on padded [B,N,*] arrays -> [B*N, out_dim]."""
+    obs1, obs2 = _c32(obs1), _c32(obs2)
+    B, N = obs2.shape[0], obs2.shape[1]
+    hidden = _c32(hidden) if hidden is not None else np.zeros((B, N, model.c.H), dtype=np.float32)
+    out = np.empty((B * N, model.c.P), dtype=np.float32)
+    lib().orc_pool_module(ctypes.byref(model.c), _p(hidden), _p(obs1), _p(obs2), B, N, _p(out))
+    return out
 
 
 def cell_ids(obs, n, cell_side, pool_size=1, front=False):

@@ -30,7 +30,9 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
-enum { ORC_OCCUPANCY = 0, ORC_DIRECTIONAL = 1, ORC_SOCIAL = 2, ORC_NOPOOL = -1 };
+enum { ORC_OCCUPANCY = 0, ORC_DIRECTIONAL = 1, ORC_SOCIAL = 2, ORC_NOPOOL = -1,
+       ORC_NN = 4,        /* NearestNeighborMLP, lstm/non_gridbased_pooling.py:64-147 */
+       ORC_HIDDENMLP = 5  /* HiddenStateMLPPooling, lstm/non_gridbased_pooling.py:150-239 */ };
 
 /* torch.nan_to_num defaults (lstm/gridbased_pooling.py:140,166): nan->0, +-inf->+-FLT_MAX */
 static inline float nan_to_num_f(float v) {
@@ -299,7 +301,7 @@ typedef struct {
     int H;            /* hidden_dim (128) */
     int goal_flag;    /* lstm/lstm.py:73-76 */
     int goal_dim;
-    int pool_type;    /* ORC_NOPOOL / OCCUPANCY / DIRECTIONAL / SOCIAL */
+    int pool_type;    /* ORC_NOPOOL / OCCUPANCY / DIRECTIONAL / SOCIAL / NN / HIDDENMLP */
     int n;            /* cells per side */
     int C;            /* pooling_dim */
     int P;            /* pool out_dim */
@@ -322,12 +324,105 @@ typedef struct {
     const float *enc_WihT, *enc_WhhT, *dec_WihT, *dec_WhhT;
 } orc_model;
 
+/* NearestNeighborMLP.forward (lstm/non_gridbased_pooling.py:98-147) on the padded [B,N,2] tensors.
+ * Model fields: n = neighbours kept, C = input_dim (4, or 2 with no_vel), Wp[0] [P/n, C], bp[0], P = out_dim.
+ * For every ego: distances to the other slots (NaN -> 1000, :132-133), the n nearest in ascending distance
+ * (torch.topk of the negated distance, :136-139; ties between absent neighbours are irrelevant because their
+ * attributes become 0 after nan_to_num, :142), attributes [rel pos | rel vel] with NaN -> 0, zero rows when the
+ * scene has fewer than n other slots (:134-137), Linear(C -> P/n) + ReLU per neighbour, concatenated (:145-147). */
+static void pool_nn_forward(const orc_model *md, const float *obs1, const float *obs2, int B, int N, float *out) {
+    const int n = md->n, C = md->C, d = md->P / md->n;
+    float *dist = (float *)malloc(sizeof(float) * (size_t)(N > 1 ? N - 1 : 1));
+    int *order = (int *)malloc(sizeof(int) * (size_t)(N > 1 ? N - 1 : 1));
+    for (int b = 0; b < B; ++b) {
+        const float *p1 = obs1 + (size_t)b * N * 2, *p2 = obs2 + (size_t)b * N * 2;
+        for (int i = 0; i < N; ++i) {
+            int cnt = 0;
+            for (int j = 0; j < N; ++j) {
+                if (j == i) continue;
+                float dx = p2[2 * j] - p2[2 * i], dy = p2[2 * j + 1] - p2[2 * i + 1];
+                float dd = sqrtf(dx * dx + dy * dy);               /* torch.norm, :132 */
+                dist[cnt] = (dd != dd) ? 1000.0f : dd;             /* :133 */
+                order[cnt] = j;
+                ++cnt;
+            }
+            /* stable selection of the n smallest distances */
+            for (int k = 0; k < cnt && k < n; ++k) {
+                int best = k;
+                for (int q = k + 1; q < cnt; ++q) if (dist[q] < dist[best]) best = q;
+                float td = dist[best]; int tj = order[best];
+                for (int q = best; q > k; --q) { dist[q] = dist[q - 1]; order[q] = order[q - 1]; }
+                dist[k] = td; order[k] = tj;
+            }
+            float *o = out + ((size_t)b * N + i) * md->P;
+            for (int k = 0; k < n; ++k) {
+                float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (k < cnt) {
+                    int j = order[k];
+                    a[0] = nan_to_num_f(p2[2 * j] - p2[2 * i]);
+                    a[1] = nan_to_num_f(p2[2 * j + 1] - p2[2 * i + 1]);
+                    if (C == 4) { /* rel_directional, :25-38 */
+                        a[2] = nan_to_num_f((p2[2 * j] - p1[2 * j]) - (p2[2 * i] - p1[2 * i]));
+                        a[3] = nan_to_num_f((p2[2 * j + 1] - p1[2 * j + 1]) - (p2[2 * i + 1] - p1[2 * i + 1]));
+                    }
+                }
+                orc_linear(a, 1, C, md->Wp[0], md->bp[0], d, 1, o + (size_t)k * d);
+            }
+        }
+    }
+    free(dist); free(order);
+}
+
+/* HiddenStateMLPPooling.forward (lstm/non_gridbased_pooling.py:196-239).  Model fields: dims[0] = mlp_dim_spatial,
+ * dims[1] = mlp_dim_vel, dims[2] = mlp_dim_hidden (= C); Wp[0]/bp[0] spatial_embedding [ms,2], Wp[1]/bp[1]
+ * vel_embedding [mv,2], Wh/bh hidden_embedding [mh,H], Wp[2]/bp[2] out_projection [P, ms+mh+mv].
+ * Per (ego i, slot j) INCLUDING j == i: ReLU(Linear) of the relative position (fill -100 where NaN, :53-61),
+ * of slot j's hidden state (fill -100 where NaN) and of 4x the relative velocity; max over j (:238); projection. */
+static void pool_hiddenmlp_forward(const orc_model *md, const float *hidden, const float *obs1, const float *obs2,
+                                   int B, int N, float *out) {
+    const int ms = md->dims[0], mv = md->dims[1], mh = md->dims[2], H = md->H;
+    const int D = ms + mh + mv;
+    float *hemb = (float *)malloc(sizeof(float) * (size_t)(N * (mh > 0 ? mh : 1)));
+    float *pooled = (float *)malloc(sizeof(float) * (size_t)D);
+    float *e = (float *)malloc(sizeof(float) * (size_t)D);
+    for (int b = 0; b < B; ++b) {
+        const float *p1 = obs1 + (size_t)b * N * 2, *p2 = obs2 + (size_t)b * N * 2;
+        for (int j = 0; j < N && mh > 0; ++j) {
+            const float *hj = hidden + ((size_t)b * N + j) * H;
+            int nan = 0;
+            for (int k = 0; k < H; ++k) nan |= (hj[k] != hj[k]);
+            if (nan) for (int k = 0; k < mh; ++k) hemb[(size_t)j * mh + k] = -100.0f;
+            else orc_linear(hj, 1, H, md->Wh, md->bh, mh, 1, hemb + (size_t)j * mh);
+        }
+        for (int i = 0; i < N; ++i) {
+            for (int k = 0; k < D; ++k) pooled[k] = -INFINITY;
+            for (int j = 0; j < N; ++j) {
+                float r[2] = { p2[2 * j] - p2[2 * i], p2[2 * j + 1] - p2[2 * i + 1] };          /* rel_obs, :13-22 */
+                if (r[0] != r[0] || r[1] != r[1]) for (int k = 0; k < ms; ++k) e[k] = -100.0f;
+                else orc_linear(r, 1, 2, md->Wp[0], md->bp[0], ms, 1, e);
+                for (int k = 0; k < mh; ++k) e[ms + k] = hemb[(size_t)j * mh + k];              /* :222-227, order :227,234 */
+                if (mv > 0) {
+                    float v[2] = { ((p2[2 * j] - p1[2 * j]) - (p2[2 * i] - p1[2 * i])) * 4.0f,
+                                   ((p2[2 * j + 1] - p1[2 * j + 1]) - (p2[2 * i + 1] - p1[2 * i + 1])) * 4.0f };
+                    if (v[0] != v[0] || v[1] != v[1]) for (int k = 0; k < mv; ++k) e[ms + mh + k] = -100.0f;
+                    else orc_linear(v, 1, 2, md->Wp[1], md->bp[1], mv, 1, e + ms + mh);
+                }
+                for (int k = 0; k < D; ++k) if (e[k] > pooled[k]) pooled[k] = e[k];             /* torch.max, :238 */
+            }
+            orc_linear(pooled, 1, D, md->Wp[2], md->bp[2], md->P, 0, out + ((size_t)b * N + i) * md->P);
+        }
+    }
+    free(hemb); free(pooled); free(e);
+}
+
 /* GridBasedPooling.forward (lstm/gridbased_pooling.py:94-110) on the padded
  * [B,N,*] tensors produced by generate_pooling_inputs (lstm/lstm.py:25-42).
  * need[B*N] marks rows whose embedding is consumed (lstm/lstm.py:146); the
  * MLP is row-wise, so skipping the others changes nothing. out [B*N,P]. */
 static void pool_forward(const orc_model *md, const float *hidden, const float *obs1, const float *obs2,
                          int B, int N, const uint8_t *need, float *out, float *grid_dbg) {
+    if (md->pool_type == ORC_NN) { pool_nn_forward(md, obs1, obs2, B, N, out); return; }
+    if (md->pool_type == ORC_HIDDENMLP) { pool_hiddenmlp_forward(md, hidden, obs1, obs2, B, N, out); return; }
     const int Fin = md->C * md->n * md->n;
     size_t rows = (size_t)B * N;
     float *enc = NULL;
@@ -456,6 +551,13 @@ static void lstm_step(const orc_model *md, int decoder, float *h, float *c, cons
 }
 
 /* One public step for step-level parity tests (state in/out, optional grid dump). */
+/* Stand-alone pooling module call on padded [B,N,*] tensors (module-level parity tests). */
+ORC_API void orc_pool_module(const orc_model *md, const float *hidden, const float *obs1, const float *obs2, int B, int N,
+                             float *out) {
+    if (md->pool_type == ORC_NN) pool_nn_forward(md, obs1, obs2, B, N, out);
+    else if (md->pool_type == ORC_HIDDENMLP) pool_hiddenmlp_forward(md, hidden, obs1, obs2, B, N, out);
+}
+
 ORC_API void orc_lstm_step(const orc_model *md, int decoder, float *h, float *c, const float *obs1,
                            const float *obs2, const float *goals, const int64_t *split, int B, int M,
                            float *normal, float *grid_dbg) {
