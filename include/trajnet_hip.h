@@ -36,6 +36,8 @@ extern "C" {
 #define TNP_POOL_OCCUPANCY   0
 #define TNP_POOL_DIRECTIONAL 1
 #define TNP_POOL_SOCIAL      2
+#define TNP_POOL_NN          4   /* NearestNeighborMLP, lstm/non_gridbased_pooling.py:64-147   */
+#define TNP_POOL_HIDDENMLP   5   /* HiddenStateMLPPooling, lstm/non_gridbased_pooling.py:150-239 */
 
 TNP_API int tnp_abi_version(void);
 TNP_API const char *tnp_last_error(void);
@@ -97,6 +99,26 @@ TNP_API int tnp_pool_embed_sparse_forward(const int16_t *winners, const float *v
                                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Non-grid interaction modules on concatenated tracks (scene s = rows scene_start[s]..scene_start[s+1]).
+ *   tnp_pool_nn_forward: NearestNeighborMLP.forward (lstm/non_gridbased_pooling.py:98-147):
+ *     out[i, k*d:(k+1)*d] = ReLU(W [d,in_dim] . attr(i, k-th nearest other track) + bias), k < n_sel;
+ *     attr = [rel pos | rel vel] (in_dim 4) or rel pos (in_dim 2), NaN -> 0, missing neighbours -> 0.
+ *   tnp_pool_hiddenmlp_forward: HiddenStateMLPPooling.forward (:196-239) up to the max-pool:
+ *     pooled[i] = max over the slots j of the scene (incl. i) of
+ *       [ReLU(W_spatial.(p_j - p_i) + b) | hidden_emb[j] | ReLU(W_vel.4(v_j - v_i) + b)], fill -100 where NaN;
+ *     hidden_emb [M, mh] = Linear(H -> mh) of the slots' hidden state, ReLU applied here if hidden_emb_relu
+ *     (else the caller passes ReLU'd / -100-masked values); the out_projection is a tnp_linear_forward call.
+ * ----------------------------------------------------------------------------------------- */
+TNP_API int tnp_pool_nn_forward(const float *obs1, const float *obs2, const int32_t *scene_start, int B,
+                                int n_sel, int in_dim, const float *W, const float *bias, int d,
+                                float *out, int ldo, void *stream);
+TNP_API int tnp_pool_hiddenmlp_forward(const float *obs1, const float *obs2, const float *hidden_emb, int ldh,
+                                       int hidden_emb_relu, const int32_t *scene_start, int B, int ms, int mv,
+                                       int mh, const float *W_spatial, const float *b_spatial,
+                                       const float *W_vel, const float *b_vel, float *pooled, int ldp,
+                                       void *stream);
+
+/* -------------------------------------------------------------------------------------------
  * Model descriptor of trajnetbaselines.lstm.LSTM (lstm/lstm.py:45-89) with its
  * GridBasedPooling (lstm/gridbased_pooling.py:15-92).  All pointers are device pointers to
  * the parameters in PyTorch layout (may alias nn.Parameter storage; nothing is copied).
@@ -107,11 +129,13 @@ typedef struct tnp_lstm_model {
     int32_t goal_flag;    /* lstm/lstm.py:73-76                                    */
     int32_t goal_dim;
     int32_t pool_type;    /* TNP_POOL_*                                           */
-    int32_t n;            /* grid cells per side                                  */
-    int32_t C;            /* pooling_dim: 1 / 2 / latent_dim                      */
+    int32_t n;            /* grid cells per side (TNP_POOL_NN: neighbours kept)   */
+    int32_t C;            /* pooling_dim: 1 / 2 / latent_dim (NN: input_dim 2|4; HIDDENMLP: mlp_dim_hidden) */
     int32_t P;            /* pool.out_dim                                         */
     int32_t n_layers;     /* embedding MLP depth 1..3 (one_/two_/three_layer)     */
-    int32_t dims[4];      /* dims[0] = C*n*n ... dims[n_layers] = P               */
+    int32_t dims[4];      /* dims[0] = C*n*n ... dims[n_layers] = P; HIDDENMLP: {mlp_dim_spatial, mlp_dim_vel,
+                             mlp_dim_hidden}, Wp/bp[0] spatial, [1] vel, [2] out_projection, Wh/bh hidden_embedding;
+                             NN: Wp/bp[0] = embedding Linear(C -> P/n) */
     float cell;           /* float32(cell_side / pool_size)                       */
     float half_x, half_y; /* n/2 ; front=True: half_y = 0                         */
     float constant;       /* background value of the grid                         */

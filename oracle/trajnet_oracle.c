@@ -324,6 +324,19 @@ typedef struct {
     const float *enc_WihT, *enc_WhhT, *dec_WihT, *dec_WhhT;
 } orc_model;
 
+/* One row of torch.nn.Linear (+ReLU) without the OpenMP region / transposed copy of orc_linear: same axpy order
+ * (sequential in k per output, zeros skipped), for the per-pair embeddings of the non-grid modules. */
+static void small_linear(const float *x, int K, const float *W, const float *bias, int Nout, int relu, float *y) {
+    for (int o = 0; o < Nout; ++o) {
+        float acc = bias ? bias[o] : 0.0f;
+        for (int k = 0; k < K; ++k) {
+            if (x[k] == 0.0f) continue;
+            acc += x[k] * W[(size_t)o * K + k];
+        }
+        y[o] = (relu && !(acc > 0.0f)) ? 0.0f : acc;
+    }
+}
+
 /* NearestNeighborMLP.forward (lstm/non_gridbased_pooling.py:98-147) on the padded [B,N,2] tensors.
  * Model fields: n = neighbours kept, C = input_dim (4, or 2 with no_vel), Wp[0] [P/n, C], bp[0], P = out_dim.
  * For every ego: distances to the other slots (NaN -> 1000, :132-133), the n nearest in ascending distance
@@ -366,7 +379,7 @@ static void pool_nn_forward(const orc_model *md, const float *obs1, const float 
                         a[3] = nan_to_num_f((p2[2 * j + 1] - p1[2 * j + 1]) - (p2[2 * i + 1] - p1[2 * i + 1]));
                     }
                 }
-                orc_linear(a, 1, C, md->Wp[0], md->bp[0], d, 1, o + (size_t)k * d);
+                small_linear(a, C, md->Wp[0], md->bp[0], d, 1, o + (size_t)k * d);
             }
         }
     }
@@ -392,24 +405,24 @@ static void pool_hiddenmlp_forward(const orc_model *md, const float *hidden, con
             int nan = 0;
             for (int k = 0; k < H; ++k) nan |= (hj[k] != hj[k]);
             if (nan) for (int k = 0; k < mh; ++k) hemb[(size_t)j * mh + k] = -100.0f;
-            else orc_linear(hj, 1, H, md->Wh, md->bh, mh, 1, hemb + (size_t)j * mh);
+            else small_linear(hj, H, md->Wh, md->bh, mh, 1, hemb + (size_t)j * mh);
         }
         for (int i = 0; i < N; ++i) {
             for (int k = 0; k < D; ++k) pooled[k] = -INFINITY;
             for (int j = 0; j < N; ++j) {
                 float r[2] = { p2[2 * j] - p2[2 * i], p2[2 * j + 1] - p2[2 * i + 1] };          /* rel_obs, :13-22 */
                 if (r[0] != r[0] || r[1] != r[1]) for (int k = 0; k < ms; ++k) e[k] = -100.0f;
-                else orc_linear(r, 1, 2, md->Wp[0], md->bp[0], ms, 1, e);
+                else small_linear(r, 2, md->Wp[0], md->bp[0], ms, 1, e);
                 for (int k = 0; k < mh; ++k) e[ms + k] = hemb[(size_t)j * mh + k];              /* :222-227, order :227,234 */
                 if (mv > 0) {
                     float v[2] = { ((p2[2 * j] - p1[2 * j]) - (p2[2 * i] - p1[2 * i])) * 4.0f,
                                    ((p2[2 * j + 1] - p1[2 * j + 1]) - (p2[2 * i + 1] - p1[2 * i + 1])) * 4.0f };
                     if (v[0] != v[0] || v[1] != v[1]) for (int k = 0; k < mv; ++k) e[ms + mh + k] = -100.0f;
-                    else orc_linear(v, 1, 2, md->Wp[1], md->bp[1], mv, 1, e + ms + mh);
+                    else small_linear(v, 2, md->Wp[1], md->bp[1], mv, 1, e + ms + mh);
                 }
                 for (int k = 0; k < D; ++k) if (e[k] > pooled[k]) pooled[k] = e[k];             /* torch.max, :238 */
             }
-            orc_linear(pooled, 1, D, md->Wp[2], md->bp[2], md->P, 0, out + ((size_t)b * N + i) * md->P);
+            small_linear(pooled, D, md->Wp[2], md->bp[2], md->P, 0, out + ((size_t)b * N + i) * md->P);
         }
     }
     free(hemb); free(pooled); free(e);

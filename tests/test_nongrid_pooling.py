@@ -53,3 +53,73 @@ def test_oracle_lstm_forward_matches_reference(kind, batch):
     rel, pred = om.forward(xy[:9], goals, split, prediction_truth=xy[9:20])
     helpers.assert_close_nan(rel, GOLD[pre + 'rel_truth'], 2e-5, 'rel truth')
     helpers.assert_close_nan(pred, GOLD[pre + 'pred_truth'], 2e-5, 'pred truth')
+
+
+# ---- HIP path ---------------------------------------------------------------------------------------------------
+def build_amd(kind, device='cuda'):
+    import torch
+    from trajnetplusplusbaselines_amd.lstm import LSTM, NearestNeighborMLP, HiddenStateMLPPooling
+    pool = NearestNeighborMLP(n=4, out_dim=32) if kind == 'nn' else HiddenStateMLPPooling(hidden_dim=128, out_dim=48)
+    model = LSTM(pool=pool)
+    model.load_state_dict({k: torch.tensor(v) for k, v in state_dict(kind).items()})   # same keys as the reference
+    return model.to(device).eval()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', KINDS)
+def test_gpu_module_matches_reference(kind):
+    import torch
+    model = build_amd(kind)
+    pre = kind + '_m_'
+    h, o1, o2 = (torch.tensor(GOLD[pre + k]) for k in ('hidden', 'obs1', 'obs2'))
+    got = model.pool(h, o1, o2).cpu().numpy()
+    assert_rel_close(got, GOLD[pre + 'out'], 5e-5, 'module output')
+    got3 = model.pool(h[:1, :3], o1[:1, :3], o2[:1, :3]).cpu().numpy()
+    assert_rel_close(got3, GOLD[kind + '_m3_out'], 5e-5, '3-slot scene')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', KINDS)
+@pytest.mark.parametrize('batch', ['lin', 'rag'])
+def test_gpu_lstm_forward_matches_reference(kind, batch):
+    """LSTM.forward with the non-grid module inside the fused sequence driver vs the reference's outputs (2e-5)."""
+    import torch
+    model = build_amd(kind)
+    pre = '%s_%s_' % (kind, batch)
+    xy, split = torch.tensor(GOLD[pre + 'xy']), torch.tensor(GOLD[pre + 'split'])
+    goals = torch.zeros(xy.shape[1], 2)
+    rel, pred = model(xy[:9], goals, split, n_predict=12)
+    helpers.assert_close_nan(rel.cpu().numpy(), GOLD[pre + 'rel_npredict'], 2e-5, 'rel n_predict')
+    helpers.assert_close_nan(pred.cpu().numpy(), GOLD[pre + 'pred_npredict'], 2e-5, 'pred n_predict')
+    rel, pred = model(xy[:9], goals, split, prediction_truth=xy[9:20].clone())
+    helpers.assert_close_nan(rel.cpu().numpy(), GOLD[pre + 'rel_truth'], 2e-5, 'rel truth')
+    helpers.assert_close_nan(pred.cpu().numpy(), GOLD[pre + 'pred_truth'], 2e-5, 'pred truth')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', KINDS)
+def test_gpu_full_size_vs_oracle(kind):
+    """64 scenes x 32 agents with entering / leaving tracks: HIP path vs the oracle, primaries' ADE/FDE within 1e-4 m."""
+    import torch
+    from trajnetplusplusbaselines_amd import synth
+    model = build_amd(kind)
+    xy, split = synth.ragged_crowd(64, 8, 32, seed=91)
+    M = xy.shape[1]
+    rel, pred = model(xy[:9], torch.zeros(M, 2), split, n_predict=12)
+    om = oracle_model(kind)
+    _, want = om.forward(xy[:9].numpy(), np.zeros((M, 2), np.float32), split.numpy(), n_predict=12)
+    prim = split[:-1].numpy()
+    a0, f0 = helpers.ade_fde(want[-12:, prim], xy[9:21, prim].numpy())
+    a1, f1 = helpers.ade_fde(pred.cpu().numpy()[-12:, prim], xy[9:21, prim].numpy())
+    ok = ~np.isnan(a0)
+    assert (np.isnan(a0) == np.isnan(a1)).all()
+    assert np.abs(a0[ok] - a1[ok]).max() < 1e-4 and np.abs(f0[ok] - f1[ok]).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_training_through_nongrid_module_raises():
+    import torch
+    model = build_amd('nn').train()
+    xy, split = torch.tensor(GOLD['nn_lin_xy']), torch.tensor(GOLD['nn_lin_split'])
+    with pytest.raises(NotImplementedError):
+        model(xy[:9], torch.zeros(xy.shape[1], 2), split, prediction_truth=xy[9:20].clone())

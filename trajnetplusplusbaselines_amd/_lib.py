@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libtrajnet_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'trajnet_hip.h')
 
 POOL_NONE, POOL_OCCUPANCY, POOL_DIRECTIONAL, POOL_SOCIAL = -1, 0, 1, 2
+POOL_NN, POOL_HIDDENMLP = 4, 5
 POOL_TYPES = {None: POOL_NONE, 'occupancy': POOL_OCCUPANCY, 'directional': POOL_DIRECTIONAL, 'social': POOL_SOCIAL}
 
 _fp = ctypes.c_void_p
@@ -85,6 +86,10 @@ def lib():
     L.tnp_pool_embed_sparse_workspace_bytes.restype = ctypes.c_size_t
     L.tnp_pool_embed_sparse_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.tnp_row_base.argtypes = [_fp, ctypes.c_int, _fp, _fp]
+    L.tnp_pool_nn_forward.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, ctypes.c_int,
+                                      _fp, ctypes.c_int, _fp]
+    L.tnp_pool_hiddenmlp_forward.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, _fp]
     L.tnp_pool_embed_sparse_forward.argtypes = [_fp, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp,
                                                 ctypes.c_size_t, _fp]

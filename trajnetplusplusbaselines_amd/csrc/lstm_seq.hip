@@ -247,7 +247,8 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     const bool pool = md->pool_type != TNP_POOL_NONE;
     const int P = pool ? md->P : 0;
     w.I = E + GD + P;
-    w.Fin = pool ? md->C * md->n * md->n : 0;
+    const bool grid_pool = pool && md->pool_type <= TNP_POOL_SOCIAL;
+    w.Fin = grid_pool ? md->C * md->n * md->n : 0;
     w.ldg = (w.Fin + 3) & ~3;
     size_t off = 0;
     char *b = reinterpret_cast<char *>(base);
@@ -261,11 +262,12 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     w.enc = (float *)take((size_t)M * (md->C > 0 ? md->C : 1) * 4);
     w.grid = (float *)take((size_t)M * (w.ldg > 0 ? w.ldg : 4) * 4);
     int maxmid = 4;
-    for (int l = 1; l < md->n_layers; ++l) if (md->dims[l] > maxmid) maxmid = md->dims[l];
+    for (int l = 1; grid_pool && l < md->n_layers; ++l) if (md->dims[l] > maxmid) maxmid = md->dims[l];
+    if (md->pool_type == TNP_POOL_HIDDENMLP) maxmid = md->dims[0] + md->dims[1] + md->dims[2];   // pooled [M, mlp_dim]
     w.y[0] = (float *)take((size_t)M * maxmid * 4);
     w.y[1] = (float *)take((size_t)M * maxmid * 4);
     w.mask = (uint8_t *)take((size_t)M);
-    w.sparse = pool && md->pool_type == TNP_POOL_SOCIAL && md->Wp0_cell_major != nullptr && md->constant == 0.0f &&
+    w.sparse = grid_pool && md->pool_type == TNP_POOL_SOCIAL && md->Wp0_cell_major != nullptr && md->constant == 0.0f &&
                ((md->variant >> 16) & 1) == 0 && sparse_supported(md->C, md->dims[1], md->n * md->n) && (w.I % 4 == 0);
     w.winners = nullptr; w.row_base = nullptr; w.partial = nullptr;
     if (w.sparse) {
@@ -282,6 +284,17 @@ static int validate_model(const tnp_lstm_model *md) {
     if (!md) TNP_FAIL(-1, "null model");
     if (md->H <= 0 || md->H % 32 != 0) TNP_FAIL(-1, "hidden_dim must be a positive multiple of 32 (got %d)", md->H);
     if (md->E < 4) TNP_FAIL(-1, "embedding_dim too small (%d)", md->E);
+    if (md->pool_type == TNP_POOL_NN) {
+        if (md->n < 1 || md->n > 8 || md->P <= 0 || md->P % md->n != 0) TNP_FAIL(-1, "NearestNeighborMLP: n=%d must divide out_dim=%d, n <= 8", md->n, md->P);
+        if (md->C != 2 && md->C != 4) TNP_FAIL(-1, "NearestNeighborMLP: input_dim %d", md->C);
+        return 0;
+    }
+    if (md->pool_type == TNP_POOL_HIDDENMLP) {
+        if (md->dims[0] <= 0 || md->dims[1] < 0 || md->dims[2] < 0 || md->C != md->dims[2] || md->P <= 0)
+            TNP_FAIL(-1, "HiddenStateMLPPooling: bad dims %d/%d/%d", md->dims[0], md->dims[1], md->dims[2]);
+        if (md->C > 64) TNP_FAIL(-1, "HiddenStateMLPPooling: mlp_dim_hidden %d > 64 not supported", md->C);
+        return 0;
+    }
     if (md->pool_type < TNP_POOL_NONE || md->pool_type > TNP_POOL_SOCIAL) TNP_FAIL(-1, "unknown pool_type %d", md->pool_type);
     if (md->pool_type != TNP_POOL_NONE) {
         if (md->n_layers < 1 || md->n_layers > 3) TNP_FAIL(-1, "embedding MLP depth %d not in 1..3", md->n_layers);
@@ -297,7 +310,25 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, const Workspace 
                          const float *c_in, float *c_out, const int32_t *scene_start, int B, int M, int n_max,
                          hipStream_t s) {
     const int H = md->H;
-    if (md->pool_type != TNP_POOL_NONE) {
+    if (md->pool_type == TNP_POOL_NN) {          // NearestNeighborMLP straight into the pooled columns of X
+        int rc = launch_pool_nn(w.obs1, w.obs2, scene_start, B, md->n, md->C, md->Wp[0], md->bp[0], md->P / md->n,
+                                w.X + (w.I - md->P), w.I, s);
+        if (rc) return rc;
+    } else if (md->pool_type == TNP_POOL_HIDDENMLP) {   // pair embeddings + max-pool, then the projection GEMM
+        const int ms = md->dims[0], mv = md->dims[1], mh = md->dims[2];
+        int rc = launch_pool_hiddenmlp(w.obs1, w.obs2, mh > 0 ? w.enc : nullptr, mh, 1, scene_start, B, ms, mv, mh,
+                                       md->Wp[0], md->bp[0], md->Wp[1], md->bp[1], w.y[0], ms + mh + mv, s);
+        if (rc) return rc;
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.A1 = w.y[0]; g.lda1 = ms + mh + mv; g.K1 = ms + mh + mv;
+        g.B1 = md->Wp[2]; g.ldb1 = ms + mh + mv;
+        g.bias1 = md->bp[2];
+        g.M = M; g.N = md->P; g.relu = 0;
+        g.C = w.X + (w.I - md->P); g.ldc = w.I;
+        rc = launch_linear(g, 0, s);
+        if (rc) return rc;
+    } else if (md->pool_type != TNP_POOL_NONE) {
         GridArgs ga;
         ga.obs1 = w.obs1; ga.obs2 = w.obs2; ga.values = w.enc; ga.ldv = md->C; ga.scene_start = scene_start;
         ga.B = B; ga.n_max = n_max; ga.type = md->pool_type; ga.n = md->n; ga.C = md->C;
@@ -357,12 +388,13 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, const Workspace 
 static void fill_prep_common(PrepArgs &p, const tnp_lstm_model *md, const Workspace &w, int M) {
     memset(&p, 0, sizeof(p));
     p.M = M; p.H = md->H; p.E = md->E; p.goal_flag = md->goal_flag; p.goal_dim = md->goal_dim;
-    p.C = (md->pool_type == TNP_POOL_SOCIAL) ? md->C : 0;
+    const bool wants_enc = md->pool_type == TNP_POOL_SOCIAL || (md->pool_type == TNP_POOL_HIDDENMLP && md->C > 0);
+    p.C = wants_enc ? md->C : 0;
     p.I = w.I;
     p.Wn = md->Wn; p.bn = md->bn; p.We = md->We; p.be = md->be; p.Wg = md->Wg; p.bg = md->bg;
     p.Wh = md->Wh; p.bh = md->bh;
     p.obs1_buf = w.obs1; p.obs2_buf = w.obs2; p.mask = w.mask; p.X = w.X;
-    p.enc = (md->pool_type == TNP_POOL_SOCIAL) ? w.enc : nullptr;
+    p.enc = wants_enc ? w.enc : nullptr;
 }
 
 // h[:, H-nd:H] = z (one noise vector shared by all tracks, sgan/sgan.py:213-216)

@@ -1,0 +1,159 @@
+// Non-grid interaction modules (reference lstm/non_gridbased_pooling.py), gfx950.
+//
+//   pool_nn_kernel         NearestNeighborMLP.forward (:98-147): per ego the n nearest other tracks of its scene
+//                          (distance NaN -> 1000, ascending, first index wins exact ties), attributes
+//                          [rel pos | rel vel] with NaN -> 0, Linear(C -> d) + ReLU per neighbour, concatenated.
+//   pool_hiddenmlp_kernel  HiddenStateMLPPooling.forward (:196-239) up to the max-pool: per (ego, slot) incl. the
+//                          ego itself ReLU(Linear) of the relative position, of the slot's hidden state and of 4x the
+//                          relative velocity (fill -100 where NaN, :53-61), max over the slots.  The projection
+//                          Linear(mlp_dim -> out_dim) runs on the fp32 MFMA GEMM (tnp_linear_forward).
+//
+// Tracks are the concatenated rows of the batch (scene s = rows scene_start[s] .. scene_start[s+1]); the padded
+// slots of the reference's [B, N, *] tensors only ever contribute absent neighbours / -100 fill values, which
+// never win against a present slot, so they are simply not visited.  Both kernels are latency-bound O(N^2) pair
+// loops with a few flops per pair (A*(A-1) pairs per scene: 992 at config 2); HBM traffic is the positions and
+// the [M, out] result.
+#include "tnp_internal.h"
+
+namespace tnp {
+
+constexpr int NN_MAX_SEL = 8;
+
+__global__ void __launch_bounds__(64) pool_nn_kernel(const float *__restrict__ obs1, const float *__restrict__ obs2,
+                                                     const int32_t *__restrict__ scene_start, int n_sel, int in_dim,
+                                                     const float *__restrict__ W, const float *__restrict__ bias, int d,
+                                                     float *__restrict__ out, int ldo) {
+    const int lo = scene_start[blockIdx.x], hi = scene_start[blockIdx.x + 1];
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const float xi = obs2[2 * i], yi = obs2[2 * i + 1];
+        const float vxi = xi - obs1[2 * i], vyi = yi - obs1[2 * i + 1];
+        float bd[NN_MAX_SEL];
+        int bj[NN_MAX_SEL];
+        int cnt = 0;
+        for (int j = lo; j < hi; ++j) {
+            if (j == i) continue;
+            const float dx = obs2[2 * j] - xi, dy = obs2[2 * j + 1] - yi;
+            float dd = sqrtf(dx * dx + dy * dy);
+            if (dd != dd) dd = 1000.0f;                    // absent neighbour (or absent ego): high dummy distance
+            // insertion into the ascending list of the cnt <= n_sel best so far (fully unrolled: static register
+            // indices); the new entry goes AFTER equal distances, so the earlier index wins exact ties
+            int pos = 0;
+#pragma unroll
+            for (int k = 0; k < NN_MAX_SEL; ++k)
+                if (k < cnt && bd[k] <= dd) pos = k + 1;
+            if (pos < n_sel) {
+#pragma unroll
+                for (int k = NN_MAX_SEL - 1; k > 0; --k)
+                    if (k > pos && k <= cnt && k < n_sel) { bd[k] = bd[k - 1]; bj[k] = bj[k - 1]; }
+#pragma unroll
+                for (int k = 0; k < NN_MAX_SEL; ++k)
+                    if (k == pos) { bd[k] = dd; bj[k] = j; }
+                if (cnt < n_sel) ++cnt;
+            }
+        }
+        float *o = out + (size_t)i * ldo;
+        for (int k = 0; k < n_sel; ++k) {
+            float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            int j = -1;
+#pragma unroll
+            for (int q = 0; q < NN_MAX_SEL; ++q)
+                if (q == k && k < cnt) j = bj[q];
+            if (j >= 0) {
+                float v;
+                v = obs2[2 * j] - xi;                       a[0] = (v == v) ? v : 0.0f;
+                v = obs2[2 * j + 1] - yi;                   a[1] = (v == v) ? v : 0.0f;
+                if (in_dim == 4) {
+                    v = (obs2[2 * j] - obs1[2 * j]) - vxi;          a[2] = (v == v) ? v : 0.0f;
+                    v = (obs2[2 * j + 1] - obs1[2 * j + 1]) - vyi;  a[3] = (v == v) ? v : 0.0f;
+                }
+            }
+            for (int q = 0; q < d; ++q) {
+                float acc = bias[q];
+                for (int c = 0; c < in_dim; ++c) acc = fmaf(a[c], W[q * in_dim + c], acc);
+                o[k * d + q] = acc > 0.0f ? acc : 0.0f;
+            }
+        }
+    }
+}
+
+// blockIdx.x = scene, blockIdx.y strides over its egos; thread <-> one of the D = ms + mh + mv pooled dimensions
+__global__ void __launch_bounds__(256) pool_hiddenmlp_kernel(const float *__restrict__ obs1, const float *__restrict__ obs2,
+                                                             const float *__restrict__ henc, int ldh, int henc_relu,
+                                                             const int32_t *__restrict__ scene_start, int ms, int mv,
+                                                             int mh, const float *__restrict__ Ws,
+                                                             const float *__restrict__ bs, const float *__restrict__ Wv,
+                                                             const float *__restrict__ bv, float *__restrict__ pooled,
+                                                             int ldp) {
+    const int lo = scene_start[blockIdx.x], hi = scene_start[blockIdx.x + 1];
+    const int D = ms + mh + mv;
+    for (int k = threadIdx.x; k < D; k += blockDim.x) {
+        const int part = k < ms ? 0 : (k < ms + mh ? 1 : 2);
+        float w0 = 0.0f, w1 = 0.0f, b0 = 0.0f;
+        if (part == 0) { w0 = Ws[2 * k]; w1 = Ws[2 * k + 1]; b0 = bs[k]; }
+        if (part == 2) { const int q = k - ms - mh; w0 = Wv[2 * q]; w1 = Wv[2 * q + 1]; b0 = bv[q]; }
+        for (int i = lo + blockIdx.y; i < hi; i += gridDim.y) {
+            const float xi = obs2[2 * i], yi = obs2[2 * i + 1];
+            const float vxi = xi - obs1[2 * i], vyi = yi - obs1[2 * i + 1];
+            float best = -INFINITY;
+            for (int j = lo; j < hi; ++j) {
+                float e;
+                if (part == 0) {
+                    const float rx = obs2[2 * j] - xi, ry = obs2[2 * j + 1] - yi;
+                    if (rx != rx || ry != ry) e = -100.0f;
+                    else { e = fmaf(ry, w1, fmaf(rx, w0, b0)); e = e > 0.0f ? e : 0.0f; }
+                } else if (part == 1) {
+                    e = henc[(size_t)j * ldh + (k - ms)];
+                    if (henc_relu) e = e > 0.0f ? e : 0.0f;
+                } else {
+                    const float rx = ((obs2[2 * j] - obs1[2 * j]) - vxi) * 4.0f;
+                    const float ry = ((obs2[2 * j + 1] - obs1[2 * j + 1]) - vyi) * 4.0f;
+                    if (rx != rx || ry != ry) e = -100.0f;
+                    else { e = fmaf(ry, w1, fmaf(rx, w0, b0)); e = e > 0.0f ? e : 0.0f; }
+                }
+                best = e > best ? e : best;
+            }
+            pooled[(size_t)i * ldp + k] = best;
+        }
+    }
+}
+
+int launch_pool_nn(const float *obs1, const float *obs2, const int32_t *scene_start, int B, int n_sel, int in_dim,
+                   const float *W, const float *bias, int d, float *out, int ldo, hipStream_t s) {
+    if (B <= 0) return 0;
+    if (n_sel < 1 || n_sel > NN_MAX_SEL) TNP_FAIL(-1, "NearestNeighborMLP: n = %d not in 1..%d", n_sel, NN_MAX_SEL);
+    if (in_dim != 2 && in_dim != 4) TNP_FAIL(-1, "NearestNeighborMLP: input_dim %d not 2 or 4", in_dim);
+    hipLaunchKernelGGL(pool_nn_kernel, dim3(B), dim3(64), 0, s, obs1, obs2, scene_start, n_sel, in_dim, W, bias, d, out, ldo);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_pool_hiddenmlp(const float *obs1, const float *obs2, const float *henc, int ldh, int henc_relu,
+                          const int32_t *scene_start, int B, int ms, int mv, int mh, const float *Ws, const float *bs,
+                          const float *Wv, const float *bv, float *pooled, int ldp, hipStream_t s) {
+    if (B <= 0) return 0;
+    if (ms <= 0) TNP_FAIL(-1, "HiddenStateMLPPooling: mlp_dim_spatial must be positive");
+    if (mh > 0 && !henc) TNP_FAIL(-1, "HiddenStateMLPPooling: hidden embedding missing");
+    const int D = ms + mh + mv;
+    const int threads = D <= 64 ? 64 : (D <= 128 ? 128 : 256);
+    hipLaunchKernelGGL(pool_hiddenmlp_kernel, dim3(B, 8), dim3(threads), 0, s, obs1, obs2, henc, ldh, henc_relu,
+                       scene_start, ms, mv, mh, Ws, bs, Wv, bv, pooled, ldp);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace tnp
+
+extern "C" TNP_API int tnp_pool_nn_forward(const float *obs1, const float *obs2, const int32_t *scene_start, int B,
+                                           int n_sel, int in_dim, const float *W, const float *bias, int d,
+                                           float *out, int ldo, void *stream) {
+    return tnp::launch_pool_nn(obs1, obs2, scene_start, B, n_sel, in_dim, W, bias, d, out, ldo, (hipStream_t)stream);
+}
+
+extern "C" TNP_API int tnp_pool_hiddenmlp_forward(const float *obs1, const float *obs2, const float *hidden_emb, int ldh,
+                                                  int hidden_emb_relu, const int32_t *scene_start, int B, int ms,
+                                                  int mv, int mh, const float *W_spatial, const float *b_spatial,
+                                                  const float *W_vel, const float *b_vel, float *pooled, int ldp,
+                                                  void *stream) {
+    return tnp::launch_pool_hiddenmlp(obs1, obs2, hidden_emb, ldh, hidden_emb_relu, scene_start, B, ms, mv, mh,
+                                      W_spatial, b_spatial, W_vel, b_vel, pooled, ldp, (hipStream_t)stream);
+}

@@ -98,9 +98,26 @@ class LSTM(torch.nn.Module):
         m.pool_type = _lib.POOL_NONE
         m.n, m.C, m.P, m.n_layers = 0, 0, 0, 0
         pool = self.pool
-        if pool is not None:
+        from .non_gridbased_pooling import NearestNeighborMLP, HiddenStateMLPPooling
+        if isinstance(pool, NearestNeighborMLP):
+            lin = pool.embedding[0]
+            m.pool_type, m.n, m.C, m.P = _lib.POOL_NN, pool.n, pool.input_dim, pool.out_dim
+            m.Wp[0], m.bp[0] = P(lin.weight), P(lin.bias)
+        elif isinstance(pool, HiddenStateMLPPooling):
+            m.pool_type, m.P = _lib.POOL_HIDDENMLP, pool.out_dim
+            m.dims[0], m.dims[1], m.dims[2] = pool.mlp_dim_spatial, pool.mlp_dim_vel, pool.mlp_dim_hidden
+            m.C = pool.mlp_dim_hidden
+            m.Wp[0], m.bp[0] = P(pool.spatial_embedding[0].weight), P(pool.spatial_embedding[0].bias)
+            if pool.mlp_dim_vel:
+                m.Wp[1], m.bp[1] = P(pool.vel_embedding[0].weight), P(pool.vel_embedding[0].bias)
+            if pool.mlp_dim_hidden:
+                m.Wh, m.bh = P(pool.hidden_embedding[0].weight), P(pool.hidden_embedding[0].bias)
+            m.Wp[2], m.bp[2] = P(pool.out_projection.weight), P(pool.out_projection.bias)
+        elif pool is not None:
             if not hasattr(pool, 'embedding_layers'):
-                raise NotImplementedError('only GridBasedPooling interaction modules run on the MI355X path')
+                raise NotImplementedError('interaction module %s does not run on the MI355X path (supported: '
+                                          'GridBasedPooling, NearestNeighborMLP, HiddenStateMLPPooling)'
+                                          % type(pool).__name__)
             if pool.pool_size != 1 or pool.blur_size != 1:
                 raise NotImplementedError('the fused step supports pool_size = blur_size = 1 (the trainer defaults)')
             m.pool_type = _lib.POOL_TYPES[pool.type_]
@@ -181,6 +198,9 @@ class LSTM(torch.nn.Module):
         T_dec = prediction_truth.size(0) if prediction_truth is not None else n_predict - 1
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # training: same kernels step by step + an explicit backward sweep (lstm/training.py)
+            if self.pool is not None and not hasattr(self.pool, 'embedding_layers'):
+                raise NotImplementedError('training (backward) through %s is not available on the MI355X path yet; '
+                                          'use model.eval() / torch.no_grad() for inference' % type(self.pool).__name__)
             from .training import run_sequence_with_grad
             return run_sequence_with_grad(self, observed, goals, batch_split, prediction_truth, T_dec)
         rel_pred, pred, _ = self._run_sequence(observed, goals, batch_split, prediction_truth, T_dec)

@@ -1,0 +1,108 @@
+"""Non-grid interaction modules on the MI355X path (reference lstm/non_gridbased_pooling.py).
+
+Same constructor arguments, sub-module names (=> state_dict keys) and the same
+``forward(hidden_state [B,N,H], obs1 [B,N,2], obs2 [B,N,2]) -> [B*N, out_dim]`` contract as the reference; the all-pairs
+work runs in csrc/pool_nongrid.hip.  Inside ``LSTM.forward`` the modules are driven by the fused sequence kernel
+(pool types TNP_POOL_NN / TNP_POOL_HIDDENMLP), so ``forward`` here is only the stand-alone module call.
+Inference only (no backward through these modules yet).
+"""
+import torch
+
+from .. import _lib
+
+
+def _padded_starts(B, N, device):
+    return torch.arange(0, B * N + 1, N, dtype=torch.int32, device=device)
+
+
+class NearestNeighborMLP(torch.nn.Module):
+    """Concatenated embeddings of the relative position (and velocity) of the n nearest neighbours
+    (reference lstm/non_gridbased_pooling.py:64-147)."""
+
+    def __init__(self, n=4, out_dim=32, no_vel=False):
+        super(NearestNeighborMLP, self).__init__()
+        if n < 1 or n > 8 or out_dim % n != 0:
+            raise ValueError('n must divide out_dim (reference :85) and be <= 8 on the MI355X path')
+        self.n = n
+        self.out_dim = out_dim
+        self.no_velocity = no_vel
+        self.input_dim = 2 if self.no_velocity else 4
+        self.embedding = torch.nn.Sequential(
+            torch.nn.Linear(self.input_dim, int(out_dim / self.n)),
+            torch.nn.ReLU(),)
+
+    def reset(self, num_tracks, max_num_neigh, device):
+        self.track_mask = None
+
+    def forward(self, _, obs1, obs2):
+        lin = self.embedding[0]
+        dev = lin.weight.device
+        _lib.require_device(lin.weight, 'NearestNeighborMLP parameters')
+        B, N = obs2.size(0), obs2.size(1)
+        o1 = _lib.f32c(obs1, dev).reshape(B * N, 2)
+        o2 = _lib.f32c(obs2, dev).reshape(B * N, 2)
+        out = torch.empty(B * N, self.out_dim, dtype=torch.float32, device=dev)
+        starts = _padded_starts(B, N, dev)
+        _lib.check(_lib.lib().tnp_pool_nn_forward(
+            _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(starts), B, self.n, self.input_dim, _lib.ptr(_lib.f32c(lin.weight.detach(), dev)),
+            _lib.ptr(_lib.f32c(lin.bias.detach(), dev)), self.out_dim // self.n, _lib.ptr(out), self.out_dim,
+            _lib.stream_ptr()), 'tnp_pool_nn_forward')
+        return out
+
+
+class HiddenStateMLPPooling(torch.nn.Module):
+    """Max-pooled embeddings of relative position, hidden state and relative velocity of all tracks of the scene,
+    as in Social GAN (reference lstm/non_gridbased_pooling.py:150-239)."""
+
+    def __init__(self, hidden_dim=128, mlp_dim=128, mlp_dim_spatial=32, mlp_dim_vel=32, out_dim=None):
+        super(HiddenStateMLPPooling, self).__init__()
+        self.out_dim = out_dim or hidden_dim
+        self.hidden_dim = hidden_dim
+        self.mlp_dim = mlp_dim
+        self.mlp_dim_spatial = mlp_dim_spatial
+        self.mlp_dim_vel = mlp_dim_vel
+        self.mlp_dim_hidden = mlp_dim - mlp_dim_spatial - mlp_dim_vel
+        if self.mlp_dim_hidden > 64:
+            raise NotImplementedError('mlp_dim_hidden > 64 is not supported on the MI355X path')
+        self.spatial_embedding = torch.nn.Sequential(
+            torch.nn.Linear(2, self.mlp_dim_spatial),
+            torch.nn.ReLU(),)
+        if self.mlp_dim_vel:
+            self.vel_embedding = torch.nn.Sequential(
+                torch.nn.Linear(2, self.mlp_dim_vel),
+                torch.nn.ReLU(),)
+        if self.mlp_dim_hidden:
+            self.hidden_embedding = torch.nn.Sequential(
+                torch.nn.Linear(self.hidden_dim, self.mlp_dim_hidden),
+                torch.nn.ReLU(),)
+        self.out_projection = torch.nn.Linear(self.mlp_dim, self.out_dim)
+
+    def reset(self, num_tracks, max_num_neigh, device):
+        self.track_mask = None
+
+    def forward(self, hidden_states, obs1, obs2):
+        dev = self.out_projection.weight.device
+        _lib.require_device(self.out_projection.weight, 'HiddenStateMLPPooling parameters')
+        B, N = obs2.size(0), obs2.size(1)
+        o1 = _lib.f32c(obs1, dev).reshape(B * N, 2)
+        o2 = _lib.f32c(obs2, dev).reshape(B * N, 2)
+        ms, mv, mh = self.mlp_dim_spatial, self.mlp_dim_vel, self.mlp_dim_hidden
+        henc = None
+        if mh:
+            # embed_with_masking (reference :53-61): rows with a NaN hidden state -> fill value -100
+            h = _lib.f32c(hidden_states, dev).reshape(B * N, -1)
+            nan_rows = torch.isnan(h).any(dim=1, keepdim=True)
+            lin = self.hidden_embedding[0]
+            henc = _lib.linear_forward(torch.nan_to_num(h), lin.weight.detach(), lin.bias.detach(), relu=True)
+            henc = torch.where(nan_rows, torch.full_like(henc, -100.0), henc).contiguous()
+        pooled = torch.empty(B * N, ms + mh + mv, dtype=torch.float32, device=dev)
+        sp = self.spatial_embedding[0]
+        ve = self.vel_embedding[0] if mv else None
+        starts = _padded_starts(B, N, dev)
+        _lib.check(_lib.lib().tnp_pool_hiddenmlp_forward(
+            _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(henc), mh, 0, _lib.ptr(starts), B, ms, mv, mh,
+            _lib.ptr(_lib.f32c(sp.weight.detach(), dev)), _lib.ptr(_lib.f32c(sp.bias.detach(), dev)),
+            _lib.ptr(_lib.f32c(ve.weight.detach(), dev)) if ve is not None else None,
+            _lib.ptr(_lib.f32c(ve.bias.detach(), dev)) if ve is not None else None,
+            _lib.ptr(pooled), ms + mh + mv, _lib.stream_ptr()), 'tnp_pool_hiddenmlp_forward')
+        return _lib.linear_forward(pooled, self.out_projection.weight.detach(), self.out_projection.bias.detach())
