@@ -33,12 +33,22 @@ CONFIGS = {
     # BASELINE.json configs[2], per-GPU shard of 256 scenes x 64 agents over 8 GPUs
     'directional': dict(type_='directional', n=12, arch='one_layer', layer_dims=None, out_dim=256, scenes=32,
                         agents=64, name='D-LSTM directional n=12 one_layer'),
+    # BASELINE.json configs[3], per-GPU shard of 128 scenes x 32 agents over 4 GPUs: SGAN.forward with k = 3 generator
+    # samples (noise_dim 16) + real / fake discriminator scores (reference sgan/sgan.py:78-132), inference
+    'sgan': dict(type_='directional', n=12, arch='one_layer', layer_dims=None, out_dim=256, scenes=32, agents=32,
+                 name='S-GAN directional n=12 k=3 (generator x3 + discriminator x2)', sgan=True),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 
 
 def build_model(cfg, device):
     torch.manual_seed(0)
+    if cfg.get('sgan'):
+        from trajnetplusplusbaselines_amd.sgan import SGAN, LSTMGenerator, LSTMDiscriminator
+        mk = lambda: GridBasedPooling(type_=cfg['type_'], hidden_dim=128, cell_side=0.6, n=cfg['n'], out_dim=cfg['out_dim'],
+                                      embedding_arch=cfg['arch'], layer_dims=cfg['layer_dims'], latent_dim=16)
+        return SGAN(generator=LSTMGenerator(pool=mk(), noise_dim=16), discriminator=LSTMDiscriminator(pool=mk()),
+                    k=3, d_steps=1, g_steps=1).eval().to(device)
     pool = GridBasedPooling(type_=cfg['type_'], hidden_dim=128, cell_side=0.6, n=cfg['n'], out_dim=cfg['out_dim'],
                             embedding_arch=cfg['arch'], layer_dims=cfg['layer_dims'], latent_dim=16)
     return LSTM(pool=pool).eval().to(device)
@@ -105,8 +115,10 @@ def main():
 
     cfg = CONFIGS[args.config]
     model = build_model(cfg, device)
-    model.kernel_variant = args.variant
-    model.sparse_embedding = not args.dense
+    is_sgan = bool(cfg.get('sgan'))
+    if not is_sgan:
+        model.kernel_variant = args.variant
+        model.sparse_embedding = not args.dense
     # every rank gets its own shard of scenes (different seed): weak scaling, no data-path collective
     xy, split = synth.linear_crowd(cfg['scenes'], cfg['agents'], seed=100 + rank)
     M = xy.shape[1]
@@ -123,6 +135,11 @@ def main():
         def step():
             return train_batch(model, optimizer, criterion, scene_dev, goals, split, 9, 12, batch_size=cfg['scenes'] * world,
                                n_global_scenes=cfg['scenes'] * world)
+    elif is_sgan:
+        truth = xy[9:21].to(device)
+
+        def step():
+            return model(observed, goals, split, prediction_truth=truth, step_type='g', pred_length=12)
     else:
         def step():
             return model(observed, goals, split, n_predict=12)
@@ -149,7 +166,7 @@ def main():
         # ---- roofline leg: same region again with HIP events around every launch of the dominant kernel ----
         L = _lib.lib()
         roof = None
-        if rank == 0 and not args.train:
+        if rank == 0 and not args.train and not is_sgan:
             import ctypes
             _lib.check(L.tnp_profile_begin(0), 'tnp_profile_begin')
             torch.cuda.synchronize()
@@ -206,16 +223,17 @@ def main():
             'config': {'workload': '%s, %d scenes x %d agents x (9 obs + 12 pred) per GPU, %s' % (
                            cfg['name'], cfg['scenes'], cfg['agents'],
                            'training step (Trainer.train_batch: teacher-forced forward, NLL loss, backward, Adam)'
-                           if args.train else 'inference forward (LSTM.forward, n_predict=12)'),
+                           if args.train else ('SGAN.forward (k=3 generator samples, teacher-forced, + real/fake discriminator scores)'
+                                               if is_sgan else 'inference forward (LSTM.forward, n_predict=12)')),
                        'scenes_per_gpu': cfg['scenes'], 'agents_per_scene': cfg['agents'],
                        'mode': 'training step (fwd + bwd + Adam%s)' % (' + gradient all-reduce' if world > 1 else '') if args.train else 'inference forward',
-                       'recurrent_steps_per_forward': 19, 'parallelism': 'dp%d (scene sharding)' % world,
+                       'recurrent_steps_per_forward': (3 * 19 + 2 * 20) if is_sgan else 19, 'parallelism': 'dp%d (scene sharding)' % world,
                        'kernel_variant': args.variant,
                        'first_embedding_layer': 'dense mfma' if args.dense else 'sparse gather (social) / dense mfma'},
-            'recurrent_scene_steps_per_s': scenes_total * 19 * args.steps / elapsed,
+            'recurrent_scene_steps_per_s': scenes_total * ((3 * 19 + 2 * 20) if is_sgan else 19) * args.steps / elapsed,
             'roofline': roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not is_sgan:
             out['cpu_baseline'] = cpu_baseline(cfg, xy, split)
         else:
             out['cpu_baseline'] = None

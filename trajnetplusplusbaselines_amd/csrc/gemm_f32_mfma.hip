@@ -758,6 +758,9 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
         case 13: TNP_TRY_FAST(2, 1, 1, 2, 64, EPI_BIAS); break;  // 64x64, 2 waves x 2 blocks, BK 64
         case 14: TNP_TRY_FAST(4, 1, 1, 2, 64, EPI_BIAS); break;  // 128x64, 4 waves x 2 blocks, BK 64
         case 15: TNP_TRY_FAST(2, 2, 1, 2, 32, EPI_BIAS); break;  // 64x128, 4 waves x 2 blocks
+        case 16: TNP_TRY_FAST(1, 1, 4, 1, 16, EPI_BIAS); break;  // 32x32, split-K 4, BK 16 (3 workgroups / CU)
+        case 17: TNP_TRY_FAST(1, 1, 4, 1, 32, EPI_BIAS); break;  // 32x32, split-K 4 (2 workgroups / CU)
+        case 29: TNP_TRY_PIPE(1, 1, 4, 1, 16, EPI_BIAS); break;  // pipelined: 32x32, split-K 4, BK 16 (2 workgroups / CU)
         case 20: TNP_TRY_PIPE(2, 4, 1, 1, 32, EPI_BIAS); break;  // pipelined: 64x128, 8 waves
         case 21: TNP_TRY_PIPE(4, 2, 1, 1, 32, EPI_BIAS); break;  // pipelined: 128x64, 8 waves
         case 22: TNP_TRY_PIPE(2, 2, 1, 1, 32, EPI_BIAS); break;  // pipelined: 64x64, 4 waves
