@@ -330,9 +330,11 @@ def nongrid_cases(ref):
     padded [B,N,*] tensors with NaN slots, and LSTM.forward with the module as `pool` (both decoder modes)."""
     import trajnetbaselines.lstm.non_gridbased_pooling as ng
     out = {}
-    for kind in ('nn', 'hiddenstatemlp'):
-        torch.manual_seed({'nn': 81, 'hiddenstatemlp': 82}[kind])
-        pool = ng.NearestNeighborMLP(n=4, out_dim=32) if kind == 'nn' else ng.HiddenStateMLPPooling(hidden_dim=128, out_dim=48)
+    for kind in ('nn', 'hiddenstatemlp', 'attentionmlp'):
+        torch.manual_seed({'nn': 81, 'hiddenstatemlp': 82, 'attentionmlp': 86}[kind])
+        pool = {'nn': lambda: ng.NearestNeighborMLP(n=4, out_dim=32),
+                'hiddenstatemlp': lambda: ng.HiddenStateMLPPooling(hidden_dim=128, out_dim=48),
+                'attentionmlp': lambda: ng.AttentionMLPPooling(hidden_dim=128, out_dim=48)}[kind]()
         model = ref.LSTM(pool=pool).eval()
         pre = kind + '_'
         for k, v in model.state_dict().items():

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-POOL_TYPES = {'occupancy': 0, 'directional': 1, 'social': 2, None: -1, 'nn': 4, 'hiddenstatemlp': 5}
+POOL_TYPES = {'occupancy': 0, 'directional': 1, 'social': 2, None: -1, 'nn': 4, 'hiddenstatemlp': 5, 'attentionmlp': 6}
 
 _f = ctypes.POINTER(ctypes.c_float)
 
@@ -32,6 +32,8 @@ class _Model(ctypes.Structure):
         ('Wn', _f), ('bn', _f), ('Wh', _f), ('bh', _f),
         ('Wp', _f * 3), ('bp', _f * 3),
         ('WpT', _f * 3), ('enc_WihT', _f), ('enc_WhhT', _f), ('dec_WihT', _f), ('dec_WhhT', _f),
+        ('att_wq', _f), ('att_wk', _f), ('att_wv', _f), ('att_in_w', _f), ('att_in_b', _f), ('att_out_w', _f),
+        ('att_out_b', _f),
     ]
 
 
@@ -92,7 +94,7 @@ class OracleModel(object):
             w = sd['pool.embedding.0.weight']
             m.C, m.P = w.shape[1], w.shape[0] * n
             m.Wp[0], m.bp[0] = _p(w), _p(sd['pool.embedding.0.bias'])
-        elif pool_type == 'hiddenstatemlp':   # HiddenStateMLPPooling (lstm/non_gridbased_pooling.py:150-239)
+        elif pool_type in ('hiddenstatemlp', 'attentionmlp'):   # lstm/non_gridbased_pooling.py:150-239 / :242-351
             ws = sd['pool.spatial_embedding.0.weight']
             m.dims[0] = ws.shape[0]
             m.Wp[0], m.bp[0] = _p(ws), _p(sd['pool.spatial_embedding.0.bias'])
@@ -105,6 +107,12 @@ class OracleModel(object):
             m.C = m.dims[2]
             m.Wp[2], m.bp[2] = _p(sd['pool.out_projection.weight']), _p(sd['pool.out_projection.bias'])
             m.P = sd['pool.out_projection.weight'].shape[0]
+            if pool_type == 'attentionmlp':
+                m.constant = float(constant)          # fill_value of embed_with_masking (-10 by default)
+                m.att_wq, m.att_wk, m.att_wv = _p(sd['pool.wq.weight']), _p(sd['pool.wk.weight']), _p(sd['pool.wv.weight'])
+                m.att_in_w, m.att_in_b = _p(sd['pool.multihead_attn.in_proj_weight']), _p(sd['pool.multihead_attn.in_proj_bias'])
+                m.att_out_w = _p(sd['pool.multihead_attn.out_proj.weight'])
+                m.att_out_b = _p(sd['pool.multihead_attn.out_proj.bias'])
         elif pool_type is not None:
             if pool_type == 'directional':
                 m.C = 2

@@ -32,7 +32,8 @@
 
 enum { ORC_OCCUPANCY = 0, ORC_DIRECTIONAL = 1, ORC_SOCIAL = 2, ORC_NOPOOL = -1,
        ORC_NN = 4,        /* NearestNeighborMLP, lstm/non_gridbased_pooling.py:64-147 */
-       ORC_HIDDENMLP = 5  /* HiddenStateMLPPooling, lstm/non_gridbased_pooling.py:150-239 */ };
+       ORC_HIDDENMLP = 5, /* HiddenStateMLPPooling, lstm/non_gridbased_pooling.py:150-239 */
+       ORC_ATTNMLP = 6    /* AttentionMLPPooling, lstm/non_gridbased_pooling.py:242-351 */ };
 
 /* torch.nan_to_num defaults (lstm/gridbased_pooling.py:140,166): nan->0, +-inf->+-FLT_MAX */
 static inline float nan_to_num_f(float v) {
@@ -322,6 +323,9 @@ typedef struct {
     /* optional cached transposes [in,out] of the big matrices (speed only; may be NULL) */
     const float *WpT[3];
     const float *enc_WihT, *enc_WhhT, *dec_WihT, *dec_WhhT;
+    /* AttentionMLPPooling only: wq, wk, wv [D,D] (no bias), MultiheadAttention in_proj_weight [3D,D] / in_proj_bias [3D],
+     * out_proj weight [D,D] / bias [D] */
+    const float *att_wq, *att_wk, *att_wv, *att_in_w, *att_in_b, *att_out_w, *att_out_b;
 } orc_model;
 
 /* One row of torch.nn.Linear (+ReLU) without the OpenMP region / transposed copy of orc_linear: same axpy order
@@ -428,6 +432,74 @@ static void pool_hiddenmlp_forward(const orc_model *md, const float *hidden, con
     free(hemb); free(pooled); free(e);
 }
 
+/* AttentionMLPPooling.forward (lstm/non_gridbased_pooling.py:297-351).  Model fields as for HIDDENMLP (dims[0..2],
+ * Wp[0]/bp[0] spatial, Wp[1]/bp[1] vel, Wh/bh hidden, Wp[2]/bp[2] out_projection), `constant` = fill_value (-10),
+ * plus att_*.  Per ego i the sequence is ALL N slots of the padded scene (padded / absent slots included, there is
+ * no key padding mask): embedding of slot j relative to i (fill_value where NaN, 0 for a NaN hidden state, :319-335),
+ * wq / wk / wv, single-head torch.nn.MultiheadAttention (in_proj, softmax(q k^T / sqrt(D)) v, out_proj), of which only
+ * the output at sequence position j == i is kept (:347-350), then out_projection. */
+static void pool_attnmlp_forward(const orc_model *md, const float *hidden, const float *obs1, const float *obs2,
+                                 int B, int N, float *out) {
+    const int ms = md->dims[0], mv = md->dims[1], mh = md->dims[2], H = md->H;
+    const int D = ms + mh + mv;
+    const float fill = md->constant;
+    const float scale = 1.0f / sqrtf((float)D);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int bi = 0; bi < B * N; ++bi) {
+        const int b = bi / N, i = bi - b * N;
+        const float *p1 = obs1 + (size_t)b * N * 2, *p2 = obs2 + (size_t)b * N * 2;
+        float *emb = (float *)malloc(sizeof(float) * (size_t)N * D);
+        float *kk = (float *)malloc(sizeof(float) * (size_t)N * D);
+        float *vv = (float *)malloc(sizeof(float) * (size_t)N * D);
+        float *t = (float *)malloc(sizeof(float) * (size_t)D);
+        float *q = (float *)malloc(sizeof(float) * (size_t)D);
+        float *sc = (float *)malloc(sizeof(float) * (size_t)N);
+        float *ao = (float *)malloc(sizeof(float) * (size_t)D);
+        for (int j = 0; j < N; ++j) {
+            float *e = emb + (size_t)j * D;
+            float r[2] = { p2[2 * j] - p2[2 * i], p2[2 * j + 1] - p2[2 * i + 1] };
+            if (r[0] != r[0] || r[1] != r[1]) for (int k = 0; k < ms; ++k) e[k] = fill;
+            else small_linear(r, 2, md->Wp[0], md->bp[0], ms, 1, e);
+            if (mh > 0) {
+                const float *hj = hidden + ((size_t)b * N + j) * H;
+                int nan = 0;
+                for (int k = 0; k < H; ++k) nan |= (hj[k] != hj[k]);
+                if (nan) for (int k = 0; k < mh; ++k) e[ms + k] = 0.0f;                       /* fill_value=0, :327 */
+                else small_linear(hj, H, md->Wh, md->bh, mh, 1, e + ms);
+            }
+            if (mv > 0) {
+                float v[2] = { ((p2[2 * j] - p1[2 * j]) - (p2[2 * i] - p1[2 * i])) * 4.0f,
+                               ((p2[2 * j + 1] - p1[2 * j + 1]) - (p2[2 * i + 1] - p1[2 * i + 1])) * 4.0f };
+                if (v[0] != v[0] || v[1] != v[1]) for (int k = 0; k < mv; ++k) e[ms + mh + k] = fill;
+                else small_linear(v, 2, md->Wp[1], md->bp[1], mv, 1, e + ms + mh);
+            }
+            small_linear(e, D, md->att_wk, NULL, D, 0, t);                                      /* key = wk(emb), :341 */
+            small_linear(t, D, md->att_in_w + (size_t)D * D, md->att_in_b + D, D, 0, kk + (size_t)j * D);
+            small_linear(e, D, md->att_wv, NULL, D, 0, t);                                      /* value, :342 */
+            small_linear(t, D, md->att_in_w + (size_t)2 * D * D, md->att_in_b + 2 * D, D, 0, vv + (size_t)j * D);
+        }
+        small_linear(emb + (size_t)i * D, D, md->att_wq, NULL, D, 0, t);                        /* query at position i */
+        small_linear(t, D, md->att_in_w, md->att_in_b, D, 0, q);
+        float mx = -INFINITY;
+        for (int j = 0; j < N; ++j) {
+            float a = 0.0f;
+            for (int k = 0; k < D; ++k) a += (q[k] * scale) * kk[(size_t)j * D + k];            /* q scaled, then q k^T */
+            sc[j] = a;
+            if (a > mx) mx = a;
+        }
+        float den = 0.0f;
+        for (int j = 0; j < N; ++j) { sc[j] = expf(sc[j] - mx); den += sc[j]; }
+        for (int k = 0; k < D; ++k) ao[k] = 0.0f;
+        for (int j = 0; j < N; ++j) {
+            const float a = sc[j] / den;
+            for (int k = 0; k < D; ++k) ao[k] += a * vv[(size_t)j * D + k];
+        }
+        small_linear(ao, D, md->att_out_w, md->att_out_b, D, 0, t);                             /* out_proj */
+        small_linear(t, D, md->Wp[2], md->bp[2], md->P, 0, out + (size_t)bi * md->P);           /* out_projection, :351 */
+        free(emb); free(kk); free(vv); free(t); free(q); free(sc); free(ao);
+    }
+}
+
 /* GridBasedPooling.forward (lstm/gridbased_pooling.py:94-110) on the padded
  * [B,N,*] tensors produced by generate_pooling_inputs (lstm/lstm.py:25-42).
  * need[B*N] marks rows whose embedding is consumed (lstm/lstm.py:146); the
@@ -436,6 +508,7 @@ static void pool_forward(const orc_model *md, const float *hidden, const float *
                          int B, int N, const uint8_t *need, float *out, float *grid_dbg) {
     if (md->pool_type == ORC_NN) { pool_nn_forward(md, obs1, obs2, B, N, out); return; }
     if (md->pool_type == ORC_HIDDENMLP) { pool_hiddenmlp_forward(md, hidden, obs1, obs2, B, N, out); return; }
+    if (md->pool_type == ORC_ATTNMLP) { pool_attnmlp_forward(md, hidden, obs1, obs2, B, N, out); return; }
     const int Fin = md->C * md->n * md->n;
     size_t rows = (size_t)B * N;
     float *enc = NULL;
@@ -569,6 +642,7 @@ ORC_API void orc_pool_module(const orc_model *md, const float *hidden, const flo
                              float *out) {
     if (md->pool_type == ORC_NN) pool_nn_forward(md, obs1, obs2, B, N, out);
     else if (md->pool_type == ORC_HIDDENMLP) pool_hiddenmlp_forward(md, hidden, obs1, obs2, B, N, out);
+    else if (md->pool_type == ORC_ATTNMLP) pool_attnmlp_forward(md, hidden, obs1, obs2, B, N, out);
 }
 
 ORC_API void orc_lstm_step(const orc_model *md, int decoder, float *h, float *c, const float *obs1,

@@ -9,7 +9,7 @@ from oracle import oracle
 from tests import helpers
 
 GOLD = np.load(os.path.join(helpers.GOLDEN, 'nongrid_cases.npz'))
-KINDS = ['nn', 'hiddenstatemlp']
+KINDS = ['nn', 'hiddenstatemlp', 'attentionmlp']
 
 
 def state_dict(kind):
@@ -27,7 +27,7 @@ def assert_rel_close(got, want, tol, what):
 
 
 def oracle_model(kind):
-    return oracle.OracleModel(state_dict(kind), pool_type=kind, n=4)
+    return oracle.OracleModel(state_dict(kind), pool_type=kind, n=4, constant=-10.0 if kind == 'attentionmlp' else 0.0)
 
 
 @pytest.mark.parametrize('kind', KINDS)
