@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNP_ABI_VERSION 1
+#define TNP_ABI_VERSION 2
 #define TNP_API __attribute__((visibility("default")))
 
 /* pooling types: GridBasedPooling(type_=...)  lstm/gridbased_pooling.py:16-19,55-66 */
@@ -38,6 +38,7 @@ extern "C" {
 #define TNP_POOL_SOCIAL      2
 #define TNP_POOL_NN          4   /* NearestNeighborMLP, lstm/non_gridbased_pooling.py:64-147   */
 #define TNP_POOL_HIDDENMLP   5   /* HiddenStateMLPPooling, lstm/non_gridbased_pooling.py:150-239 */
+#define TNP_POOL_ATTNMLP     6   /* AttentionMLPPooling, lstm/non_gridbased_pooling.py:242-351   */
 
 TNP_API int tnp_abi_version(void);
 TNP_API const char *tnp_last_error(void);
@@ -117,6 +118,20 @@ TNP_API int tnp_pool_hiddenmlp_forward(const float *obs1, const float *obs2, con
                                        int mh, const float *W_spatial, const float *b_spatial,
                                        const float *W_vel, const float *b_vel, float *pooled, int ldp,
                                        void *stream);
+/* AttentionMLPPooling.forward (lstm/non_gridbased_pooling.py:297-351) in two kernels around three tnp_linear_forward
+ * calls (see tnp_lstm_model.Wx):
+ *   tnp_pool_attn_self : e_self[i] = embedding of slot i relative to itself ([ReLU(b_spatial) | hidden_emb[i] |
+ *                        ReLU(b_vel)], fill where the ego's position / velocity is NaN)            -> [M, D]
+ *   tnp_pool_attn_pair : a_ij = softmax_j((u[i,0:D] . e_ij + u[i,D]) / sqrt(D)) over ALL n_max slots of the padded
+ *                        scene (slots beyond the scene's tracks count as padded: fill / 0 / fill), ebar[i] = sum_j a_ij e_ij */
+TNP_API int tnp_pool_attn_self(const float *obs1, const float *obs2, const float *hidden_emb, int ldh,
+                               int hidden_emb_relu, int M, int ms, int mv, int mh, const float *b_spatial,
+                               const float *b_vel, float fill, float *e_self, int lde, void *stream);
+TNP_API int tnp_pool_attn_pair(const float *obs1, const float *obs2, const float *hidden_emb, int ldh,
+                               int hidden_emb_relu, const int32_t *scene_start, int B, int n_max, int ms, int mv,
+                               int mh, const float *W_spatial, const float *b_spatial, const float *W_vel,
+                               const float *b_vel, float fill, const float *u, int ldu, float *ebar, int lde,
+                               void *stream);
 
 /* -------------------------------------------------------------------------------------------
  * Model descriptor of trajnetbaselines.lstm.LSTM (lstm/lstm.py:45-89) with its
@@ -151,6 +166,14 @@ typedef struct tnp_lstm_model {
                                     Wp[0][o][ch*n*n + c]); enables the sparse first layer
                                     for social pooling with constant == 0; NULL = dense   */
     int32_t variant;      /* kernel-variant selector (0 = default), see DESIGN.md  */
+    /* TNP_POOL_ATTNMLP only (fields as for HIDDENMLP, `constant` = fill_value): the linear maps around the single-head
+     * attention folded on the host, D = mlp_dim:
+     *   Wx[0] [D,D], bx[0] [D]  query  q = (in_proj_q . wq) e_ii + in_proj_bias_q
+     *   Wx[1] [D+4,D]           rows 0..D-1 = (in_proj_k . wk)^T, row D = in_proj_bias_k, rows D+1.. = 0:
+     *                            u = Wx[1] q gives score_ij = (u[0:D] . e_ij + u[D]) / sqrt(D)
+     *   Wx[2] [P,D], bx[2] [P]  out_projection . out_proj . (in_proj_v . wv) applied to sum_j a_ij e_ij (+ biases) */
+    const float *Wx[3];
+    const float *bx[3];
 } tnp_lstm_model;
 
 /* bytes of scratch HBM tnp_lstm_forward / tnp_lstm_step need for M tracks in B scenes */

@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libtrajnet_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'trajnet_hip.h')
 
 POOL_NONE, POOL_OCCUPANCY, POOL_DIRECTIONAL, POOL_SOCIAL = -1, 0, 1, 2
-POOL_NN, POOL_HIDDENMLP = 4, 5
+POOL_NN, POOL_HIDDENMLP, POOL_ATTNMLP = 4, 5, 6
+ABI_VERSION = 2   # TNP_ABI_VERSION of include/trajnet_hip.h this binding was written against
 POOL_TYPES = {None: POOL_NONE, 'occupancy': POOL_OCCUPANCY, 'directional': POOL_DIRECTIONAL, 'social': POOL_SOCIAL}
 
 _fp = ctypes.c_void_p
@@ -34,6 +35,7 @@ class LstmModel(ctypes.Structure):
         ('Wp', _fp * 3), ('bp', _fp * 3),
         ('Wp0_cell_major', _fp),
         ('variant', ctypes.c_int32),
+        ('Wx', _fp * 3), ('bx', _fp * 3),
     ]
 
 
@@ -88,6 +90,11 @@ def lib():
     L.tnp_row_base.argtypes = [_fp, ctypes.c_int, _fp, _fp]
     L.tnp_pool_nn_forward.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, ctypes.c_int,
                                       _fp, ctypes.c_int, _fp]
+    L.tnp_pool_attn_self.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, _fp, _fp, ctypes.c_float, _fp, ctypes.c_int, _fp]
+    L.tnp_pool_attn_pair.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, ctypes.c_float, _fp,
+                                     ctypes.c_int, _fp, ctypes.c_int, _fp]
     L.tnp_pool_hiddenmlp_forward.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, _fp]
     L.tnp_pool_embed_sparse_forward.argtypes = [_fp, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int,
@@ -107,7 +114,7 @@ def lib():
     L.tnp_pool_pair_cells.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_float, _fp, _fp]
     L.tnp_mfma_probe.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]
-    if L.tnp_abi_version() != 1:
+    if L.tnp_abi_version() != ABI_VERSION:
         raise RuntimeError('libtrajnet_hip.so ABI version mismatch')
     _LIB = L
     return L

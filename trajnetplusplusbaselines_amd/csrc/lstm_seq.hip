@@ -264,6 +264,7 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     int maxmid = 4;
     for (int l = 1; grid_pool && l < md->n_layers; ++l) if (md->dims[l] > maxmid) maxmid = md->dims[l];
     if (md->pool_type == TNP_POOL_HIDDENMLP) maxmid = md->dims[0] + md->dims[1] + md->dims[2];   // pooled [M, mlp_dim]
+    if (md->pool_type == TNP_POOL_ATTNMLP) maxmid = md->dims[0] + md->dims[1] + md->dims[2] + 4;  // u [M, mlp_dim + 4]
     w.y[0] = (float *)take((size_t)M * maxmid * 4);
     w.y[1] = (float *)take((size_t)M * maxmid * 4);
     w.mask = (uint8_t *)take((size_t)M);
@@ -289,7 +290,9 @@ static int validate_model(const tnp_lstm_model *md) {
         if (md->C != 2 && md->C != 4) TNP_FAIL(-1, "NearestNeighborMLP: input_dim %d", md->C);
         return 0;
     }
-    if (md->pool_type == TNP_POOL_HIDDENMLP) {
+    if (md->pool_type == TNP_POOL_HIDDENMLP || md->pool_type == TNP_POOL_ATTNMLP) {
+        if (md->pool_type == TNP_POOL_ATTNMLP && (!md->Wx[0] || !md->Wx[1] || !md->Wx[2] || !md->bx[0] || !md->bx[2]))
+            TNP_FAIL(-1, "AttentionMLPPooling: folded attention matrices (Wx/bx) missing");
         if (md->dims[0] <= 0 || md->dims[1] < 0 || md->dims[2] < 0 || md->C != md->dims[2] || md->P <= 0)
             TNP_FAIL(-1, "HiddenStateMLPPooling: bad dims %d/%d/%d", md->dims[0], md->dims[1], md->dims[2]);
         if (md->C > 64) TNP_FAIL(-1, "HiddenStateMLPPooling: mlp_dim_hidden %d > 64 not supported", md->C);
@@ -326,6 +329,31 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, const Workspace 
         g.bias1 = md->bp[2];
         g.M = M; g.N = md->P; g.relu = 0;
         g.C = w.X + (w.I - md->P); g.ldc = w.I;
+        rc = launch_linear(g, 0, s);
+        if (rc) return rc;
+    } else if (md->pool_type == TNP_POOL_ATTNMLP) {     // AttentionMLPPooling with the linear maps folded (Wx / bx)
+        const int ms = md->dims[0], mv = md->dims[1], mh = md->dims[2], D = ms + mh + mv;
+        const float *henc = mh > 0 ? w.enc : nullptr;
+        int rc = launch_pool_attn_self(w.obs1, w.obs2, henc, mh, 1, M, ms, mv, mh, md->bp[0], md->bp[1], md->constant,
+                                       w.y[0], D, s);
+        if (rc) return rc;
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));                      // q = Wq e_self + bq
+        g.A1 = w.y[0]; g.lda1 = D; g.K1 = D; g.B1 = md->Wx[0]; g.ldb1 = D; g.bias1 = md->bx[0];
+        g.M = M; g.N = D; g.C = w.y[1]; g.ldc = D;
+        rc = launch_linear(g, 0, s);
+        if (rc) return rc;
+        memset(&g, 0, sizeof(g));                      // u = [Wk^T q ; bk . q ; 0 0 0]
+        g.A1 = w.y[1]; g.lda1 = D; g.K1 = D; g.B1 = md->Wx[1]; g.ldb1 = D;
+        g.M = M; g.N = D + 4; g.C = w.y[0]; g.ldc = D + 4;
+        rc = launch_linear(g, 0, s);
+        if (rc) return rc;
+        rc = launch_pool_attn_pair(w.obs1, w.obs2, henc, mh, 1, scene_start, B, n_max, ms, mv, mh, md->Wp[0], md->bp[0],
+                                   md->Wp[1], md->bp[1], md->constant, w.y[0], D + 4, w.y[1], D, s);
+        if (rc) return rc;
+        memset(&g, 0, sizeof(g));                      // pooled = Wfin ebar + bfin
+        g.A1 = w.y[1]; g.lda1 = D; g.K1 = D; g.B1 = md->Wx[2]; g.ldb1 = D; g.bias1 = md->bx[2];
+        g.M = M; g.N = md->P; g.C = w.X + (w.I - md->P); g.ldc = w.I;
         rc = launch_linear(g, 0, s);
         if (rc) return rc;
     } else if (md->pool_type != TNP_POOL_NONE) {
@@ -388,7 +416,8 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, const Workspace 
 static void fill_prep_common(PrepArgs &p, const tnp_lstm_model *md, const Workspace &w, int M) {
     memset(&p, 0, sizeof(p));
     p.M = M; p.H = md->H; p.E = md->E; p.goal_flag = md->goal_flag; p.goal_dim = md->goal_dim;
-    const bool wants_enc = md->pool_type == TNP_POOL_SOCIAL || (md->pool_type == TNP_POOL_HIDDENMLP && md->C > 0);
+    const bool wants_enc = md->pool_type == TNP_POOL_SOCIAL ||
+                           ((md->pool_type == TNP_POOL_HIDDENMLP || md->pool_type == TNP_POOL_ATTNMLP) && md->C > 0);
     p.C = wants_enc ? md->C : 0;
     p.I = w.I;
     p.Wn = md->Wn; p.bn = md->bn; p.We = md->We; p.be = md->be; p.Wg = md->Wg; p.bg = md->bg;

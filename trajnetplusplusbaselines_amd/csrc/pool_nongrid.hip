@@ -141,6 +141,176 @@ int launch_pool_hiddenmlp(const float *obs1, const float *obs2, const float *hen
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// AttentionMLPPooling (reference :242-351).  The reference runs a single-head torch.nn.MultiheadAttention over the
+// N slots of every ego's padded scene and keeps only the output at the ego's own position.  All maps around the
+// softmax are linear, so they are folded on the host (tnp_lstm_model.Wx): with q_i = Wq e_ii + bq and
+// u_i = [Wk^T q_i ; bk . q_i] the score of slot j is (u_i[0:D] . e_ij + u_i[D]) / sqrt(D), and because the
+// attention weights sum to one the output is Wfin (sum_j a_ij e_ij) + bfin.  What is left for this file is the
+// O(N^2) part: the pair embeddings e_ij, the scores, the softmax and the weighted sum of the embeddings.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float attn_embed(int k, int ms, int mh, float fill, float xi, float yi, float vxi,
+                                            float vyi, float xj, float yj, float vxj, float vyj, float henc_jk,
+                                            float w0, float w1, float b0) {
+    if (k < ms) {
+        const float rx = xj - xi, ry = yj - yi;
+        if (rx != rx || ry != ry) return fill;
+        const float e = fmaf(ry, w1, fmaf(rx, w0, b0));
+        return e > 0.0f ? e : 0.0f;
+    }
+    if (k < ms + mh) return henc_jk;
+    const float rx = (vxj - vxi) * 4.0f, ry = (vyj - vyi) * 4.0f;
+    if (rx != rx || ry != ry) return fill;
+    const float e = fmaf(ry, w1, fmaf(rx, w0, b0));
+    return e > 0.0f ? e : 0.0f;
+}
+
+__global__ void __launch_bounds__(256) pool_attn_self_kernel(const float *__restrict__ obs1, const float *__restrict__ obs2,
+                                                             const float *__restrict__ henc, int ldh, int henc_relu, int M,
+                                                             int ms, int mv, int mh, const float *__restrict__ bs,
+                                                             const float *__restrict__ bv, float fill,
+                                                             float *__restrict__ e_self, int lde) {
+    const int D = ms + mh + mv;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= M * D) return;
+    const int i = q / D, k = q - i * D;
+    const float xi = obs2[2 * i], yi = obs2[2 * i + 1];
+    const float vxi = xi - obs1[2 * i], vyi = yi - obs1[2 * i + 1];
+    float h = 0.0f, b0 = 0.0f;
+    if (k < ms) b0 = bs[k];
+    else if (k < ms + mh) { h = henc[(size_t)i * ldh + (k - ms)]; if (henc_relu) h = h > 0.0f ? h : 0.0f; }
+    else b0 = bv[k - ms - mh];
+    e_self[(size_t)i * lde + k] = attn_embed(k, ms, mh, fill, xi, yi, vxi, vyi, xi, yi, vxi, vyi, h, 0.0f, 0.0f, b0);
+}
+
+constexpr int ATT_MAXD_PER_LANE = 4;   // D <= 256
+
+// one wave per ego (blockIdx.x = scene, blockIdx.y strides over its egos); lane <-> dims lane, lane + 64, ...
+__global__ void __launch_bounds__(64) pool_attn_pair_kernel(const float *__restrict__ obs1, const float *__restrict__ obs2,
+                                                            const float *__restrict__ henc, int ldh, int henc_relu,
+                                                            const int32_t *__restrict__ scene_start, int n_max, int ms,
+                                                            int mv, int mh, const float *__restrict__ Ws,
+                                                            const float *__restrict__ bs, const float *__restrict__ Wv,
+                                                            const float *__restrict__ bv, float fill,
+                                                            const float *__restrict__ u, int ldu,
+                                                            float *__restrict__ ebar, int lde) {
+    extern __shared__ float att_sc[];                      // [n_scene] scores of the current ego
+    const int lo = scene_start[blockIdx.x], hi = scene_start[blockIdx.x + 1];
+    const int D = ms + mh + mv, lane = threadIdx.x;
+    const float scale = 1.0f / sqrtf((float)D);
+    const int npad = n_max - (hi - lo);                    // virtual padded slots: [fill.., 0.., fill..]
+    float w0[ATT_MAXD_PER_LANE], w1[ATT_MAXD_PER_LANE], b0[ATT_MAXD_PER_LANE];
+#pragma unroll
+    for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) {
+        const int k = lane + 64 * t;
+        w0[t] = w1[t] = b0[t] = 0.0f;
+        if (k < ms) { w0[t] = Ws[2 * k]; w1[t] = Ws[2 * k + 1]; b0[t] = bs[k]; }
+        else if (k >= ms + mh && k < D) { const int q = k - ms - mh; w0[t] = Wv[2 * q]; w1[t] = Wv[2 * q + 1]; b0[t] = bv[q]; }
+    }
+    for (int i = lo + blockIdx.y; i < hi; i += gridDim.y) {
+        const float xi = obs2[2 * i], yi = obs2[2 * i + 1];
+        const float vxi = xi - obs1[2 * i], vyi = yi - obs1[2 * i + 1];
+        float ui[ATT_MAXD_PER_LANE];
+#pragma unroll
+        for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) { const int k = lane + 64 * t; ui[t] = k < D ? u[(size_t)i * ldu + k] : 0.0f; }
+        const float ci = u[(size_t)i * ldu + D];
+        auto embed = [&](int j, float (&e)[ATT_MAXD_PER_LANE]) {
+            const float xj = obs2[2 * j], yj = obs2[2 * j + 1];
+            const float vxj = xj - obs1[2 * j], vyj = yj - obs1[2 * j + 1];
+#pragma unroll
+            for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) {
+                const int k = lane + 64 * t;
+                float h = 0.0f;
+                if (k >= ms && k < ms + mh) { h = henc[(size_t)j * ldh + (k - ms)]; if (henc_relu) h = h > 0.0f ? h : 0.0f; }
+                e[t] = k < D ? attn_embed(k, ms, mh, fill, xi, yi, vxi, vyi, xj, yj, vxj, vyj, h, w0[t], w1[t], b0[t]) : 0.0f;
+            }
+        };
+        auto wave_sum = [&](float v) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            return v;
+        };
+        // pass 1: scores
+        float mx = -INFINITY;
+        for (int j = lo; j < hi; ++j) {
+            float e[ATT_MAXD_PER_LANE];
+            embed(j, e);
+            float part = 0.0f;
+#pragma unroll
+            for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) part = fmaf(ui[t], e[t], part);
+            const float sj = (wave_sum(part) + ci) * scale;
+            if (lane == 0) att_sc[j - lo] = sj;
+            mx = fmaxf(mx, sj);
+        }
+        float s_pad = 0.0f;
+        if (npad > 0) {
+            float part = 0.0f;
+#pragma unroll
+            for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) {
+                const int k = lane + 64 * t;
+                const float ep = (k < D && !(k >= ms && k < ms + mh)) ? fill : 0.0f;
+                part = fmaf(ui[t], ep, part);
+            }
+            s_pad = (wave_sum(part) + ci) * scale;
+            mx = fmaxf(mx, s_pad);
+        }
+        __syncthreads();
+        // pass 2: softmax weights and the weighted sum of the embeddings
+        float acc[ATT_MAXD_PER_LANE] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float den = 0.0f;
+        for (int j = lo; j < hi; ++j) {
+            float e[ATT_MAXD_PER_LANE];
+            embed(j, e);
+            const float a = expf(att_sc[j - lo] - mx);
+            den += a;
+#pragma unroll
+            for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) acc[t] = fmaf(a, e[t], acc[t]);
+        }
+        if (npad > 0) {
+            const float a = expf(s_pad - mx) * (float)npad;
+            den += a;
+#pragma unroll
+            for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) {
+                const int k = lane + 64 * t;
+                const float ep = (k < D && !(k >= ms && k < ms + mh)) ? fill : 0.0f;
+                acc[t] = fmaf(a, ep, acc[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) {
+            const int k = lane + 64 * t;
+            if (k < D) ebar[(size_t)i * lde + k] = acc[t] / den;
+        }
+        __syncthreads();
+    }
+}
+
+int launch_pool_attn_self(const float *obs1, const float *obs2, const float *henc, int ldh, int henc_relu, int M, int ms,
+                          int mv, int mh, const float *bs, const float *bv, float fill, float *e_self, int lde,
+                          hipStream_t s) {
+    if (M <= 0) return 0;
+    const int D = ms + mh + mv;
+    const long total = (long)M * D;
+    hipLaunchKernelGGL(pool_attn_self_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, obs1, obs2, henc, ldh,
+                       henc_relu, M, ms, mv, mh, bs, bv, fill, e_self, lde);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_pool_attn_pair(const float *obs1, const float *obs2, const float *henc, int ldh, int henc_relu,
+                          const int32_t *scene_start, int B, int n_max, int ms, int mv, int mh, const float *Ws,
+                          const float *bs, const float *Wv, const float *bv, float fill, const float *u, int ldu,
+                          float *ebar, int lde, hipStream_t s) {
+    if (B <= 0) return 0;
+    const int D = ms + mh + mv;
+    if (D > 64 * ATT_MAXD_PER_LANE) TNP_FAIL(-1, "AttentionMLPPooling: mlp_dim %d > %d", D, 64 * ATT_MAXD_PER_LANE);
+    if (n_max < 1 || (size_t)n_max * 4 > 60000) TNP_FAIL(-1, "AttentionMLPPooling: n_max %d out of range", n_max);
+    hipLaunchKernelGGL(pool_attn_pair_kernel, dim3(B, 16), dim3(64), (size_t)n_max * sizeof(float), s, obs1, obs2, henc, ldh,
+                       henc_relu, scene_start, n_max, ms, mv, mh, Ws, bs, Wv, bv, fill, u, ldu, ebar, lde);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace tnp
 
 extern "C" TNP_API int tnp_pool_nn_forward(const float *obs1, const float *obs2, const int32_t *scene_start, int B,
@@ -156,4 +326,20 @@ extern "C" TNP_API int tnp_pool_hiddenmlp_forward(const float *obs1, const float
                                                   void *stream) {
     return tnp::launch_pool_hiddenmlp(obs1, obs2, hidden_emb, ldh, hidden_emb_relu, scene_start, B, ms, mv, mh,
                                       W_spatial, b_spatial, W_vel, b_vel, pooled, ldp, (hipStream_t)stream);
+}
+
+extern "C" TNP_API int tnp_pool_attn_self(const float *obs1, const float *obs2, const float *hidden_emb, int ldh,
+                                          int hidden_emb_relu, int M, int ms, int mv, int mh, const float *b_spatial,
+                                          const float *b_vel, float fill, float *e_self, int lde, void *stream) {
+    return tnp::launch_pool_attn_self(obs1, obs2, hidden_emb, ldh, hidden_emb_relu, M, ms, mv, mh, b_spatial, b_vel, fill,
+                                      e_self, lde, (hipStream_t)stream);
+}
+
+extern "C" TNP_API int tnp_pool_attn_pair(const float *obs1, const float *obs2, const float *hidden_emb, int ldh,
+                                          int hidden_emb_relu, const int32_t *scene_start, int B, int n_max, int ms,
+                                          int mv, int mh, const float *W_spatial, const float *b_spatial,
+                                          const float *W_vel, const float *b_vel, float fill, const float *u, int ldu,
+                                          float *ebar, int lde, void *stream) {
+    return tnp::launch_pool_attn_pair(obs1, obs2, hidden_emb, ldh, hidden_emb_relu, scene_start, B, n_max, ms, mv, mh,
+                                      W_spatial, b_spatial, W_vel, b_vel, fill, u, ldu, ebar, lde, (hipStream_t)stream);
 }

@@ -69,6 +69,14 @@ int launch_pool_hiddenmlp(const float *obs1, const float *obs2, const float *hen
                           const int32_t *scene_start, int B, int ms, int mv, int mh, const float *Ws, const float *bs,
                           const float *Wv, const float *bv, float *pooled, int ldp, hipStream_t s);
 
+int launch_pool_attn_self(const float *obs1, const float *obs2, const float *henc, int ldh, int henc_relu, int M, int ms,
+                          int mv, int mh, const float *bs, const float *bv, float fill, float *e_self, int lde,
+                          hipStream_t s);
+int launch_pool_attn_pair(const float *obs1, const float *obs2, const float *henc, int ldh, int henc_relu,
+                          const int32_t *scene_start, int B, int n_max, int ms, int mv, int mh, const float *Ws,
+                          const float *bs, const float *Wv, const float *bv, float fill, const float *u, int ldu,
+                          float *ebar, int lde, hipStream_t s);
+
 // ---- profiling hook -------------------------------------------------------------------------
 enum { PROF_GEMM1 = 0, PROF_ALL_GEMM = 1 };
 void prof_before(int cls, hipStream_t s);

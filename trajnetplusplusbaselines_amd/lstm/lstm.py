@@ -98,13 +98,18 @@ class LSTM(torch.nn.Module):
         m.pool_type = _lib.POOL_NONE
         m.n, m.C, m.P, m.n_layers = 0, 0, 0, 0
         pool = self.pool
-        from .non_gridbased_pooling import NearestNeighborMLP, HiddenStateMLPPooling
+        from .non_gridbased_pooling import NearestNeighborMLP, HiddenStateMLPPooling, AttentionMLPPooling
         if isinstance(pool, NearestNeighborMLP):
             lin = pool.embedding[0]
             m.pool_type, m.n, m.C, m.P = _lib.POOL_NN, pool.n, pool.input_dim, pool.out_dim
             m.Wp[0], m.bp[0] = P(lin.weight), P(lin.bias)
-        elif isinstance(pool, HiddenStateMLPPooling):
-            m.pool_type, m.P = _lib.POOL_HIDDENMLP, pool.out_dim
+        elif isinstance(pool, (HiddenStateMLPPooling, AttentionMLPPooling)):
+            attn = isinstance(pool, AttentionMLPPooling)
+            m.pool_type, m.P = (_lib.POOL_ATTNMLP if attn else _lib.POOL_HIDDENMLP), pool.out_dim
+            if attn:
+                wq, bq, wu, wfin, bfin = pool.folded()
+                m.constant = float(pool.fill_value)
+                m.Wx[0], m.bx[0], m.Wx[1], m.Wx[2], m.bx[2] = P(wq), P(bq), P(wu), P(wfin), P(bfin)
             m.dims[0], m.dims[1], m.dims[2] = pool.mlp_dim_spatial, pool.mlp_dim_vel, pool.mlp_dim_hidden
             m.C = pool.mlp_dim_hidden
             m.Wp[0], m.bp[0] = P(pool.spatial_embedding[0].weight), P(pool.spatial_embedding[0].bias)

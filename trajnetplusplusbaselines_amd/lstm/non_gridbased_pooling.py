@@ -106,3 +106,99 @@ class HiddenStateMLPPooling(torch.nn.Module):
             _lib.ptr(_lib.f32c(ve.bias.detach(), dev)) if ve is not None else None,
             _lib.ptr(pooled), ms + mh + mv, _lib.stream_ptr()), 'tnp_pool_hiddenmlp_forward')
         return _lib.linear_forward(pooled, self.out_projection.weight.detach(), self.out_projection.bias.detach())
+
+
+class AttentionMLPPooling(torch.nn.Module):
+    """Attention-weighted embeddings of relative position, hidden state and relative velocity of all slots of the
+    padded scene, as in S-BiGAT (reference lstm/non_gridbased_pooling.py:242-351).  Same parameters / state_dict keys
+    as the reference (``wq wk wv`` without bias, a single-head ``torch.nn.MultiheadAttention``, ``out_projection``);
+    the module objects only hold the parameters, the computation runs in csrc/pool_nongrid.hip with the linear maps
+    around the softmax folded into three small matrices (``folded()``)."""
+
+    def __init__(self, hidden_dim=128, mlp_dim=128, mlp_dim_spatial=32, mlp_dim_vel=32, out_dim=None, fill_value=-10):
+        super(AttentionMLPPooling, self).__init__()
+        self.out_dim = out_dim or hidden_dim
+        self.hidden_dim = hidden_dim
+        self.fill_value = fill_value
+        self.mlp_dim = mlp_dim
+        self.mlp_dim_spatial = mlp_dim_spatial
+        self.mlp_dim_vel = mlp_dim_vel
+        self.mlp_dim_hidden = mlp_dim - mlp_dim_spatial - mlp_dim_vel
+        if self.mlp_dim_hidden > 64 or mlp_dim > 256:
+            raise NotImplementedError('mlp_dim_hidden > 64 / mlp_dim > 256 is not supported on the MI355X path')
+        self.spatial_embedding = torch.nn.Sequential(
+            torch.nn.Linear(2, self.mlp_dim_spatial),
+            torch.nn.ReLU(),)
+        if self.mlp_dim_vel:
+            self.vel_embedding = torch.nn.Sequential(
+                torch.nn.Linear(2, self.mlp_dim_vel),
+                torch.nn.ReLU(),)
+        if self.mlp_dim_hidden:
+            self.hidden_embedding = torch.nn.Sequential(
+                torch.nn.Linear(self.hidden_dim, self.mlp_dim_hidden),
+                torch.nn.ReLU(),)
+        self.wq = torch.nn.Linear(self.mlp_dim, self.mlp_dim, bias=False)
+        self.wk = torch.nn.Linear(self.mlp_dim, self.mlp_dim, bias=False)
+        self.wv = torch.nn.Linear(self.mlp_dim, self.mlp_dim, bias=False)
+        self.multihead_attn = torch.nn.MultiheadAttention(embed_dim=self.mlp_dim, num_heads=1)
+        self.out_projection = torch.nn.Linear(self.mlp_dim, self.out_dim)
+        self._folded = None
+
+    def reset(self, num_tracks, max_num_neigh, device):
+        self.track_mask = None
+
+    def folded(self):
+        """(Wq [D,D], bq [D], Wu [D+4,D], Wfin [P,D], bfin [P]) on the parameters' device, recomputed when a parameter
+        changes: q = Wq e + bq;  u = Wu q with rows 0..D-1 = (in_proj_k wk)^T and row D = in_proj_bias_k;
+        pooled = Wfin (sum_j a_j e_j) + bfin  (the attention weights sum to one, so the value / output biases fold)."""
+        params = [self.wq.weight, self.wk.weight, self.wv.weight, self.multihead_attn.in_proj_weight,
+                  self.multihead_attn.in_proj_bias, self.multihead_attn.out_proj.weight,
+                  self.multihead_attn.out_proj.bias, self.out_projection.weight, self.out_projection.bias]
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+        if self._folded is None or self._folded[0] != key:
+            D = self.mlp_dim
+            wq, wk, wv, w_in, b_in, wo, bo, wop, bop = (p.detach().double() for p in params)
+            wq_eff = w_in[:D] @ wq
+            wk_eff = w_in[D:2 * D] @ wk
+            wv_eff = w_in[2 * D:] @ wv
+            wu = torch.zeros(D + 4, D, dtype=torch.float64, device=wq.device)
+            wu[:D] = wk_eff.t()
+            wu[D] = b_in[D:2 * D]
+            wfin = wop @ wo @ wv_eff
+            bfin = wop @ (wo @ b_in[2 * D:] + bo) + bop
+            self._folded = (key, tuple(t.float().contiguous() for t in (wq_eff, b_in[:D], wu, wfin, bfin)))
+        return self._folded[1]
+
+    def forward(self, hidden_states, obs1, obs2):
+        dev = self.out_projection.weight.device
+        _lib.require_device(self.out_projection.weight, 'AttentionMLPPooling parameters')
+        B, N = obs2.size(0), obs2.size(1)
+        o1 = _lib.f32c(obs1, dev).reshape(B * N, 2)
+        o2 = _lib.f32c(obs2, dev).reshape(B * N, 2)
+        ms, mv, mh = self.mlp_dim_spatial, self.mlp_dim_vel, self.mlp_dim_hidden
+        D = self.mlp_dim
+        henc = None
+        if mh:   # embed_with_masking(..., fill_value=0) (reference :327)
+            h = _lib.f32c(hidden_states, dev).reshape(B * N, -1)
+            nan_rows = torch.isnan(h).any(dim=1, keepdim=True)
+            lin = self.hidden_embedding[0]
+            henc = _lib.linear_forward(torch.nan_to_num(h), lin.weight.detach(), lin.bias.detach(), relu=True)
+            henc = torch.where(nan_rows, torch.zeros_like(henc), henc).contiguous()
+        sp = self.spatial_embedding[0]
+        ve = self.vel_embedding[0] if mv else None
+        f = lambda t: _lib.ptr(_lib.f32c(t.detach(), dev)) if t is not None else None
+        wq, bq, wu, wfin, bfin = self.folded()
+        L = _lib.lib()
+        e_self = torch.empty(B * N, D, dtype=torch.float32, device=dev)
+        _lib.check(L.tnp_pool_attn_self(_lib.ptr(o1), _lib.ptr(o2), _lib.ptr(henc), mh, 0, B * N, ms, mv, mh, f(sp.bias),
+                                        f(ve.bias) if ve is not None else None, float(self.fill_value), _lib.ptr(e_self), D,
+                                        _lib.stream_ptr()), 'tnp_pool_attn_self')
+        q = _lib.linear_forward(e_self, wq, bq)
+        u = _lib.linear_forward(q, wu, None)
+        ebar = torch.empty(B * N, D, dtype=torch.float32, device=dev)
+        starts = _padded_starts(B, N, dev)
+        _lib.check(L.tnp_pool_attn_pair(_lib.ptr(o1), _lib.ptr(o2), _lib.ptr(henc), mh, 0, _lib.ptr(starts), B, N, ms, mv, mh,
+                                        f(sp.weight), f(sp.bias), f(ve.weight) if ve is not None else None,
+                                        f(ve.bias) if ve is not None else None, float(self.fill_value), _lib.ptr(u), D + 4,
+                                        _lib.ptr(ebar), D, _lib.stream_ptr()), 'tnp_pool_attn_pair')
+        return _lib.linear_forward(ebar, wfin, bfin)
