@@ -330,11 +330,13 @@ def nongrid_cases(ref):
     padded [B,N,*] tensors with NaN slots, and LSTM.forward with the module as `pool` (both decoder modes)."""
     import trajnetbaselines.lstm.non_gridbased_pooling as ng
     out = {}
-    for kind in ('nn', 'hiddenstatemlp', 'attentionmlp'):
-        torch.manual_seed({'nn': 81, 'hiddenstatemlp': 82, 'attentionmlp': 86}[kind])
+    for kind in ('nn', 'hiddenstatemlp', 'attentionmlp', 'nn_lstm', 'traj_pool'):
+        torch.manual_seed({'nn': 81, 'hiddenstatemlp': 82, 'attentionmlp': 86, 'nn_lstm': 87, 'traj_pool': 88}[kind])
         pool = {'nn': lambda: ng.NearestNeighborMLP(n=4, out_dim=32),
                 'hiddenstatemlp': lambda: ng.HiddenStateMLPPooling(hidden_dim=128, out_dim=48),
-                'attentionmlp': lambda: ng.AttentionMLPPooling(hidden_dim=128, out_dim=48)}[kind]()
+                'attentionmlp': lambda: ng.AttentionMLPPooling(hidden_dim=128, out_dim=48),
+                'nn_lstm': lambda: ng.NearestNeighborLSTM(n=4, hidden_dim=256, out_dim=32),
+                'traj_pool': lambda: ng.TrajectronPooling(hidden_dim=256, out_dim=32)}[kind]()
         model = ref.LSTM(pool=pool).eval()
         pre = kind + '_'
         for k, v in model.state_dict().items():
@@ -348,11 +350,13 @@ def nongrid_cases(ref):
         obs1[1, 4] = NAN                                # position known, velocity unknown
         obs2[2, 4:] = NAN; obs1[2, 4:] = NAN; hidden[2, 4:] = NAN   # padded slots
         with torch.no_grad():
+            pool.reset(3 * 6, 5, 'cpu')      # zero interaction-encoder state (stateful modules)
             y = pool(hidden.clone(), obs1.clone(), obs2.clone())
         out.update({pre + 'm_obs1': obs1.numpy(), pre + 'm_obs2': obs2.numpy(), pre + 'm_hidden': hidden.numpy(),
                     pre + 'm_out': y.numpy()})
         # a 3-slot scene for the "fewer than n neighbours" branch of NearestNeighborMLP (:134-137)
         with torch.no_grad():
+            pool.reset(3, 2, 'cpu')
             y3 = pool(hidden[:1, :3].clone(), obs1[:1, :3].clone(), obs2[:1, :3].clone())
         out[pre + 'm3_out'] = y3.numpy()
         for tag, (xy, split) in (('lin', synth.linear_crowd(3, 6, seed=84)), ('rag', synth.ragged_crowd(5, 1, 9, seed=85))):

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-POOL_TYPES = {'occupancy': 0, 'directional': 1, 'social': 2, None: -1, 'nn': 4, 'hiddenstatemlp': 5, 'attentionmlp': 6}
+POOL_TYPES = {'occupancy': 0, 'directional': 1, 'social': 2, None: -1, 'nn': 4, 'hiddenstatemlp': 5, 'attentionmlp': 6, 'nn_lstm': 7, 'traj_pool': 8}
 
 _f = ctypes.POINTER(ctypes.c_float)
 
@@ -34,6 +34,7 @@ class _Model(ctypes.Structure):
         ('WpT', _f * 3), ('enc_WihT', _f), ('enc_WhhT', _f), ('dec_WihT', _f), ('dec_WhhT', _f),
         ('att_wq', _f), ('att_wk', _f), ('att_wv', _f), ('att_in_w', _f), ('att_in_b', _f), ('att_out_w', _f),
         ('att_out_b', _f),
+        ('Hp', ctypes.c_int), ('pl_Wih', _f), ('pl_Whh', _f), ('pl_bih', _f), ('pl_bhh', _f), ('pl_Wo', _f), ('pl_bo', _f),
     ]
 
 
@@ -90,7 +91,16 @@ class OracleModel(object):
             setattr(m, pre + '_bhh', _p(sd[full + '.bias_hh']))
         m.Wn, m.bn = _p(sd['hidden2normal.linear.weight']), _p(sd['hidden2normal.linear.bias'])
         m.C, m.P, m.n_layers = 1, 0, 0
-        if pool_type == 'nn':            # NearestNeighborMLP (lstm/non_gridbased_pooling.py:64-147); n = neighbours kept
+        if pool_type in ('nn_lstm', 'traj_pool'):   # stateful interaction encoders (lstm/non_gridbased_pooling.py:354-538)
+            w = sd['pool.embedding.0.weight']
+            m.C = w.shape[1] if pool_type == 'nn_lstm' else 4
+            m.P = sd['pool.hidden2pool.weight'].shape[0]
+            m.Wp[0], m.bp[0] = _p(w), _p(sd['pool.embedding.0.bias'])
+            m.Hp = sd['pool.pool_lstm.weight_hh'].shape[1]
+            m.pl_Wih, m.pl_Whh = _p(sd['pool.pool_lstm.weight_ih']), _p(sd['pool.pool_lstm.weight_hh'])
+            m.pl_bih, m.pl_bhh = _p(sd['pool.pool_lstm.bias_ih']), _p(sd['pool.pool_lstm.bias_hh'])
+            m.pl_Wo, m.pl_bo = _p(sd['pool.hidden2pool.weight']), _p(sd['pool.hidden2pool.bias'])
+        elif pool_type == 'nn':            # NearestNeighborMLP (lstm/non_gridbased_pooling.py:64-147); n = neighbours kept
             w = sd['pool.embedding.0.weight']
             m.C, m.P = w.shape[1], w.shape[0] * n
             m.Wp[0], m.bp[0] = _p(w), _p(sd['pool.embedding.0.bias'])

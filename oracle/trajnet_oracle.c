@@ -33,7 +33,9 @@
 enum { ORC_OCCUPANCY = 0, ORC_DIRECTIONAL = 1, ORC_SOCIAL = 2, ORC_NOPOOL = -1,
        ORC_NN = 4,        /* NearestNeighborMLP, lstm/non_gridbased_pooling.py:64-147 */
        ORC_HIDDENMLP = 5, /* HiddenStateMLPPooling, lstm/non_gridbased_pooling.py:150-239 */
-       ORC_ATTNMLP = 6    /* AttentionMLPPooling, lstm/non_gridbased_pooling.py:242-351 */ };
+       ORC_ATTNMLP = 6,   /* AttentionMLPPooling, lstm/non_gridbased_pooling.py:242-351 */
+       ORC_NNLSTM = 7,    /* NearestNeighborLSTM, lstm/non_gridbased_pooling.py:354-455 */
+       ORC_TRAJ = 8       /* TrajectronPooling, lstm/non_gridbased_pooling.py:457-538 */ };
 
 /* torch.nan_to_num defaults (lstm/gridbased_pooling.py:140,166): nan->0, +-inf->+-FLT_MAX */
 static inline float nan_to_num_f(float v) {
@@ -326,6 +328,10 @@ typedef struct {
     /* AttentionMLPPooling only: wq, wk, wv [D,D] (no bias), MultiheadAttention in_proj_weight [3D,D] / in_proj_bias [3D],
      * out_proj weight [D,D] / bias [D] */
     const float *att_wq, *att_wk, *att_wv, *att_in_w, *att_in_b, *att_out_w, *att_out_b;
+    /* NearestNeighborLSTM / TrajectronPooling only: interaction-encoder pool_lstm (LSTMCell(P -> Hp)) and hidden2pool
+     * Linear(Hp -> P) */
+    int Hp;
+    const float *pl_Wih, *pl_Whh, *pl_bih, *pl_bhh, *pl_Wo, *pl_bo;
 } orc_model;
 
 /* One row of torch.nn.Linear (+ReLU) without the OpenMP region / transposed copy of orc_linear: same axpy order
@@ -500,6 +506,59 @@ static void pool_attnmlp_forward(const orc_model *md, const float *hidden, const
     }
 }
 
+/* State of the interaction-encoder LSTM of NearestNeighborLSTM / TrajectronPooling: one (h, c) pair per PADDED slot,
+ * zeroed by pool.reset() at the start of every LSTM.forward (lstm/lstm.py:213-216, non_gridbased_pooling.py:385-389). */
+static float *g_pool_h = NULL, *g_pool_c = NULL;
+static size_t g_pool_rows = 0;
+static void pool_state_reset(void) { free(g_pool_h); free(g_pool_c); g_pool_h = g_pool_c = NULL; g_pool_rows = 0; }
+static void pool_state_need(size_t rows, int Hp) {
+    if (g_pool_h && g_pool_rows == rows) return;
+    pool_state_reset();
+    g_pool_h = (float *)calloc(rows * Hp, sizeof(float));
+    g_pool_c = (float *)calloc(rows * Hp, sizeof(float));
+    g_pool_rows = rows;
+}
+
+static void pool_lstm_tail(const orc_model *md, const float *feat, size_t rows, float *out);
+
+/* NearestNeighborLSTM.forward (:391-455): the NearestNeighborMLP features (always with velocities), then the
+ * interaction-encoder LSTMCell over ALL padded slots (no presence mask, :450) and hidden2pool. */
+static void pool_nnlstm_forward(const orc_model *md, const float *obs1, const float *obs2, int B, int N, float *out) {
+    size_t rows = (size_t)B * N;
+    float *feat = (float *)malloc(sizeof(float) * rows * md->P);
+    pool_nn_forward(md, obs1, obs2, B, N, feat);
+    pool_lstm_tail(md, feat, rows, out);
+    free(feat);
+}
+
+/* TrajectronPooling.forward (:499-538): per visible slot [pos, vel] of the slot ++ the SUM of [pos, vel] over all
+ * other visible slots OF THE WHOLE BATCH (one_cold over states_vis, :525-527 -- not per scene), Linear(8 -> P) + ReLU;
+ * invisible slots get a zero row (:521,529); then the interaction-encoder LSTMCell over all slots and hidden2pool. */
+static void pool_traj_forward(const orc_model *md, const float *obs1, const float *obs2, int B, int N, float *out) {
+    size_t rows = (size_t)B * N;
+    float *st = (float *)malloc(sizeof(float) * rows * 4);
+    uint8_t *vis = (uint8_t *)malloc(rows);
+    for (size_t r = 0; r < rows; ++r) {
+        st[4 * r] = obs2[2 * r]; st[4 * r + 1] = obs2[2 * r + 1];
+        st[4 * r + 2] = obs2[2 * r] - obs1[2 * r]; st[4 * r + 3] = obs2[2 * r + 1] - obs1[2 * r + 1];
+        int nan = 0;
+        for (int k = 0; k < 4; ++k) nan |= (st[4 * r + k] != st[4 * r + k]);
+        vis[r] = !nan;
+    }
+    float *feat = (float *)calloc(rows * md->P, sizeof(float));
+    for (size_t i = 0; i < rows; ++i) {
+        if (!vis[i]) continue;
+        float x[8] = { st[4 * i], st[4 * i + 1], st[4 * i + 2], st[4 * i + 3], 0.0f, 0.0f, 0.0f, 0.0f };
+        for (size_t k = 0; k < rows; ++k) {
+            if (k == i || !vis[k]) continue;
+            for (int q = 0; q < 4; ++q) x[4 + q] += st[4 * k + q];
+        }
+        small_linear(x, 8, md->Wp[0], md->bp[0], md->P, 1, feat + i * md->P);
+    }
+    pool_lstm_tail(md, feat, rows, out);
+    free(st); free(vis); free(feat);
+}
+
 /* GridBasedPooling.forward (lstm/gridbased_pooling.py:94-110) on the padded
  * [B,N,*] tensors produced by generate_pooling_inputs (lstm/lstm.py:25-42).
  * need[B*N] marks rows whose embedding is consumed (lstm/lstm.py:146); the
@@ -509,6 +568,8 @@ static void pool_forward(const orc_model *md, const float *hidden, const float *
     if (md->pool_type == ORC_NN) { pool_nn_forward(md, obs1, obs2, B, N, out); return; }
     if (md->pool_type == ORC_HIDDENMLP) { pool_hiddenmlp_forward(md, hidden, obs1, obs2, B, N, out); return; }
     if (md->pool_type == ORC_ATTNMLP) { pool_attnmlp_forward(md, hidden, obs1, obs2, B, N, out); return; }
+    if (md->pool_type == ORC_NNLSTM) { pool_nnlstm_forward(md, obs1, obs2, B, N, out); return; }
+    if (md->pool_type == ORC_TRAJ) { pool_traj_forward(md, obs1, obs2, B, N, out); return; }
     const int Fin = md->C * md->n * md->n;
     size_t rows = (size_t)B * N;
     float *enc = NULL;
@@ -543,6 +604,20 @@ static void pool_forward(const orc_model *md, const float *hidden, const float *
         else for (int p = 0; p < md->P; ++p) out[r * md->P + p] = NAN;
     }
     free(a); free(grid); free(enc);
+}
+
+/* pool_lstm + hidden2pool of the stateful interaction encoders (non_gridbased_pooling.py:450-455, 531-538) */
+static void pool_lstm_tail(const orc_model *md, const float *feat, size_t rows, float *out) {
+    const int Hp = md->Hp;
+    pool_state_need(rows, Hp);
+    float *ho = (float *)malloc(sizeof(float) * rows * Hp);
+    float *co = (float *)malloc(sizeof(float) * rows * Hp);
+    lstm_cell_any(feat, (int)rows, md->P, g_pool_h, g_pool_c, Hp, md->pl_Wih, md->pl_Whh, NULL, NULL, md->pl_bih, md->pl_bhh,
+                  ho, co);
+    memcpy(g_pool_h, ho, sizeof(float) * rows * Hp);
+    memcpy(g_pool_c, co, sizeof(float) * rows * Hp);
+    orc_linear(ho, (int)rows, Hp, md->pl_Wo, md->pl_bo, md->P, 0, out);
+    free(ho); free(co);
 }
 
 /* LSTM.step, lstm/lstm.py:91-168, on dense state h,c [M,H] (the reference keeps
@@ -643,6 +718,8 @@ ORC_API void orc_pool_module(const orc_model *md, const float *hidden, const flo
     if (md->pool_type == ORC_NN) pool_nn_forward(md, obs1, obs2, B, N, out);
     else if (md->pool_type == ORC_HIDDENMLP) pool_hiddenmlp_forward(md, hidden, obs1, obs2, B, N, out);
     else if (md->pool_type == ORC_ATTNMLP) pool_attnmlp_forward(md, hidden, obs1, obs2, B, N, out);
+    else if (md->pool_type == ORC_NNLSTM) { pool_state_reset(); pool_nnlstm_forward(md, obs1, obs2, B, N, out); pool_state_reset(); }
+    else if (md->pool_type == ORC_TRAJ) { pool_state_reset(); pool_traj_forward(md, obs1, obs2, B, N, out); pool_state_reset(); }
 }
 
 ORC_API void orc_lstm_step(const orc_model *md, int decoder, float *h, float *c, const float *obs1,
@@ -665,6 +742,7 @@ ORC_API int orc_lstm_forward(const orc_model *md, const float *observed, int T_o
     const size_t F = (size_t)M * 2;
     float *h = (float *)calloc((size_t)M * H, sizeof(float)); /* :207-210 */
     float *c = (float *)calloc((size_t)M * H, sizeof(float));
+    pool_state_reset();   /* pool.reset(), lstm/lstm.py:213-216 */
     int npos = 0, nnorm = 0;
     if (T_obs == 2) { memcpy(pred, observed + F, sizeof(float) * F); npos = 1; } /* :222-223 */
     /* encoder :226-232 */
@@ -702,6 +780,7 @@ ORC_API int orc_lstm_forward(const orc_model *md, const float *observed, int T_o
         prev_is_none = (truth == NULL);
     }
     free(h); free(c); free(pt_prev); free(pt_cur);
+    pool_state_reset();
     return npos;
 }
 

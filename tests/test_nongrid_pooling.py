@@ -9,7 +9,7 @@ from oracle import oracle
 from tests import helpers
 
 GOLD = np.load(os.path.join(helpers.GOLDEN, 'nongrid_cases.npz'))
-KINDS = ['nn', 'hiddenstatemlp', 'attentionmlp']
+KINDS = ['nn', 'hiddenstatemlp', 'attentionmlp', 'nn_lstm', 'traj_pool']
 
 
 def state_dict(kind):
