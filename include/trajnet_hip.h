@@ -39,6 +39,8 @@ extern "C" {
 #define TNP_POOL_NN          4   /* NearestNeighborMLP, lstm/non_gridbased_pooling.py:64-147   */
 #define TNP_POOL_HIDDENMLP   5   /* HiddenStateMLPPooling, lstm/non_gridbased_pooling.py:150-239 */
 #define TNP_POOL_ATTNMLP     6   /* AttentionMLPPooling, lstm/non_gridbased_pooling.py:242-351   */
+#define TNP_POOL_NNLSTM      7   /* NearestNeighborLSTM, lstm/non_gridbased_pooling.py:354-455   */
+#define TNP_POOL_TRAJ        8   /* TrajectronPooling, lstm/non_gridbased_pooling.py:457-538      */
 
 TNP_API int tnp_abi_version(void);
 TNP_API const char *tnp_last_error(void);
@@ -118,6 +120,11 @@ TNP_API int tnp_pool_hiddenmlp_forward(const float *obs1, const float *obs2, con
                                        int mh, const float *W_spatial, const float *b_spatial,
                                        const float *W_vel, const float *b_vel, float *pooled, int ldp,
                                        void *stream);
+/* TrajectronPooling features (lstm/non_gridbased_pooling.py:513-529): out[i] = ReLU(W [P,8] . [pos_i, vel_i,
+ * sum over the other visible tracks of the batch of (pos, vel)] + bias), zero rows for invisible tracks;
+ * scratch4 = 4 doubles of device memory */
+TNP_API int tnp_pool_traj_forward(const float *obs1, const float *obs2, int M, const float *W, const float *bias,
+                                  int P, float *out, int ldo, double *scratch4, void *stream);
 /* AttentionMLPPooling.forward (lstm/non_gridbased_pooling.py:297-351) in two kernels around three tnp_linear_forward
  * calls (see tnp_lstm_model.Wx):
  *   tnp_pool_attn_self : e_self[i] = embedding of slot i relative to itself ([ReLU(b_spatial) | hidden_emb[i] |
@@ -172,6 +179,9 @@ typedef struct tnp_lstm_model {
      *   Wx[1] [D+4,D]           rows 0..D-1 = (in_proj_k . wk)^T, row D = in_proj_bias_k, rows D+1.. = 0:
      *                            u = Wx[1] q gives score_ij = (u[0:D] . e_ij + u[D]) / sqrt(D)
      *   Wx[2] [P,D], bx[2] [P]  out_projection . out_proj . (in_proj_v . wv) applied to sum_j a_ij e_ij (+ biases) */
+    /* TNP_POOL_NNLSTM / TNP_POOL_TRAJ (stateful interaction encoders; tnp_lstm_forward only): Wp/bp[0] = embedding
+     * Linear(4 -> P/n) resp. Linear(8 -> P), dims[0] = Hp, Wx/bx[0] = pool_lstm.weight_ih/bias_ih [4Hp,P],
+     * Wx/bx[1] = pool_lstm.weight_hh/bias_hh [4Hp,Hp], Wx/bx[2] = hidden2pool [P,Hp] */
     const float *Wx[3];
     const float *bx[3];
 } tnp_lstm_model;

@@ -58,10 +58,13 @@ def test_oracle_lstm_forward_matches_reference(kind, batch):
 # ---- HIP path ---------------------------------------------------------------------------------------------------
 def build_amd(kind, device='cuda'):
     import torch
-    from trajnetplusplusbaselines_amd.lstm import LSTM, NearestNeighborMLP, HiddenStateMLPPooling, AttentionMLPPooling
+    from trajnetplusplusbaselines_amd.lstm import (LSTM, NearestNeighborMLP, HiddenStateMLPPooling, AttentionMLPPooling,
+                                                   NearestNeighborLSTM, TrajectronPooling)
     pool = {'nn': lambda: NearestNeighborMLP(n=4, out_dim=32),
             'hiddenstatemlp': lambda: HiddenStateMLPPooling(hidden_dim=128, out_dim=48),
-            'attentionmlp': lambda: AttentionMLPPooling(hidden_dim=128, out_dim=48)}[kind]()
+            'attentionmlp': lambda: AttentionMLPPooling(hidden_dim=128, out_dim=48),
+            'nn_lstm': lambda: NearestNeighborLSTM(n=4, hidden_dim=256, out_dim=32),
+            'traj_pool': lambda: TrajectronPooling(hidden_dim=256, out_dim=32)}[kind]()
     model = LSTM(pool=pool)
     model.load_state_dict({k: torch.tensor(v) for k, v in state_dict(kind).items()})   # same keys as the reference
     return model.to(device).eval()
@@ -74,8 +77,10 @@ def test_gpu_module_matches_reference(kind):
     model = build_amd(kind)
     pre = kind + '_m_'
     h, o1, o2 = (torch.tensor(GOLD[pre + k]) for k in ('hidden', 'obs1', 'obs2'))
+    model.pool.reset(h.shape[0] * h.shape[1], h.shape[1] - 1, 'cuda')
     got = model.pool(h, o1, o2).cpu().numpy()
     assert_rel_close(got, GOLD[pre + 'out'], 5e-5, 'module output')
+    model.pool.reset(3, 2, 'cuda')
     got3 = model.pool(h[:1, :3], o1[:1, :3], o2[:1, :3]).cpu().numpy()
     assert_rel_close(got3, GOLD[kind + '_m3_out'], 5e-5, '3-slot scene')
 

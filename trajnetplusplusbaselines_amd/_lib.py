@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libtrajnet_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'trajnet_hip.h')
 
 POOL_NONE, POOL_OCCUPANCY, POOL_DIRECTIONAL, POOL_SOCIAL = -1, 0, 1, 2
-POOL_NN, POOL_HIDDENMLP, POOL_ATTNMLP = 4, 5, 6
+POOL_NN, POOL_HIDDENMLP, POOL_ATTNMLP, POOL_NNLSTM, POOL_TRAJ = 4, 5, 6, 7, 8
 ABI_VERSION = 2   # TNP_ABI_VERSION of include/trajnet_hip.h this binding was written against
 POOL_TYPES = {None: POOL_NONE, 'occupancy': POOL_OCCUPANCY, 'directional': POOL_DIRECTIONAL, 'social': POOL_SOCIAL}
 
@@ -90,6 +90,7 @@ def lib():
     L.tnp_row_base.argtypes = [_fp, ctypes.c_int, _fp, _fp]
     L.tnp_pool_nn_forward.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, ctypes.c_int,
                                       _fp, ctypes.c_int, _fp]
+    L.tnp_pool_traj_forward.argtypes = [_fp, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp]
     L.tnp_pool_attn_self.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, _fp, _fp, ctypes.c_float, _fp, ctypes.c_int, _fp]
     L.tnp_pool_attn_pair.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,

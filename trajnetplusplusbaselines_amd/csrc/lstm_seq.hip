@@ -236,6 +236,11 @@ struct Workspace {
     float *partial;
     int sparse;   // first embedding layer runs on the winner table (pool_embed_sparse.hip)
     int I, Fin, ldg;
+    // stateful interaction encoders (NearestNeighborLSTM / TrajectronPooling): pool_lstm state, all-ones mask
+    float *ph[2], *pc;
+    uint8_t *ones;
+    double *scratch;
+    int pcur;
     size_t bytes;
 };
 
@@ -265,6 +270,7 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     for (int l = 1; grid_pool && l < md->n_layers; ++l) if (md->dims[l] > maxmid) maxmid = md->dims[l];
     if (md->pool_type == TNP_POOL_HIDDENMLP) maxmid = md->dims[0] + md->dims[1] + md->dims[2];   // pooled [M, mlp_dim]
     if (md->pool_type == TNP_POOL_ATTNMLP) maxmid = md->dims[0] + md->dims[1] + md->dims[2] + 4;  // u [M, mlp_dim + 4]
+    if (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ) maxmid = md->P;      // features [M, P]
     w.y[0] = (float *)take((size_t)M * maxmid * 4);
     w.y[1] = (float *)take((size_t)M * maxmid * 4);
     w.mask = (uint8_t *)take((size_t)M);
@@ -277,6 +283,15 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
         const size_t pb = sparse_partial_bytes(M, md->dims[1], md->n * md->n);
         if (pb) w.partial = (float *)take(pb);
     }
+    w.ph[0] = w.ph[1] = w.pc = nullptr; w.ones = nullptr; w.scratch = nullptr; w.pcur = 0;
+    if (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ) {
+        const int Hp = md->dims[0];
+        w.ph[0] = (float *)take((size_t)M * Hp * 4);
+        w.ph[1] = (float *)take((size_t)M * Hp * 4);
+        w.pc = (float *)take((size_t)M * Hp * 4);
+        w.ones = (uint8_t *)take((size_t)M);
+        w.scratch = (double *)take(4 * sizeof(double));
+    }
     w.bytes = off;
     return 0;
 }
@@ -288,6 +303,16 @@ static int validate_model(const tnp_lstm_model *md) {
     if (md->pool_type == TNP_POOL_NN) {
         if (md->n < 1 || md->n > 8 || md->P <= 0 || md->P % md->n != 0) TNP_FAIL(-1, "NearestNeighborMLP: n=%d must divide out_dim=%d, n <= 8", md->n, md->P);
         if (md->C != 2 && md->C != 4) TNP_FAIL(-1, "NearestNeighborMLP: input_dim %d", md->C);
+        return 0;
+    }
+    if (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ) {
+        const int Hp = md->dims[0];
+        if (Hp <= 0 || Hp % 32 != 0) TNP_FAIL(-1, "interaction-encoder LSTM: hidden_dim %d must be a positive multiple of 32", Hp);
+        if (md->P <= 0 || md->P % 4 != 0) TNP_FAIL(-1, "interaction encoder: out_dim %d must be a multiple of 4", md->P);
+        if (md->pool_type == TNP_POOL_NNLSTM && (md->n < 1 || md->n > 8 || md->P % md->n != 0 || md->C != 4))
+            TNP_FAIL(-1, "NearestNeighborLSTM: n=%d must divide out_dim=%d (n <= 8)", md->n, md->P);
+        for (int k = 0; k < 3; ++k)
+            if (!md->Wx[k] || !md->bx[k]) TNP_FAIL(-1, "interaction encoder: pool_lstm / hidden2pool weights (Wx/bx) missing");
         return 0;
     }
     if (md->pool_type == TNP_POOL_HIDDENMLP || md->pool_type == TNP_POOL_ATTNMLP) {
@@ -309,7 +334,7 @@ static int validate_model(const tnp_lstm_model *md) {
 }
 
 // pool + gates of one step; obs/mask/X[:,0:E+GD]/enc already prepared
-static int run_step_body(const tnp_lstm_model *md, int decoder, const Workspace &w, const float *h_in, float *h_out,
+static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, const float *h_in, float *h_out,
                          const float *c_in, float *c_out, const int32_t *scene_start, int B, int M, int n_max,
                          hipStream_t s) {
     const int H = md->H;
@@ -329,6 +354,31 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, const Workspace 
         g.bias1 = md->bp[2];
         g.M = M; g.N = md->P; g.relu = 0;
         g.C = w.X + (w.I - md->P); g.ldc = w.I;
+        rc = launch_linear(g, 0, s);
+        if (rc) return rc;
+    } else if (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ) {
+        // features -> interaction-encoder LSTMCell over ALL tracks (no presence mask, :450 / :531) -> hidden2pool
+        const int Hp = md->dims[0];
+        int rc;
+        if (md->pool_type == TNP_POOL_NNLSTM)
+            rc = launch_pool_nn(w.obs1, w.obs2, scene_start, B, md->n, 4, md->Wp[0], md->bp[0], md->P / md->n, w.y[0], md->P, s);
+        else
+            rc = launch_pool_traj(w.obs1, w.obs2, M, md->Wp[0], md->bp[0], md->P, w.y[0], md->P, w.scratch, s);
+        if (rc) return rc;
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.A1 = w.y[0]; g.lda1 = md->P; g.K1 = md->P;
+        g.A2 = w.ph[w.pcur]; g.lda2 = Hp; g.K2 = Hp;
+        g.B1 = md->Wx[0]; g.ldb1 = md->P; g.B2 = md->Wx[1]; g.ldb2 = Hp;
+        g.bias1 = md->bx[0]; g.bias2 = md->bx[1];
+        g.M = M; g.N = 4 * Hp; g.H = Hp;
+        g.h_in = w.ph[w.pcur]; g.h_out = w.ph[w.pcur ^ 1]; g.c_in = w.pc; g.c_out = w.pc; g.mask = w.ones;
+        rc = launch_lstm_gates(g, 0, s);
+        if (rc) return rc;
+        w.pcur ^= 1;
+        memset(&g, 0, sizeof(g));
+        g.A1 = w.ph[w.pcur]; g.lda1 = Hp; g.K1 = Hp; g.B1 = md->Wx[2]; g.ldb1 = Hp; g.bias1 = md->bx[2];
+        g.M = M; g.N = md->P; g.C = w.X + (w.I - md->P); g.ldc = w.I;
         rc = launch_linear(g, 0, s);
         if (rc) return rc;
     } else if (md->pool_type == TNP_POOL_ATTNMLP) {     // AttentionMLPPooling with the linear maps folded (Wx / bx)
@@ -472,6 +522,11 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
     if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s); if (rc) return rc; }
     TNP_HIP(hipMemsetAsync(w.h[0], 0, (size_t)M * H * 4, s));  // lstm.py:207-210
     TNP_HIP(hipMemsetAsync(w.c, 0, (size_t)M * H * 4, s));
+    if (w.ph[0]) {  // pool.reset() (lstm/lstm.py:213-216): zero interaction-encoder state, all tracks "present"
+        TNP_HIP(hipMemsetAsync(w.ph[0], 0, (size_t)M * md->dims[0] * 4, s));
+        TNP_HIP(hipMemsetAsync(w.pc, 0, (size_t)M * md->dims[0] * 4, s));
+        TNP_HIP(hipMemsetAsync(w.ones, 1, (size_t)M, s));
+    }
     int npos = 0, nnorm = 0, cur = 0;
     if (T_obs == 2) {  // lstm.py:222-223
         TNP_HIP(hipMemcpyAsync(pred, observed + F, F * 4, hipMemcpyDeviceToDevice, s));
@@ -572,6 +627,8 @@ extern "C" TNP_API int tnp_lstm_step(const tnp_lstm_model *md, int decoder, cons
     if (rc) return rc;
     if (M <= 0 || B <= 0) return 0;
     if (h_in == h_out) TNP_FAIL(-1, "tnp_lstm_step: h_in and h_out must not alias");
+    if (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ)
+        TNP_FAIL(-1, "tnp_lstm_step: stateful interaction encoders (pool_lstm) only run inside tnp_lstm_forward");
     Workspace w;
     plan_workspace(md, M, workspace, w);
     if (workspace == nullptr || workspace_bytes < w.bytes)

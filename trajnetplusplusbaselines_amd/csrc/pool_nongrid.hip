@@ -311,6 +311,64 @@ int launch_pool_attn_pair(const float *obs1, const float *obs2, const float *hen
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// TrajectronPooling features (reference :513-529): per visible track [pos, vel] ++ the sum of [pos, vel] over all
+// OTHER visible tracks of the WHOLE batch (the reference's one_cold loop is not per scene), Linear(8 -> P) + ReLU;
+// invisible tracks get a zero row.  The batch total is one deterministic fp64 tree reduction by a single workgroup;
+// "total - own" in fp64 is then closer to the exact sum than the reference's own fp32 summation.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) traj_total_kernel(const float *__restrict__ obs1, const float *__restrict__ obs2, int M,
+                                                         double *__restrict__ total) {
+    __shared__ double red[256][4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < M; i += 256) {
+        const float x = obs2[2 * i], y = obs2[2 * i + 1];
+        const float vx = x - obs1[2 * i], vy = y - obs1[2 * i + 1];
+        if (x == x && y == y && vx == vx && vy == vy) { acc[0] += x; acc[1] += y; acc[2] += vx; acc[3] += vy; }
+    }
+    for (int q = 0; q < 4; ++q) red[threadIdx.x][q] = acc[q];
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d)
+            for (int q = 0; q < 4; ++q) red[threadIdx.x][q] += red[threadIdx.x + d][q];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) total[threadIdx.x] = red[0][threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) traj_feature_kernel(const float *__restrict__ obs1, const float *__restrict__ obs2,
+                                                           int M, const double *__restrict__ total,
+                                                           const float *__restrict__ W, const float *__restrict__ bias,
+                                                           int P, float *__restrict__ out, int ldo) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= M * P) return;
+    const int i = q / P, o = q - i * P;
+    const float x = obs2[2 * i], y = obs2[2 * i + 1];
+    const float vx = x - obs1[2 * i], vy = y - obs1[2 * i + 1];
+    float r = 0.0f;
+    if (x == x && y == y && vx == vx && vy == vy) {
+        const float in[8] = {x, y, vx, vy, (float)(total[0] - (double)x), (float)(total[1] - (double)y),
+                             (float)(total[2] - (double)vx), (float)(total[3] - (double)vy)};
+        float acc = bias[o];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc = fmaf(in[c], W[o * 8 + c], acc);
+        r = acc > 0.0f ? acc : 0.0f;
+    }
+    out[(size_t)i * ldo + o] = r;
+}
+
+int launch_pool_traj(const float *obs1, const float *obs2, int M, const float *W, const float *bias, int P, float *out,
+                     int ldo, double *scratch4, hipStream_t s) {
+    if (M <= 0) return 0;
+    if (!scratch4) TNP_FAIL(-1, "TrajectronPooling: scratch (4 doubles) missing");
+    hipLaunchKernelGGL(traj_total_kernel, dim3(1), dim3(256), 0, s, obs1, obs2, M, scratch4);
+    const long tot = (long)M * P;
+    hipLaunchKernelGGL(traj_feature_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, obs1, obs2, M, scratch4, W,
+                       bias, P, out, ldo);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace tnp
 
 extern "C" TNP_API int tnp_pool_nn_forward(const float *obs1, const float *obs2, const int32_t *scene_start, int B,
@@ -342,4 +400,9 @@ extern "C" TNP_API int tnp_pool_attn_pair(const float *obs1, const float *obs2, 
                                           float *ebar, int lde, void *stream) {
     return tnp::launch_pool_attn_pair(obs1, obs2, hidden_emb, ldh, hidden_emb_relu, scene_start, B, n_max, ms, mv, mh,
                                       W_spatial, b_spatial, W_vel, b_vel, fill, u, ldu, ebar, lde, (hipStream_t)stream);
+}
+
+extern "C" TNP_API int tnp_pool_traj_forward(const float *obs1, const float *obs2, int M, const float *W, const float *bias,
+                                             int P, float *out, int ldo, double *scratch4, void *stream) {
+    return tnp::launch_pool_traj(obs1, obs2, M, W, bias, P, out, ldo, scratch4, (hipStream_t)stream);
 }

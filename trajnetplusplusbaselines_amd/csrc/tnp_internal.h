@@ -77,6 +77,9 @@ int launch_pool_attn_pair(const float *obs1, const float *obs2, const float *hen
                           const float *bs, const float *Wv, const float *bv, float fill, const float *u, int ldu,
                           float *ebar, int lde, hipStream_t s);
 
+int launch_pool_traj(const float *obs1, const float *obs2, int M, const float *W, const float *bias, int P, float *out,
+                     int ldo, double *scratch4, hipStream_t s);
+
 // ---- profiling hook -------------------------------------------------------------------------
 enum { PROF_GEMM1 = 0, PROF_ALL_GEMM = 1 };
 void prof_before(int cls, hipStream_t s);

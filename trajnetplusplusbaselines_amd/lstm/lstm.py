@@ -98,8 +98,19 @@ class LSTM(torch.nn.Module):
         m.pool_type = _lib.POOL_NONE
         m.n, m.C, m.P, m.n_layers = 0, 0, 0, 0
         pool = self.pool
-        from .non_gridbased_pooling import NearestNeighborMLP, HiddenStateMLPPooling, AttentionMLPPooling
-        if isinstance(pool, NearestNeighborMLP):
+        from .non_gridbased_pooling import (NearestNeighborMLP, HiddenStateMLPPooling, AttentionMLPPooling,
+                                            NearestNeighborLSTM, TrajectronPooling)
+        if isinstance(pool, (NearestNeighborLSTM, TrajectronPooling)):
+            nnl = isinstance(pool, NearestNeighborLSTM)
+            lin, cell = pool.embedding[0], pool.pool_lstm
+            m.pool_type, m.P, m.C = (_lib.POOL_NNLSTM if nnl else _lib.POOL_TRAJ), pool.out_dim, 4
+            m.n = pool.n if nnl else 0
+            m.dims[0] = pool.hidden_dim
+            m.Wp[0], m.bp[0] = P(lin.weight), P(lin.bias)
+            m.Wx[0], m.bx[0] = P(cell.weight_ih), P(cell.bias_ih)
+            m.Wx[1], m.bx[1] = P(cell.weight_hh), P(cell.bias_hh)
+            m.Wx[2], m.bx[2] = P(pool.hidden2pool.weight), P(pool.hidden2pool.bias)
+        elif isinstance(pool, NearestNeighborMLP):
             lin = pool.embedding[0]
             m.pool_type, m.n, m.C, m.P = _lib.POOL_NN, pool.n, pool.input_dim, pool.out_dim
             m.Wp[0], m.bp[0] = P(lin.weight), P(lin.bias)

@@ -202,3 +202,101 @@ class AttentionMLPPooling(torch.nn.Module):
                                         f(ve.bias) if ve is not None else None, float(self.fill_value), _lib.ptr(u), D + 4,
                                         _lib.ptr(ebar), D, _lib.stream_ptr()), 'tnp_pool_attn_pair')
         return _lib.linear_forward(ebar, wfin, bfin)
+
+
+class _StatefulInteractionEncoder(torch.nn.Module):
+    """Shared part of NearestNeighborLSTM / TrajectronPooling: the interaction-encoder ``pool_lstm`` whose state lives
+    per padded slot and is zeroed by ``reset`` at the start of every ``LSTM.forward`` (reference :385-389, :483-487).
+    Inside ``LSTM.forward`` the state is kept by the fused sequence driver; the stand-alone ``forward`` below keeps it
+    in ``self.hidden_cell_state`` as the reference does."""
+
+    def _init_encoder(self, hidden_dim, out_dim):
+        self.hidden_dim = hidden_dim
+        self.pool_lstm = torch.nn.LSTMCell(out_dim, hidden_dim)
+        self.hidden2pool = torch.nn.Linear(hidden_dim, out_dim)
+        self.hidden_cell_state = None
+
+    def reset(self, num_tracks, max_num_neigh, device):
+        dev = self.hidden2pool.weight.device
+        self.hidden_cell_state = [torch.zeros(num_tracks, self.hidden_dim, device=dev),
+                                  torch.zeros(num_tracks, self.hidden_dim, device=dev)]
+
+    def _encode(self, feat):
+        """pool_lstm + hidden2pool on the feature rows (GEMMs on the matrix cores, gate nonlinearities pointwise)."""
+        if self.hidden_cell_state is None or self.hidden_cell_state[0].size(0) != feat.size(0):
+            self.reset(feat.size(0), 0, feat.device)
+        h, c = self.hidden_cell_state
+        cell = self.pool_lstm
+        gates = _lib.linear_forward(feat, cell.weight_ih.detach(), cell.bias_ih.detach()) + \
+            _lib.linear_forward(h, cell.weight_hh.detach(), cell.bias_hh.detach())
+        H = self.hidden_dim
+        i, f, g, o = torch.sigmoid(gates[:, :H]), torch.sigmoid(gates[:, H:2 * H]), torch.tanh(gates[:, 2 * H:3 * H]), \
+            torch.sigmoid(gates[:, 3 * H:])
+        c = f * c + i * g
+        h = o * torch.tanh(c)
+        self.hidden_cell_state = [h, c]
+        return _lib.linear_forward(h, self.hidden2pool.weight.detach(), self.hidden2pool.bias.detach())
+
+
+class NearestNeighborLSTM(_StatefulInteractionEncoder):
+    """NearestNeighborMLP features passed through an interaction-encoder LSTM
+    (reference lstm/non_gridbased_pooling.py:354-455)."""
+
+    def __init__(self, n=4, hidden_dim=256, out_dim=32):
+        super(NearestNeighborLSTM, self).__init__()
+        if n < 1 or n > 8 or out_dim % n != 0 or out_dim % 4 != 0 or hidden_dim % 32 != 0:
+            raise ValueError('n must divide out_dim (n <= 8, out_dim % 4 == 0, hidden_dim % 32 == 0 on the MI355X path)')
+        self.n = n
+        self.out_dim = out_dim
+        self.input_dim = 4
+        self.embedding = torch.nn.Sequential(
+            torch.nn.Linear(self.input_dim, int(out_dim / self.n)),
+            torch.nn.ReLU(),)
+        self._init_encoder(hidden_dim, out_dim)
+
+    def forward(self, _, obs1, obs2):
+        lin = self.embedding[0]
+        dev = lin.weight.device
+        _lib.require_device(lin.weight, 'NearestNeighborLSTM parameters')
+        B, N = obs2.size(0), obs2.size(1)
+        o1 = _lib.f32c(obs1, dev).reshape(B * N, 2)
+        o2 = _lib.f32c(obs2, dev).reshape(B * N, 2)
+        feat = torch.empty(B * N, self.out_dim, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().tnp_pool_nn_forward(
+            _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(_padded_starts(B, N, dev)), B, self.n, 4,
+            _lib.ptr(_lib.f32c(lin.weight.detach(), dev)), _lib.ptr(_lib.f32c(lin.bias.detach(), dev)),
+            self.out_dim // self.n, _lib.ptr(feat), self.out_dim, _lib.stream_ptr()), 'tnp_pool_nn_forward')
+        return self._encode(feat)
+
+
+class TrajectronPooling(_StatefulInteractionEncoder):
+    """Own state ++ sum of the other visible tracks' states, embedded and passed through an interaction-encoder LSTM
+    (reference lstm/non_gridbased_pooling.py:457-538).  As in the reference the sum runs over all visible tracks of
+    the BATCH, not of the scene."""
+
+    def __init__(self, n=4, hidden_dim=256, out_dim=32, track_mask=None):
+        super(TrajectronPooling, self).__init__()
+        if out_dim % 4 != 0 or hidden_dim % 32 != 0:
+            raise ValueError('out_dim % 4 == 0 and hidden_dim % 32 == 0 required on the MI355X path')
+        self.n = n
+        self.out_dim = out_dim
+        self.embedding = torch.nn.Sequential(
+            torch.nn.Linear(8, out_dim),
+            torch.nn.ReLU(),)
+        self._init_encoder(hidden_dim, out_dim)
+        self.track_mask = track_mask
+
+    def forward(self, _, obs1, obs2):
+        lin = self.embedding[0]
+        dev = lin.weight.device
+        _lib.require_device(lin.weight, 'TrajectronPooling parameters')
+        B, N = obs2.size(0), obs2.size(1)
+        o1 = _lib.f32c(obs1, dev).reshape(B * N, 2)
+        o2 = _lib.f32c(obs2, dev).reshape(B * N, 2)
+        feat = torch.empty(B * N, self.out_dim, dtype=torch.float32, device=dev)
+        scratch = torch.empty(4, dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib().tnp_pool_traj_forward(
+            _lib.ptr(o1), _lib.ptr(o2), B * N, _lib.ptr(_lib.f32c(lin.weight.detach(), dev)),
+            _lib.ptr(_lib.f32c(lin.bias.detach(), dev)), self.out_dim, _lib.ptr(feat), self.out_dim, _lib.ptr(scratch),
+            _lib.stream_ptr()), 'tnp_pool_traj_forward')
+        return self._encode(feat)
