@@ -172,7 +172,9 @@ typedef struct tnp_lstm_model {
     const float *Wp0_cell_major; /* optional [n*n][C][dims[1]] copy of Wp[0] (W'[c][ch][o] =
                                     Wp[0][o][ch*n*n + c]); enables the sparse first layer
                                     for social pooling with constant == 0; NULL = dense   */
-    int32_t variant;      /* kernel-variant selector (0 = default), see DESIGN.md  */
+    int32_t variant;      /* bits 0-15 kernel-variant selector (0 = default); bit 16: force the dense first
+                             embedding layer; bit 17: LSTM(pool_to_input=False) -- the interaction vector (P == H) is
+                             added to the hidden operand of the LSTMCell instead of concatenated to its input */
     /* TNP_POOL_ATTNMLP only (fields as for HIDDENMLP, `constant` = fill_value): the linear maps around the single-head
      * attention folded on the host, D = mlp_dim:
      *   Wx[0] [D,D], bx[0] [D]  query  q = (in_proj_q . wq) e_ii + in_proj_bias_q

@@ -128,7 +128,7 @@ def grid_cases(ref):
 
 
 def lstm_case(ref, kind):
-    torch.manual_seed({'vanilla': 1, 'occupancy': 2, 'directional': 3, 'social': 4, 'social_goals': 5}[kind])
+    torch.manual_seed({'vanilla': 1, 'occupancy': 2, 'directional': 3, 'social': 4, 'social_goals': 5, 'lstmlayer': 6, 'addhidden': 7}[kind])
     goal_flag = kind == 'social_goals'
     cfg = dict(kind=kind, type='', n=0, cell_side=0.6, goal_flag=int(goal_flag))
     pool = None
@@ -140,11 +140,19 @@ def lstm_case(ref, kind):
         cfg.update(type='directional', n=12)
         pool = ref.GridBasedPooling(type_='directional', hidden_dim=128, cell_side=0.6, n=12, out_dim=64,
                                     embedding_arch='one_layer')
+    elif kind == 'addhidden':   # LSTM(pool_to_input=False): interaction vector added to the hidden state, out_dim == H
+        cfg.update(type='occupancy', n=8)
+        pool = ref.GridBasedPooling(type_='occupancy', hidden_dim=128, cell_side=0.6, n=8, out_dim=128,
+                                    embedding_arch='one_layer')
+    elif kind == 'lstmlayer':   # embedding_arch='lstm_layer': Linear + ReLU, pool_lstm / hidden2pool unused by forward
+        cfg.update(type='directional', n=12)
+        pool = ref.GridBasedPooling(type_='directional', hidden_dim=128, cell_side=0.6, n=12, out_dim=64,
+                                    embedding_arch='lstm_layer')
     elif kind in ('social', 'social_goals'):
         cfg.update(type='social', n=8)
         pool = ref.GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=8, out_dim=64,
                                     embedding_arch='two_layer', layer_dims=[128], latent_dim=8)
-    model = ref.LSTM(pool=pool, goal_flag=goal_flag).eval()
+    model = ref.LSTM(pool=pool, goal_flag=goal_flag, pool_to_input=(kind != 'addhidden')).eval()
     out = {'cfg_' + k: np.asarray(v) for k, v in cfg.items()}
     for k, v in model.state_dict().items():
         out['sd_' + k] = v.numpy().copy()
@@ -420,6 +428,11 @@ def real_cases(ref):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.import_reference()
+    if '--only-lstmlayer' in sys.argv:
+        lstm_case(ref, 'addhidden')
+        return lstm_case(ref, 'lstmlayer')
+    lstm_case(ref, 'lstmlayer')
+    lstm_case(ref, 'addhidden')
     if '--only-nongrid' in sys.argv:
         return nongrid_cases(ref)
     nongrid_cases(ref)

@@ -35,6 +35,7 @@ class _Model(ctypes.Structure):
         ('att_wq', _f), ('att_wk', _f), ('att_wv', _f), ('att_in_w', _f), ('att_in_b', _f), ('att_out_w', _f),
         ('att_out_b', _f),
         ('Hp', ctypes.c_int), ('pl_Wih', _f), ('pl_Whh', _f), ('pl_bih', _f), ('pl_bhh', _f), ('pl_Wo', _f), ('pl_bo', _f),
+        ('pool_to_hidden', ctypes.c_int),
     ]
 
 
@@ -68,7 +69,7 @@ class OracleModel(object):
     """Holds fp32 copies of the weights and the ctypes struct that points at them."""
 
     def __init__(self, state_dict, pool_type=None, n=4, cell_side=2.0, constant=0.0, front=False,
-                 pool_size=1, blur_size=1, goal_flag=False, embedding_dim=64, hidden_dim=128):
+                 pool_size=1, blur_size=1, goal_flag=False, embedding_dim=64, hidden_dim=128, pool_to_input=True):
         sd = {k: _c32(v.detach().cpu().numpy() if hasattr(v, 'detach') else v) for k, v in state_dict.items()}
         self._keep = sd
         m = _Model()
@@ -141,6 +142,7 @@ class OracleModel(object):
                 m.WpT[li] = _p(sd['pool.embedding.%d.weight.T' % idx])
                 m.bp[li] = _p(sd['pool.embedding.%d.bias' % idx])
             m.P = m.dims[m.n_layers]
+        m.pool_to_hidden = int(pool_type is not None and not pool_to_input)
         self.c = m
 
     # -- LSTM.forward (lstm/lstm.py:170-264) --------------------------------

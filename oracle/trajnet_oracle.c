@@ -332,6 +332,7 @@ typedef struct {
      * Linear(Hp -> P) */
     int Hp;
     const float *pl_Wih, *pl_Whh, *pl_bih, *pl_bhh, *pl_Wo, *pl_bo;
+    int pool_to_hidden; /* LSTM(pool_to_input=False): the interaction vector is ADDED to the hidden state (lstm/lstm.py:150-151) */
 } orc_model;
 
 /* One row of torch.nn.Linear (+ReLU) without the OpenMP region / transposed copy of orc_linear: same axpy order
@@ -629,7 +630,7 @@ static void lstm_step(const orc_model *md, int decoder, float *h, float *c, cons
     const int H = md->H, E = md->E;
     const int GD = md->goal_flag ? md->goal_dim : 0;
     const int P = (md->pool_type != ORC_NOPOOL) ? md->P : 0;
-    const int I = E + GD + P;
+    const int I = E + GD + (md->pool_to_hidden ? 0 : P);
     uint8_t *mask = (uint8_t *)malloc(M);
     int cnt = 0;
     for (int m = 0; m < M; ++m) { /* :118 */
@@ -687,11 +688,12 @@ static void lstm_step(const orc_model *md, int decoder, float *h, float *c, cons
             orc_input_embedding(gd, 1, md->Wg, md->bg, md->goal_dim, 4.0f, emb);
             memcpy(x + (size_t)q * I + E, emb, sizeof(float) * GD);
         }
+        memcpy(hc + (size_t)q * H, h + (size_t)m * H, sizeof(float) * H);
         if (pooled) {
             size_t r = (size_t)s * N + (m - (int)split[s]);
-            memcpy(x + (size_t)q * I + E + GD, pooled + r * P, sizeof(float) * P); /* :146,149 */
+            if (!md->pool_to_hidden) memcpy(x + (size_t)q * I + E + GD, pooled + r * P, sizeof(float) * P); /* :146,149 */
+            else for (int k = 0; k < H; ++k) hc[(size_t)q * H + k] += pooled[r * P + k];               /* :151, P == H */
         }
-        memcpy(hc + (size_t)q * H, h + (size_t)m * H, sizeof(float) * H);
         memcpy(cc + (size_t)q * H, c + (size_t)m * H, sizeof(float) * H);
         ++q;
     }

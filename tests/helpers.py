@@ -36,7 +36,7 @@ def load_lstm_case(kind):
 
 def oracle_model(sd, cfg):
     return oracle.OracleModel(sd, pool_type=cfg['type'], n=cfg['n'] or 4, cell_side=cfg['cell_side'],
-                              goal_flag=cfg['goal_flag'])
+                              goal_flag=cfg['goal_flag'], pool_to_input=cfg['kind'] != 'addhidden')
 
 
 def social_enc(rec):
@@ -65,12 +65,15 @@ def build_amd_model(sd, cfg, device='cuda'):
         layers = sorted(int(k.split('.')[2]) for k in sd if k.startswith('pool.embedding.') and k.endswith('.weight'))
         dims = [sd['pool.embedding.%d.weight' % i].shape[0] for i in layers]
         arch = {1: 'one_layer', 2: 'two_layer', 3: 'three_layer'}[len(layers)]
+        if 'pool.pool_lstm.weight_ih' in sd:
+            arch = 'lstm_layer'
         latent = sd['pool.hidden_dim_encoding.weight'].shape[0] if cfg['type'] == 'social' else 16
         pool = GridBasedPooling(type_=cfg['type'], hidden_dim=sd['encoder.weight_hh'].shape[1],
                                 cell_side=cfg['cell_side'], n=cfg['n'], out_dim=dims[-1], embedding_arch=arch,
                                 layer_dims=dims[:-1], latent_dim=latent)
     model = LSTM(embedding_dim=sd['input_embedding.input_embeddings.0.weight'].shape[0] + 2,
-                 hidden_dim=sd['encoder.weight_hh'].shape[1], pool=pool, goal_flag=cfg['goal_flag'])
+                 hidden_dim=sd['encoder.weight_hh'].shape[1], pool=pool, goal_flag=cfg['goal_flag'],
+                 pool_to_input=cfg['kind'] != 'addhidden')
     model.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
     return model.to(device).eval()
 

@@ -51,7 +51,11 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         GridBasedPooling(type_='dir_social')
     with pytest.raises(NotImplementedError):
-        GridBasedPooling(embedding_arch='lstm_layer')
+        GridBasedPooling(pretrained_pool_encoder=torch.nn.Sequential(torch.nn.Linear(4, 4)))
+    with pytest.raises(ValueError):   # pool_to_input=False adds the pooled vector to the hidden state: out_dim == H
+        LSTM(pool=GridBasedPooling(out_dim=32), hidden_dim=128, pool_to_input=False)
+    # 'lstm_layer' behaves like 'one_layer' in the reference's forward and keeps its extra parameters
+    assert 'pool_lstm.weight_ih' in GridBasedPooling(embedding_arch='lstm_layer', out_dim=16).state_dict()
 
 
 def test_start_tags():

@@ -83,7 +83,7 @@ def test_fp32_cell_edges():
     assert oi[0, 0, 0] == 0 * 12 + 6
 
 
-@pytest.mark.parametrize('kind', ['vanilla', 'occupancy', 'directional', 'social', 'social_goals'])
+@pytest.mark.parametrize('kind', ['vanilla', 'occupancy', 'directional', 'social', 'social_goals', 'lstmlayer', 'addhidden'])
 @pytest.mark.parametrize('batch', ['lin', 'rag'])
 def test_lstm_forward_matches_reference(kind, batch):
     sd, cfg, d = helpers.load_lstm_case(kind)

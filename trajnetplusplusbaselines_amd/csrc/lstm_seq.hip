@@ -241,6 +241,10 @@ struct Workspace {
     uint8_t *ones;
     double *scratch;
     int pcur;
+    int to_hidden;   // pooled vector goes to hplus (= h + pooled, the LSTMCell's hidden operand) instead of X
+    float *hplus;
+    float *pdst;     // where the interaction module writes its [M, P] result, and its leading dimension
+    int pld;
     size_t bytes;
 };
 
@@ -251,7 +255,10 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     const int GD = md->goal_flag ? md->goal_dim : 0;
     const bool pool = md->pool_type != TNP_POOL_NONE;
     const int P = pool ? md->P : 0;
-    w.I = E + GD + P;
+    // variant bit 17: LSTM(pool_to_input=False) -- the interaction vector is added to the hidden state
+    // (lstm/lstm.py:150-151) instead of being concatenated to the input embedding
+    w.to_hidden = pool && ((md->variant >> 17) & 1);
+    w.I = E + GD + (w.to_hidden ? 0 : P);
     const bool grid_pool = pool && md->pool_type <= TNP_POOL_SOCIAL;
     w.Fin = grid_pool ? md->C * md->n * md->n : 0;
     w.ldg = (w.Fin + 3) & ~3;
@@ -284,6 +291,9 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
         if (pb) w.partial = (float *)take(pb);
     }
     w.ph[0] = w.ph[1] = w.pc = nullptr; w.ones = nullptr; w.scratch = nullptr; w.pcur = 0;
+    w.hplus = w.to_hidden ? (float *)take((size_t)M * md->H * 4) : nullptr;
+    w.pdst = w.to_hidden ? w.hplus : (pool ? w.X + (w.I - P) : nullptr);
+    w.pld = w.to_hidden ? md->H : w.I;
     if (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ) {
         const int Hp = md->dims[0];
         w.ph[0] = (float *)take((size_t)M * Hp * 4);
@@ -298,6 +308,8 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
 
 static int validate_model(const tnp_lstm_model *md) {
     if (!md) TNP_FAIL(-1, "null model");
+    if (md->pool_type != TNP_POOL_NONE && ((md->variant >> 17) & 1) && md->P != md->H)
+        TNP_FAIL(-1, "pool_to_input=False adds the interaction vector to the hidden state: out_dim %d must equal hidden_dim %d", md->P, md->H);
     if (md->H <= 0 || md->H % 32 != 0) TNP_FAIL(-1, "hidden_dim must be a positive multiple of 32 (got %d)", md->H);
     if (md->E < 4) TNP_FAIL(-1, "embedding_dim too small (%d)", md->E);
     if (md->pool_type == TNP_POOL_NN) {
@@ -333,6 +345,16 @@ static int validate_model(const tnp_lstm_model *md) {
     return 0;
 }
 
+// y[q] += x[q] on float4 groups
+__global__ void add_rows_kernel(float *__restrict__ y, const float *__restrict__ x, long n4) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n4) return;
+    float4 a = reinterpret_cast<float4 *>(y)[q];
+    const float4 b = reinterpret_cast<const float4 *>(x)[q];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    reinterpret_cast<float4 *>(y)[q] = a;
+}
+
 // pool + gates of one step; obs/mask/X[:,0:E+GD]/enc already prepared
 static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, const float *h_in, float *h_out,
                          const float *c_in, float *c_out, const int32_t *scene_start, int B, int M, int n_max,
@@ -340,7 +362,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
     const int H = md->H;
     if (md->pool_type == TNP_POOL_NN) {          // NearestNeighborMLP straight into the pooled columns of X
         int rc = launch_pool_nn(w.obs1, w.obs2, scene_start, B, md->n, md->C, md->Wp[0], md->bp[0], md->P / md->n,
-                                w.X + (w.I - md->P), w.I, s);
+                                w.pdst, w.pld, s);
         if (rc) return rc;
     } else if (md->pool_type == TNP_POOL_HIDDENMLP) {   // pair embeddings + max-pool, then the projection GEMM
         const int ms = md->dims[0], mv = md->dims[1], mh = md->dims[2];
@@ -353,7 +375,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
         g.B1 = md->Wp[2]; g.ldb1 = ms + mh + mv;
         g.bias1 = md->bp[2];
         g.M = M; g.N = md->P; g.relu = 0;
-        g.C = w.X + (w.I - md->P); g.ldc = w.I;
+        g.C = w.pdst; g.ldc = w.pld;
         rc = launch_linear(g, 0, s);
         if (rc) return rc;
     } else if (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ) {
@@ -378,7 +400,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
         w.pcur ^= 1;
         memset(&g, 0, sizeof(g));
         g.A1 = w.ph[w.pcur]; g.lda1 = Hp; g.K1 = Hp; g.B1 = md->Wx[2]; g.ldb1 = Hp; g.bias1 = md->bx[2];
-        g.M = M; g.N = md->P; g.C = w.X + (w.I - md->P); g.ldc = w.I;
+        g.M = M; g.N = md->P; g.C = w.pdst; g.ldc = w.pld;
         rc = launch_linear(g, 0, s);
         if (rc) return rc;
     } else if (md->pool_type == TNP_POOL_ATTNMLP) {     // AttentionMLPPooling with the linear maps folded (Wx / bx)
@@ -403,7 +425,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
         if (rc) return rc;
         memset(&g, 0, sizeof(g));                      // pooled = Wfin ebar + bfin
         g.A1 = w.y[1]; g.lda1 = D; g.K1 = D; g.B1 = md->Wx[2]; g.ldb1 = D; g.bias1 = md->bx[2];
-        g.M = M; g.N = md->P; g.C = w.X + (w.I - md->P); g.ldc = w.I;
+        g.M = M; g.N = md->P; g.C = w.pdst; g.ldc = w.pld;
         rc = launch_linear(g, 0, s);
         if (rc) return rc;
     } else if (md->pool_type != TNP_POOL_NONE) {
@@ -419,8 +441,8 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
         int l0 = 0;
         if (w.sparse) {  // first layer straight from the winner table
             const bool last = (md->n_layers == 1);
-            float *dst = last ? (w.X + (w.I - md->P)) : w.y[0];
-            const int ldo = last ? w.I : md->dims[1];
+            float *dst = last ? w.pdst : w.y[0];
+            const int ldo = last ? w.pld : md->dims[1];
             prof_before(PROF_GEMM1, s);
             rc = launch_pool_embed_sparse(w.winners, w.enc, md->C, w.row_base, md->Wp0_cell_major, md->bp[0], M,
                                           md->n * md->n, md->C, md->dims[1], 1, dst, ldo, w.partial, s);
@@ -437,7 +459,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
             g.bias1 = md->bp[l];
             g.M = M; g.N = md->dims[l + 1];
             g.relu = 1;
-            if (last) { g.C = w.X + (w.I - md->P); g.ldc = w.I; }
+            if (last) { g.C = w.pdst; g.ldc = w.pld; }
             else { g.C = w.y[l & 1]; g.ldc = md->dims[l + 1]; }
             const int cls = (l == 0) ? PROF_GEMM1 : PROF_ALL_GEMM;
             prof_before(cls, s);
@@ -449,8 +471,13 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
     }
     GemmArgs g;
     memset(&g, 0, sizeof(g));
+    if (w.to_hidden) {   // hplus = h_in + pooled (rows of absent tracks are never used: their state is copied through)
+        const long tot4 = (long)M * H / 4;
+        hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((tot4 + 255) / 256)), dim3(256), 0, s, w.hplus, h_in, tot4);
+        TNP_HIP(hipGetLastError());
+    }
     g.A1 = w.X; g.lda1 = w.I; g.K1 = w.I;
-    g.A2 = h_in; g.lda2 = H; g.K2 = H;
+    g.A2 = w.to_hidden ? w.hplus : h_in; g.lda2 = H; g.K2 = H;
     g.B1 = decoder ? md->dec_Wih : md->enc_Wih; g.ldb1 = w.I;
     g.B2 = decoder ? md->dec_Whh : md->enc_Whh; g.ldb2 = H;
     g.bias1 = decoder ? md->dec_bih : md->enc_bih;

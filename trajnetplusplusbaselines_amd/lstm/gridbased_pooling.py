@@ -57,7 +57,7 @@ class GridBasedPooling(torch.nn.Module):
         elif self.embedding_arch == 'three_layer':
             self.embedding = self.three_layer(None, layer_dims)
         elif self.embedding_arch == 'lstm_layer':
-            raise NotImplementedError("embedding_arch 'lstm_layer' is not supported on the MI355X path")
+            self.embedding = self.lstm_layer(hidden_dim)
 
     # ---- embedding architectures (reference :308-335) --------------------------------------------
     def one_layer(self, input_dim=None):
@@ -87,8 +87,20 @@ class GridBasedPooling(torch.nn.Module):
             torch.nn.Linear(layer_dims[1], self.out_dim),
             torch.nn.ReLU(),)
 
+    def lstm_layer(self, hidden_dim):
+        """reference :337-343.  `forward` only ever applies the returned Linear + ReLU (:107-109): `lstm_forward`
+        (:353-379) is never called, so `pool_lstm` / `hidden2pool` exist for state_dict compatibility (and are created
+        first, so that seeded initialisation matches the reference) and the arch behaves like 'one_layer'."""
+        self.hidden_dim = hidden_dim
+        self.pool_lstm = torch.nn.LSTMCell(self.out_dim, self.hidden_dim)
+        self.hidden2pool = torch.nn.Linear(self.hidden_dim, self.out_dim)
+        return torch.nn.Sequential(
+            torch.nn.Linear(self.n * self.n * self.pooling_dim, self.out_dim),
+            torch.nn.ReLU(),)
+
     def reset(self, num_tracks, max_num_neigh, device):
-        """Called once per forward by the reference (lstm/lstm.py:213-216); nothing to reset here."""
+        """Called once per forward by the reference (lstm/lstm.py:213-216); nothing to reset here (the reference's
+        'lstm_layer' state, :347-351, is never read by its forward)."""
         self.track_mask = None
 
     # ---- helpers -----------------------------------------------------------------------------------

@@ -33,8 +33,9 @@ class LSTM(torch.nn.Module):
         self.embedding_dim = embedding_dim
         self.pool = pool
         self.pool_to_input = pool_to_input
-        if pool is not None and not pool_to_input:
-            raise NotImplementedError('pool_to_input=False is not supported on the MI355X path')
+        if pool is not None and not pool_to_input and pool.out_dim != hidden_dim:
+            raise ValueError('pool_to_input=False adds the interaction vector to the hidden state: pool.out_dim must '
+                             'equal hidden_dim (reference lstm/lstm.py:150-151)')
 
         scale = 4.0
         self.input_embedding = InputEmbedding(2, self.embedding_dim, scale)
@@ -155,6 +156,8 @@ class LSTM(torch.nn.Module):
                         and layers[0].weight.shape[0] % 4 == 0:
                     m.Wp0_cell_major = P(self._cell_major_weight(layers[0].weight, pool))
         m.variant = int(self.kernel_variant)
+        if pool is not None and not self.pool_to_input:
+            m.variant |= 1 << 17   # interaction vector added to the hidden state (lstm/lstm.py:150-151)
         return m, keep, dev
 
     def _cell_major_weight(self, weight, pool):
@@ -214,9 +217,10 @@ class LSTM(torch.nn.Module):
         T_dec = prediction_truth.size(0) if prediction_truth is not None else n_predict - 1
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # training: same kernels step by step + an explicit backward sweep (lstm/training.py)
-            if self.pool is not None and not hasattr(self.pool, 'embedding_layers'):
-                raise NotImplementedError('training (backward) through %s is not available on the MI355X path yet; '
-                                          'use model.eval() / torch.no_grad() for inference' % type(self.pool).__name__)
+            if self.pool is not None and (not hasattr(self.pool, 'embedding_layers') or not self.pool_to_input):
+                raise NotImplementedError('training (backward) through %s%s is not available on the MI355X path yet; '
+                                          'use model.eval() / torch.no_grad() for inference'
+                                          % (type(self.pool).__name__, '' if self.pool_to_input else ' with pool_to_input=False'))
             from .training import run_sequence_with_grad
             return run_sequence_with_grad(self, observed, goals, batch_split, prediction_truth, T_dec)
         rel_pred, pred, _ = self._run_sequence(observed, goals, batch_split, prediction_truth, T_dec)
