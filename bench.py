@@ -90,8 +90,8 @@ def cpu_baseline(cfg, xy, split, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', default='social', choices=sorted(CONFIGS))
     ap.add_argument('--variant', type=int, default=0, help='kernel variant selector (DESIGN.md)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
