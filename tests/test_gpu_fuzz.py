@@ -1,0 +1,95 @@
+"""Randomised end-to-end parity: LSTM.forward on the HIP path vs the oracle over random batch shapes (1..9 scenes of
+1..70 tracks, so n_max crosses 32 / 64 and M is rarely a multiple of any tile size), random presence patterns, every
+interaction module, goals on / off, both decoder modes.  The oracle is pinned to the reference by the golden tests;
+this test only looks for shape- / padding-dependent bugs the fixed fixtures cannot see."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def make_model(kind, goal_flag, rng):
+    from trajnetplusplusbaselines_amd import lstm as L
+    torch.manual_seed(int(rng.randint(1 << 30)))
+    pool_to_input = True
+    if kind == 'vanilla':
+        pool = None
+    elif kind in ('occupancy', 'directional', 'social'):
+        n = int(rng.choice([4, 8, 12, 16]))
+        arch = str(rng.choice(['one_layer', 'two_layer']))
+        pool = L.GridBasedPooling(type_=kind, hidden_dim=128, cell_side=float(rng.choice([0.4, 0.6, 1.0])), n=n,
+                                  out_dim=int(rng.choice([32, 64, 128])), embedding_arch=arch,
+                                  layer_dims=[int(rng.choice([64, 256]))], latent_dim=int(rng.choice([8, 16])),
+                                  front=bool(rng.rand() < 0.2))
+        if pool.out_dim == 128 and rng.rand() < 0.5:
+            pool_to_input = False
+    else:
+        pool = {'nn': lambda: L.NearestNeighborMLP(n=4, out_dim=32),
+                'hiddenstatemlp': lambda: L.HiddenStateMLPPooling(hidden_dim=128, out_dim=32),
+                'attentionmlp': lambda: L.AttentionMLPPooling(hidden_dim=128, out_dim=32),
+                'nn_lstm': lambda: L.NearestNeighborLSTM(n=4, hidden_dim=64, out_dim=32),
+                'traj_pool': lambda: L.TrajectronPooling(hidden_dim=64, out_dim=32)}[kind]()
+    model = L.LSTM(pool=pool, goal_flag=goal_flag, pool_to_input=pool_to_input).cuda().eval()
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    kw = {}
+    if kind in ('occupancy', 'directional', 'social'):
+        kw = dict(n=pool.n, cell_side=pool.cell_side, front=pool.front)
+    elif kind in ('nn', 'nn_lstm'):
+        kw = dict(n=4)
+    if kind == 'attentionmlp':
+        kw['constant'] = -10.0
+    om = oracle.OracleModel(sd, pool_type=None if kind == 'vanilla' else kind, goal_flag=goal_flag,
+                            pool_to_input=pool_to_input, **kw)
+    return model, om
+
+
+def random_batch(rng):
+    B = int(rng.randint(1, 10))
+    sizes = [int(rng.choice([1, 2, 3, 5, 9, 17, 31, 33, 40, 65, 70], p=[.08, .1, .12, .15, .15, .12, .08, .06, .06, .04, .04]))
+             for _ in range(B)]
+    split = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    M = int(split[-1])
+    T = 21
+    x0 = rng.uniform(-4, 4, size=(M, 2))
+    v = rng.normal(0, 0.3, size=(M, 2))
+    xy = (x0[None] + v[None] * np.arange(T)[:, None, None] + rng.normal(0, 0.02, size=(T, M, 2))).astype(np.float32)
+    for m in range(M):
+        if m in split[:-1]:
+            continue                                     # primaries are fully observed
+        r = rng.rand()
+        if r < 0.25:
+            xy[:int(rng.randint(1, 12)), m] = np.nan     # enters late
+        elif r < 0.45:
+            xy[int(rng.randint(3, 20)):, m] = np.nan     # leaves
+        elif r < 0.5:
+            xy[:, m] = np.nan                            # never visible
+    return xy, split
+
+
+KINDS = ['vanilla', 'occupancy', 'directional', 'social', 'nn', 'hiddenstatemlp', 'attentionmlp', 'nn_lstm', 'traj_pool']
+
+
+@pytest.mark.parametrize('seed', range(27))
+def test_random_batches_match_oracle(seed):
+    rng = np.random.RandomState(1000 + seed)
+    kind = KINDS[seed % len(KINDS)]
+    goal_flag = bool(rng.rand() < 0.3)
+    model, om = make_model(kind, goal_flag, rng)
+    xy, split = random_batch(rng)
+    M = xy.shape[1]
+    goals = rng.uniform(-5, 5, size=(M, 2)).astype(np.float32)
+    xt, gt, st = torch.tensor(xy), torch.tensor(goals), torch.tensor(split)
+    for mode in ('n_predict', 'truth'):
+        if mode == 'n_predict':
+            rel, pred = model(xt[:9], gt, st, n_predict=12)
+            rel_o, pred_o = om.forward(xy[:9], goals, split, n_predict=12)
+        else:
+            rel, pred = model(xt[:9], gt, st, prediction_truth=xt[9:20].clone())
+            rel_o, pred_o = om.forward(xy[:9], goals, split, prediction_truth=xy[9:20])
+        what = '%s goal=%d sizes=%s %s' % (kind, goal_flag, np.diff(split).tolist(), mode)
+        helpers.assert_close_nan(rel.cpu().numpy(), rel_o, 1e-4, 'rel ' + what)
+        helpers.assert_close_nan(pred.cpu().numpy(), pred_o, 1e-4, 'pred ' + what)
