@@ -262,6 +262,14 @@ constexpr int TL_MAXCELL_LDS = 440;   // the int16 winner tile [ncell][34] must 
 // Scalar (SMEM) load of one C-float neighbour row, issued as inline asm so that the U loads of a hit group are all
 // in flight before the single s_waitcnt (the compiler otherwise sinks each load next to its use, exposing one
 // scalar-load latency per hit).
+// lowest set bit of a wave-uniform mask, cleared in place: s_ff1_i32_b64 + s_bitset0_b64 (the C expression
+// mask &= mask - 1 costs three SALU instructions)
+__device__ __forceinline__ int pop_bit(unsigned long long &mask) {
+    const int b = __builtin_ctzll(mask);
+    asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(b));
+    return b;
+}
+
 template <int C> struct SRow;
 template <> struct SRow<4> { typedef float type __attribute__((ext_vector_type(4))); };
 template <> struct SRow<8> { typedef float type __attribute__((ext_vector_type(8))); };
@@ -315,7 +323,7 @@ __global__ void __launch_bounds__(1024) pool_embed_cellsplit_kernel(const Sparse
         if constexpr (SASM && C <= 16) {
             // lean path: the byte offset of every lane's neighbour row is one VALU op per cell; a hit then costs
             // ff1 + bit clear + one readlane + one SMEM load (SGPR offset) + LDS read-modify-write + C FMAs
-            const unsigned off = (unsigned)(rb + wv) * (unsigned)(a.ldv * 4);
+            const unsigned off = __umul24((unsigned)(rb + wv), (unsigned)(a.ldv * 4));   // rows, row bytes < 2^24: full-rate multiply
             auto one = [&](int b, typename SRow<C>::type &ev, float &av) {
                 sload_row<C>(ev, a.enc, (unsigned)__builtin_amdgcn_readlane((int)off, b));
                 av = accl[b * OB];
@@ -335,8 +343,8 @@ __global__ void __launch_bounds__(1024) pool_embed_cellsplit_kernel(const Sparse
             };
             if constexpr (U >= 2) {
                 while (mask & (mask - 1ull)) {                      // at least two hits left
-                    const int b0 = __ffsll((long long)mask) - 1; mask &= mask - 1ull;
-                    const int b1 = __ffsll((long long)mask) - 1; mask &= mask - 1ull;
+                    const int b0 = pop_bit(mask);
+                    const int b1 = pop_bit(mask);
                     typename SRow<C>::type e0, e1;
                     float a0, a1;
                     one(b0, e0, a0);
@@ -347,7 +355,7 @@ __global__ void __launch_bounds__(1024) pool_embed_cellsplit_kernel(const Sparse
                 }
             }
             while (mask) {
-                const int b0 = __ffsll((long long)mask) - 1; mask &= mask - 1ull;
+                const int b0 = pop_bit(mask);
                 typename SRow<C>::type e0;
                 float a0;
                 one(b0, e0, a0);
