@@ -282,11 +282,12 @@ __device__ __forceinline__ void sload_row(typename SRow<C>::type &v, const float
 }
 
 // ABL: measurement only (4 = no weight loads, 8 = no hits).
-template <int C, int PF, int U, bool SASM, int ABL = 0>
-__global__ void __launch_bounds__(1024) pool_embed_cellsplit_kernel(const SparseArgs a) {
-    typedef int16_t WT;
-    constexpr int TE = TL_TE, OB = TL_OB, NCS = OB / 64;
-    constexpr int NQ = TL_NQ, WLS = TE + 2, NTH = 64 * NQ * NCS;
+// TE egos x 8192/TE columns per workgroup.  TE = 64 (experiment, TNP_SPARSE_VARIANT 6/7): half the weight stream, 8 waves,
+// winner tile stored as int8 (needs n_max <= 127).
+template <int C, int PF, int U, bool SASM, int ABL = 0, int TE = TL_TE, typename WT = int16_t>
+__global__ void __launch_bounds__(64 * TL_NQ * (8192 / TE / 64)) pool_embed_cellsplit_kernel(const SparseArgs a) {
+    constexpr int OB = 8192 / TE, NCS = OB / 64;
+    constexpr int NQ = TL_NQ, WLS = TE + (sizeof(WT) == 1 ? 4 : 2), NTH = 64 * NQ * NCS;
     extern __shared__ __attribute__((aligned(16))) float csm[];
     float *acc = csm;                                                        // [NQ][TE][OB]
     WT *wl = reinterpret_cast<WT *>(csm + NQ * TE * OB);    // [ncell][WLS]
@@ -341,6 +342,18 @@ __global__ void __launch_bounds__(1024) pool_embed_cellsplit_kernel(const Sparse
                 }
                 accl[b * OB] = p.x + p.y;
             };
+            if constexpr (U >= 4) {
+                while (__builtin_popcountll(mask) >= 4) {           // four hits in flight (64-ego tiles: ~5 hits per cell)
+                    int b[4];
+                    typename SRow<C>::type e[4];
+                    float av[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { b[u] = pop_bit(mask); one(b[u], e[u], av[u]); }
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e[0]), "+s"(e[1]), "+s"(e[2]), "+s"(e[3]));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) fin(b[u], e[u], av[u]);
+                }
+            }
             if constexpr (U >= 2) {
                 while (mask & (mask - 1ull)) {                      // at least two hits left
                     const int b0 = pop_bit(mask);
@@ -478,6 +491,19 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
     SparseArgs a;
     a.winners = winners; a.enc = enc; a.ldv = ldv; a.row_base = row_base; a.Wp = Wp; a.bias = bias;
     a.M = M; a.ncell = ncell; a.C = C; a.N1 = N1; a.relu = relu; a.ldo = ldo;
+    if (ncell <= TL_MAXCELL_LDS && (sp_variant == 6 || sp_variant == 7) && C == 16) {
+        // experiment: 64-ego tiles (assumes n_max <= 127: int8 winner tile)
+        a.out = out;
+        a.S = 1; a.cps = ncell; a.ego_tiles = (M + 63) / 64; a.out_blocks = (N1 + 127) / 128;
+        const size_t smem64 = (size_t)TL_NQ * 8192 * 4 + (((size_t)ncell * 68 + 15) & ~(size_t)15);
+        const int blocks64 = a.ego_tiles * a.out_blocks;
+#define CS_LAUNCH64(UU) { static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
+        pool_embed_cellsplit_kernel<16, 2, UU, true, 0, 64, int8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((pool_embed_cellsplit_kernel<16, 2, UU, true, 0, 64, int8_t>), dim3(blocks64), dim3(512), smem64, s, a); }
+        if (sp_variant == 6) CS_LAUNCH64(4) else CS_LAUNCH64(2)
+        TNP_HIP(hipGetLastError());
+        return 0;
+    }
     if (ncell <= TL_MAXCELL_LDS) {
         a.out = out;
         a.S = 1; a.cps = ncell; a.ego_tiles = (M + TL_TE - 1) / TL_TE; a.out_blocks = (N1 + TL_OB - 1) / TL_OB;
