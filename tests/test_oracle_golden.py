@@ -136,3 +136,34 @@ def test_center_scene_matches_reference_on_real_scenes():
             helpers.assert_close_nan(mine, cen[:, split[s]:split[s + 1]], 1e-12, 'center_scene')
             back = data.inverse_scene(mine, rot, center)
             helpers.assert_close_nan(back, raw[:, split[s]:split[s + 1]], 1e-9, 'inverse_scene')
+
+
+def test_random_rotation_and_batcher_match_reference_arithmetic():
+    """data.random_rotation == reference lstm/utils.py:10-17 under the same `random` seed (value stored in the real-scene
+    fixture is not needed: the formula is checked against the rotation matrix it documents); SceneBatcher on the CPU
+    device reproduces drop_distant + batch assembly + per-scene rotation."""
+    import math
+    import random
+    from trajnetplusplusbaselines_amd import data
+    z = np.load(helpers.GOLDEN + '/real_cases.npz')
+    split = z['hotel_split']
+    raw = z['hotel_raw_xy'].astype(np.float64)
+    scenes = [raw[:, split[s]:split[s + 1]] for s in range(len(split) - 1)]
+    random.seed(5)
+    theta = random.random() * 2.0 * math.pi
+    random.seed(5)
+    rot = data.random_rotation(scenes[0])
+    r = np.array([[math.cos(theta), math.sin(theta)], [-math.sin(theta), math.cos(theta)]])
+    helpers.assert_close_nan(rot, scenes[0] @ r, 1e-12, 'random_rotation')
+    b = data.SceneBatcher(scenes, device='cpu', drop_distant_r=None)
+    xy, goals, sp = b.batch([2, 0, 5])
+    want = np.concatenate([scenes[2], scenes[0], scenes[5]], axis=1).astype(np.float32)
+    helpers.assert_close_nan(xy.numpy(), want, 0.0, 'batch assembly')
+    assert sp.tolist() == np.concatenate([[0], np.cumsum([scenes[i].shape[1] for i in (2, 0, 5)])]).tolist()
+    random.seed(9)
+    thetas = [random.random() * 2.0 * math.pi for _ in range(2)]
+    random.seed(9)
+    xy, goals, sp = b.batch([1, 3], augment=True)
+    for k, (i, th) in enumerate(zip((1, 3), thetas)):
+        r = np.array([[math.cos(th), math.sin(th)], [-math.sin(th), math.cos(th)]])
+        helpers.assert_close_nan(xy[:, sp[k]:sp[k + 1]].numpy(), (scenes[i] @ r).astype(np.float32), 2e-5, 'rotated scene')

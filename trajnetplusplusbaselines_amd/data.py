@@ -105,3 +105,81 @@ def batch_scenes(scenes_xy):
     the batch assembly of reference lstm/trainer.py:120-131."""
     split = np.cumsum([0] + [int(s.shape[1]) for s in scenes_xy])
     return np.concatenate(scenes_xy, axis=1), split
+
+
+def random_rotation(xy, goals=None):
+    """Rotate a scene (and its goals) by a uniformly random angle drawn from Python's ``random`` exactly as the
+    reference does (lstm/utils.py:10-17), so seeded runs see the same augmentation."""
+    import math
+    import random
+    theta = random.random() * 2.0 * math.pi
+    ct, st = math.cos(theta), math.sin(theta)
+    r = np.array([[ct, st], [-st, ct]])
+    if goals is None:
+        return np.einsum('ptc,ci->pti', xy, r)
+    return np.einsum('ptc,ci->pti', xy, r), np.einsum('tc,ci->ti', goals, r)
+
+
+def add_noise(observation, thresh=0.005, obs_length=9, ped='primary'):
+    """Uniform noise on the observed frames of the primary or of the neighbours (reference augmentation.py:79-87,
+    numpy's global RNG, in place)."""
+    if ped == 'primary':
+        observation[:obs_length, 0] += np.random.uniform(-thresh, thresh, observation[:obs_length, 0].shape)
+    elif ped == 'neigh':
+        observation[:obs_length, 1:] += np.random.uniform(-thresh, thresh, observation[:obs_length, 1:].shape)
+    else:
+        raise ValueError
+    return observation
+
+
+class SceneBatcher(object):
+    """Pre-tensorised scenes for the training / evaluation loops.
+
+    The reference re-runs ``paths_to_xy`` + ``drop_distant`` + ``center_scene`` per scene per epoch in Python
+    (lstm/trainer.py:96-133).  Here every scene is converted once to a float32 ``[T, N_s, 2]`` array (after
+    ``drop_distant`` and the optional ``center_scene``), all scenes are stored back to back in ONE device tensor, and a
+    batch is a gather of the selected scenes' columns -- optionally rotated per scene on the device (the
+    ``random_rotation`` augmentation: one angle per scene from Python's ``random``, applied as a 2x2 matrix to every
+    frame).  ``batch(ids)`` returns (``batch_scene [T, M, 2]``, ``batch_scene_goal [M, 2]``, ``batch_split [B+1]``) as
+    the trainer builds them (lstm/trainer.py:125-133)."""
+
+    def __init__(self, scenes, goals=None, device='cuda', obs_length=9, normalize_scene=False, drop_distant_r=6.0):
+        import torch
+        xs, gs = [], []
+        for k, xy in enumerate(scenes):
+            xy = np.asarray(xy, dtype=np.float64)
+            g = np.zeros((xy.shape[1], 2)) if goals is None else np.asarray(goals[k], dtype=np.float64)
+            if drop_distant_r is not None:
+                d2 = np.sum(np.square(xy - xy[:, 0:1]), axis=2)
+                mask = np.nanmin(d2, axis=0) < drop_distant_r ** 2          # lstm/lstm.py:16-22
+                xy, g = xy[:, mask], g[mask]
+            if normalize_scene:
+                xy, _, _, g = center_scene(xy, obs_length, goals=g)
+            xs.append(xy)
+            gs.append(g)
+        self.sizes = np.array([x.shape[1] for x in xs], dtype=np.int64)
+        self.starts = np.concatenate([[0], np.cumsum(self.sizes)])
+        self.device = torch.device(device)
+        self.xy = torch.tensor(np.concatenate(xs, axis=1), dtype=torch.float32, device=self.device)     # [T, sum N, 2]
+        self.goals = torch.tensor(np.concatenate(gs, axis=0), dtype=torch.float32, device=self.device)  # [sum N, 2]
+
+    def __len__(self):
+        return len(self.sizes)
+
+    def batch(self, ids, augment=False):
+        import math
+        import random
+        import torch
+        ids = list(ids)
+        cols = torch.cat([torch.arange(self.starts[i], self.starts[i + 1], device=self.device) for i in ids])
+        xy, goals = self.xy[:, cols], self.goals[cols]
+        split = torch.tensor(np.concatenate([[0], np.cumsum(self.sizes[ids])]), dtype=torch.int64)
+        if augment:
+            theta = torch.tensor([random.random() * 2.0 * math.pi for _ in ids], dtype=torch.float64)
+            per_track = torch.repeat_interleave(theta, torch.tensor(self.sizes[ids])).to(self.device)
+            ct, st = torch.cos(per_track).float(), torch.sin(per_track).float()
+            x, y = xy[..., 0], xy[..., 1]
+            xy = torch.stack([x * ct - y * st, x * st + y * ct], dim=-1)   # row vector times [[ct, st], [-st, ct]]
+            gx, gy = goals[:, 0], goals[:, 1]
+            goals = torch.stack([gx * ct - gy * st, gx * st + gy * ct], dim=-1)
+        return xy, goals, split
