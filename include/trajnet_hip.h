@@ -238,6 +238,46 @@ TNP_API int tnp_lstm_step(const tnp_lstm_model *model, int decoder, const float 
                   size_t workspace_bytes, void *stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Training support (loss.backward() through LSTM.forward, lstm/trainer.py:229-269).
+ *   tnp_lstm_step_train: tnp_lstm_step that also keeps what the backward pass needs, written straight into the
+ *   caller's buffers (any pointer may be NULL): X [M, I] the LSTMCell input (embedding | goal | interaction vector),
+ *   act[l] [M, dims[l+1]] the ReLU outputs of the embedding MLP layers before the last, gates [M, 4H] the
+ *   post-activation i, f, g, o of the present rows, enc [M, C] the social encoding.
+ *   The backward kernels below are the pointwise / gather parts of the reverse sweep; every contraction is a
+ *   tnp_linear_forward call on (transposed) operands.
+ *   tnp_h2n_backward:      d(normal) -> d(Linear output) of Hidden2Normal (lstm/modules.py:56-64) and
+ *                          dh_tot = dh_in + dlin . Wn; rows of absent tracks get dlin = 0
+ *   tnp_lstm_cell_backward: torch.nn.LSTMCell backward from the saved gates: dG [M,4H] (pre-activation gradients,
+ *                          gate order i,f,g,o), dc_prev, and dh_pass = gradient that bypasses the cell for absent
+ *                          tracks (their state is copied through, lstm/lstm.py:158-166)
+ *   tnp_relu_mask:         out = dy * (act > 0) on column slices (leading dimensions given)
+ *   tnp_social_scatter_backward: d(social encoding)[j] = sum over the egos i of j's scene of dgrid[i, :, cell(i,j)]
+ *                          with cells from tnp_pool_pair_cells (every in-range neighbour)
+ * ----------------------------------------------------------------------------------------- */
+typedef struct tnp_step_saves {
+    float *X;
+    float *act[2];
+    float *gates;
+    float *enc;
+} tnp_step_saves;
+TNP_API int tnp_lstm_step_train(const tnp_lstm_model *model, int decoder, const float *h_in, const float *c_in,
+                                const float *obs1, const float *obs2, const float *goals,
+                                const int32_t *scene_start, int B, int M, int n_max, float *h_out, float *c_out,
+                                float *normal, const tnp_step_saves *saves, void *workspace,
+                                size_t workspace_bytes, void *stream);
+TNP_API int tnp_h2n_backward(const float *h_out, const float *Wn, const float *bn, const float *d_normal,
+                             const float *d_pos, const float *obs1, const float *obs2, const float *dh_in, int M, int H,
+                             float *dlin, float *dh_tot, void *stream);
+TNP_API int tnp_lstm_cell_backward(const float *gates, const float *c_prev, const float *dh_tot, const float *dc,
+                                   const float *obs1, const float *obs2, int M, int H, float *dG, float *dc_prev,
+                                   float *dh_pass, void *stream);
+TNP_API int tnp_relu_mask(const float *dy, int ld_dy, const float *act, int ld_act, int M, int N, float *out, int ld_out,
+                          void *stream);
+TNP_API int tnp_social_scatter_backward(const float *dgrid, int ldg, const int32_t *cells, const int32_t *row_base,
+                                        const int32_t *row_count, int M, int n_max, int C, int ncell, float *denc,
+                                        void *stream);
+
+/* -------------------------------------------------------------------------------------------
  * Losses on the primaries (rows scene_start[s]) of a batch, lstm/loss.py:
  *   mode 0  PredictionLoss.forward (:52-91): -log(0.01 + bg*N(x;mu,3,3,0) + (0.99-bg)*N(x;mu,sigma,rho))
  *   mode 1  L2Loss.forward (:107-135): squared error of (mu_x, mu_y); scale carries the x100 (and the 1/2 of the

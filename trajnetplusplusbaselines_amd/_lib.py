@@ -90,6 +90,13 @@ def lib():
     L.tnp_row_base.argtypes = [_fp, ctypes.c_int, _fp, _fp]
     L.tnp_pool_nn_forward.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, ctypes.c_int,
                                       _fp, ctypes.c_int, _fp]
+    L.tnp_lstm_step_train.argtypes = [ctypes.POINTER(LstmModel), ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, _fp, _fp, _fp, _fp, _fp, ctypes.c_size_t, _fp]
+    L.tnp_h2n_backward.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]
+    L.tnp_lstm_cell_backward.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]
+    L.tnp_relu_mask.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]
+    L.tnp_social_scatter_backward.argtypes = [_fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, _fp, _fp]
     L.tnp_pool_traj_forward.argtypes = [_fp, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp]
     L.tnp_pool_attn_self.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, _fp, _fp, ctypes.c_float, _fp, ctypes.c_int, _fp]

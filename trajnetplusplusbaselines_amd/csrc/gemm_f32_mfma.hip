@@ -86,6 +86,10 @@ __device__ __forceinline__ void lstm_cell_store(const GemmArgs &g, int row, int 
         const float cn = fg * g.c_in[o] + ig * gg;
         g.c_out[o] = cn;
         g.h_out[o] = og * tanhf(cn);
+        if (g.gates_out) {
+            float *go = g.gates_out + (size_t)row * 4 * g.H + unit;
+            go[0] = ig; go[g.H] = fg; go[2 * g.H] = gg; go[3 * g.H] = og;
+        }
     } else {  // absent track: state frozen (reference lstm/lstm.py:118-124,158-166)
         g.c_out[o] = g.c_in[o];
         g.h_out[o] = g.h_in[o];

@@ -245,6 +245,7 @@ struct Workspace {
     float *hplus;
     float *pdst;     // where the interaction module writes its [M, P] result, and its leading dimension
     int pld;
+    float *gates_save;   // training: post-activation gates of the step
     size_t bytes;
 };
 
@@ -294,6 +295,7 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     w.hplus = w.to_hidden ? (float *)take((size_t)M * md->H * 4) : nullptr;
     w.pdst = w.to_hidden ? w.hplus : (pool ? w.X + (w.I - P) : nullptr);
     w.pld = w.to_hidden ? md->H : w.I;
+    w.gates_save = nullptr;
     if (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ) {
         const int Hp = md->dims[0];
         w.ph[0] = (float *)take((size_t)M * Hp * 4);
@@ -484,6 +486,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
     g.bias2 = decoder ? md->dec_bhh : md->enc_bhh;
     g.M = M; g.N = 4 * H; g.H = H;
     g.h_in = h_in; g.h_out = h_out; g.c_in = c_in; g.c_out = c_out; g.mask = w.mask;
+    g.gates_out = w.gates_save;
     prof_before(PROF_ALL_GEMM, s);
     int rc = launch_lstm_gates(g, (md->variant >> 8) & 0xff, s);
     prof_after(PROF_ALL_GEMM, s);
@@ -645,10 +648,10 @@ extern "C" TNP_API int tnp_lstm_forward_ex(const tnp_lstm_model *md, const float
                              pred, workspace, workspace_bytes, extras, stream);
 }
 
-extern "C" TNP_API int tnp_lstm_step(const tnp_lstm_model *md, int decoder, const float *h_in, const float *c_in,
+static int lstm_step_impl(const tnp_lstm_model *md, int decoder, const float *h_in, const float *c_in,
                              const float *obs1, const float *obs2, const float *goals, const int32_t *scene_start,
                              int B, int M, int n_max, float *h_out, float *c_out, float *normal, void *workspace,
-                             size_t workspace_bytes, void *stream) {
+                             size_t workspace_bytes, const tnp_step_saves *sv, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc = validate_model(md);
     if (rc) return rc;
@@ -660,6 +663,13 @@ extern "C" TNP_API int tnp_lstm_step(const tnp_lstm_model *md, int decoder, cons
     plan_workspace(md, M, workspace, w);
     if (workspace == nullptr || workspace_bytes < w.bytes)
         TNP_FAIL(-1, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    if (sv) {   // training: the step writes its intermediates straight into the caller's buffers
+        if (sv->X) { w.X = sv->X; w.pdst = w.to_hidden ? w.hplus : (md->pool_type != TNP_POOL_NONE ? w.X + (w.I - md->P) : nullptr); }
+        if (sv->act[0]) w.y[0] = sv->act[0];
+        if (sv->act[1]) w.y[1] = sv->act[1];
+        if (sv->enc) w.enc = sv->enc;
+        w.gates_save = sv->gates;
+    }
     if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s); if (rc) return rc; }
     PrepArgs p;
     fill_prep_common(p, md, w, M);
@@ -678,6 +688,23 @@ extern "C" TNP_API int tnp_lstm_step(const tnp_lstm_model *md, int decoder, cons
     q.h = h_out; q.have_prev = 1; q.have_next = 0;
     q.mask_prev = w.mask; q.obs2_prev = w.obs2; q.normal_out = normal; q.pos_out = w.obs1;  // scratch
     return launch_prepare(q, s);
+}
+
+extern "C" TNP_API int tnp_lstm_step(const tnp_lstm_model *md, int decoder, const float *h_in, const float *c_in,
+                             const float *obs1, const float *obs2, const float *goals, const int32_t *scene_start,
+                             int B, int M, int n_max, float *h_out, float *c_out, float *normal, void *workspace,
+                             size_t workspace_bytes, void *stream) {
+    return lstm_step_impl(md, decoder, h_in, c_in, obs1, obs2, goals, scene_start, B, M, n_max, h_out, c_out, normal,
+                          workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" TNP_API int tnp_lstm_step_train(const tnp_lstm_model *md, int decoder, const float *h_in, const float *c_in,
+                                   const float *obs1, const float *obs2, const float *goals,
+                                   const int32_t *scene_start, int B, int M, int n_max, float *h_out, float *c_out,
+                                   float *normal, const tnp_step_saves *saves, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+    return lstm_step_impl(md, decoder, h_in, c_in, obs1, obs2, goals, scene_start, B, M, n_max, h_out, c_out, normal,
+                          workspace, workspace_bytes, saves, stream);
 }
 
 extern "C" TNP_API int tnp_linear_forward(const float *A, int lda, const float *W, int ldw, const float *bias, float *C,

@@ -34,6 +34,7 @@ struct GemmArgs {
     float *C; int ldc; int relu;
     // EPI_LSTM: N == 4*H, tile columns = 4 gates x 32 hidden units
     int H; const float *h_in; float *h_out; const float *c_in; float *c_out; const uint8_t *mask;
+    float *gates_out;     // optional [M, 4H]: post-activation i, f, g, o of the present rows (training saves)
 };
 
 // generic dense layer (variant selects the tile configuration)

@@ -1,14 +1,20 @@
 """Training path of the LSTM forecaster: autograd through the whole sequence (reference lstm/trainer.py:229-269 calls
 ``loss.backward()`` on the outputs of ``LSTM.forward``).
 
-Round-1 status (interim): the forward of every step runs on the HIP kernels (``LSTM.step``); the
-backward is an explicit reverse sweep over the steps with activation recomputation.  All contractions (dgrad /
-wgrad GEMMs of the LSTM cell, the embedding MLP, Hidden2Normal, the social encoding) run on the fp32 MFMA GEMM
-(``tnp_linear_forward``) with transposed operands; the pointwise derivatives and the index bookkeeping are plain
-device-tensor expressions, and the grid scatter's backward uses ``tnp_pool_pair_cells`` (every in-range neighbour
-receives the gradient of its cell, overwritten duplicates included -- SURVEY.md 8a quirk 4).  Positions fed back to
-the decoder are detached exactly as in the reference (lstm/lstm.py:240-250), hidden states pooled from neighbours are
-not (lstm/lstm.py:26), so BPTT couples the agents of a scene through the social encoding.
+Forward: every recurrent step is one ``tnp_lstm_step_train`` call -- the inference step kernels, which additionally
+leave what the backward pass needs (LSTMCell input ``X``, embedding-MLP activations, post-activation gates, social
+encoding) in per-step slices of buffers allocated once per sequence.  Nothing is recomputed in the backward pass
+except the dense grid of a step (needed for the first embedding layer's weight gradient), which the grid kernel
+rebuilds from the saved positions and encodings.
+
+Backward: an explicit reverse sweep.  Per step: ``tnp_h2n_backward`` and ``tnp_lstm_cell_backward`` (pointwise
+derivatives from the saved gates), data-gradient GEMMs on the fp32 MFMA kernel against weights transposed once per
+sweep, ``tnp_relu_mask`` for the ReLU derivatives, and for social pooling ``tnp_pool_pair_cells`` +
+``tnp_social_scatter_backward`` (every in-range neighbour receives the gradient of its cell, overwritten duplicates
+included -- SURVEY.md 8a quirk 4).  Weight gradients are contractions over the tracks of ALL steps, so they run as ONE
+GEMM per parameter over the stacked per-step operands at the end of the sweep.  Positions fed back to the decoder are
+detached exactly as in the reference (lstm/lstm.py:240-250), hidden states pooled from neighbours are not
+(lstm/lstm.py:26), so BPTT couples the agents of a scene through the social encoding.
 """
 import ctypes
 
@@ -17,8 +23,8 @@ import torch
 from .. import _lib
 
 
-def _lin(x, w, b=None, relu=False):
-    return _lib.linear_forward(x, w, b, relu=relu)
+def _lin(x, w, b=None, relu=False, out=None):
+    return _lib.linear_forward(x, w, b, relu=relu, out=out)
 
 
 def _mm(a, b_t):
@@ -26,8 +32,18 @@ def _mm(a, b_t):
     return _lib.linear_forward(a.contiguous(), b_t.contiguous(), None)
 
 
+def _off(t, floats):
+    """device pointer `floats` elements past the start of tensor t"""
+    return ctypes.c_void_p(t.data_ptr() + 4 * floats)
+
+
+class StepSaves(ctypes.Structure):
+    """mirror of ``struct tnp_step_saves`` (include/trajnet_hip.h)"""
+    _fields_ = [('X', ctypes.c_void_p), ('act', ctypes.c_void_p * 2), ('gates', ctypes.c_void_p), ('enc', ctypes.c_void_p)]
+
+
 class SequenceFn(torch.autograd.Function):
-    """rel_pred, pred = SequenceFn.apply(model, observed, goals, batch_split, truth, T_dec, extras, *params)"""
+    """rel_pred, pred = SequenceFn.apply(model, observed, goals, batch_split, truth, T_dec, *params)"""
 
     @staticmethod
     def forward(ctx, model, observed, goals, batch_split, truth, T_dec, *params):
@@ -42,18 +58,47 @@ class SequenceFn(torch.autograd.Function):
         idx = _lib.SceneIndex.get(batch_split, dev)
         prim = idx.starts[:-1].long()
         H = model.hidden_dim
-        h = torch.zeros(M, H, device=dev)
-        c = torch.zeros(M, H, device=dev)
-        normals, positions, steps = [], [], []
-        if T_obs == 2:
-            positions = [observed[-1]]
+        pool = model.pool
+        S = (T_obs - 1) + T_dec
+        L = _lib.lib()
+        m, keep, _ = model._descriptor()
+        ws, need = model._workspace(m, M, idx.B, dev)
+        I = model.encoder.weight_ih.shape[1]
+        layers = pool.embedding_layers() if pool is not None else []
+        if len(layers) > 3:
+            raise NotImplementedError('embedding MLPs deeper than three layers')
+        # per-step slices of buffers allocated once per sequence
+        h_all = torch.zeros(S + 1, M, H, device=dev)
+        c_all = torch.zeros(S + 1, M, H, device=dev)
+        X_all = torch.empty(S, M, I, device=dev)
+        gates_all = torch.empty(S, M, 4 * H, device=dev)
+        act_all = [torch.empty(S, M, lin.weight.shape[0], device=dev) for lin in layers[:-1]]
+        enc_all = torch.empty(S, M, pool.pooling_dim, device=dev) if (pool is not None and pool.type_ == 'social') else None
+        normals = torch.empty(S, M, 5, device=dev)
+        o1s, o2s, decs = [], [], []
+        positions = [observed[-1]] if T_obs == 2 else []
+
+        def run(s, decoder, o1, o2):
+            sv = StepSaves()
+            sv.X = X_all[s].data_ptr()
+            for li, a in enumerate(act_all):
+                sv.act[li] = a[s].data_ptr()
+            sv.gates = gates_all[s].data_ptr()
+            sv.enc = enc_all[s].data_ptr() if enc_all is not None else None
+            _lib.check(L.tnp_lstm_step_train(
+                ctypes.byref(m), decoder, _lib.ptr(h_all[s]), _lib.ptr(c_all[s]), _lib.ptr(o1), _lib.ptr(o2),
+                _lib.ptr(goals_t), _lib.ptr(idx.starts), idx.B, M, idx.n_max, _lib.ptr(h_all[s + 1]), _lib.ptr(c_all[s + 1]),
+                _lib.ptr(normals[s]), ctypes.byref(sv), _lib.ptr(ws), need, _lib.stream_ptr()), 'tnp_lstm_step_train')
+            o1s.append(o1)
+            o2s.append(o2)
+            decs.append(decoder)
+            positions.append(o2 + normals[s][:, :2])
+
         with torch.no_grad():
+            s = 0
             for t in range(1, T_obs):
-                o1, o2 = observed[t - 1], observed[t]
-                steps.append((0, o1, o2, h, c))
-                (h, c), normal = model.step(model.encoder, (h, c), o1, o2, goals_t, batch_split)
-                normals.append(normal)
-                positions.append(o2 + normal[:, :2])
+                run(s, 0, observed[t - 1].contiguous(), observed[t].contiguous())
+                s += 1
             pt_prev = observed[-1].clone()
             prev_none = False
             for k in range(T_dec):
@@ -67,161 +112,159 @@ class SequenceFn(torch.autograd.Function):
                 else:
                     o2 = truth[k].clone()
                     o2[prim] = positions[-1][prim]
-                steps.append((1, o1, o2, h, c))
-                (h, c), normal = model.step(model._decoder_cell(), (h, c), o1, o2, goals_t, batch_split)
-                normals.append(normal)
-                positions.append(o2 + normal[:, :2])
+                run(s, 1, o1, o2)
+                s += 1
                 pt_prev = o2
                 prev_none = truth is None
-        ctx.model, ctx.steps, ctx.idx, ctx.goals = model, steps, idx, goals_t
-        ctx.batch_split = batch_split
+        del keep
+        ctx.model, ctx.idx, ctx.goals = model, idx, goals_t
+        ctx.saved = (h_all, c_all, X_all, gates_all, act_all, enc_all, o1s, o2s, decs)
         ctx.pos_offset = 1 if T_obs == 2 else 0
         ctx.param_names = [n for n, _ in model.named_parameters()]
         ctx.save_for_backward(*params)
-        return torch.stack(normals, dim=0), torch.stack(positions, dim=0)
+        return normals, torch.stack(positions, dim=0)
 
     @staticmethod
     def backward(ctx, d_rel, d_pred):
         model, idx = ctx.model, ctx.idx
         P = dict(zip(ctx.param_names, ctx.saved_tensors))
-        grads = {n: torch.zeros_like(p) for n, p in P.items()}
-        dev = d_rel.device if d_rel is not None else d_pred.device
-        M, H, E = idx.M, model.hidden_dim, model.embedding_dim
+        h_all, c_all, X_all, gates_all, act_all, enc_all, o1s, o2s, decs = ctx.saved
+        dev = h_all.device
+        S, M, H, E = len(decs), idx.M, model.hidden_dim, model.embedding_dim
+        I = X_all.shape[2]
         pool = model.pool
         GD = model.goal_dim if model.goal_flag else 0
+        L = _lib.lib()
+        sp = _lib.stream_ptr
+        d_rel = _lib.f32c(d_rel, dev) if d_rel is not None else None
+        d_pred = _lib.f32c(d_pred, dev) if d_pred is not None else None
+        grads = {}
+
+        # weights of the data-gradient GEMMs, transposed once per sweep ([in, out] rows for the NT kernel)
+        def T(name):
+            return P[name].detach().t().contiguous()
+        wT = {pre: (T(pre + '.weight_ih'), T(pre + '.weight_hh')) for pre in set('decoder' if d else 'encoder' for d in decs)}
+        wn = P['hidden2normal.linear.weight'].detach().contiguous()
+        bn = P['hidden2normal.linear.bias'].detach().contiguous()
+        layers = pool.embedding_layers() if pool is not None else []
+        lay_names = ['pool.embedding.%d' % i for i, mod in enumerate(pool.embedding) if isinstance(mod, torch.nn.Linear)] \
+            if pool is not None else []
+        social = pool is not None and pool.type_ == 'social'
+        layT = [T(n + '.weight') if (li > 0 or social) else None for li, n in enumerate(lay_names)]
+        whT = T('pool.hidden_dim_encoding.weight') if social else None
+
+        # per-step operands of the deferred weight-gradient GEMMs
+        dlin_all = torch.empty(S, M, 5, device=dev)
+        dG_all = torch.empty(S, M, 4 * H, device=dev)
+        de_all = torch.empty(S, M, E - 2, device=dev)
+        dgoal_all = torch.empty(S, M, GD - 2, device=dev) if GD else None
+        gdir_all = torch.empty(S, M, 2, device=dev) if GD else None
+        dy_all = [torch.empty(S, M, lin.weight.shape[0], device=dev) for lin in layers]
+        denc_all = torch.empty(S, M, pool.pooling_dim, device=dev) if social else None
+        grid_all = None
+        if pool is not None:
+            tid = _lib.POOL_TYPES[pool.type_]
+            G, cell, half_x, half_y = pool._geometry()
+            C = pool.pooling_dim
+            grid_all = torch.empty(S, M, C * G * G, device=dev)
+            if social:
+                sizes = (idx.starts[1:] - idx.starts[:-1]).long()
+                row_base = torch.repeat_interleave(idx.starts[:-1].long(), sizes).to(torch.int32)
+                row_count = torch.repeat_interleave(sizes, sizes).to(torch.int32)
+                cells = torch.empty(M, idx.n_max, dtype=torch.int32, device=dev)
+                dgrid = torch.empty(M, C * G * G, device=dev)
+
         dh = torch.zeros(M, H, device=dev)
         dc = torch.zeros(M, H, device=dev)
-        sizes = (idx.starts[1:] - idx.starts[:-1]).long()
-        row_base = torch.repeat_interleave(idx.starts[:-1].long(), sizes).to(torch.int32)
-        row_count = torch.repeat_interleave(sizes, sizes).to(torch.int32)
-        L = _lib.lib()
-        emb_w, emb_b = P['input_embedding.input_embeddings.0.weight'], P['input_embedding.input_embeddings.0.bias']
-        wn, bn = P['hidden2normal.linear.weight'], P['hidden2normal.linear.bias']
-        layers = pool.embedding_layers() if pool is not None else []
-        lay_names = []
-        if pool is not None:
-            lay_names = ['pool.embedding.%d' % i for i, mod in enumerate(pool.embedding) if isinstance(mod, torch.nn.Linear)]
+        dh_tot = torch.empty(M, H, device=dev)
+        dh_pass = torch.empty(M, H, device=dev)
+        dX = torch.empty(M, I, device=dev)
+        P0 = E + GD                                           # first pooled column of X
 
-        for s in range(len(ctx.steps) - 1, -1, -1):
-            dec, o1, o2, h_prev, c_prev = ctx.steps[s]
-            pre = 'decoder' if dec else 'encoder'
-            w_ih, w_hh = P[pre + '.weight_ih'], P[pre + '.weight_hh']
-            b_ih, b_hh = P[pre + '.bias_ih'], P[pre + '.bias_hh']
-            mask = ~(torch.isnan(o1[:, 0]) | torch.isnan(o2[:, 0]))
-            mk = mask.unsqueeze(1).float()
-            # ---------------- recompute the step's activations ----------------
-            vel = torch.nan_to_num(o2 - o1) * 4.0
-            emb_lin = _lin(vel, emb_w, emb_b)
-            parts = [torch.relu(emb_lin), torch.zeros(M, 2, device=dev)]
+        for s in range(S - 1, -1, -1):
+            o1, o2 = o1s[s], o2s[s]
+            pre = 'decoder' if decs[s] else 'encoder'
+            w_ihT, w_hhT = wT[pre]
+            # ---- Hidden2Normal backward + gradient of the new hidden state ----
+            _lib.check(L.tnp_h2n_backward(_lib.ptr(h_all[s + 1]), _lib.ptr(wn), _lib.ptr(bn),
+                                          _lib.ptr(d_rel[s]) if d_rel is not None else None,
+                                          _lib.ptr(d_pred[s + ctx.pos_offset]) if d_pred is not None else None,
+                                          _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(dh), M, H, _lib.ptr(dlin_all[s]), _lib.ptr(dh_tot),
+                                          sp()), 'tnp_h2n_backward')
+            # ---- LSTMCell backward (absent rows pass the state gradient through) ----
+            dc_prev = torch.empty(M, H, device=dev)
+            _lib.check(L.tnp_lstm_cell_backward(_lib.ptr(gates_all[s]), _lib.ptr(c_all[s]), _lib.ptr(dh_tot), _lib.ptr(dc),
+                                                _lib.ptr(o1), _lib.ptr(o2), M, H, _lib.ptr(dG_all[s]), _lib.ptr(dc_prev),
+                                                _lib.ptr(dh_pass), sp()), 'tnp_lstm_cell_backward')
+            _lin(dG_all[s], w_ihT, out=dX)                                  # dX = dG . W_ih
+            dh_prev = _lin(dG_all[s], w_hhT)                                # dG . W_hh
+            dh_prev += dh_pass
+            # ---- input / goal embedding backward (X holds the ReLU outputs) ----
+            Xs = X_all[s]
+            _lib.check(L.tnp_relu_mask(_lib.ptr(dX), I, _lib.ptr(Xs), I, M, E - 2, _lib.ptr(de_all[s]), E - 2, sp()), 'relu_mask')
             if GD:
+                _lib.check(L.tnp_relu_mask(_off(dX, E), I, _off(Xs, E), I, M, GD - 2, _lib.ptr(dgoal_all[s]), GD - 2, sp()),
+                           'relu_mask')
                 gd = o2 - ctx.goals
                 nf = gd.norm(dim=1, keepdim=True)
-                gdir = torch.nan_to_num(torch.where(nf == 0, torch.zeros_like(gd), gd / nf)) * 4.0
-                g_lin = _lin(gdir, P['goal_embedding.input_embeddings.0.weight'], P['goal_embedding.input_embeddings.0.bias'])
-                parts += [torch.relu(g_lin), torch.zeros(M, 2, device=dev)]
-            acts = []
-            enc = None
+                gdir_all[s] = torch.nan_to_num(torch.where(nf == 0, torch.zeros_like(gd), gd / nf)) * 4.0
+            # ---- grid embedding MLP + scatter + social encoding backward ----
             if pool is not None:
-                tid = _lib.POOL_TYPES[pool.type_]
-                G, cell, half_x, half_y = pool._geometry()
-                C = pool.pooling_dim
-                if pool.type_ == 'social':
-                    enc = _lin(h_prev, P['pool.hidden_dim_encoding.weight'], P['pool.hidden_dim_encoding.bias'])
-                grid = torch.empty(M, C * G * G, device=dev)
                 o1c, o2c = o1.contiguous(), o2.contiguous()
+                enc = enc_all[s] if social else None
                 _lib.check(L.tnp_pool_grid_forward(tid, _lib.ptr(o1c), _lib.ptr(o2c), _lib.ptr(enc), C, _lib.ptr(idx.starts),
                                                    idx.B, idx.n_max, G, C, cell, half_x, half_y, float(pool.constant),
-                                                   _lib.ptr(grid), C * G * G, None, _lib.stream_ptr()), 'grid')
-                x = grid
-                for lin, name in zip(layers, lay_names):
-                    acts.append(x)
-                    x = _lin(x, P[name + '.weight'], P[name + '.bias'], relu=True)
-                parts.append(x)
-                pooled = x
-            X = torch.cat(parts, dim=1)
-            gates = _lin(X, w_ih, b_ih) + _lin(h_prev, w_hh, b_hh)
-            gi, gf, gg, go = torch.sigmoid(gates[:, :H]), torch.sigmoid(gates[:, H:2 * H]), torch.tanh(gates[:, 2 * H:3 * H]), \
-                torch.sigmoid(gates[:, 3 * H:])
-            c_new = gf * c_prev + gi * gg
-            tc = torch.tanh(c_new)
-            h_out = go * tc
-            # ---------------- Hidden2Normal backward (lstm/modules.py:56-64) ----------------
-            dn = torch.zeros(M, 5, device=dev)
-            if d_rel is not None:
-                dn = dn + torch.nan_to_num(d_rel[s])
-            if d_pred is not None:
-                dn[:, :2] = dn[:, :2] + torch.nan_to_num(d_pred[s + ctx.pos_offset])
-            dn = dn * mk
-            lin_n = _lin(h_out, wn, bn)
-            sg = torch.sigmoid(lin_n[:, 2:5])
-            dlin = dn.clone()
-            dlin[:, 2:4] = dn[:, 2:4] * 0.2 * sg[:, 0:2] * (1 - sg[:, 0:2])
-            dlin[:, 4] = dn[:, 4] * 0.7 * sg[:, 2] * (1 - sg[:, 2])
-            grads['hidden2normal.linear.weight'] += _mm(dlin.t(), h_out.t())
-            grads['hidden2normal.linear.bias'] += dlin.sum(0)
-            dh_tot = dh + _mm(dlin, wn.t())
-            # ---------------- LSTMCell backward (present rows; absent rows pass the state gradient through) --------
-            dh_m, dc_m = dh_tot * mk, dc * mk
-            do = dh_m * tc
-            dct = dc_m + dh_m * go * (1 - tc * tc)
-            dG = torch.cat([dct * gg * gi * (1 - gi), dct * c_prev * gf * (1 - gf), dct * gi * (1 - gg * gg),
-                            do * go * (1 - go)], dim=1)
-            dG_t = dG.t().contiguous()
-            grads[pre + '.weight_ih'] += _mm(dG_t, X.t())
-            grads[pre + '.weight_hh'] += _mm(dG_t, h_prev.t())
-            bsum = dG.sum(0)
-            grads[pre + '.bias_ih'] += bsum
-            grads[pre + '.bias_hh'] += bsum
-            dX = _mm(dG, w_ih.t())
-            dh_prev = _mm(dG, w_hh.t()) + dh_tot * (1 - mk)
-            dc_prev = dct * gf + dc * (1 - mk)
-            # ---------------- input / goal embedding backward ----------------
-            de = dX[:, :E - 2] * (emb_lin > 0).float()
-            grads['input_embedding.input_embeddings.0.weight'] += _mm(de.t(), vel.t())
-            grads['input_embedding.input_embeddings.0.bias'] += de.sum(0)
-            if GD:
-                dg_ = dX[:, E:E + GD - 2] * (g_lin > 0).float()
-                grads['goal_embedding.input_embeddings.0.weight'] += _mm(dg_.t(), gdir.t())
-                grads['goal_embedding.input_embeddings.0.bias'] += dg_.sum(0)
-            # ---------------- grid embedding MLP + scatter + social encoding backward ----------------
-            if pool is not None:
-                dy = dX[:, E + GD:]
-                out_act = pooled
-                for li in range(len(layers) - 1, -1, -1):
-                    name = lay_names[li]
-                    w = P[name + '.weight']
-                    dy = dy * (out_act > 0).float()
-                    grads[name + '.weight'] += _mm(dy.t(), acts[li].t())
-                    grads[name + '.bias'] += dy.sum(0)
-                    need_din = li > 0 or pool.type_ == 'social'
-                    if need_din:
-                        dy = _mm(dy, w.t())
-                    out_act = acts[li]
-                if pool.type_ == 'social':
-                    dgrid = dy.view(M, C, G * G)
-                    cells = torch.empty(M, idx.n_max, dtype=torch.int32, device=dev)
+                                                   _lib.ptr(grid_all[s]), C * G * G, None, sp()), 'grid')
+                nl = len(layers)
+                # last layer: its ReLU output is the pooled part of X
+                Pdim = layers[-1].weight.shape[0]
+                _lib.check(L.tnp_relu_mask(_off(dX, P0), I, _off(Xs, P0), I, M, Pdim, _lib.ptr(dy_all[nl - 1][s]), Pdim, sp()),
+                           'relu_mask')
+                for li in range(nl - 1, 0, -1):
+                    d_in = _lin(dy_all[li][s], layT[li])                    # dy . W_li: gradient of layer li's input
+                    a_prev = act_all[li - 1][s]
+                    n_prev = a_prev.shape[1]
+                    _lib.check(L.tnp_relu_mask(_lib.ptr(d_in), n_prev, _lib.ptr(a_prev), n_prev, M, n_prev,
+                                               _lib.ptr(dy_all[li - 1][s]), n_prev, sp()), 'relu_mask')
+                if social:
+                    _lin(dy_all[0][s], layT[0], out=dgrid)                  # gradient of the dense grid
                     _lib.check(L.tnp_pool_pair_cells(_lib.ptr(o2c), _lib.ptr(row_base), _lib.ptr(row_count), M, idx.n_max, G,
-                                                     cell, half_x, half_y, _lib.ptr(cells), _lib.stream_ptr()), 'pair_cells')
-                    valid = cells >= 0
-                    rows, js = valid.nonzero(as_tuple=True)
-                    cl = cells[rows, js].long()
-                    contrib = dgrid[rows, :, cl]                                  # [pairs, C]
-                    denc = torch.zeros(M, C, device=dev)
-                    denc.index_add_(0, row_base[rows].long() + js, contrib)
-                    grads['pool.hidden_dim_encoding.weight'] += _mm(denc.t(), h_prev.t())
-                    grads['pool.hidden_dim_encoding.bias'] += denc.sum(0)
-                    dh_prev = dh_prev + _mm(denc, P['pool.hidden_dim_encoding.weight'].t())
+                                                     cell, half_x, half_y, _lib.ptr(cells), sp()), 'pair_cells')
+                    _lib.check(L.tnp_social_scatter_backward(_lib.ptr(dgrid), C * G * G, _lib.ptr(cells), _lib.ptr(row_base),
+                                                             _lib.ptr(row_count), M, idx.n_max, C, G * G,
+                                                             _lib.ptr(denc_all[s]), sp()), 'scatter_backward')
+                    dh_prev += _lin(denc_all[s], whT)
             dh, dc = dh_prev, dc_prev
+
+        # ---- deferred weight gradients: one GEMM per parameter over the stacked steps ----
+        def wgrad(name, dy, x, bias_name):
+            dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+            grads[name] = _mm(dy2.t(), x2.t())
+            if bias_name is not None:
+                grads[bias_name] = dy2.sum(0)
+
+        h_out_all, h_prev_all = h_all[1:], h_all[:-1]
+        wgrad('hidden2normal.linear.weight', dlin_all, h_out_all, 'hidden2normal.linear.bias')
+        n_enc = sum(1 for d in decs if not d)
+        for pre, lo, hi in (('encoder', 0, n_enc), ('decoder', n_enc, S)):
+            if hi > lo:
+                wgrad(pre + '.weight_ih', dG_all[lo:hi], X_all[lo:hi], pre + '.bias_ih')
+                wgrad(pre + '.weight_hh', dG_all[lo:hi], h_prev_all[lo:hi], None)
+                grads[pre + '.bias_hh'] = grads[pre + '.bias_ih'].clone()
+        vel_all = torch.nan_to_num(torch.stack(o2s, dim=0) - torch.stack(o1s, dim=0)) * 4.0
+        wgrad('input_embedding.input_embeddings.0.weight', de_all, vel_all, 'input_embedding.input_embeddings.0.bias')
+        if GD:
+            wgrad('goal_embedding.input_embeddings.0.weight', dgoal_all, gdir_all, 'goal_embedding.input_embeddings.0.bias')
+        for li, name in enumerate(lay_names):
+            wgrad(name + '.weight', dy_all[li], grid_all if li == 0 else act_all[li - 1], name + '.bias')
+        if social:
+            wgrad('pool.hidden_dim_encoding.weight', denc_all, h_prev_all, 'pool.hidden_dim_encoding.bias')
 
         # parameters the forward never touches get no gradient (None, as autograd does for the reference), so that
         # optimizers skip them: a zero gradient would still let Adam + weight decay move them
-        def unused(n):
-            if n.startswith('goal_embedding.') and not model.goal_flag:
-                return True
-            return n.startswith('pool.hidden_dim_encoding.') and (pool is None or pool.type_ != 'social')
         out = [None] * 6
         for n in ctx.param_names:
-            out.append(None if unused(n) else grads[n])
+            out.append(grads.get(n))
         return tuple(out)
 
 
