@@ -379,6 +379,52 @@ def nongrid_cases(ref):
     print('nongrid_cases.npz')
 
 
+def sgan_train_case(ref):
+    """Parameter gradients of the reference for one discriminator step and one generator step of S-GAN training
+    (sgan/trainer.py:258-369: SGAN.forward in train mode, loss_criterion, loss.backward()) with seeded noise / labels.
+    The discriminator's last ReLU is dead at initialisation (scores 0, zero gradients), so its last bias is raised to
+    keep the adversarial terms alive."""
+    import random
+    import types
+    import trajnetbaselines.sgan.sgan as ref_sgan
+    import trajnetbaselines.sgan.trainer as ref_tr
+    import trajnetbaselines.lstm.loss as ref_loss
+    torch.manual_seed(23)
+    mk = lambda: ref.GridBasedPooling(type_='directional', hidden_dim=128, cell_side=0.6, n=12, out_dim=64,
+                                      embedding_arch='one_layer')
+    gen = ref_sgan.LSTMGenerator(pool=mk(), noise_dim=16)
+    disc = ref_sgan.LSTMDiscriminator(pool=mk())
+    model = ref_sgan.SGAN(generator=gen, discriminator=disc, k=3, d_steps=1, g_steps=1).train()
+    with torch.no_grad():
+        last = [mod for mod in disc.real_classifier if isinstance(mod, torch.nn.Linear)][-1]
+        last.bias.fill_(0.5)
+    out = {}
+    for k, v in model.state_dict().items():
+        out['sd_' + k] = v.numpy().copy()
+    xy, split = synth.ragged_crowd(4, 2, 7, seed=33)
+    M = xy.shape[1]
+    goals = torch.zeros(M, 2)
+    out.update(xy=xy.numpy(), split=split.numpy())
+    fake_self = types.SimpleNamespace(model=model, criterion=ref_loss.PredictionLoss(keep_batch_dim=True), pred_length=12)
+    fake_self.variety_loss = lambda *a: ref_tr.Trainer.variety_loss(fake_self, *a)
+    targets = xy[9:21] - xy[8:20]
+    for step_type in ('d', 'g'):
+        model.zero_grad()
+        torch.manual_seed(41)
+        random.seed(7)
+        rel, outs, s_real, s_fake = model(xy[:9].clone(), goals, split, xy[9:21].clone(), step_type=step_type, pred_length=12)
+        loss = ref_tr.Trainer.loss_criterion(fake_self, rel, targets, split, s_fake, s_real, step_type)
+        loss.backward()
+        out[step_type + '_loss'] = np.float64(loss.item())
+        out[step_type + '_scores_real'] = s_real.detach().numpy()
+        out[step_type + '_scores_fake'] = s_fake.detach().numpy()
+        for k, p in model.named_parameters():
+            out[step_type + '_grad_' + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+            out[step_type + '_hasgrad_' + k] = np.asarray(p.grad is not None)
+    np.savez_compressed(os.path.join(OUT, 'sgan_train_case.npz'), **out)
+    print('sgan_train_case.npz', out['d_loss'], out['g_loss'], out['d_scores_fake'].ravel())
+
+
 REAL_SEED = 123
 
 
@@ -428,6 +474,9 @@ def real_cases(ref):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.import_reference()
+    if '--only-sgantrain' in sys.argv:
+        return sgan_train_case(ref)
+    sgan_train_case(ref)
     if '--only-lstmlayer' in sys.argv:
         lstm_case(ref, 'addhidden')
         return lstm_case(ref, 'lstmlayer')

@@ -59,3 +59,46 @@ def test_sgan_predictor_modes():
     out = SGANPredictor(model)(make_paths(xy), np.zeros((xy.shape[1], 2)), n_predict=12, modes=3)
     assert sorted(out.keys()) == [0, 1, 2]
     assert out[0][0].shape == (12, 2) and out[1][1] == []
+
+
+def test_sgan_training_gradients_match_reference():
+    """One discriminator step and one generator step of S-GAN training (sgan/trainer.py:258-369) in train mode:
+    losses, scores and the gradient of EVERY parameter against the reference's autograd with the same noise / label
+    seeds (tests/golden/sgan_train_case.npz).  The generator step exercises the gradient that flows from the
+    discriminator's scores through its input positions back into the generator."""
+    import random
+    from trajnetplusplusbaselines_amd.lstm import GridBasedPooling, PredictionLoss
+    from trajnetplusplusbaselines_amd.sgan import SGAN, LSTMGenerator, LSTMDiscriminator
+    from trajnetplusplusbaselines_amd.sgan.train_step import loss_criterion
+    z = np.load(os.path.join(helpers.GOLDEN, 'sgan_train_case.npz'))
+    mk = lambda: GridBasedPooling(type_='directional', hidden_dim=128, cell_side=0.6, n=12, out_dim=64,
+                                  embedding_arch='one_layer')
+    model = SGAN(generator=LSTMGenerator(pool=mk(), noise_dim=16), discriminator=LSTMDiscriminator(pool=mk()), k=3,
+                 d_steps=1, g_steps=1)
+    model.load_state_dict({k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith('sd_')})
+    model = model.cuda().train()
+    xy, split = torch.tensor(z['xy']), torch.tensor(z['split'])
+    goals = torch.zeros(xy.shape[1], 2)
+    targets = (xy[9:21] - xy[8:20]).cuda()
+    crit = PredictionLoss(keep_batch_dim=True)
+    for step_type in ('d', 'g'):
+        model.zero_grad()
+        torch.manual_seed(41)
+        random.seed(7)
+        rel, outs, s_real, s_fake = model(xy[:9].clone(), goals, split, xy[9:21].clone(), step_type=step_type, pred_length=12)
+        np.testing.assert_allclose(s_real.detach().cpu().numpy(), z[step_type + '_scores_real'], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(s_fake.detach().cpu().numpy(), z[step_type + '_scores_fake'], rtol=2e-4, atol=2e-5)
+        loss = loss_criterion(model, crit, rel, targets, split, s_fake, s_real, step_type)
+        np.testing.assert_allclose(float(loss.detach()), float(z[step_type + '_loss']), rtol=5e-5)
+        loss.backward()
+        worst = 0.0
+        for name, p in model.named_parameters():
+            want = z[step_type + '_grad_' + name]
+            if p.grad is None:
+                assert not np.any(want), '%s step: %s has no gradient here but the reference has' % (step_type, name)
+                continue
+            scale = max(1e-6, float(np.abs(want).max()))
+            err = float(np.abs(p.grad.cpu().numpy() - want).max()) / scale
+            worst = max(worst, err)
+            assert err < 2e-3, '%s step, %s: relative error %.2e (scale %.2e)' % (step_type, name, err, scale)
+        print(step_type, 'step: worst relative gradient error %.2e' % worst)

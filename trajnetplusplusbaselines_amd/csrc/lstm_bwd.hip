@@ -121,7 +121,51 @@ __global__ void __launch_bounds__(256) social_scatter_backward_kernel(const floa
     denc[q] = acc;
 }
 
+// Backward of the directional grid's values with respect to the tracks' velocities (reference gridbased_pooling.py:
+// 118-143: value(i, j) = nan_to_num(v_j - v_i) scattered to cell(i, j); autograd gives every in-range pair its cell's
+// gradient and nothing through the integer cell index).  thread <-> track t:
+//   dvel[t] = sum_i dgrid[i, :, cell(i,t)]  (t as neighbour of ego i)  -  sum_j dgrid[t, :, cell(t,j)]  (t as ego)
+// over the pairs of t's scene whose two velocities are finite.
+__global__ void __launch_bounds__(256) directional_scatter_backward_kernel(const float *__restrict__ dgrid, int ldg,
+                                                                           const int32_t *__restrict__ cells,
+                                                                           const int32_t *__restrict__ row_base,
+                                                                           const int32_t *__restrict__ row_count,
+                                                                           const float *__restrict__ obs1,
+                                                                           const float *__restrict__ obs2, int M, int n_max,
+                                                                           int ncell, float *__restrict__ dvel) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M) return;
+    const int lo = row_base[t], ns = row_count[t], tt = t - lo;
+    auto finite_vel = [&](int r) {
+        const float a = obs1[2 * r], b = obs1[2 * r + 1], c = obs2[2 * r], d = obs2[2 * r + 1];
+        return (a == a) && (b == b) && (c == c) && (d == d);
+    };
+    float ax = 0.0f, ay = 0.0f;
+    if (finite_vel(t)) {
+        for (int i = lo; i < lo + ns; ++i) {
+            if (i == t || !finite_vel(i)) continue;
+            const int c1 = cells[(size_t)i * n_max + tt];
+            if (c1 >= 0) { ax += dgrid[(size_t)i * ldg + c1]; ay += dgrid[(size_t)i * ldg + ncell + c1]; }
+            const int c2 = cells[(size_t)t * n_max + (i - lo)];
+            if (c2 >= 0) { ax -= dgrid[(size_t)t * ldg + c2]; ay -= dgrid[(size_t)t * ldg + ncell + c2]; }
+        }
+    }
+    dvel[2 * t] = ax;
+    dvel[2 * t + 1] = ay;
+}
+
 }  // namespace tnp
+
+extern "C" TNP_API int tnp_directional_scatter_backward(const float *dgrid, int ldg, const int32_t *cells,
+                                                        const int32_t *row_base, const int32_t *row_count,
+                                                        const float *obs1, const float *obs2, int M, int n_max, int ncell,
+                                                        float *dvel, void *stream) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(tnp::directional_scatter_backward_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       dgrid, ldg, cells, row_base, row_count, obs1, obs2, M, n_max, ncell, dvel);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" TNP_API int tnp_h2n_backward(const float *h_out, const float *Wn, const float *bn, const float *d_normal,
                                         const float *d_pos, const float *obs1, const float *obs2, const float *dh_in, int M,

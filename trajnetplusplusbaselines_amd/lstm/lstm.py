@@ -222,7 +222,8 @@ class LSTM(torch.nn.Module):
                                           'use model.eval() / torch.no_grad() for inference'
                                           % (type(self.pool).__name__, '' if self.pool_to_input else ' with pool_to_input=False'))
             from .training import run_sequence_with_grad
-            return run_sequence_with_grad(self, observed, goals, batch_split, prediction_truth, T_dec)
+            rel_pred, pred, _ = run_sequence_with_grad(self, observed, goals, batch_split, prediction_truth, T_dec)
+            return rel_pred, pred
         rel_pred, pred, _ = self._run_sequence(observed, goals, batch_split, prediction_truth, T_dec)
         return rel_pred, pred
 

@@ -43,14 +43,25 @@ class StepSaves(ctypes.Structure):
 
 
 class SequenceFn(torch.autograd.Function):
-    """rel_pred, pred = SequenceFn.apply(model, observed, goals, batch_split, truth, T_dec, *params)"""
+    """rel_pred, pred, h_last = SequenceFn.apply(model, observed, goals, batch_split, truth, T_dec, opts, *params)
+
+    ``opts`` (dict): ``noise`` -- the S-GAN generator's noise vector: after the encoder the hidden state becomes
+    [ReLU(mlp_decoder_context(h)) | noise] (sgan/sgan.py:200-221); ``input_grad`` -- also return the gradient with
+    respect to ``observed`` (the S-GAN discriminator scores positions predicted by the generator): through the velocity
+    embedding and, for directional pooling, through the relative velocities stored in the grid.  ``h_last`` is the
+    hidden state after the last step (the discriminator's classifier input)."""
 
     @staticmethod
-    def forward(ctx, model, observed, goals, batch_split, truth, T_dec, *params):
+    def forward(ctx, model, observed, goals, batch_split, truth, T_dec, opts, *params):
         dev = params[0].device
         if dev.type != 'cuda':
             raise RuntimeError('LSTM parameters live on %s: move the model to a ROCm device (model.to("cuda")); '
                                'the MI355X path has no CPU fallback' % dev)
+        opts = opts or {}
+        noise = opts.get('noise')
+        ctx.input_grad = bool(opts.get('input_grad')) and observed.requires_grad
+        if ctx.input_grad and (model.goal_flag or T_dec != 0):
+            raise NotImplementedError('gradients with respect to the observed positions: encoder-only runs without goals')
         observed = _lib.f32c(observed.detach(), dev)
         truth = _lib.f32c(truth.detach(), dev) if truth is not None else None
         goals_t = _lib.f32c(goals.detach(), dev) if (goals is not None and model.goal_flag) else None
@@ -99,6 +110,15 @@ class SequenceFn(torch.autograd.Function):
             for t in range(1, T_obs):
                 run(s, 0, observed[t - 1].contiguous(), observed[t].contiguous())
                 s += 1
+            ctx.noise_at = None
+            if noise is not None:        # adding_noise (sgan/sgan.py:200-221): h <- [ReLU(W_ctx h + b_ctx) | z]
+                pd = dict(zip([n for n, _ in model.named_parameters()], params))
+                wc, bc = pd['mlp_decoder_context.0.weight'].detach(), pd['mlp_decoder_context.0.bias'].detach()
+                h_enc = h_all[s].clone()
+                ctx_act = _lin(h_enc, wc, bc, relu=True)
+                z = _lib.f32c(noise, dev).reshape(1, -1).expand(M, -1)
+                h_all[s] = torch.cat([ctx_act, z], dim=1)
+                ctx.noise_at = (s, h_enc, ctx_act)
             pt_prev = observed[-1].clone()
             prev_none = False
             for k in range(T_dec):
@@ -122,10 +142,11 @@ class SequenceFn(torch.autograd.Function):
         ctx.pos_offset = 1 if T_obs == 2 else 0
         ctx.param_names = [n for n, _ in model.named_parameters()]
         ctx.save_for_backward(*params)
-        return normals, torch.stack(positions, dim=0)
+        ctx.T_obs = T_obs
+        return normals, torch.stack(positions, dim=0), h_all[S].clone()
 
     @staticmethod
-    def backward(ctx, d_rel, d_pred):
+    def backward(ctx, d_rel, d_pred, d_hlast):
         model, idx = ctx.model, ctx.idx
         P = dict(zip(ctx.param_names, ctx.saved_tensors))
         h_all, c_all, X_all, gates_all, act_all, enc_all, o1s, o2s, decs = ctx.saved
@@ -144,13 +165,20 @@ class SequenceFn(torch.autograd.Function):
         def T(name):
             return P[name].detach().t().contiguous()
         wT = {pre: (T(pre + '.weight_ih'), T(pre + '.weight_hh')) for pre in set('decoder' if d else 'encoder' for d in decs)}
-        wn = P['hidden2normal.linear.weight'].detach().contiguous()
-        bn = P['hidden2normal.linear.bias'].detach().contiguous()
+        has_h2n = 'hidden2normal.linear.weight' in P            # the S-GAN discriminator has no output head
+        wn = P['hidden2normal.linear.weight'].detach().contiguous() if has_h2n else None
+        bn = P['hidden2normal.linear.bias'].detach().contiguous() if has_h2n else None
+
+        def h_out_of(step):     # hidden state produced by `step` (before the generator's noise replaced it)
+            if ctx.noise_at is not None and step == ctx.noise_at[0] - 1:
+                return ctx.noise_at[1]
+            return h_all[step + 1]
         layers = pool.embedding_layers() if pool is not None else []
         lay_names = ['pool.embedding.%d' % i for i, mod in enumerate(pool.embedding) if isinstance(mod, torch.nn.Linear)] \
             if pool is not None else []
         social = pool is not None and pool.type_ == 'social'
-        layT = [T(n + '.weight') if (li > 0 or social) else None for li, n in enumerate(lay_names)]
+        directional_in = ctx.input_grad and pool is not None and pool.type_ == 'directional'
+        layT = [T(n + '.weight') if (li > 0 or social or directional_in) else None for li, n in enumerate(lay_names)]
         whT = T('pool.hidden_dim_encoding.weight') if social else None
 
         # per-step operands of the deferred weight-gradient GEMMs
@@ -167,15 +195,20 @@ class SequenceFn(torch.autograd.Function):
             G, cell, half_x, half_y = pool._geometry()
             C = pool.pooling_dim
             grid_all = torch.empty(S, M, C * G * G, device=dev)
-            if social:
+            if social or directional_in:
                 sizes = (idx.starts[1:] - idx.starts[:-1]).long()
                 row_base = torch.repeat_interleave(idx.starts[:-1].long(), sizes).to(torch.int32)
                 row_count = torch.repeat_interleave(sizes, sizes).to(torch.int32)
                 cells = torch.empty(M, idx.n_max, dtype=torch.int32, device=dev)
                 dgrid = torch.empty(M, C * G * G, device=dev)
 
-        dh = torch.zeros(M, H, device=dev)
+        dh = _lib.f32c(d_hlast, dev).clone() if d_hlast is not None else torch.zeros(M, H, device=dev)
         dc = torch.zeros(M, H, device=dev)
+        d_obs = torch.zeros(ctx.T_obs, M, 2, device=dev) if ctx.input_grad else None
+        if ctx.input_grad:
+            emb_wT4 = torch.zeros(4, E - 2, device=dev)          # [W_emb^T ; 0 0] so that the GEMM's N is a multiple of 4
+            emb_wT4[:2] = P['input_embedding.input_embeddings.0.weight'].detach().t()
+            dvel_pool = torch.empty(M, 2, device=dev)
         dh_tot = torch.empty(M, H, device=dev)
         dh_pass = torch.empty(M, H, device=dev)
         dX = torch.empty(M, I, device=dev)
@@ -185,12 +218,24 @@ class SequenceFn(torch.autograd.Function):
             o1, o2 = o1s[s], o2s[s]
             pre = 'decoder' if decs[s] else 'encoder'
             w_ihT, w_hhT = wT[pre]
+            if ctx.noise_at is not None and s == ctx.noise_at[0] - 1:
+                # backward of adding_noise: dh is the gradient of [ReLU(W_ctx h + b_ctx) | z]
+                _, h_enc, ctx_act = ctx.noise_at
+                nc = ctx_act.shape[1]
+                dctx = torch.empty(M, nc, device=dev)
+                _lib.check(L.tnp_relu_mask(_lib.ptr(dh), H, _lib.ptr(ctx_act), nc, M, nc, _lib.ptr(dctx), nc, sp()), 'relu_mask')
+                grads['mlp_decoder_context.0.weight'] = _mm(dctx.t(), h_enc.t())
+                grads['mlp_decoder_context.0.bias'] = dctx.sum(0)
+                dh = _lin(dctx, T('mlp_decoder_context.0.weight'))
             # ---- Hidden2Normal backward + gradient of the new hidden state ----
-            _lib.check(L.tnp_h2n_backward(_lib.ptr(h_all[s + 1]), _lib.ptr(wn), _lib.ptr(bn),
-                                          _lib.ptr(d_rel[s]) if d_rel is not None else None,
-                                          _lib.ptr(d_pred[s + ctx.pos_offset]) if d_pred is not None else None,
-                                          _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(dh), M, H, _lib.ptr(dlin_all[s]), _lib.ptr(dh_tot),
-                                          sp()), 'tnp_h2n_backward')
+            if has_h2n:
+                _lib.check(L.tnp_h2n_backward(_lib.ptr(h_out_of(s)), _lib.ptr(wn), _lib.ptr(bn),
+                                              _lib.ptr(d_rel[s]) if d_rel is not None else None,
+                                              _lib.ptr(d_pred[s + ctx.pos_offset]) if d_pred is not None else None,
+                                              _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(dh), M, H, _lib.ptr(dlin_all[s]),
+                                              _lib.ptr(dh_tot), sp()), 'tnp_h2n_backward')
+            else:
+                dh_tot.copy_(dh)
             # ---- LSTMCell backward (absent rows pass the state gradient through) ----
             dc_prev = torch.empty(M, H, device=dev)
             _lib.check(L.tnp_lstm_cell_backward(_lib.ptr(gates_all[s]), _lib.ptr(c_all[s]), _lib.ptr(dh_tot), _lib.ptr(dc),
@@ -226,6 +271,13 @@ class SequenceFn(torch.autograd.Function):
                     n_prev = a_prev.shape[1]
                     _lib.check(L.tnp_relu_mask(_lib.ptr(d_in), n_prev, _lib.ptr(a_prev), n_prev, M, n_prev,
                                                _lib.ptr(dy_all[li - 1][s]), n_prev, sp()), 'relu_mask')
+                if directional_in:
+                    _lin(dy_all[0][s], layT[0], out=dgrid)
+                    _lib.check(L.tnp_pool_pair_cells(_lib.ptr(o2c), _lib.ptr(row_base), _lib.ptr(row_count), M, idx.n_max, G,
+                                                     cell, half_x, half_y, _lib.ptr(cells), sp()), 'pair_cells')
+                    _lib.check(L.tnp_directional_scatter_backward(_lib.ptr(dgrid), C * G * G, _lib.ptr(cells), _lib.ptr(row_base),
+                                                                  _lib.ptr(row_count), _lib.ptr(o1c), _lib.ptr(o2c), M, idx.n_max,
+                                                                  G * G, _lib.ptr(dvel_pool), sp()), 'directional_scatter_backward')
                 if social:
                     _lin(dy_all[0][s], layT[0], out=dgrid)                  # gradient of the dense grid
                     _lib.check(L.tnp_pool_pair_cells(_lib.ptr(o2c), _lib.ptr(row_base), _lib.ptr(row_count), M, idx.n_max, G,
@@ -234,6 +286,12 @@ class SequenceFn(torch.autograd.Function):
                                                              _lib.ptr(row_count), M, idx.n_max, C, G * G,
                                                              _lib.ptr(denc_all[s]), sp()), 'scatter_backward')
                     dh_prev += _lin(denc_all[s], whT)
+            if ctx.input_grad:   # vel = o2 - o1 feeds the input embedding (x4) and the directional grid values
+                dvel = _lin(de_all[s], emb_wT4)[:, :2] * 4.0
+                if directional_in:
+                    dvel = dvel + dvel_pool
+                d_obs[s + 1] += dvel
+                d_obs[s] -= dvel
             dh, dc = dh_prev, dc_prev
 
         # ---- deferred weight gradients: one GEMM per parameter over the stacked steps ----
@@ -244,7 +302,11 @@ class SequenceFn(torch.autograd.Function):
                 grads[bias_name] = dy2.sum(0)
 
         h_out_all, h_prev_all = h_all[1:], h_all[:-1]
-        wgrad('hidden2normal.linear.weight', dlin_all, h_out_all, 'hidden2normal.linear.bias')
+        if ctx.noise_at is not None:     # the last encoder step's output is the hidden state BEFORE the noise was added
+            h_out_all = h_out_all.clone()
+            h_out_all[ctx.noise_at[0] - 1] = ctx.noise_at[1]
+        if has_h2n:
+            wgrad('hidden2normal.linear.weight', dlin_all, h_out_all, 'hidden2normal.linear.bias')
         n_enc = sum(1 for d in decs if not d)
         for pre, lo, hi in (('encoder', 0, n_enc), ('decoder', n_enc, S)):
             if hi > lo:
@@ -262,12 +324,14 @@ class SequenceFn(torch.autograd.Function):
 
         # parameters the forward never touches get no gradient (None, as autograd does for the reference), so that
         # optimizers skip them: a zero gradient would still let Adam + weight decay move them
-        out = [None] * 6
+        out = [None, d_obs, None, None, None, None, None]
         for n in ctx.param_names:
             out.append(grads.get(n))
         return tuple(out)
 
 
-def run_sequence_with_grad(model, observed, goals, batch_split, truth, T_dec):
+def run_sequence_with_grad(model, observed, goals, batch_split, truth, T_dec, opts=None):
+    """(rel_pred, pred, h_last) attached to the autograd graph of the model's parameters (and of `observed` when
+    opts['input_grad'] is set and it requires grad)."""
     params = [p for _, p in model.named_parameters()]
-    return SequenceFn.apply(model, observed, goals, batch_split, truth, T_dec, *params)
+    return SequenceFn.apply(model, observed, goals, batch_split, truth, T_dec, opts, *params)

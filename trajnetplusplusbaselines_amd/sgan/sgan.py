@@ -56,11 +56,22 @@ class LSTMGenerator(LSTM):
             T_dec = truth.size(0)
         else:
             truth, T_dec = None, n_predict - 1
+        training = self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if training and (self.pool is not None and not hasattr(self.pool, 'embedding_layers')):
+            raise NotImplementedError('training through non-grid interaction modules is not available yet')
         if self.no_noise:
+            if training:
+                from ..lstm.training import run_sequence_with_grad
+                rel, pred, _ = run_sequence_with_grad(self, observed, goals, batch_split, truth, T_dec)
+                return rel, pred
             rel, pred, _ = self._run_sequence(observed, goals, batch_split, truth, T_dec)
             return rel, pred
         if noise is None:
             noise = get_noise((self.noise_dim,), self.noise_type, device='cpu')
+        if training:   # autograd through the sequence incl. the noise / context MLP (lstm/training.py)
+            from ..lstm.training import run_sequence_with_grad
+            rel, pred, _ = run_sequence_with_grad(self, observed, goals, batch_split, truth, T_dec, {'noise': noise})
+            return rel, pred
         lin = self.mlp_decoder_context[0]
         rel, pred, _ = self._run_sequence(observed, goals, batch_split, truth, T_dec, w_ctx=lin.weight, b_ctx=lin.bias,
                                           noise=noise)
@@ -92,6 +103,14 @@ class LSTMDiscriminator(LSTM):
     def forward(self, observed, prediction, goals, batch_split):
         """[T_obs,M,2], [T_pred,M,2] -> scores [B,1] of the primaries (reference sgan/sgan.py:512-576)."""
         dev = self.encoder.weight_ih.device
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training: gradients for the discriminator's parameters and, when the scored prediction comes from the
+            # generator, for the positions themselves (lstm/training.py, opts input_grad)
+            from ..lstm.training import run_sequence_with_grad
+            frames = torch.cat([observed.to(dev, torch.float32), prediction.to(dev, torch.float32)], dim=0)
+            _, _, h = run_sequence_with_grad(self, frames, goals, batch_split, None, 0, {'input_grad': True})
+            split = torch.as_tensor(batch_split, dtype=torch.int64).to(dev)
+            return self.real_classifier(h[split[:-1]])
         frames = torch.cat([_lib.f32c(observed, dev), _lib.f32c(prediction, dev)], dim=0)
         _, _, h = self._run_sequence(frames, goals, batch_split, None, 0, want_h_final=True)
         split = torch.as_tensor(batch_split, dtype=torch.int64).to(dev)
