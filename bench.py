@@ -125,7 +125,19 @@ def main():
     observed = xy[:9].to(device)
     goals = torch.zeros(M, 2, device=device)
 
-    if args.train:
+    if args.train and is_sgan:
+        # one discriminator step + one generator step (g_steps = d_steps = 1, sgan/trainer.py:119-135, 258-300)
+        from trajnetplusplusbaselines_amd.lstm import PredictionLoss
+        from trajnetplusplusbaselines_amd.sgan.train_step import train_batch as sgan_train_batch
+        g_opt = torch.optim.Adam(model.generator.parameters(), lr=1e-3, weight_decay=1e-4)
+        d_opt = torch.optim.Adam(model.discriminator.parameters(), lr=1e-3, weight_decay=1e-4)
+        criterion = PredictionLoss(keep_batch_dim=True)
+        scene_dev = xy.to(device)
+
+        def step():
+            sgan_train_batch(model, g_opt, d_opt, criterion, scene_dev, goals, split, 'd')
+            return sgan_train_batch(model, g_opt, d_opt, criterion, scene_dev, goals, split, 'g')
+    elif args.train:
         from trajnetplusplusbaselines_amd.lstm import PredictionLoss
         from trajnetplusplusbaselines_amd.lstm.train_step import train_batch
         optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)   # lstm/trainer.py:497
@@ -204,6 +216,14 @@ def main():
                             dense_equivalent_tflops=dense_flops / avg_s / 1e12,
                             share_of_step=ms.value * 1e-3 / elapsed)
 
+    if args.train and is_sgan:
+        workload_mode = 'S-GAN training: one discriminator step + one generator step (k=3, Adam)'
+    elif args.train:
+        workload_mode = 'training step (Trainer.train_batch: teacher-forced forward, NLL loss, backward, Adam)'
+    elif is_sgan:
+        workload_mode = 'SGAN.forward (k=3 generator samples, teacher-forced, + real/fake discriminator scores)'
+    else:
+        workload_mode = 'inference forward (LSTM.forward, n_predict=12)'
     if rank == 0:
         scenes_total = cfg['scenes'] * world
         value = scenes_total * 21 * args.steps / elapsed
@@ -221,10 +241,7 @@ def main():
             'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': '%s, %d scenes x %d agents x (9 obs + 12 pred) per GPU, %s' % (
-                           cfg['name'], cfg['scenes'], cfg['agents'],
-                           'training step (Trainer.train_batch: teacher-forced forward, NLL loss, backward, Adam)'
-                           if args.train else ('SGAN.forward (k=3 generator samples, teacher-forced, + real/fake discriminator scores)'
-                                               if is_sgan else 'inference forward (LSTM.forward, n_predict=12)')),
+                           cfg['name'], cfg['scenes'], cfg['agents'], workload_mode),
                        'scenes_per_gpu': cfg['scenes'], 'agents_per_scene': cfg['agents'],
                        'mode': 'training step (fwd + bwd + Adam%s)' % (' + gradient all-reduce' if world > 1 else '') if args.train else 'inference forward',
                        'recurrent_steps_per_forward': (3 * 19 + 2 * 20) if is_sgan else 19, 'parallelism': 'dp%d (scene sharding)' % world,

@@ -421,6 +421,23 @@ def sgan_train_case(ref):
         for k, p in model.named_parameters():
             out[step_type + '_grad_' + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
             out[step_type + '_hasgrad_' + k] = np.asarray(p.grad is not None)
+    # a short adversarial run: d, g, d, g with Adam(lr 1e-3, weight_decay 1e-4) on both networks (sgan/trainer.py:540-546)
+    model.zero_grad()
+    g_opt = torch.optim.Adam(model.generator.parameters(), lr=1e-3, weight_decay=1e-4)
+    d_opt = torch.optim.Adam(model.discriminator.parameters(), lr=1e-3, weight_decay=1e-4)
+    curve = []
+    for it, step_type in enumerate(('d', 'g', 'd', 'g')):
+        torch.manual_seed(50 + it)
+        random.seed(60 + it)
+        rel, outs, s_real, s_fake = model(xy[:9].clone(), goals, split, xy[9:21].clone(), step_type=step_type, pred_length=12)
+        loss = ref_tr.Trainer.loss_criterion(fake_self, rel, targets, split, s_fake, s_real, step_type)
+        opt = g_opt if step_type == 'g' else d_opt
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        curve.append(loss.item())
+    out['curve'] = np.asarray(curve, dtype=np.float64)
+    print('curve', curve)
     np.savez_compressed(os.path.join(OUT, 'sgan_train_case.npz'), **out)
     print('sgan_train_case.npz', out['d_loss'], out['g_loss'], out['d_scores_fake'].ravel())
 
