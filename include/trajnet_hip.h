@@ -276,6 +276,8 @@ TNP_API int tnp_relu_mask(const float *dy, int ld_dy, const float *act, int ld_a
 TNP_API int tnp_social_scatter_backward(const float *dgrid, int ldg, const int32_t *cells, const int32_t *row_base,
                                         const int32_t *row_count, int M, int n_max, int C, int ncell, float *denc,
                                         void *stream);
+/* out [cols, rows] = in [rows, cols]^T (LDS-tiled; operands of the weight-gradient GEMMs) */
+TNP_API int tnp_transpose(const float *in, int ld_in, int rows, int cols, float *out, int ld_out, void *stream);
 /* gradient of the directional grid's values (v_j - v_i, lstm/gridbased_pooling.py:118-143) with respect to the tracks'
  * velocities: dvel [M,2]; needed when the positions fed to the sequence carry gradient (S-GAN discriminator input) */
 TNP_API int tnp_directional_scatter_backward(const float *dgrid, int ldg, const int32_t *cells,

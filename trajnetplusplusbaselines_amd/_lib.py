@@ -97,6 +97,7 @@ def lib():
     L.tnp_relu_mask.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]
     L.tnp_social_scatter_backward.argtypes = [_fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, _fp, _fp]
+    L.tnp_transpose.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]
     L.tnp_directional_scatter_backward.argtypes = [_fp, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, _fp, _fp]
     L.tnp_pool_traj_forward.argtypes = [_fp, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp]

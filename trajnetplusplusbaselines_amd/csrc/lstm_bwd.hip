@@ -154,7 +154,34 @@ __global__ void __launch_bounds__(256) directional_scatter_backward_kernel(const
     dvel[2 * t + 1] = ay;
 }
 
+// out[c][r] = in[r][c]: 64x64 tiles through LDS (row stride 65 floats: conflict-free on both sides), coalesced 256-byte
+// reads and writes.  The weight-gradient GEMMs contract over the tracks, so both operands are needed K-major; the
+// stacked per-step operands are hundreds of MB and a strided copy kernel would run far below HBM speed.
+__global__ void __launch_bounds__(256) transpose_kernel(const float *__restrict__ in, int ld_in, int R, int C,
+                                                        float *__restrict__ out, int ld_out) {
+    __shared__ float tile[64][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 4 rows of 64 lanes
+    for (int k = ty; k < 64; k += 4) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < R && c < C) ? in[(size_t)r * ld_in + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < C && r < R) out[(size_t)c * ld_out + r] = tile[tx][k];
+    }
+}
+
 }  // namespace tnp
+
+extern "C" TNP_API int tnp_transpose(const float *in, int ld_in, int rows, int cols, float *out, int ld_out, void *stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(tnp::transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, in,
+                       ld_in, rows, cols, out, ld_out);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" TNP_API int tnp_directional_scatter_backward(const float *dgrid, int ldg, const int32_t *cells,
                                                         const int32_t *row_base, const int32_t *row_count,

@@ -32,6 +32,15 @@ def _mm(a, b_t):
     return _lib.linear_forward(a.contiguous(), b_t.contiguous(), None)
 
 
+def _transpose(x):
+    """[R, C] -> contiguous [C, R] with the LDS-tiled kernel (tnp_transpose)."""
+    x = x if x.stride(-1) == 1 else x.contiguous()
+    out = torch.empty(x.shape[1], x.shape[0], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().tnp_transpose(_lib.ptr(x), x.stride(0), x.shape[0], x.shape[1], _lib.ptr(out), x.shape[0],
+                                        _lib.stream_ptr()), 'tnp_transpose')
+    return out
+
+
 def _off(t, floats):
     """device pointer `floats` elements past the start of tensor t"""
     return ctypes.c_void_p(t.data_ptr() + 4 * floats)
@@ -164,7 +173,9 @@ class SequenceFn(torch.autograd.Function):
         # weights of the data-gradient GEMMs, transposed once per sweep ([in, out] rows for the NT kernel)
         def T(name):
             return P[name].detach().t().contiguous()
-        wT = {pre: (T(pre + '.weight_ih'), T(pre + '.weight_hh')) for pre in set('decoder' if d else 'encoder' for d in decs)}
+        # [W_ih^T ; W_hh^T]: one GEMM per step gives the gradients of the cell's input and of its previous hidden state
+        wT = {pre: torch.cat([T(pre + '.weight_ih'), T(pre + '.weight_hh')], dim=0)
+              for pre in set('decoder' if d else 'encoder' for d in decs)}
         has_h2n = 'hidden2normal.linear.weight' in P            # the S-GAN discriminator has no output head
         wn = P['hidden2normal.linear.weight'].detach().contiguous() if has_h2n else None
         bn = P['hidden2normal.linear.bias'].detach().contiguous() if has_h2n else None
@@ -211,13 +222,14 @@ class SequenceFn(torch.autograd.Function):
             dvel_pool = torch.empty(M, 2, device=dev)
         dh_tot = torch.empty(M, H, device=dev)
         dh_pass = torch.empty(M, H, device=dev)
-        dX = torch.empty(M, I, device=dev)
+        dXH = torch.empty(M, I + H, device=dev)                # [dX | dG . W_hh]
+        dX = dXH[:, :I]
+        LDX = I + H                                           # leading dimension of dX
         P0 = E + GD                                           # first pooled column of X
 
         for s in range(S - 1, -1, -1):
             o1, o2 = o1s[s], o2s[s]
             pre = 'decoder' if decs[s] else 'encoder'
-            w_ihT, w_hhT = wT[pre]
             if ctx.noise_at is not None and s == ctx.noise_at[0] - 1:
                 # backward of adding_noise: dh is the gradient of [ReLU(W_ctx h + b_ctx) | z]
                 _, h_enc, ctx_act = ctx.noise_at
@@ -241,14 +253,13 @@ class SequenceFn(torch.autograd.Function):
             _lib.check(L.tnp_lstm_cell_backward(_lib.ptr(gates_all[s]), _lib.ptr(c_all[s]), _lib.ptr(dh_tot), _lib.ptr(dc),
                                                 _lib.ptr(o1), _lib.ptr(o2), M, H, _lib.ptr(dG_all[s]), _lib.ptr(dc_prev),
                                                 _lib.ptr(dh_pass), sp()), 'tnp_lstm_cell_backward')
-            _lin(dG_all[s], w_ihT, out=dX)                                  # dX = dG . W_ih
-            dh_prev = _lin(dG_all[s], w_hhT)                                # dG . W_hh
-            dh_prev += dh_pass
+            _lin(dG_all[s], wT[pre], out=dXH)                               # [dG . W_ih | dG . W_hh]
+            dh_prev = dXH[:, I:] + dh_pass
             # ---- input / goal embedding backward (X holds the ReLU outputs) ----
             Xs = X_all[s]
-            _lib.check(L.tnp_relu_mask(_lib.ptr(dX), I, _lib.ptr(Xs), I, M, E - 2, _lib.ptr(de_all[s]), E - 2, sp()), 'relu_mask')
+            _lib.check(L.tnp_relu_mask(_lib.ptr(dX), LDX, _lib.ptr(Xs), I, M, E - 2, _lib.ptr(de_all[s]), E - 2, sp()), 'relu_mask')
             if GD:
-                _lib.check(L.tnp_relu_mask(_off(dX, E), I, _off(Xs, E), I, M, GD - 2, _lib.ptr(dgoal_all[s]), GD - 2, sp()),
+                _lib.check(L.tnp_relu_mask(_off(dX, E), LDX, _off(Xs, E), I, M, GD - 2, _lib.ptr(dgoal_all[s]), GD - 2, sp()),
                            'relu_mask')
                 gd = o2 - ctx.goals
                 nf = gd.norm(dim=1, keepdim=True)
@@ -263,7 +274,7 @@ class SequenceFn(torch.autograd.Function):
                 nl = len(layers)
                 # last layer: its ReLU output is the pooled part of X
                 Pdim = layers[-1].weight.shape[0]
-                _lib.check(L.tnp_relu_mask(_off(dX, P0), I, _off(Xs, P0), I, M, Pdim, _lib.ptr(dy_all[nl - 1][s]), Pdim, sp()),
+                _lib.check(L.tnp_relu_mask(_off(dX, P0), LDX, _off(Xs, P0), I, M, Pdim, _lib.ptr(dy_all[nl - 1][s]), Pdim, sp()),
                            'relu_mask')
                 for li in range(nl - 1, 0, -1):
                     d_in = _lin(dy_all[li][s], layT[li])                    # dy . W_li: gradient of layer li's input
@@ -297,7 +308,7 @@ class SequenceFn(torch.autograd.Function):
         # ---- deferred weight gradients: one GEMM per parameter over the stacked steps ----
         def wgrad(name, dy, x, bias_name):
             dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
-            grads[name] = _mm(dy2.t(), x2.t())
+            grads[name] = _lib.linear_forward(_transpose(dy2), _transpose(x2), None)
             if bias_name is not None:
                 grads[bias_name] = dy2.sum(0)
 
