@@ -242,7 +242,8 @@ TNP_API int tnp_lstm_step(const tnp_lstm_model *model, int decoder, const float 
  *   tnp_lstm_step_train: tnp_lstm_step that also keeps what the backward pass needs, written straight into the
  *   caller's buffers (any pointer may be NULL): X [M, I] the LSTMCell input (embedding | goal | interaction vector),
  *   act[l] [M, dims[l+1]] the ReLU outputs of the embedding MLP layers before the last, gates [M, 4H] the
- *   post-activation i, f, g, o of the present rows, enc [M, C] the social encoding.
+ *   post-activation i, f, g, o of the present rows, enc [M, C] the social encoding, nn_attrs the inputs of
+ *   NearestNeighborMLP's embedding.
  *   The backward kernels below are the pointwise / gather parts of the reverse sweep; every contraction is a
  *   tnp_linear_forward call on (transposed) operands.
  *   tnp_h2n_backward:      d(normal) -> d(Linear output) of Hidden2Normal (lstm/modules.py:56-64) and
@@ -259,6 +260,7 @@ typedef struct tnp_step_saves {
     float *act[2];
     float *gates;
     float *enc;
+    float *nn_attrs;   /* TNP_POOL_NN: [M, n, input_dim] gathered neighbour attributes */
 } tnp_step_saves;
 TNP_API int tnp_lstm_step_train(const tnp_lstm_model *model, int decoder, const float *h_in, const float *c_in,
                                 const float *obs1, const float *obs2, const float *goals,

@@ -266,14 +266,17 @@ def grad_case(ref):
     """Parameter gradients of the reference (loss.backward()) for small models: the trainer's loss
     PredictionLoss(rel[-12:], targets) * batch_size (lstm/trainer.py:252-265) plus a term on the predicted positions."""
     out = {}
-    for kind in ('social', 'directional', 'vanilla'):
-        torch.manual_seed({'social': 41, 'directional': 42, 'vanilla': 43}[kind])
+    import trajnetbaselines.lstm.non_gridbased_pooling as ng
+    for kind in ('social', 'directional', 'vanilla', 'nn'):
+        torch.manual_seed({'social': 41, 'directional': 42, 'vanilla': 43, 'nn': 44}[kind])
         pool = None
         if kind == 'social':
             pool = ref.GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=8, out_dim=64,
                                         embedding_arch='two_layer', layer_dims=[128], latent_dim=8)
         elif kind == 'directional':
             pool = ref.GridBasedPooling(type_='directional', hidden_dim=128, cell_side=0.6, n=12, out_dim=64)
+        elif kind == 'nn':
+            pool = ng.NearestNeighborMLP(n=4, out_dim=32)
         model = ref.LSTM(pool=pool).train()
         xy, split = synth.ragged_crowd(4, 2, 8, seed=51)
         M = xy.shape[1]

@@ -246,6 +246,7 @@ struct Workspace {
     float *pdst;     // where the interaction module writes its [M, P] result, and its leading dimension
     int pld;
     float *gates_save;   // training: post-activation gates of the step
+    float *nn_attrs_save;
     size_t bytes;
 };
 
@@ -296,6 +297,7 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     w.pdst = w.to_hidden ? w.hplus : (pool ? w.X + (w.I - P) : nullptr);
     w.pld = w.to_hidden ? md->H : w.I;
     w.gates_save = nullptr;
+    w.nn_attrs_save = nullptr;
     if (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ) {
         const int Hp = md->dims[0];
         w.ph[0] = (float *)take((size_t)M * Hp * 4);
@@ -364,7 +366,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
     const int H = md->H;
     if (md->pool_type == TNP_POOL_NN) {          // NearestNeighborMLP straight into the pooled columns of X
         int rc = launch_pool_nn(w.obs1, w.obs2, scene_start, B, md->n, md->C, md->Wp[0], md->bp[0], md->P / md->n,
-                                w.pdst, w.pld, s);
+                                w.pdst, w.pld, s, w.nn_attrs_save);
         if (rc) return rc;
     } else if (md->pool_type == TNP_POOL_HIDDENMLP) {   // pair embeddings + max-pool, then the projection GEMM
         const int ms = md->dims[0], mv = md->dims[1], mh = md->dims[2];
@@ -669,6 +671,7 @@ static int lstm_step_impl(const tnp_lstm_model *md, int decoder, const float *h_
         if (sv->act[1]) w.y[1] = sv->act[1];
         if (sv->enc) w.enc = sv->enc;
         w.gates_save = sv->gates;
+        w.nn_attrs_save = sv->nn_attrs;
     }
     if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s); if (rc) return rc; }
     PrepArgs p;

@@ -22,7 +22,7 @@ constexpr int NN_MAX_SEL = 8;
 __global__ void __launch_bounds__(64) pool_nn_kernel(const float *__restrict__ obs1, const float *__restrict__ obs2,
                                                      const int32_t *__restrict__ scene_start, int n_sel, int in_dim,
                                                      const float *__restrict__ W, const float *__restrict__ bias, int d,
-                                                     float *__restrict__ out, int ldo) {
+                                                     float *__restrict__ out, int ldo, float *__restrict__ attrs) {
     const int lo = scene_start[blockIdx.x], hi = scene_start[blockIdx.x + 1];
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const float xi = obs2[2 * i], yi = obs2[2 * i + 1];
@@ -67,6 +67,8 @@ __global__ void __launch_bounds__(64) pool_nn_kernel(const float *__restrict__ o
                     v = (obs2[2 * j + 1] - obs1[2 * j + 1]) - vyi;  a[3] = (v == v) ? v : 0.0f;
                 }
             }
+            if (attrs)   // training: the gathered (NaN -> 0) attributes are the embedding's input in the backward pass
+                for (int c = 0; c < in_dim; ++c) attrs[((size_t)i * n_sel + k) * in_dim + c] = a[c];
             for (int q = 0; q < d; ++q) {
                 float acc = bias[q];
                 for (int c = 0; c < in_dim; ++c) acc = fmaf(a[c], W[q * in_dim + c], acc);
@@ -118,11 +120,12 @@ __global__ void __launch_bounds__(256) pool_hiddenmlp_kernel(const float *__rest
 }
 
 int launch_pool_nn(const float *obs1, const float *obs2, const int32_t *scene_start, int B, int n_sel, int in_dim,
-                   const float *W, const float *bias, int d, float *out, int ldo, hipStream_t s) {
+                   const float *W, const float *bias, int d, float *out, int ldo, hipStream_t s, float *attrs) {
     if (B <= 0) return 0;
     if (n_sel < 1 || n_sel > NN_MAX_SEL) TNP_FAIL(-1, "NearestNeighborMLP: n = %d not in 1..%d", n_sel, NN_MAX_SEL);
     if (in_dim != 2 && in_dim != 4) TNP_FAIL(-1, "NearestNeighborMLP: input_dim %d not 2 or 4", in_dim);
-    hipLaunchKernelGGL(pool_nn_kernel, dim3(B), dim3(64), 0, s, obs1, obs2, scene_start, n_sel, in_dim, W, bias, d, out, ldo);
+    hipLaunchKernelGGL(pool_nn_kernel, dim3(B), dim3(64), 0, s, obs1, obs2, scene_start, n_sel, in_dim, W, bias, d, out, ldo,
+                       attrs);
     TNP_HIP(hipGetLastError());
     return 0;
 }
@@ -374,7 +377,7 @@ int launch_pool_traj(const float *obs1, const float *obs2, int M, const float *W
 extern "C" TNP_API int tnp_pool_nn_forward(const float *obs1, const float *obs2, const int32_t *scene_start, int B,
                                            int n_sel, int in_dim, const float *W, const float *bias, int d,
                                            float *out, int ldo, void *stream) {
-    return tnp::launch_pool_nn(obs1, obs2, scene_start, B, n_sel, in_dim, W, bias, d, out, ldo, (hipStream_t)stream);
+    return tnp::launch_pool_nn(obs1, obs2, scene_start, B, n_sel, in_dim, W, bias, d, out, ldo, (hipStream_t)stream, nullptr);
 }
 
 extern "C" TNP_API int tnp_pool_hiddenmlp_forward(const float *obs1, const float *obs2, const float *hidden_emb, int ldh,

@@ -48,7 +48,8 @@ def _off(t, floats):
 
 class StepSaves(ctypes.Structure):
     """mirror of ``struct tnp_step_saves`` (include/trajnet_hip.h)"""
-    _fields_ = [('X', ctypes.c_void_p), ('act', ctypes.c_void_p * 2), ('gates', ctypes.c_void_p), ('enc', ctypes.c_void_p)]
+    _fields_ = [('X', ctypes.c_void_p), ('act', ctypes.c_void_p * 2), ('gates', ctypes.c_void_p), ('enc', ctypes.c_void_p),
+                ('nn_attrs', ctypes.c_void_p)]
 
 
 class SequenceFn(torch.autograd.Function):
@@ -84,7 +85,8 @@ class SequenceFn(torch.autograd.Function):
         m, keep, _ = model._descriptor()
         ws, need = model._workspace(m, M, idx.B, dev)
         I = model.encoder.weight_ih.shape[1]
-        layers = pool.embedding_layers() if pool is not None else []
+        nn_pool = pool is not None and type(pool).__name__ == 'NearestNeighborMLP'
+        layers = pool.embedding_layers() if (pool is not None and not nn_pool) else []
         if len(layers) > 3:
             raise NotImplementedError('embedding MLPs deeper than three layers')
         # per-step slices of buffers allocated once per sequence
@@ -93,7 +95,9 @@ class SequenceFn(torch.autograd.Function):
         X_all = torch.empty(S, M, I, device=dev)
         gates_all = torch.empty(S, M, 4 * H, device=dev)
         act_all = [torch.empty(S, M, lin.weight.shape[0], device=dev) for lin in layers[:-1]]
-        enc_all = torch.empty(S, M, pool.pooling_dim, device=dev) if (pool is not None and pool.type_ == 'social') else None
+        enc_all = torch.empty(S, M, pool.pooling_dim, device=dev) \
+            if (pool is not None and not nn_pool and pool.type_ == 'social') else None
+        attrs_all = torch.empty(S, M, pool.n * pool.input_dim, device=dev) if nn_pool else None
         normals = torch.empty(S, M, 5, device=dev)
         o1s, o2s, decs = [], [], []
         positions = [observed[-1]] if T_obs == 2 else []
@@ -105,6 +109,7 @@ class SequenceFn(torch.autograd.Function):
                 sv.act[li] = a[s].data_ptr()
             sv.gates = gates_all[s].data_ptr()
             sv.enc = enc_all[s].data_ptr() if enc_all is not None else None
+            sv.nn_attrs = attrs_all[s].data_ptr() if attrs_all is not None else None
             _lib.check(L.tnp_lstm_step_train(
                 ctypes.byref(m), decoder, _lib.ptr(h_all[s]), _lib.ptr(c_all[s]), _lib.ptr(o1), _lib.ptr(o2),
                 _lib.ptr(goals_t), _lib.ptr(idx.starts), idx.B, M, idx.n_max, _lib.ptr(h_all[s + 1]), _lib.ptr(c_all[s + 1]),
@@ -148,6 +153,7 @@ class SequenceFn(torch.autograd.Function):
         del keep
         ctx.model, ctx.idx, ctx.goals = model, idx, goals_t
         ctx.saved = (h_all, c_all, X_all, gates_all, act_all, enc_all, o1s, o2s, decs)
+        ctx.attrs_all = attrs_all
         ctx.pos_offset = 1 if T_obs == 2 else 0
         ctx.param_names = [n for n, _ in model.named_parameters()]
         ctx.save_for_backward(*params)
@@ -184,11 +190,15 @@ class SequenceFn(torch.autograd.Function):
             if ctx.noise_at is not None and step == ctx.noise_at[0] - 1:
                 return ctx.noise_at[1]
             return h_all[step + 1]
-        layers = pool.embedding_layers() if pool is not None else []
+        nn_pool = ctx.attrs_all is not None                      # NearestNeighborMLP: only its embedding has parameters
+        layers = pool.embedding_layers() if (pool is not None and not nn_pool) else []
         lay_names = ['pool.embedding.%d' % i for i, mod in enumerate(pool.embedding) if isinstance(mod, torch.nn.Linear)] \
-            if pool is not None else []
-        social = pool is not None and pool.type_ == 'social'
-        directional_in = ctx.input_grad and pool is not None and pool.type_ == 'directional'
+            if (pool is not None and not nn_pool) else []
+        social = pool is not None and not nn_pool and pool.type_ == 'social'
+        dnn_all = torch.empty(S, M, pool.out_dim, device=dev) if nn_pool else None
+        directional_in = ctx.input_grad and pool is not None and not nn_pool and pool.type_ == 'directional'
+        if ctx.input_grad and nn_pool:
+            raise NotImplementedError('position gradients through NearestNeighborMLP')
         layT = [T(n + '.weight') if (li > 0 or social or directional_in) else None for li, n in enumerate(lay_names)]
         whT = T('pool.hidden_dim_encoding.weight') if social else None
 
@@ -201,7 +211,7 @@ class SequenceFn(torch.autograd.Function):
         dy_all = [torch.empty(S, M, lin.weight.shape[0], device=dev) for lin in layers]
         denc_all = torch.empty(S, M, pool.pooling_dim, device=dev) if social else None
         grid_all = None
-        if pool is not None:
+        if pool is not None and not nn_pool:
             tid = _lib.POOL_TYPES[pool.type_]
             G, cell, half_x, half_y = pool._geometry()
             C = pool.pooling_dim
@@ -264,8 +274,11 @@ class SequenceFn(torch.autograd.Function):
                 gd = o2 - ctx.goals
                 nf = gd.norm(dim=1, keepdim=True)
                 gdir_all[s] = torch.nan_to_num(torch.where(nf == 0, torch.zeros_like(gd), gd / nf)) * 4.0
+            if nn_pool:   # the pooled part of X is the concatenated ReLU(Linear(attrs)) of the n neighbours
+                _lib.check(L.tnp_relu_mask(_off(dX, P0), LDX, _off(Xs, P0), I, M, pool.out_dim, _lib.ptr(dnn_all[s]),
+                                           pool.out_dim, sp()), 'relu_mask')
             # ---- grid embedding MLP + scatter + social encoding backward ----
-            if pool is not None:
+            if pool is not None and not nn_pool:
                 o1c, o2c = o1.contiguous(), o2.contiguous()
                 enc = enc_all[s] if social else None
                 _lib.check(L.tnp_pool_grid_forward(tid, _lib.ptr(o1c), _lib.ptr(o2c), _lib.ptr(enc), C, _lib.ptr(idx.starts),
@@ -330,6 +343,10 @@ class SequenceFn(torch.autograd.Function):
             wgrad('goal_embedding.input_embeddings.0.weight', dgoal_all, gdir_all, 'goal_embedding.input_embeddings.0.bias')
         for li, name in enumerate(lay_names):
             wgrad(name + '.weight', dy_all[li], grid_all if li == 0 else act_all[li - 1], name + '.bias')
+        if nn_pool:       # rows = (step, track, neighbour slot)
+            d = pool.out_dim // pool.n
+            wgrad('pool.embedding.0.weight', dnn_all.reshape(-1, d), ctx.attrs_all.reshape(-1, pool.input_dim),
+                  'pool.embedding.0.bias')
         if social:
             wgrad('pool.hidden_dim_encoding.weight', denc_all, h_prev_all, 'pool.hidden_dim_encoding.bias')
 
