@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNP_ABI_VERSION 2
+#define TNP_ABI_VERSION 3
 #define TNP_API __attribute__((visibility("default")))
 
 /* pooling types: GridBasedPooling(type_=...)  lstm/gridbased_pooling.py:16-19,55-66 */
@@ -261,6 +261,7 @@ typedef struct tnp_step_saves {
     float *gates;
     float *enc;
     float *nn_attrs;   /* TNP_POOL_NN: [M, n, input_dim] gathered neighbour attributes */
+    int16_t *winners;  /* sparse first layer (tnp_lstm_sparse_first_layer() == 1): [M, n*n] winner of every cell, -1 = empty */
 } tnp_step_saves;
 TNP_API int tnp_lstm_step_train(const tnp_lstm_model *model, int decoder, const float *h_in, const float *c_in,
                                 const float *obs1, const float *obs2, const float *goals,
@@ -278,6 +279,33 @@ TNP_API int tnp_relu_mask(const float *dy, int ld_dy, const float *act, int ld_a
 TNP_API int tnp_social_scatter_backward(const float *dgrid, int ldg, const int32_t *cells, const int32_t *row_base,
                                         const int32_t *row_count, int M, int n_max, int C, int ncell, float *denc,
                                         void *stream);
+/* Sparse backward of the first grid-embedding layer (social pooling; replaces one dense [M,N1]x[N1,C*n*n] GEMM per step
+ * and the [N1, S*M]x[S*M, C*n*n] weight-gradient GEMM of autograd through gridbased_pooling.py:160-167 + the embedding
+ * Linear, lstm/gridbased_pooling.py:60-75).  w_cell_major / dw_cell_major: [n*n][C][N1], W'[c][ch][o] = W[o][ch*n*n+c].
+ *   tnp_lstm_sparse_first_layer: 1 when the step kernels of this model run the first layer from the winner table
+ *   tnp_pair_ego_lists:       cells [R = steps*M][n_max] (tnp_pool_pair_cells over the stacked steps) -> per step and
+ *                             cell the egos with an in-range neighbour in that cell: list [n*n][R][2] (ego row, -),
+ *                             count [n*n][steps]; occ [R][n*n] bytes and occ_t [n*n][R] are scratch
+ *   tnp_social_dgrid_cells:   dcell[i][c][ch] = dy[i, :] . W'[c][ch][:] for the listed (ego i, cell c) of one step
+ *                             (16 egos x 16 channels per v_mfma_f32_16x16x4_f32; other entries of dcell untouched)
+ *   tnp_social_scatter_backward_cells: denc[j, ch] = sum_{i: cell(i,j) >= 0} dcell[i][cell(i,j)][ch]
+ *                             (the three together = dense dgrid GEMM + tnp_social_scatter_backward)
+ *   tnp_sparse_hits_build:    winners [R = steps*M][n*n] (saved by tnp_lstm_step_train) -> per-cell hit lists
+ *                             list [n*n][R][2] = (ego row, encoding row), count [n*n]; hit_t [n*n][R] is scratch
+ *   tnp_sparse_wgrad:         dW'[c][ch][o] = sum over the hits (r, e) of cell c of dy[r, o] * enc[e, ch] */
+TNP_API int tnp_lstm_sparse_first_layer(const tnp_lstm_model *model, int M);
+TNP_API int tnp_pair_ego_lists(const int32_t *cells, int R, int M, int n_max, int ncell, uint8_t *occ, int32_t *occ_t,
+                               int32_t *list, int32_t *count, void *stream);
+TNP_API int tnp_social_dgrid_cells(const float *dy, int ldy, const float *w_cell_major, const int32_t *list,
+                                   const int32_t *count, int R, int step, int M, int C, int ncell, int N1, float *dcell,
+                                   void *stream);
+TNP_API int tnp_social_scatter_backward_cells(const float *dcell, const int32_t *cells, const int32_t *row_base,
+                                              const int32_t *row_count, int M, int n_max, int C, int ncell, float *denc,
+                                              void *stream);
+TNP_API int tnp_sparse_hits_build(const int16_t *winners, const int32_t *row_base, int R, int M, int ncell, int32_t *hit_t,
+                                  int32_t *list, int32_t *count, void *stream);
+TNP_API int tnp_sparse_wgrad(const float *dy, int ldy, const float *enc, int lde, const int32_t *list, const int32_t *count,
+                             int R, int C, int ncell, int N1, float *dw_cell_major, void *stream);
 /* out [cols, rows] = in [rows, cols]^T (LDS-tiled; operands of the weight-gradient GEMMs) */
 TNP_API int tnp_transpose(const float *in, int ld_in, int rows, int cols, float *out, int ld_out, void *stream);
 /* gradient of the directional grid's values (v_j - v_i, lstm/gridbased_pooling.py:118-143) with respect to the tracks'

@@ -114,3 +114,41 @@ def test_training_curve_matches_reference():
     a1, f1 = helpers.ade_fde(pred.cpu().numpy()[-12:, prim], truth)
     assert np.abs(a0 - a1).max() < 1e-4 and np.abs(f0 - f1).max() < 1e-4   # the 1e-4 m bar, after training
     print('losses', losses, 'ref', z['losses'].tolist(), 'dADE %.2e dFDE %.2e' % (np.abs(a0 - a1).max(), np.abs(f0 - f1).max()))
+
+
+def test_sparse_first_layer_backward_equals_dense_backward():
+    """The social first-layer gradients computed from the winner tables (tnp_social_dgrid_sparse, tnp_sparse_wgrad)
+    equal the dense GEMM backward on a crowd with duplicates, empty cells and ragged scenes; the golden social case
+    above runs the sparse form against the reference's autograd."""
+    import ctypes
+    from trajnetplusplusbaselines_amd import _lib
+    from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling, PredictionLoss
+    torch.manual_seed(5)
+    g = torch.Generator().manual_seed(11)
+    sizes = [7, 1, 19, 12, 3, 30]
+    split = torch.tensor([0] + list(np.cumsum(sizes)))
+    M = int(split[-1])
+    start = torch.rand(M, 2, generator=g) * 5.0
+    vel = (torch.rand(M, 2, generator=g) - 0.5) * 0.8
+    xy = start[None] + vel[None] * torch.arange(21)[:, None, None] * 0.4 + 0.02 * torch.randn(21, M, 2, generator=g)
+    xy[:5, 9] = float('nan')        # a late-appearing neighbour
+    xy[15:, 20] = float('nan')      # one that leaves
+    grads = {}
+    for sparse in (True, False):
+        torch.manual_seed(3)
+        pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.5, n=12, out_dim=64,
+                                embedding_arch='two_layer', layer_dims=[192], latent_dim=16)
+        model = LSTM(pool=pool).cuda().train()
+        model.sparse_backward = sparse
+        m, keep, _ = model._descriptor()
+        assert _lib.lib().tnp_lstm_sparse_first_layer(ctypes.byref(m), M) == 1
+        rel, pred = model(xy[:9].clone(), torch.zeros(M, 2), split, xy[9:20].clone())
+        targets = (xy[9:21] - xy[8:20]).cuda()
+        loss = PredictionLoss()(rel[-12:], targets, split) * len(sizes)
+        loss.backward()
+        grads[sparse] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert grads[True].keys() == grads[False].keys()
+    for n in grads[True]:
+        a, b = grads[True][n], grads[False][n]
+        scale = max(1e-6, float(b.abs().max()))
+        assert float((a - b).abs().max()) / scale < 2e-5, n

@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'trajnet_hip.h')
 
 POOL_NONE, POOL_OCCUPANCY, POOL_DIRECTIONAL, POOL_SOCIAL = -1, 0, 1, 2
 POOL_NN, POOL_HIDDENMLP, POOL_ATTNMLP, POOL_NNLSTM, POOL_TRAJ = 4, 5, 6, 7, 8
-ABI_VERSION = 2   # TNP_ABI_VERSION of include/trajnet_hip.h this binding was written against
+ABI_VERSION = 3   # TNP_ABI_VERSION of include/trajnet_hip.h this binding was written against
 POOL_TYPES = {None: POOL_NONE, 'occupancy': POOL_OCCUPANCY, 'directional': POOL_DIRECTIONAL, 'social': POOL_SOCIAL}
 
 _fp = ctypes.c_void_p
@@ -97,6 +97,15 @@ def lib():
     L.tnp_relu_mask.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]
     L.tnp_social_scatter_backward.argtypes = [_fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, _fp, _fp]
+    L.tnp_lstm_sparse_first_layer.argtypes = [ctypes.POINTER(LstmModel), ctypes.c_int]
+    L.tnp_pair_ego_lists.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp]
+    L.tnp_social_dgrid_cells.argtypes = [_fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]
+    L.tnp_social_scatter_backward_cells.argtypes = [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_int, _fp, _fp]
+    L.tnp_sparse_hits_build.argtypes = [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]
+    L.tnp_sparse_wgrad.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_int, _fp, _fp]
     L.tnp_transpose.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]
     L.tnp_directional_scatter_backward.argtypes = [_fp, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, _fp, _fp]

@@ -173,6 +173,251 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float *__restrict_
     }
 }
 
+
+// ---- sparse backward of the first grid-embedding layer (social pooling) ------------------------------------------
+// Forward (pool_embed_sparse.hip): y1[i, :] = sum over the occupied cells c of ego i of  W'[c][ch][:] * enc[winner(i,c), ch]
+// with W' the cell-major copy of pool.embedding[0].weight.  A scene of 32 agents occupies a few of the 256 cells, so
+// both gradients touch ~3 % of the dense [M, C*ncell] grid; the dense forms (one [M,N1]x[N1,C*ncell] GEMM per step
+// and one [N1, S*M] x [S*M, C*ncell] GEMM per sweep) were a third of the optimisation step.
+
+// Gradient of the occupied part of the grid, grouped by cell: for cell c and the egos r that have an in-range
+// neighbour in c (ego lists from pair_occupancy + hits_transpose + hits_compact),
+//     dcell[r][c][ch] = dy1[r, :] . W'[c][ch][:]
+// is a gathered [egos x N1] x [N1 x C] product per cell, so the 64 KB weight block of a cell is read once per workgroup
+// instead of once per (ego, neighbour) pair (the per-pair form moved 2.6 GB through L2 per step).  16 egos x 16 channels
+// per v_mfma_f32_16x16x4_f32; the four waves of a workgroup split N1 and their partial tiles are summed through LDS in a
+// fixed order.  The cell's weights sit in LDS in the lanes' operand order (wave-private, linear ds_read_b128).
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int NB>
+__global__ void __launch_bounds__(256) dgrid_cells_kernel(const float *__restrict__ dy, int ldy, const float *__restrict__ Wc,
+                                                          const int2 *__restrict__ list, const int32_t *__restrict__ count,
+                                                          int R, int nseg, int seg, int M, int C, int ncell, int N1,
+                                                          float *__restrict__ dcell) {
+    extern __shared__ __attribute__((aligned(16))) float4 cell_lds[];
+    const int c = blockIdx.x;
+    const int cnt = count[c * nseg + seg];
+    const int ngroups = (cnt + 15) >> 4;
+    if ((int)blockIdx.y >= ngroups) return;
+    const int2 *L = list + (size_t)c * R + (size_t)seg * M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane & 15, kq = lane >> 4;
+    const int KQ = N1 >> 2, T = KQ >> 4, k0 = wave * KQ;
+    float4 *Bw = cell_lds + (size_t)wave * T * NB * 64;
+    float *red = reinterpret_cast<float *>(cell_lds + (size_t)4 * T * NB * 64);   // [4 waves][NB][16 egos][16 ch]
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int ch = nb * 16 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ch < C) v = *reinterpret_cast<const float4 *>(Wc + ((size_t)c * C + ch) * N1 + k0 + 16 * t + 4 * kq);
+            Bw[(t * NB + nb) * 64 + lane] = v;
+        }
+    const int row_off = seg * M;
+    for (int g = blockIdx.y; g < ngroups; g += gridDim.y) {
+        const int idx = g * 16 + row;
+        const int rl = L[idx < cnt ? idx : 0].x - row_off;
+        const float *src = dy + (size_t)rl * ldy + k0 + 4 * kq;
+        floatx4 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int t0 = 0; t0 < T; t0 += 16) {
+            float4 a[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (t0 + u < T) a[u] = *reinterpret_cast<const float4 *>(src + 16 * (t0 + u));
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (t0 + u < T) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const float4 b = Bw[((t0 + u) * NB + nb) * 64 + lane];
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b.x, acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b.y, acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b.z, acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b.w, acc[nb], 0, 0, 0);
+                    }
+                }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) red[((wave * NB + nb) * 16 + 4 * kq + v) * 16 + row] = acc[nb][v];
+        __syncthreads();
+        for (int o = tid; o < NB * 256; o += 256) {
+            const int nb = o >> 8, i = (o >> 4) & 15, ch = nb * 16 + (o & 15);
+            const int at = (nb * 16 + i) * 16 + (o & 15);
+            const float sum = (red[at] + red[NB * 256 + at]) + (red[2 * NB * 256 + at] + red[3 * NB * 256 + at]);
+            const int id2 = g * 16 + i;
+            if (id2 < cnt && ch < C) dcell[((size_t)(L[id2].x - row_off) * ncell + c) * C + ch] = sum;
+        }
+        __syncthreads();
+    }
+}
+
+// occ[r][c] = 1 when ego row r has an in-range neighbour in cell c (cells from pair_cells_kernel; occ zeroed before)
+__global__ void __launch_bounds__(256) pair_occupancy_kernel(const int32_t *__restrict__ cells, long tot, int n_max, int ncell,
+                                                             uint8_t *__restrict__ occ) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= tot) return;
+    const int c = cells[q];
+    if (c >= 0) occ[(q / n_max) * ncell + c] = 1;
+}
+
+// d(enc)[j, ch] = sum over the egos i of j's scene with cell(i,j) >= 0 of dcell[i][cell(i,j)][ch]   (the scatter's
+// autograd gives every in-range neighbour its cell's gradient); fixed summation order
+__global__ void __launch_bounds__(256) social_scatter_backward_cells_kernel(const float *__restrict__ dcell,
+                                                                            const int32_t *__restrict__ cells,
+                                                                            const int32_t *__restrict__ row_base,
+                                                                            const int32_t *__restrict__ row_count, int M,
+                                                                            int n_max, int C, int ncell,
+                                                                            float *__restrict__ denc) {
+    // one wave per neighbour track j: lanes = (ego slice, channel); the four ego slices are combined in a fixed order
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, sub = lane >> 4;
+    if (j >= M) return;
+    const int lo = row_base[j], ns = row_count[j], jj = j - lo;
+    for (int ch = lane & 15; ch < ((C + 15) & ~15); ch += 16) {
+        float acc = 0.0f;
+#pragma unroll 4
+        for (int i = lo + sub; i < lo + ns; i += 4) {
+            const int c = cells[(size_t)i * n_max + jj];
+            if (c >= 0 && ch < C) acc += dcell[((size_t)i * ncell + c) * C + ch];
+        }
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        if (sub == 0 && ch < C) denc[(size_t)j * C + ch] = acc;
+    }
+}
+
+// hit_t[c][r] = global row (step*M + track) of the encoding stored in cell c of ego row r, or -1: the winner tables of
+// all steps, transposed so that a cell's hits over the whole sweep are contiguous.  64 x 64 tiles through LDS.
+// OCC: the table is the 0/1 occupancy of pair_occupancy_kernel and the entry is the ego row itself.
+template <typename T, bool OCC>
+__global__ void __launch_bounds__(256) hits_transpose_kernel(const T *__restrict__ table, const int32_t *__restrict__ row_base,
+                                                             int R, int M, int ncell, int32_t *__restrict__ hit_t) {
+    __shared__ int32_t tile[64][65];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = ty; k < 64; k += 4) {
+        const int r = r0 + k, c = c0 + tx;
+        int v = -1;
+        if (r < R && c < ncell) {
+            const int w = table[(size_t)r * ncell + c];
+            if (OCC) {
+                if (w) v = r;
+            } else if (w >= 0) {
+                const int i = r % M;
+                v = r - i + row_base[i] + w;
+            }
+        }
+        tile[k][tx] = v;
+    }
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4) {
+        const int c = c0 + k, r = r0 + tx;
+        if (r < R && c < ncell) hit_t[(size_t)c * R + r] = tile[tx][k];
+    }
+}
+
+// compact list of a cell's hits in ascending row order, per segment of `seg` rows (one segment = the whole sweep for the
+// weight gradient, one step for the ego lists): list[c][y*seg + k] = (ego row, entry), count[c*nseg + y]
+__global__ void __launch_bounds__(256) hits_compact_kernel(const int32_t *__restrict__ hit_t, int R, int seg,
+                                                           int2 *__restrict__ list, int32_t *__restrict__ count) {
+    __shared__ int wcnt[4];
+    const int c = blockIdx.x, y = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t *src = hit_t + (size_t)c * R + (size_t)y * seg;
+    int2 *dst = list + (size_t)c * R + (size_t)y * seg;
+    int total = 0;
+    for (int base = 0; base < seg; base += 256) {
+        const int k = base + tid;
+        const int e = (k < seg) ? src[k] : -1;
+        const unsigned long long m = __ballot(e >= 0);
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = total;
+        for (int q = 0; q < wave; ++q) off += wcnt[q];
+        if (e >= 0) dst[off + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(y * seg + k, e);
+        total += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) count[c * gridDim.y + y] = total;
+}
+
+// dW'[c][ch][n] = sum over the hits (r, e) of cell c of  dy1[r, n] * enc[e, ch]   (all steps of the sweep at once)
+// One wave per (cell, 64 output columns); the hit list and the encodings are wave-uniform (scalar loads), the dy1 rows
+// are 256-byte coalesced reads; hits in list order -> deterministic.
+template <int C>
+__global__ void __launch_bounds__(64) sparse_wgrad_kernel(const float *__restrict__ dy, int ldy,
+                                                          const float *__restrict__ enc, int lde,
+                                                          const int2 *__restrict__ list, const int32_t *__restrict__ count,
+                                                          int R, int N1, float *__restrict__ dWc) {
+    const int c = blockIdx.x, n = blockIdx.y * 64 + threadIdx.x;
+    const int cnt = count[c];
+    const int2 *L = list + (size_t)c * R;
+    float acc[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) acc[ch] = 0.0f;
+    int k = 0;
+    for (; k + 4 <= cnt; k += 4) {
+        const int2 h0 = L[k], h1 = L[k + 1], h2 = L[k + 2], h3 = L[k + 3];
+        const float d0 = dy[(size_t)h0.x * ldy + n], d1 = dy[(size_t)h1.x * ldy + n];
+        const float d2 = dy[(size_t)h2.x * ldy + n], d3 = dy[(size_t)h3.x * ldy + n];
+        const float *e0 = enc + (size_t)h0.y * lde, *e1 = enc + (size_t)h1.y * lde;
+        const float *e2 = enc + (size_t)h2.y * lde, *e3 = enc + (size_t)h3.y * lde;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch)
+            acc[ch] = fmaf(d3, e3[ch], fmaf(d2, e2[ch], fmaf(d1, e1[ch], fmaf(d0, e0[ch], acc[ch]))));
+    }
+    for (; k < cnt; ++k) {
+        const int2 h = L[k];
+        const float d = dy[(size_t)h.x * ldy + n];
+        const float *e = enc + (size_t)h.y * lde;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) acc[ch] = fmaf(d, e[ch], acc[ch]);
+    }
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) dWc[((size_t)c * C + ch) * N1 + n] = acc[ch];
+}
+
+static int launch_hit_lists(bool occ, const void *table, const int32_t *row_base, int R, int M, int ncell, int seg,
+                            int32_t *hit_t, int32_t *list, int32_t *count, hipStream_t s) {
+    const dim3 tg((R + 63) / 64, (ncell + 63) / 64);
+    if (occ)
+        hipLaunchKernelGGL((hits_transpose_kernel<uint8_t, true>), tg, dim3(256), 0, s, (const uint8_t *)table, row_base, R, M,
+                           ncell, hit_t);
+    else
+        hipLaunchKernelGGL((hits_transpose_kernel<int16_t, false>), tg, dim3(256), 0, s, (const int16_t *)table, row_base, R, M,
+                           ncell, hit_t);
+    TNP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(hits_compact_kernel, dim3(ncell, R / seg), dim3(256), 0, s, hit_t, R, seg,
+                       reinterpret_cast<int2 *>(list), count);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int NB>
+static int launch_dgrid_cells(const float *dy, int ldy, const float *Wc, const int2 *list, const int32_t *count, int R, int nseg,
+                              int seg, int M, int C, int ncell, int N1, float *dcell, hipStream_t s) {
+    const size_t lds = (size_t)N1 * NB * 64 + (size_t)NB * 4096;
+    if (lds > 160 * 1024) TNP_FAIL(-1, "tnp_social_dgrid_cells: N1 = %d, C = %d needs %zu bytes of LDS", N1, C, lds);
+    static bool configured = false;
+    if (!configured) {
+        TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dgrid_cells_kernel<NB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    hipLaunchKernelGGL(dgrid_cells_kernel<NB>, dim3(ncell, 4), dim3(256), lds, s, dy, ldy, Wc, list, count, R, nseg, seg, M, C,
+                       ncell, N1, dcell);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int C>
+static int launch_sparse_wgrad(const float *dy, int ldy, const float *enc, int lde, const int2 *list, const int32_t *count, int R,
+                               int ncell, int N1, float *dWc, hipStream_t s) {
+    hipLaunchKernelGGL(sparse_wgrad_kernel<C>, dim3(ncell, N1 / 64), dim3(64), 0, s, dy, ldy, enc, lde, list, count, R, N1, dWc);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace tnp
 
 extern "C" TNP_API int tnp_transpose(const float *in, int ld_in, int rows, int cols, float *out, int ld_out, void *stream) {
@@ -234,4 +479,62 @@ extern "C" TNP_API int tnp_social_scatter_backward(const float *dgrid, int ldg, 
                        (hipStream_t)stream, dgrid, ldg, cells, row_base, row_count, M, n_max, C, ncell, denc);
     TNP_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" TNP_API int tnp_pair_ego_lists(const int32_t *cells, int R, int M, int n_max, int ncell, uint8_t *occ,
+                                          int32_t *occ_t, int32_t *list, int32_t *count, void *stream) {
+    if (R <= 0 || ncell <= 0 || n_max <= 0) return 0;
+    if (M <= 0 || R % M != 0) TNP_FAIL(-1, "tnp_pair_ego_lists: R = %d is not a multiple of M = %d", R, M);
+    hipStream_t s = (hipStream_t)stream;
+    TNP_HIP(hipMemsetAsync(occ, 0, (size_t)R * ncell, s));
+    const long tot = (long)R * n_max;
+    hipLaunchKernelGGL(tnp::pair_occupancy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, cells, tot, n_max, ncell,
+                       occ);
+    TNP_HIP(hipGetLastError());
+    return tnp::launch_hit_lists(true, occ, nullptr, R, M, ncell, M, occ_t, list, count, s);
+}
+
+extern "C" TNP_API int tnp_social_dgrid_cells(const float *dy, int ldy, const float *w_cell_major, const int32_t *list,
+                                              const int32_t *count, int R, int step, int M, int C, int ncell, int N1,
+                                              float *dcell, void *stream) {
+    if (M <= 0 || ncell <= 0) return 0;
+    if (N1 % 64 != 0 || ldy % 4 != 0) TNP_FAIL(-1, "tnp_social_dgrid_cells: N1 = %d must be a multiple of 64 (ldy %d of 4)", N1, ldy);
+    if (R % M != 0 || step < 0 || step >= R / M) TNP_FAIL(-1, "tnp_social_dgrid_cells: step %d outside the %d-row lists", step, R);
+    if (C < 1 || C > 32) TNP_FAIL(-1, "tnp_social_dgrid_cells: C = %d not in 1..32", C);
+    const int2 *l2 = reinterpret_cast<const int2 *>(list);
+    if (C <= 16) return tnp::launch_dgrid_cells<1>(dy, ldy, w_cell_major, l2, count, R, R / M, step, M, C, ncell, N1, dcell, (hipStream_t)stream);
+    return tnp::launch_dgrid_cells<2>(dy, ldy, w_cell_major, l2, count, R, R / M, step, M, C, ncell, N1, dcell, (hipStream_t)stream);
+}
+
+extern "C" TNP_API int tnp_social_scatter_backward_cells(const float *dcell, const int32_t *cells, const int32_t *row_base,
+                                                         const int32_t *row_count, int M, int n_max, int C, int ncell,
+                                                         float *denc, void *stream) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(tnp::social_scatter_backward_cells_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, dcell, cells, row_base, row_count, M, n_max, C, ncell, denc);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" TNP_API int tnp_sparse_hits_build(const int16_t *winners, const int32_t *row_base, int R, int M, int ncell,
+                                             int32_t *hit_t, int32_t *list, int32_t *count, void *stream) {
+    if (R <= 0 || ncell <= 0) return 0;
+    if (M <= 0 || R % M != 0) TNP_FAIL(-1, "tnp_sparse_hits_build: R = %d is not a multiple of M = %d", R, M);
+    return tnp::launch_hit_lists(false, winners, row_base, R, M, ncell, R, hit_t, list, count, (hipStream_t)stream);
+}
+
+extern "C" TNP_API int tnp_sparse_wgrad(const float *dy, int ldy, const float *enc, int lde, const int32_t *list,
+                                        const int32_t *count, int R, int C, int ncell, int N1, float *dw_cell_major,
+                                        void *stream) {
+    if (R <= 0 || ncell <= 0) return 0;
+    if (N1 % 64 != 0) TNP_FAIL(-1, "tnp_sparse_wgrad: N1 = %d must be a multiple of 64", N1);
+    const int2 *l2 = reinterpret_cast<const int2 *>(list);
+    hipStream_t s = (hipStream_t)stream;
+    switch (C) {
+        case 4: return tnp::launch_sparse_wgrad<4>(dy, ldy, enc, lde, l2, count, R, ncell, N1, dw_cell_major, s);
+        case 8: return tnp::launch_sparse_wgrad<8>(dy, ldy, enc, lde, l2, count, R, ncell, N1, dw_cell_major, s);
+        case 16: return tnp::launch_sparse_wgrad<16>(dy, ldy, enc, lde, l2, count, R, ncell, N1, dw_cell_major, s);
+        case 32: return tnp::launch_sparse_wgrad<32>(dy, ldy, enc, lde, l2, count, R, ncell, N1, dw_cell_major, s);
+        default: TNP_FAIL(-1, "tnp_sparse_wgrad: C = %d not in {4, 8, 16, 32}", C);
+    }
 }

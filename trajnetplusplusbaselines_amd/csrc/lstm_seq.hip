@@ -531,6 +531,13 @@ extern "C" TNP_API size_t tnp_lstm_workspace_bytes(const tnp_lstm_model *model, 
     return w.bytes;
 }
 
+extern "C" TNP_API int tnp_lstm_sparse_first_layer(const tnp_lstm_model *model, int M) {
+    if (validate_model(model)) return -1;
+    Workspace w;
+    plan_workspace(model, M > 0 ? M : 1, nullptr, w);
+    return w.sparse ? 1 : 0;
+}
+
 static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, int T_obs, int M,
                              const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
                              int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
@@ -672,6 +679,7 @@ static int lstm_step_impl(const tnp_lstm_model *md, int decoder, const float *h_
         if (sv->enc) w.enc = sv->enc;
         w.gates_save = sv->gates;
         w.nn_attrs_save = sv->nn_attrs;
+        if (sv->winners && w.sparse) w.winners = sv->winners;
     }
     if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s); if (rc) return rc; }
     PrepArgs p;

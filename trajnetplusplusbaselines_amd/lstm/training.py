@@ -49,7 +49,7 @@ def _off(t, floats):
 class StepSaves(ctypes.Structure):
     """mirror of ``struct tnp_step_saves`` (include/trajnet_hip.h)"""
     _fields_ = [('X', ctypes.c_void_p), ('act', ctypes.c_void_p * 2), ('gates', ctypes.c_void_p), ('enc', ctypes.c_void_p),
-                ('nn_attrs', ctypes.c_void_p)]
+                ('nn_attrs', ctypes.c_void_p), ('winners', ctypes.c_void_p)]
 
 
 class SequenceFn(torch.autograd.Function):
@@ -98,6 +98,12 @@ class SequenceFn(torch.autograd.Function):
         enc_all = torch.empty(S, M, pool.pooling_dim, device=dev) \
             if (pool is not None and not nn_pool and pool.type_ == 'social') else None
         attrs_all = torch.empty(S, M, pool.n * pool.input_dim, device=dev) if nn_pool else None
+        # sparse first embedding layer: keep every step's winner table for the sparse backward
+        win_all = None
+        if enc_all is not None and opts.get('sparse_backward', getattr(model, 'sparse_backward', True)) and layers[0].weight.shape[0] % 64 == 0 \
+                and layers[0].weight.shape[0] * 64 + 4096 <= (160 * 1024) // ((pool.pooling_dim + 15) // 16) \
+                and L.tnp_lstm_sparse_first_layer(ctypes.byref(m), M) == 1:
+            win_all = torch.empty(S, M, pool.n * pool.n, dtype=torch.int16, device=dev)
         normals = torch.empty(S, M, 5, device=dev)
         o1s, o2s, decs = [], [], []
         positions = [observed[-1]] if T_obs == 2 else []
@@ -110,6 +116,7 @@ class SequenceFn(torch.autograd.Function):
             sv.gates = gates_all[s].data_ptr()
             sv.enc = enc_all[s].data_ptr() if enc_all is not None else None
             sv.nn_attrs = attrs_all[s].data_ptr() if attrs_all is not None else None
+            sv.winners = win_all[s].data_ptr() if win_all is not None else None
             _lib.check(L.tnp_lstm_step_train(
                 ctypes.byref(m), decoder, _lib.ptr(h_all[s]), _lib.ptr(c_all[s]), _lib.ptr(o1), _lib.ptr(o2),
                 _lib.ptr(goals_t), _lib.ptr(idx.starts), idx.B, M, idx.n_max, _lib.ptr(h_all[s + 1]), _lib.ptr(c_all[s + 1]),
@@ -154,6 +161,8 @@ class SequenceFn(torch.autograd.Function):
         ctx.model, ctx.idx, ctx.goals = model, idx, goals_t
         ctx.saved = (h_all, c_all, X_all, gates_all, act_all, enc_all, o1s, o2s, decs)
         ctx.attrs_all = attrs_all
+        ctx.win_all = win_all
+        ctx.w_cell_major = model._cell_major_weight(layers[0].weight, pool) if win_all is not None else None
         ctx.pos_offset = 1 if T_obs == 2 else 0
         ctx.param_names = [n for n, _ in model.named_parameters()]
         ctx.save_for_backward(*params)
@@ -199,7 +208,9 @@ class SequenceFn(torch.autograd.Function):
         directional_in = ctx.input_grad and pool is not None and not nn_pool and pool.type_ == 'directional'
         if ctx.input_grad and nn_pool:
             raise NotImplementedError('position gradients through NearestNeighborMLP')
-        layT = [T(n + '.weight') if (li > 0 or social or directional_in) else None for li, n in enumerate(lay_names)]
+        sparse_bwd = ctx.win_all is not None      # first layer's gradients from the winner tables (csrc/lstm_bwd.hip)
+        layT = [T(n + '.weight') if (li > 0 or ((social or directional_in) and not sparse_bwd)) else None
+                for li, n in enumerate(lay_names)]
         whT = T('pool.hidden_dim_encoding.weight') if social else None
 
         # per-step operands of the deferred weight-gradient GEMMs
@@ -215,13 +226,31 @@ class SequenceFn(torch.autograd.Function):
             tid = _lib.POOL_TYPES[pool.type_]
             G, cell, half_x, half_y = pool._geometry()
             C = pool.pooling_dim
-            grid_all = torch.empty(S, M, C * G * G, device=dev)
+            grid_all = torch.empty(S, M, C * G * G, device=dev) if not sparse_bwd else None
             if social or directional_in:
                 sizes = (idx.starts[1:] - idx.starts[:-1]).long()
                 row_base = torch.repeat_interleave(idx.starts[:-1].long(), sizes).to(torch.int32)
                 row_count = torch.repeat_interleave(sizes, sizes).to(torch.int32)
                 cells = torch.empty(M, idx.n_max, dtype=torch.int32, device=dev)
-                dgrid = torch.empty(M, C * G * G, device=dev)
+                dgrid = torch.empty(M, C * G * G, device=dev) if not sparse_bwd else None
+                if sparse_bwd:
+                    # pair cells of every step in one launch, then per (step, cell) the egos with a neighbour in that cell
+                    R, ncell = S * M, G * G
+                    step_off = (torch.arange(S, device=dev, dtype=torch.int32) * M)[:, None]
+                    rb_all = (step_off + row_base[None]).reshape(-1).contiguous()
+                    rc_all = row_count.repeat(S)
+                    o2_all = torch.stack(o2s, dim=0).contiguous()
+                    cells_all = torch.empty(S, M, idx.n_max, dtype=torch.int32, device=dev)
+                    _lib.check(L.tnp_pool_pair_cells(_lib.ptr(o2_all), _lib.ptr(rb_all), _lib.ptr(rc_all), R, idx.n_max, G,
+                                                     cell, half_x, half_y, _lib.ptr(cells_all), sp()), 'pair_cells')
+                    occ = torch.empty(R, ncell, dtype=torch.uint8, device=dev)
+                    occ_t = torch.empty(ncell, R, dtype=torch.int32, device=dev)
+                    ego_list = torch.empty(ncell, R, 2, dtype=torch.int32, device=dev)
+                    ego_count = torch.empty(ncell, S, dtype=torch.int32, device=dev)
+                    _lib.check(L.tnp_pair_ego_lists(_lib.ptr(cells_all), R, M, idx.n_max, ncell, _lib.ptr(occ), _lib.ptr(occ_t),
+                                                    _lib.ptr(ego_list), _lib.ptr(ego_count), sp()), 'ego_lists')
+                    dcell = torch.empty(M, ncell, C, device=dev)
+                    del occ, occ_t, rb_all, rc_all, o2_all
 
         dh = _lib.f32c(d_hlast, dev).clone() if d_hlast is not None else torch.zeros(M, H, device=dev)
         dc = torch.zeros(M, H, device=dev)
@@ -281,9 +310,10 @@ class SequenceFn(torch.autograd.Function):
             if pool is not None and not nn_pool:
                 o1c, o2c = o1.contiguous(), o2.contiguous()
                 enc = enc_all[s] if social else None
-                _lib.check(L.tnp_pool_grid_forward(tid, _lib.ptr(o1c), _lib.ptr(o2c), _lib.ptr(enc), C, _lib.ptr(idx.starts),
-                                                   idx.B, idx.n_max, G, C, cell, half_x, half_y, float(pool.constant),
-                                                   _lib.ptr(grid_all[s]), C * G * G, None, sp()), 'grid')
+                if not sparse_bwd:     # the dense grid is the only intermediate that is recomputed
+                    _lib.check(L.tnp_pool_grid_forward(tid, _lib.ptr(o1c), _lib.ptr(o2c), _lib.ptr(enc), C, _lib.ptr(idx.starts),
+                                                       idx.B, idx.n_max, G, C, cell, half_x, half_y, float(pool.constant),
+                                                       _lib.ptr(grid_all[s]), C * G * G, None, sp()), 'grid')
                 nl = len(layers)
                 # last layer: its ReLU output is the pooled part of X
                 Pdim = layers[-1].weight.shape[0]
@@ -302,13 +332,22 @@ class SequenceFn(torch.autograd.Function):
                     _lib.check(L.tnp_directional_scatter_backward(_lib.ptr(dgrid), C * G * G, _lib.ptr(cells), _lib.ptr(row_base),
                                                                   _lib.ptr(row_count), _lib.ptr(o1c), _lib.ptr(o2c), M, idx.n_max,
                                                                   G * G, _lib.ptr(dvel_pool), sp()), 'directional_scatter_backward')
-                if social:
-                    _lin(dy_all[0][s], layT[0], out=dgrid)                  # gradient of the dense grid
+                if social and sparse_bwd:     # only the cells that hold a neighbour carry a gradient
+                    N1 = dy_all[0].shape[2]
+                    _lib.check(L.tnp_social_dgrid_cells(_lib.ptr(dy_all[0][s]), N1, _lib.ptr(ctx.w_cell_major), _lib.ptr(ego_list),
+                                                        _lib.ptr(ego_count), R, s, M, C, ncell, N1, _lib.ptr(dcell), sp()),
+                               'dgrid_cells')
+                    _lib.check(L.tnp_social_scatter_backward_cells(_lib.ptr(dcell), _lib.ptr(cells_all[s]), _lib.ptr(row_base),
+                                                                   _lib.ptr(row_count), M, idx.n_max, C, ncell,
+                                                                   _lib.ptr(denc_all[s]), sp()), 'scatter_backward_cells')
+                elif social:
                     _lib.check(L.tnp_pool_pair_cells(_lib.ptr(o2c), _lib.ptr(row_base), _lib.ptr(row_count), M, idx.n_max, G,
                                                      cell, half_x, half_y, _lib.ptr(cells), sp()), 'pair_cells')
+                    _lin(dy_all[0][s], layT[0], out=dgrid)                  # gradient of the dense grid
                     _lib.check(L.tnp_social_scatter_backward(_lib.ptr(dgrid), C * G * G, _lib.ptr(cells), _lib.ptr(row_base),
                                                              _lib.ptr(row_count), M, idx.n_max, C, G * G,
                                                              _lib.ptr(denc_all[s]), sp()), 'scatter_backward')
+                if social:
                     dh_prev += _lin(denc_all[s], whT)
             if ctx.input_grad:   # vel = o2 - o1 feeds the input embedding (x4) and the directional grid values
                 dvel = _lin(de_all[s], emb_wT4)[:, :2] * 4.0
@@ -342,6 +381,20 @@ class SequenceFn(torch.autograd.Function):
         if GD:
             wgrad('goal_embedding.input_embeddings.0.weight', dgoal_all, gdir_all, 'goal_embedding.input_embeddings.0.bias')
         for li, name in enumerate(lay_names):
+            if li == 0 and sparse_bwd:
+                # dW'[cell][ch][:] from the per-cell hit lists of the whole sweep, then back to the parameter's layout
+                N1 = dy_all[0].shape[2]
+                hit_t = torch.empty(ncell, R, dtype=torch.int32, device=dev)
+                hits = torch.empty(ncell, R, 2, dtype=torch.int32, device=dev)
+                count = torch.empty(ncell, dtype=torch.int32, device=dev)
+                _lib.check(L.tnp_sparse_hits_build(_lib.ptr(ctx.win_all), _lib.ptr(row_base), R, M, ncell, _lib.ptr(hit_t),
+                                                   _lib.ptr(hits), _lib.ptr(count), sp()), 'hits_build')
+                dwc = torch.empty(ncell, C, N1, device=dev)
+                _lib.check(L.tnp_sparse_wgrad(_lib.ptr(dy_all[0]), N1, _lib.ptr(enc_all), C, _lib.ptr(hits), _lib.ptr(count),
+                                              R, C, ncell, N1, _lib.ptr(dwc), sp()), 'sparse_wgrad')
+                grads[name + '.weight'] = dwc.permute(2, 1, 0).reshape(N1, C * ncell)
+                grads[name + '.bias'] = dy_all[0].reshape(-1, N1).sum(0)
+                continue
             wgrad(name + '.weight', dy_all[li], grid_all if li == 0 else act_all[li - 1], name + '.bias')
         if nn_pool:       # rows = (step, track, neighbour slot)
             d = pool.out_dim // pool.n
