@@ -268,6 +268,25 @@ TNP_API int tnp_lstm_step_train(const tnp_lstm_model *model, int decoder, const 
                                 const int32_t *scene_start, int B, int M, int n_max, float *h_out, float *c_out,
                                 float *normal, const tnp_step_saves *saves, void *workspace,
                                 size_t workspace_bytes, void *stream);
+/* Whole training forward in one call: tnp_lstm_forward_ex that leaves what the backward sweep needs in the caller's
+ * buffers, all [steps = T_obs-1+T_dec] x M rows, contiguous: h_all / c_all [steps+1, M, H] (state before step s and
+ * after the last one), X_all [steps, M, I] (LSTMCell input), act_all[l] (ReLU output of embedding layer l), gates_all
+ * [steps, M, 4H] (post-activation i,f,g,o), enc_all [steps, M, C] (social encodings), nn_attrs_all, winners_all
+ * [steps, M, n*n] (see tnp_step_saves), obs1_all / obs2_all [steps, M, 2] (the positions every step ran on).  With the
+ * S-GAN noise interface h_all[T_obs-1] holds [ReLU(W_ctx h + b_ctx) | z] and h_clean [M, H] the encoder state h. */
+typedef struct tnp_train_saves {
+    float *h_all, *c_all, *X_all;
+    float *act_all[2];
+    float *gates_all, *enc_all, *nn_attrs_all;
+    int16_t *winners_all;
+    float *obs1_all, *obs2_all;
+    float *h_clean;
+} tnp_train_saves;
+TNP_API int tnp_lstm_forward_train(const tnp_lstm_model *model, const float *observed, int T_obs, int M, const float *goals,
+                                   const int32_t *scene_start, const uint8_t *primary_flag, int B, int n_max,
+                                   const float *truth, int T_dec, float *rel_pred, float *pred, void *workspace,
+                                   size_t workspace_bytes, const tnp_lstm_extras *extras, const tnp_train_saves *saves,
+                                   void *stream);
 TNP_API int tnp_h2n_backward(const float *h_out, const float *Wn, const float *bn, const float *d_normal,
                              const float *d_pos, const float *obs1, const float *obs2, const float *dh_in, int M, int H,
                              float *dlin, float *dh_tot, void *stream);

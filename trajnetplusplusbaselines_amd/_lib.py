@@ -80,6 +80,9 @@ def lib():
     L.tnp_lstm_forward_ex.argtypes = [ctypes.POINTER(LstmModel), _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp,
                                       ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t,
                                       ctypes.POINTER(LstmExtras), _fp]
+    L.tnp_lstm_forward_train.argtypes = [ctypes.POINTER(LstmModel), _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp,
+                                         ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t,
+                                         ctypes.POINTER(LstmExtras), _fp, _fp]
     L.tnp_lstm_step.argtypes = [ctypes.POINTER(LstmModel), ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
                                 ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, ctypes.c_size_t, _fp]
     L.tnp_profile_begin.argtypes = [ctypes.c_int]

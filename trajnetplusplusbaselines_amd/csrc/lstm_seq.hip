@@ -541,10 +541,15 @@ extern "C" TNP_API int tnp_lstm_sparse_first_layer(const tnp_lstm_model *model, 
 static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, int T_obs, int M,
                              const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
                              int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
-                             void *workspace, size_t workspace_bytes, const tnp_lstm_extras *ex, void *stream) {
+                             void *workspace, size_t workspace_bytes, const tnp_lstm_extras *ex,
+                             const tnp_train_saves *sv, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc = validate_model(md);
     if (rc) return rc;
+    if (sv && (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ))
+        TNP_FAIL(-1, "tnp_lstm_forward_train: stateful interaction encoders are inference-only");
+    if (sv && (!sv->h_all || !sv->c_all || !sv->X_all || !sv->gates_all || !sv->obs1_all || !sv->obs2_all))
+        TNP_FAIL(-1, "tnp_lstm_forward_train: h_all, c_all, X_all, gates_all, obs1_all, obs2_all are required");
     if (T_obs < 2) TNP_FAIL(-1, "need at least 2 observed frames (got %d)", T_obs);
     if (T_dec < 0) TNP_FAIL(-1, "negative decoder length");
     if (M <= 0 || B <= 0) return 0;
@@ -559,8 +564,11 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
     const size_t F = (size_t)M * 2;
     const int H = md->H;
     if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s); if (rc) return rc; }
-    TNP_HIP(hipMemsetAsync(w.h[0], 0, (size_t)M * H * 4, s));  // lstm.py:207-210
-    TNP_HIP(hipMemsetAsync(w.c, 0, (size_t)M * H * 4, s));
+    const size_t MH = (size_t)M * H;
+    // training: the states of all steps stay in the caller's [steps + 1, M, H] buffers instead of the ping-pong pair
+    float *hcur = sv ? sv->h_all : w.h[0];
+    TNP_HIP(hipMemsetAsync(hcur, 0, MH * 4, s));  // lstm.py:207-210
+    TNP_HIP(hipMemsetAsync(sv ? sv->c_all : w.c, 0, MH * 4, s));
     if (w.ph[0]) {  // pool.reset() (lstm/lstm.py:213-216): zero interaction-encoder state, all tracks "present"
         TNP_HIP(hipMemsetAsync(w.ph[0], 0, (size_t)M * md->dims[0] * 4, s));
         TNP_HIP(hipMemsetAsync(w.pc, 0, (size_t)M * md->dims[0] * 4, s));
@@ -573,15 +581,29 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
     }
     const int n_steps = (T_obs - 1) + T_dec;
     for (int st = 0; st <= n_steps; ++st) {
+        const float *obs2_prev = w.obs2;
+        if (sv && st < n_steps) {   // this step's intermediates go straight into the caller's per-step slices
+            const size_t r = (size_t)st * M;
+            w.X = sv->X_all + r * w.I;
+            w.pdst = w.to_hidden ? w.hplus : (md->pool_type != TNP_POOL_NONE ? w.X + (w.I - md->P) : nullptr);
+            if (sv->act_all[0]) w.y[0] = sv->act_all[0] + r * md->dims[1];
+            if (sv->act_all[1]) w.y[1] = sv->act_all[1] + r * md->dims[2];
+            if (sv->enc_all) w.enc = sv->enc_all + r * md->C;
+            w.gates_save = sv->gates_all + r * 4 * H;
+            w.nn_attrs_save = sv->nn_attrs_all ? sv->nn_attrs_all + r * md->n * md->C : nullptr;
+            if (sv->winners_all && w.sparse) w.winners = sv->winners_all + r * md->n * md->n;
+            w.obs1 = sv->obs1_all + r * 2;
+            w.obs2 = sv->obs2_all + r * 2;
+        }
         PrepArgs p;
         fill_prep_common(p, md, w, M);
-        p.h = w.h[cur];
+        p.h = hcur;
         p.primary = primary_flag;
         p.goals = goals;
         p.have_prev = st > 0;
         if (p.have_prev) {
             p.mask_prev = w.mask;       // read before this launch overwrites it: each thread owns one track
-            p.obs2_prev = w.obs2;
+            p.obs2_prev = obs2_prev;
             p.normal_out = rel_pred + (size_t)nnorm * M * 5;
             p.pos_out = pred + (size_t)npos * F;
             ++nnorm; ++npos;            // the entry being written is positions[-1] for the next step
@@ -612,32 +634,55 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
             pa.have_next = 0;
             rc = launch_prepare(pa, s);
             if (rc) return rc;
+            const float *clean = hcur;
+            float *noisy = w.h[cur ^ 1];
+            if (sv) {   // h_all[st] becomes the decoder's input state; the clean encoder state is kept beside it
+                if (!sv->h_clean) TNP_FAIL(-1, "tnp_lstm_forward_train: noise interface without h_clean");
+                TNP_HIP(hipMemcpyAsync(sv->h_clean, hcur, MH * 4, hipMemcpyDeviceToDevice, s));
+                clean = sv->h_clean;
+                noisy = hcur;
+            }
             GemmArgs g;
             memset(&g, 0, sizeof(g));
-            g.A1 = w.h[cur]; g.lda1 = H; g.K1 = H;
+            g.A1 = clean; g.lda1 = H; g.K1 = H;
             g.B1 = ex->W_ctx; g.ldb1 = H; g.bias1 = ex->b_ctx;
-            g.M = M; g.N = H - ex->noise_dim; g.C = w.h[cur ^ 1]; g.ldc = H; g.relu = 1;
+            g.M = M; g.N = H - ex->noise_dim; g.C = noisy; g.ldc = H; g.relu = 1;
             rc = launch_linear(g, 0, s);
             if (rc) return rc;
             const int tot = M * ex->noise_dim;
-            hipLaunchKernelGGL(noise_broadcast_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, w.h[cur ^ 1], M, H,
+            hipLaunchKernelGGL(noise_broadcast_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, noisy, M, H,
                                ex->noise_dim, ex->noise);
             TNP_HIP(hipGetLastError());
-            cur ^= 1;
-            p.h = w.h[cur];
+            if (!sv) cur ^= 1;
+            hcur = noisy;
+            p.h = hcur;
             p.have_prev = 0;
             p.pos2 = pred + (size_t)(npos - 1) * F;
         }
         rc = launch_prepare(p, s);
         if (rc) return rc;
         if (p.have_next) {
-            rc = run_step_body(md, decoder, w, w.h[cur], w.h[cur ^ 1], w.c, w.c, scene_start, B, M, n_max, s);
+            float *hnext = sv ? sv->h_all + (size_t)(st + 1) * MH : w.h[cur ^ 1];
+            const float *c_in = sv ? sv->c_all + (size_t)st * MH : w.c;
+            float *c_out = sv ? sv->c_all + (size_t)(st + 1) * MH : w.c;
+            rc = run_step_body(md, decoder, w, hcur, hnext, c_in, c_out, scene_start, B, M, n_max, s);
             if (rc) return rc;
             cur ^= 1;
+            hcur = hnext;
         }
     }
-    if (ex && ex->h_final) TNP_HIP(hipMemcpyAsync(ex->h_final, w.h[cur], (size_t)M * H * 4, hipMemcpyDeviceToDevice, s));
+    if (ex && ex->h_final) TNP_HIP(hipMemcpyAsync(ex->h_final, hcur, MH * 4, hipMemcpyDeviceToDevice, s));
     return 0;
+}
+
+extern "C" TNP_API int tnp_lstm_forward_train(const tnp_lstm_model *md, const float *observed, int T_obs, int M,
+                                      const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
+                                      int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
+                                      void *workspace, size_t workspace_bytes, const tnp_lstm_extras *extras,
+                                      const tnp_train_saves *saves, void *stream) {
+    if (!saves) TNP_FAIL(-1, "tnp_lstm_forward_train: saves == NULL");
+    return lstm_forward_impl(md, observed, T_obs, M, goals, scene_start, primary_flag, B, n_max, truth, T_dec, rel_pred,
+                             pred, workspace, workspace_bytes, extras, saves, stream);
 }
 
 extern "C" TNP_API int tnp_lstm_forward(const tnp_lstm_model *md, const float *observed, int T_obs, int M,
@@ -645,7 +690,7 @@ extern "C" TNP_API int tnp_lstm_forward(const tnp_lstm_model *md, const float *o
                                 int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
                                 void *workspace, size_t workspace_bytes, void *stream) {
     return lstm_forward_impl(md, observed, T_obs, M, goals, scene_start, primary_flag, B, n_max, truth, T_dec, rel_pred,
-                             pred, workspace, workspace_bytes, nullptr, stream);
+                             pred, workspace, workspace_bytes, nullptr, nullptr, stream);
 }
 
 extern "C" TNP_API int tnp_lstm_forward_ex(const tnp_lstm_model *md, const float *observed, int T_obs, int M,
@@ -654,7 +699,7 @@ extern "C" TNP_API int tnp_lstm_forward_ex(const tnp_lstm_model *md, const float
                                    void *workspace, size_t workspace_bytes, const tnp_lstm_extras *extras,
                                    void *stream) {
     return lstm_forward_impl(md, observed, T_obs, M, goals, scene_start, primary_flag, B, n_max, truth, T_dec, rel_pred,
-                             pred, workspace, workspace_bytes, extras, stream);
+                             pred, workspace, workspace_bytes, extras, nullptr, stream);
 }
 
 static int lstm_step_impl(const tnp_lstm_model *md, int decoder, const float *h_in, const float *c_in,

@@ -1,11 +1,11 @@
 """Training path of the LSTM forecaster: autograd through the whole sequence (reference lstm/trainer.py:229-269 calls
 ``loss.backward()`` on the outputs of ``LSTM.forward``).
 
-Forward: every recurrent step is one ``tnp_lstm_step_train`` call -- the inference step kernels, which additionally
-leave what the backward pass needs (LSTMCell input ``X``, embedding-MLP activations, post-activation gates, social
-encoding) in per-step slices of buffers allocated once per sequence.  Nothing is recomputed in the backward pass
-except the dense grid of a step (needed for the first embedding layer's weight gradient), which the grid kernel
-rebuilds from the saved positions and encodings.
+Forward: ONE ``tnp_lstm_forward_train`` call -- the fused sequence driver of the inference path (encoder and decoder
+steps, feedback of the predicted positions), which additionally leaves what the backward pass needs (states, LSTMCell
+input ``X``, embedding-MLP activations, post-activation gates, social encodings, winner tables, the positions every
+step ran on) in per-step slices of buffers allocated once per sequence.  Nothing is recomputed in the backward pass
+except, when the first embedding layer's backward runs dense, the dense grid of a step.
 
 Backward: an explicit reverse sweep.  Per step: ``tnp_h2n_backward`` and ``tnp_lstm_cell_backward`` (pointwise
 derivatives from the saved gates), data-gradient GEMMs on the fp32 MFMA kernel against weights transposed once per
@@ -52,6 +52,14 @@ class StepSaves(ctypes.Structure):
                 ('nn_attrs', ctypes.c_void_p), ('winners', ctypes.c_void_p)]
 
 
+class TrainSaves(ctypes.Structure):
+    """mirror of ``struct tnp_train_saves`` (include/trajnet_hip.h)"""
+    _fields_ = [('h_all', ctypes.c_void_p), ('c_all', ctypes.c_void_p), ('X_all', ctypes.c_void_p),
+                ('act_all', ctypes.c_void_p * 2), ('gates_all', ctypes.c_void_p), ('enc_all', ctypes.c_void_p),
+                ('nn_attrs_all', ctypes.c_void_p), ('winners_all', ctypes.c_void_p), ('obs1_all', ctypes.c_void_p),
+                ('obs2_all', ctypes.c_void_p), ('h_clean', ctypes.c_void_p)]
+
+
 class SequenceFn(torch.autograd.Function):
     """rel_pred, pred, h_last = SequenceFn.apply(model, observed, goals, batch_split, truth, T_dec, opts, *params)
 
@@ -90,8 +98,8 @@ class SequenceFn(torch.autograd.Function):
         if len(layers) > 3:
             raise NotImplementedError('embedding MLPs deeper than three layers')
         # per-step slices of buffers allocated once per sequence
-        h_all = torch.zeros(S + 1, M, H, device=dev)
-        c_all = torch.zeros(S + 1, M, H, device=dev)
+        h_all = torch.empty(S + 1, M, H, device=dev)
+        c_all = torch.empty(S + 1, M, H, device=dev)
         X_all = torch.empty(S, M, I, device=dev)
         gates_all = torch.empty(S, M, 4 * H, device=dev)
         act_all = [torch.empty(S, M, lin.weight.shape[0], device=dev) for lin in layers[:-1]]
@@ -105,58 +113,37 @@ class SequenceFn(torch.autograd.Function):
                 and L.tnp_lstm_sparse_first_layer(ctypes.byref(m), M) == 1:
             win_all = torch.empty(S, M, pool.n * pool.n, dtype=torch.int16, device=dev)
         normals = torch.empty(S, M, 5, device=dev)
-        o1s, o2s, decs = [], [], []
-        positions = [observed[-1]] if T_obs == 2 else []
-
-        def run(s, decoder, o1, o2):
-            sv = StepSaves()
-            sv.X = X_all[s].data_ptr()
-            for li, a in enumerate(act_all):
-                sv.act[li] = a[s].data_ptr()
-            sv.gates = gates_all[s].data_ptr()
-            sv.enc = enc_all[s].data_ptr() if enc_all is not None else None
-            sv.nn_attrs = attrs_all[s].data_ptr() if attrs_all is not None else None
-            sv.winners = win_all[s].data_ptr() if win_all is not None else None
-            _lib.check(L.tnp_lstm_step_train(
-                ctypes.byref(m), decoder, _lib.ptr(h_all[s]), _lib.ptr(c_all[s]), _lib.ptr(o1), _lib.ptr(o2),
-                _lib.ptr(goals_t), _lib.ptr(idx.starts), idx.B, M, idx.n_max, _lib.ptr(h_all[s + 1]), _lib.ptr(c_all[s + 1]),
-                _lib.ptr(normals[s]), ctypes.byref(sv), _lib.ptr(ws), need, _lib.stream_ptr()), 'tnp_lstm_step_train')
-            o1s.append(o1)
-            o2s.append(o2)
-            decs.append(decoder)
-            positions.append(o2 + normals[s][:, :2])
-
-        with torch.no_grad():
-            s = 0
-            for t in range(1, T_obs):
-                run(s, 0, observed[t - 1].contiguous(), observed[t].contiguous())
-                s += 1
-            ctx.noise_at = None
-            if noise is not None:        # adding_noise (sgan/sgan.py:200-221): h <- [ReLU(W_ctx h + b_ctx) | z]
-                pd = dict(zip([n for n, _ in model.named_parameters()], params))
-                wc, bc = pd['mlp_decoder_context.0.weight'].detach(), pd['mlp_decoder_context.0.bias'].detach()
-                h_enc = h_all[s].clone()
-                ctx_act = _lin(h_enc, wc, bc, relu=True)
-                z = _lib.f32c(noise, dev).reshape(1, -1).expand(M, -1)
-                h_all[s] = torch.cat([ctx_act, z], dim=1)
-                ctx.noise_at = (s, h_enc, ctx_act)
-            pt_prev = observed[-1].clone()
-            prev_none = False
-            for k in range(T_dec):
-                if prev_none:
-                    o1 = positions[-2].clone()
-                else:
-                    o1 = pt_prev.clone()
-                    o1[prim] = positions[-2][prim]
-                if truth is None:
-                    o2 = positions[-1].clone()
-                else:
-                    o2 = truth[k].clone()
-                    o2[prim] = positions[-1][prim]
-                run(s, 1, o1, o2)
-                s += 1
-                pt_prev = o2
-                prev_none = truth is None
+        o1_all = torch.empty(S, M, 2, device=dev)
+        o2_all = torch.empty(S, M, 2, device=dev)
+        pos_all = torch.empty(S + (1 if T_obs == 2 else 0), M, 2, device=dev)
+        sv = TrainSaves()
+        sv.h_all, sv.c_all, sv.X_all, sv.gates_all = h_all.data_ptr(), c_all.data_ptr(), X_all.data_ptr(), gates_all.data_ptr()
+        for li, a in enumerate(act_all):
+            sv.act_all[li] = a.data_ptr()
+        sv.enc_all = enc_all.data_ptr() if enc_all is not None else None
+        sv.nn_attrs_all = attrs_all.data_ptr() if attrs_all is not None else None
+        sv.winners_all = win_all.data_ptr() if win_all is not None else None
+        sv.obs1_all, sv.obs2_all = o1_all.data_ptr(), o2_all.data_ptr()
+        ex = _lib.LstmExtras()
+        ctx.noise_at = None
+        if noise is not None:        # adding_noise (sgan/sgan.py:200-221): h <- [ReLU(W_ctx h + b_ctx) | z]
+            pd = dict(zip([n for n, _ in model.named_parameters()], params))
+            wc = _lib.f32c(pd['mlp_decoder_context.0.weight'].detach(), dev)
+            bc = _lib.f32c(pd['mlp_decoder_context.0.bias'].detach(), dev)
+            z = _lib.f32c(noise, dev).reshape(-1)
+            h_enc = torch.empty(M, H, device=dev)
+            sv.h_clean = h_enc.data_ptr()
+            ex.W_ctx, ex.b_ctx, ex.noise, ex.noise_dim = _lib.ptr(wc), _lib.ptr(bc), _lib.ptr(z), int(z.numel())
+        # the whole sequence (encoder + decoder steps, feedback of the predicted positions) is one driver call
+        _lib.check(L.tnp_lstm_forward_train(
+            ctypes.byref(m), _lib.ptr(observed), T_obs, M, _lib.ptr(goals_t), _lib.ptr(idx.starts), _lib.ptr(idx.primary),
+            idx.B, idx.n_max, _lib.ptr(truth), T_dec, _lib.ptr(normals), _lib.ptr(pos_all), _lib.ptr(ws), need,
+            ctypes.byref(ex), ctypes.byref(sv), _lib.stream_ptr()), 'tnp_lstm_forward_train')
+        if noise is not None:
+            s_noise = T_obs - 1
+            ctx.noise_at = (s_noise, h_enc, h_all[s_noise][:, :H - int(z.numel())].contiguous())
+        o1s, o2s = list(o1_all.unbind(0)), list(o2_all.unbind(0))
+        decs = [0] * (T_obs - 1) + [1] * T_dec
         del keep
         ctx.model, ctx.idx, ctx.goals = model, idx, goals_t
         ctx.saved = (h_all, c_all, X_all, gates_all, act_all, enc_all, o1s, o2s, decs)
@@ -167,7 +154,7 @@ class SequenceFn(torch.autograd.Function):
         ctx.param_names = [n for n, _ in model.named_parameters()]
         ctx.save_for_backward(*params)
         ctx.T_obs = T_obs
-        return normals, torch.stack(positions, dim=0), h_all[S].clone()
+        return normals, pos_all, h_all[S].clone()
 
     @staticmethod
     def backward(ctx, d_rel, d_pred, d_hlast):
