@@ -287,6 +287,39 @@ TNP_API int tnp_lstm_forward_train(const tnp_lstm_model *model, const float *obs
                                    const float *truth, int T_dec, float *rel_pred, float *pred, void *workspace,
                                    size_t workspace_bytes, const tnp_lstm_extras *extras, const tnp_train_saves *saves,
                                    void *stream);
+/* The reverse sweep over steps s_hi .. s_lo (inclusive, descending) of a sequence run by tnp_lstm_forward_train: per step
+ * tnp_h2n_backward, tnp_lstm_cell_backward, the data-gradient GEMMs against the transposed weights, ReLU masks, the
+ * embedding MLP / grid scatter / social encoding backward -- what autograd does for one LSTM.step (lstm/lstm.py:91-168).
+ * Leaves the stacked operands of the deferred weight-gradient GEMMs in the caller's [steps, M, .] buffers and the state
+ * gradient in dh / dc.  Callers split the sweep where host logic intervenes (the S-GAN noise hook). */
+typedef struct tnp_bwd_sweep {
+    const tnp_lstm_model *model;     /* geometry + hidden2normal weights (NULL Wn: no output head, S-GAN discriminator) */
+    const tnp_train_saves *saves;
+    int32_t S, M, B, n_max, n_enc;   /* steps, tracks, scenes, largest scene, encoder steps (the rest use the decoder cell) */
+    int32_t pos_offset;              /* d_pred row of step s is s + pos_offset (1 when T_obs == 2) */
+    int32_t nn_pool;                 /* 1: TNP_POOL_NN (only its embedding has parameters) */
+    int32_t social_sparse;           /* 1: first-layer backward from the ego lists (tnp_pair_ego_lists) */
+    int32_t directional_in;          /* 1: gradient of the directional grid with respect to the velocities (input_grad) */
+    int32_t h_override_step;         /* step whose output state is h_override instead of h_all[step+1] (-1: none) */
+    const float *h_override;
+    const int32_t *scene_start;
+    const float *d_rel, *d_pred;     /* upstream gradients [S,M,5] / [S+pos_offset,M,2], either may be NULL */
+    const float *wT_enc, *wT_dec;    /* [I+H, 4H] = [W_ih^T ; W_hh^T] of the two cells (wT_dec NULL when no decoder step) */
+    const float *layT[3];            /* W_l^T [in_l, out_l] of embedding layer l; l = 0 only for the dense first-layer paths */
+    const float *whT;                /* social: hidden_dim_encoding.weight^T [H, C] */
+    const float *w_cell_major;       /* social_sparse */
+    const int32_t *row_base, *row_count;            /* [M] first row / size of each track's scene */
+    const int32_t *cells_all, *ego_list, *ego_count; /* social_sparse: [S,M,n_max], [n*n,S*M,2], [n*n,S] */
+    float *dlin_all, *dG_all, *de_all, *dgoal_all;  /* [S,M,5], [S,M,4H], [S,M,E-2], [S,M,goal_dim-2] */
+    float *dy_all[3];                /* [S,M,dims[l+1]] gradient of embedding layer l's pre-activation */
+    float *denc_all, *dnn_all;       /* [S,M,C] social; [S,M,P] TNP_POOL_NN */
+    float *dvel_pool_all;            /* directional_in: [S,M,2] */
+    float *grid_all;                 /* dense first-layer weight gradient: [S,M,dims[0]] recomputed grids (else NULL) */
+    float *dh, *dc;                  /* [M,H] in: gradient of the state after step s_hi; out: of the state before s_lo */
+} tnp_bwd_sweep;
+TNP_API size_t tnp_lstm_backward_scratch_bytes(const tnp_bwd_sweep *sweep);
+TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *sweep, int s_hi, int s_lo, void *scratch, size_t scratch_bytes,
+                                    void *stream);
 TNP_API int tnp_h2n_backward(const float *h_out, const float *Wn, const float *bn, const float *d_normal,
                              const float *d_pos, const float *obs1, const float *obs2, const float *dh_in, int M, int H,
                              float *dlin, float *dh_tot, void *stream);

@@ -418,6 +418,52 @@ static int launch_sparse_wgrad(const float *dy, int ldy, const float *enc, int l
     return 0;
 }
 
+// gradient of the previous hidden state: the W_hh part of the fused data-gradient GEMM + what bypassed the cell for
+// absent rows (+ the social encoding's contribution)
+__global__ void __launch_bounds__(256) state_grad_combine_kernel(const float *__restrict__ dxh, int ld, const float *__restrict__ pass,
+                                                                 const float *__restrict__ extra, int M, int H,
+                                                                 float *__restrict__ out) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)M * H) return;
+    const int m = (int)(q / H), k = (int)(q - (long)m * H);
+    float v = dxh[(size_t)m * ld + k] + pass[q];
+    if (extra) v += extra[q];
+    out[q] = v;
+}
+
+struct SweepScratch {
+    float *dh_tot, *dh_pass, *dxh, *dc_alt, *d_in, *tmp_h, *dgrid, *dcell;
+    int32_t *cells;
+    size_t bytes;
+};
+
+static void plan_sweep(const tnp_bwd_sweep *a, void *base, SweepScratch &w) {
+    const tnp_lstm_model *md = a->model;
+    const size_t M = (size_t)a->M, H = md->H;
+    const bool grid = md->pool_type >= TNP_POOL_OCCUPANCY && md->pool_type <= TNP_POOL_SOCIAL && !a->nn_pool;
+    const bool social = grid && md->pool_type == TNP_POOL_SOCIAL;
+    const size_t I = (size_t)md->E + (md->goal_flag ? md->goal_dim : 0) + (md->pool_type != TNP_POOL_NONE ? md->P : 0);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void *p = base ? (char *)base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    w.dh_tot = (float *)take(M * H * 4);
+    w.dh_pass = (float *)take(M * H * 4);
+    w.dxh = (float *)take(M * (I + H) * 4);
+    w.dc_alt = (float *)take(M * H * 4);
+    size_t maxw = 0;
+    if (grid) for (int l = 1; l < md->n_layers; ++l) maxw = maxw > (size_t)md->dims[l] ? maxw : (size_t)md->dims[l];
+    w.d_in = (float *)take(M * maxw * 4);
+    w.tmp_h = (float *)take(social ? M * H * 4 : 0);
+    const bool dense0 = grid && ((social && !a->social_sparse) || a->directional_in);
+    w.dgrid = (float *)take(dense0 ? M * (size_t)md->dims[0] * 4 : 0);
+    w.cells = (int32_t *)take(dense0 ? M * (size_t)a->n_max * 4 : 0);
+    w.dcell = (float *)take((social && a->social_sparse) ? M * (size_t)md->dims[0] * 4 : 0);
+    w.bytes = off;
+}
+
 }  // namespace tnp
 
 extern "C" TNP_API int tnp_transpose(const float *in, int ld_in, int rows, int cols, float *out, int ld_out, void *stream) {
@@ -537,4 +583,115 @@ extern "C" TNP_API int tnp_sparse_wgrad(const float *dy, int ldy, const float *e
         case 32: return tnp::launch_sparse_wgrad<32>(dy, ldy, enc, lde, l2, count, R, ncell, N1, dw_cell_major, s);
         default: TNP_FAIL(-1, "tnp_sparse_wgrad: C = %d not in {4, 8, 16, 32}", C);
     }
+}
+
+extern "C" TNP_API size_t tnp_lstm_backward_scratch_bytes(const tnp_bwd_sweep *a) {
+    if (!a || !a->model || a->M <= 0) return 0;
+    tnp::SweepScratch w;
+    tnp::plan_sweep(a, nullptr, w);
+    return w.bytes;
+}
+
+#define TNP_RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi, int s_lo, void *scratch,
+                                               size_t scratch_bytes, void *stream) {
+    if (!a || !a->model || !a->saves) TNP_FAIL(-1, "tnp_lstm_backward_sweep: NULL arguments");
+    const tnp_lstm_model *md = a->model;
+    const tnp_train_saves *sv = a->saves;
+    const int M = a->M, H = md->H, E = md->E, S = a->S;
+    if (M <= 0 || S <= 0) return 0;
+    if (s_hi >= S || s_lo < 0 || s_lo > s_hi) TNP_FAIL(-1, "tnp_lstm_backward_sweep: steps %d..%d outside 0..%d", s_hi, s_lo, S - 1);
+    const bool grid = md->pool_type >= TNP_POOL_OCCUPANCY && md->pool_type <= TNP_POOL_SOCIAL && !a->nn_pool;
+    const bool social = grid && md->pool_type == TNP_POOL_SOCIAL;
+    if (md->pool_type != TNP_POOL_NONE && !grid && !a->nn_pool)
+        TNP_FAIL(-1, "tnp_lstm_backward_sweep: pool type %d has no backward", md->pool_type);
+    if ((md->variant >> 17) & 1) TNP_FAIL(-1, "tnp_lstm_backward_sweep: pool_to_input=False has no backward");
+    tnp::SweepScratch w;
+    tnp::plan_sweep(a, scratch, w);
+    if (!scratch || scratch_bytes < w.bytes)
+        TNP_FAIL(-1, "tnp_lstm_backward_sweep: scratch too small (need %zu bytes, got %zu)", w.bytes, scratch_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int GD = md->goal_flag ? md->goal_dim : 0;
+    const int Pw = md->pool_type != TNP_POOL_NONE ? md->P : 0;
+    const int I = E + GD + Pw, LDX = I + H, P0 = E + GD;
+    const size_t MH = (size_t)M * H;
+    const int nl = md->n_layers, ncell = md->n * md->n, C = md->C;
+    float *dc_cur = a->dc, *dc_nxt = w.dc_alt;
+    for (int st = s_hi; st >= s_lo; --st) {
+        const size_t r = (size_t)st * M;
+        const float *o1 = sv->obs1_all + r * 2, *o2 = sv->obs2_all + r * 2;
+        const float *h_out = (st == a->h_override_step) ? a->h_override : sv->h_all + (size_t)(st + 1) * MH;
+        // ---- Hidden2Normal backward + gradient of the new hidden state ----
+        if (md->Wn) {
+            TNP_RC(tnp_h2n_backward(h_out, md->Wn, md->bn, a->d_rel ? a->d_rel + r * 5 : nullptr,
+                                    a->d_pred ? a->d_pred + (r + (size_t)a->pos_offset * M) * 2 : nullptr, o1, o2, a->dh, M, H,
+                                    a->dlin_all + r * 5, w.dh_tot, stream));
+        } else {
+            TNP_HIP(hipMemcpyAsync(w.dh_tot, a->dh, MH * 4, hipMemcpyDeviceToDevice, s));
+        }
+        // ---- LSTMCell backward (absent rows pass the state gradient through) ----
+        float *dG = a->dG_all + r * 4 * H;
+        TNP_RC(tnp_lstm_cell_backward(sv->gates_all + r * 4 * H, sv->c_all + (size_t)st * MH, w.dh_tot, dc_cur, o1, o2, M, H, dG,
+                                      dc_nxt, w.dh_pass, stream));
+        const float *wT = st >= a->n_enc ? a->wT_dec : a->wT_enc;
+        if (!wT) TNP_FAIL(-1, "tnp_lstm_backward_sweep: transposed cell weights missing for step %d", st);
+        TNP_RC(tnp_linear_forward(dG, 4 * H, wT, 4 * H, nullptr, w.dxh, LDX, M, LDX, 4 * H, 0, 0, stream));   // [dG.W_ih | dG.W_hh]
+        // ---- input / goal embedding backward (X holds the ReLU outputs) ----
+        const float *Xs = sv->X_all + r * I;
+        TNP_RC(tnp_relu_mask(w.dxh, LDX, Xs, I, M, E - 2, a->de_all + r * (E - 2), E - 2, stream));
+        if (GD) TNP_RC(tnp_relu_mask(w.dxh + E, LDX, Xs + E, I, M, GD - 2, a->dgoal_all + r * (GD - 2), GD - 2, stream));
+        if (a->nn_pool) TNP_RC(tnp_relu_mask(w.dxh + P0, LDX, Xs + P0, I, M, Pw, a->dnn_all + r * Pw, Pw, stream));
+        // ---- grid embedding MLP + scatter + social encoding backward ----
+        const float *extra = nullptr;
+        if (grid) {
+            if (a->grid_all) {   // the dense grid is the only intermediate that is recomputed
+                TNP_RC(tnp_pool_grid_forward(md->pool_type, o1, o2, social ? sv->enc_all + r * C : nullptr, C, a->scene_start, a->B,
+                                             a->n_max, md->n, C, md->cell, md->half_x, md->half_y, md->constant,
+                                             a->grid_all + r * md->dims[0], md->dims[0], nullptr, stream));
+            }
+            // last layer: its ReLU output is the pooled part of X
+            TNP_RC(tnp_relu_mask(w.dxh + P0, LDX, Xs + P0, I, M, Pw, a->dy_all[nl - 1] + r * Pw, Pw, stream));
+            for (int l = nl - 1; l >= 1; --l) {
+                const int n_out = md->dims[l + 1], n_in = md->dims[l];
+                TNP_RC(tnp_linear_forward(a->dy_all[l] + r * n_out, n_out, a->layT[l], n_out, nullptr, w.d_in, n_in, M, n_in, n_out,
+                                          0, 0, stream));
+                TNP_RC(tnp_relu_mask(w.d_in, n_in, sv->act_all[l - 1] + r * n_in, n_in, M, n_in, a->dy_all[l - 1] + r * n_in, n_in,
+                                     stream));
+            }
+            const int N1 = md->dims[1];
+            const float *dy0 = a->dy_all[0] + r * N1;
+            if (a->directional_in) {
+                TNP_RC(tnp_linear_forward(dy0, N1, a->layT[0], N1, nullptr, w.dgrid, md->dims[0], M, md->dims[0], N1, 0, 0, stream));
+                TNP_RC(tnp_pool_pair_cells(o2, a->row_base, a->row_count, M, a->n_max, md->n, md->cell, md->half_x, md->half_y,
+                                           w.cells, stream));
+                TNP_RC(tnp_directional_scatter_backward(w.dgrid, md->dims[0], w.cells, a->row_base, a->row_count, o1, o2, M,
+                                                        a->n_max, ncell, a->dvel_pool_all + r * 2, stream));
+            }
+            if (social) {
+                float *denc = a->denc_all + r * C;
+                if (a->social_sparse) {   // only the cells that hold a neighbour carry a gradient
+                    TNP_RC(tnp_social_dgrid_cells(dy0, N1, a->w_cell_major, a->ego_list, a->ego_count, S * M, st, M, C, ncell, N1,
+                                                  w.dcell, stream));
+                    TNP_RC(tnp_social_scatter_backward_cells(w.dcell, a->cells_all + r * a->n_max, a->row_base, a->row_count, M,
+                                                             a->n_max, C, ncell, denc, stream));
+                } else {
+                    TNP_RC(tnp_pool_pair_cells(o2, a->row_base, a->row_count, M, a->n_max, md->n, md->cell, md->half_x,
+                                               md->half_y, w.cells, stream));
+                    TNP_RC(tnp_linear_forward(dy0, N1, a->layT[0], N1, nullptr, w.dgrid, md->dims[0], M, md->dims[0], N1, 0, 0,
+                                              stream));
+                    TNP_RC(tnp_social_scatter_backward(w.dgrid, md->dims[0], w.cells, a->row_base, a->row_count, M, a->n_max, C,
+                                                       ncell, denc, stream));
+                }
+                TNP_RC(tnp_linear_forward(denc, C, a->whT, C, nullptr, w.tmp_h, H, M, H, C, 0, 0, stream));
+                extra = w.tmp_h;
+            }
+        }
+        hipLaunchKernelGGL(tnp::state_grad_combine_kernel, dim3((unsigned)((MH + 255) / 256)), dim3(256), 0, s, w.dxh + I, LDX,
+                           w.dh_pass, extra, M, H, a->dh);
+        TNP_HIP(hipGetLastError());
+        float *t = dc_cur; dc_cur = dc_nxt; dc_nxt = t;
+    }
+    if (dc_cur != a->dc) TNP_HIP(hipMemcpyAsync(a->dc, dc_cur, MH * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
 }

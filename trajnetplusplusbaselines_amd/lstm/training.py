@@ -60,6 +60,35 @@ class TrainSaves(ctypes.Structure):
                 ('obs2_all', ctypes.c_void_p), ('h_clean', ctypes.c_void_p)]
 
 
+class BwdSweep(ctypes.Structure):
+    """mirror of ``struct tnp_bwd_sweep`` (include/trajnet_hip.h)"""
+    _fields_ = [('model', ctypes.POINTER(_lib.LstmModel)), ('saves', ctypes.POINTER(TrainSaves)),
+                ('S', ctypes.c_int32), ('M', ctypes.c_int32), ('B', ctypes.c_int32), ('n_max', ctypes.c_int32),
+                ('n_enc', ctypes.c_int32), ('pos_offset', ctypes.c_int32), ('nn_pool', ctypes.c_int32),
+                ('social_sparse', ctypes.c_int32), ('directional_in', ctypes.c_int32), ('h_override_step', ctypes.c_int32),
+                ('h_override', ctypes.c_void_p), ('scene_start', ctypes.c_void_p), ('d_rel', ctypes.c_void_p),
+                ('d_pred', ctypes.c_void_p), ('wT_enc', ctypes.c_void_p), ('wT_dec', ctypes.c_void_p),
+                ('layT', ctypes.c_void_p * 3), ('whT', ctypes.c_void_p), ('w_cell_major', ctypes.c_void_p),
+                ('row_base', ctypes.c_void_p), ('row_count', ctypes.c_void_p), ('cells_all', ctypes.c_void_p),
+                ('ego_list', ctypes.c_void_p), ('ego_count', ctypes.c_void_p), ('dlin_all', ctypes.c_void_p),
+                ('dG_all', ctypes.c_void_p), ('de_all', ctypes.c_void_p), ('dgoal_all', ctypes.c_void_p),
+                ('dy_all', ctypes.c_void_p * 3), ('denc_all', ctypes.c_void_p), ('dnn_all', ctypes.c_void_p),
+                ('dvel_pool_all', ctypes.c_void_p), ('grid_all', ctypes.c_void_p), ('dh', ctypes.c_void_p),
+                ('dc', ctypes.c_void_p)]
+
+
+def _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, win_all, o1_all, o2_all):
+    sv = TrainSaves()
+    sv.h_all, sv.c_all, sv.X_all, sv.gates_all = h_all.data_ptr(), c_all.data_ptr(), X_all.data_ptr(), gates_all.data_ptr()
+    for li, a in enumerate(act_all):
+        sv.act_all[li] = a.data_ptr()
+    sv.enc_all = enc_all.data_ptr() if enc_all is not None else None
+    sv.nn_attrs_all = attrs_all.data_ptr() if attrs_all is not None else None
+    sv.winners_all = win_all.data_ptr() if win_all is not None else None
+    sv.obs1_all, sv.obs2_all = o1_all.data_ptr(), o2_all.data_ptr()
+    return sv, (h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, win_all, o1_all, o2_all)
+
+
 class SequenceFn(torch.autograd.Function):
     """rel_pred, pred, h_last = SequenceFn.apply(model, observed, goals, batch_split, truth, T_dec, opts, *params)
 
@@ -116,14 +145,7 @@ class SequenceFn(torch.autograd.Function):
         o1_all = torch.empty(S, M, 2, device=dev)
         o2_all = torch.empty(S, M, 2, device=dev)
         pos_all = torch.empty(S + (1 if T_obs == 2 else 0), M, 2, device=dev)
-        sv = TrainSaves()
-        sv.h_all, sv.c_all, sv.X_all, sv.gates_all = h_all.data_ptr(), c_all.data_ptr(), X_all.data_ptr(), gates_all.data_ptr()
-        for li, a in enumerate(act_all):
-            sv.act_all[li] = a.data_ptr()
-        sv.enc_all = enc_all.data_ptr() if enc_all is not None else None
-        sv.nn_attrs_all = attrs_all.data_ptr() if attrs_all is not None else None
-        sv.winners_all = win_all.data_ptr() if win_all is not None else None
-        sv.obs1_all, sv.obs2_all = o1_all.data_ptr(), o2_all.data_ptr()
+        sv, sv_keep = _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, win_all, o1_all, o2_all)
         ex = _lib.LstmExtras()
         ctx.noise_at = None
         if noise is not None:        # adding_noise (sgan/sgan.py:200-221): h <- [ReLU(W_ctx h + b_ctx) | z]
@@ -142,12 +164,12 @@ class SequenceFn(torch.autograd.Function):
         if noise is not None:
             s_noise = T_obs - 1
             ctx.noise_at = (s_noise, h_enc, h_all[s_noise][:, :H - int(z.numel())].contiguous())
-        o1s, o2s = list(o1_all.unbind(0)), list(o2_all.unbind(0))
         decs = [0] * (T_obs - 1) + [1] * T_dec
         del keep
         ctx.model, ctx.idx, ctx.goals = model, idx, goals_t
-        ctx.saved = (h_all, c_all, X_all, gates_all, act_all, enc_all, o1s, o2s, decs)
+        ctx.saved = (h_all, c_all, X_all, gates_all, act_all, enc_all, decs)
         ctx.attrs_all = attrs_all
+        ctx.obs_all = (o1_all, o2_all)
         ctx.win_all = win_all
         ctx.w_cell_major = model._cell_major_weight(layers[0].weight, pool) if win_all is not None else None
         ctx.pos_offset = 1 if T_obs == 2 else 0
@@ -160,7 +182,7 @@ class SequenceFn(torch.autograd.Function):
     def backward(ctx, d_rel, d_pred, d_hlast):
         model, idx = ctx.model, ctx.idx
         P = dict(zip(ctx.param_names, ctx.saved_tensors))
-        h_all, c_all, X_all, gates_all, act_all, enc_all, o1s, o2s, decs = ctx.saved
+        h_all, c_all, X_all, gates_all, act_all, enc_all, decs = ctx.saved
         dev = h_all.device
         S, M, H, E = len(decs), idx.M, model.hidden_dim, model.embedding_dim
         I = X_all.shape[2]
@@ -179,13 +201,7 @@ class SequenceFn(torch.autograd.Function):
         wT = {pre: torch.cat([T(pre + '.weight_ih'), T(pre + '.weight_hh')], dim=0)
               for pre in set('decoder' if d else 'encoder' for d in decs)}
         has_h2n = 'hidden2normal.linear.weight' in P            # the S-GAN discriminator has no output head
-        wn = P['hidden2normal.linear.weight'].detach().contiguous() if has_h2n else None
-        bn = P['hidden2normal.linear.bias'].detach().contiguous() if has_h2n else None
-
-        def h_out_of(step):     # hidden state produced by `step` (before the generator's noise replaced it)
-            if ctx.noise_at is not None and step == ctx.noise_at[0] - 1:
-                return ctx.noise_at[1]
-            return h_all[step + 1]
+        o1_all, o2_all = ctx.obs_all
         nn_pool = ctx.attrs_all is not None                      # NearestNeighborMLP: only its embedding has parameters
         layers = pool.embedding_layers() if (pool is not None and not nn_pool) else []
         lay_names = ['pool.embedding.%d' % i for i, mod in enumerate(pool.embedding) if isinstance(mod, torch.nn.Linear)] \
@@ -205,12 +221,11 @@ class SequenceFn(torch.autograd.Function):
         dG_all = torch.empty(S, M, 4 * H, device=dev)
         de_all = torch.empty(S, M, E - 2, device=dev)
         dgoal_all = torch.empty(S, M, GD - 2, device=dev) if GD else None
-        gdir_all = torch.empty(S, M, 2, device=dev) if GD else None
+        gdir_all = None
         dy_all = [torch.empty(S, M, lin.weight.shape[0], device=dev) for lin in layers]
         denc_all = torch.empty(S, M, pool.pooling_dim, device=dev) if social else None
         grid_all = None
         if pool is not None and not nn_pool:
-            tid = _lib.POOL_TYPES[pool.type_]
             G, cell, half_x, half_y = pool._geometry()
             C = pool.pooling_dim
             grid_all = torch.empty(S, M, C * G * G, device=dev) if not sparse_bwd else None
@@ -218,15 +233,12 @@ class SequenceFn(torch.autograd.Function):
                 sizes = (idx.starts[1:] - idx.starts[:-1]).long()
                 row_base = torch.repeat_interleave(idx.starts[:-1].long(), sizes).to(torch.int32)
                 row_count = torch.repeat_interleave(sizes, sizes).to(torch.int32)
-                cells = torch.empty(M, idx.n_max, dtype=torch.int32, device=dev)
-                dgrid = torch.empty(M, C * G * G, device=dev) if not sparse_bwd else None
                 if sparse_bwd:
                     # pair cells of every step in one launch, then per (step, cell) the egos with a neighbour in that cell
                     R, ncell = S * M, G * G
                     step_off = (torch.arange(S, device=dev, dtype=torch.int32) * M)[:, None]
                     rb_all = (step_off + row_base[None]).reshape(-1).contiguous()
                     rc_all = row_count.repeat(S)
-                    o2_all = torch.stack(o2s, dim=0).contiguous()
                     cells_all = torch.empty(S, M, idx.n_max, dtype=torch.int32, device=dev)
                     _lib.check(L.tnp_pool_pair_cells(_lib.ptr(o2_all), _lib.ptr(rb_all), _lib.ptr(rc_all), R, idx.n_max, G,
                                                      cell, half_x, half_y, _lib.ptr(cells_all), sp()), 'pair_cells')
@@ -236,113 +248,82 @@ class SequenceFn(torch.autograd.Function):
                     ego_count = torch.empty(ncell, S, dtype=torch.int32, device=dev)
                     _lib.check(L.tnp_pair_ego_lists(_lib.ptr(cells_all), R, M, idx.n_max, ncell, _lib.ptr(occ), _lib.ptr(occ_t),
                                                     _lib.ptr(ego_list), _lib.ptr(ego_count), sp()), 'ego_lists')
-                    dcell = torch.empty(M, ncell, C, device=dev)
-                    del occ, occ_t, rb_all, rc_all, o2_all
+                    del occ, occ_t, rb_all, rc_all
 
         dh = _lib.f32c(d_hlast, dev).clone() if d_hlast is not None else torch.zeros(M, H, device=dev)
         dc = torch.zeros(M, H, device=dev)
-        d_obs = torch.zeros(ctx.T_obs, M, 2, device=dev) if ctx.input_grad else None
-        if ctx.input_grad:
+        dvel_pool_all = torch.empty(S, M, 2, device=dev) if directional_in else None
+
+        # ---- the reverse sweep: one driver call (two around the S-GAN noise hook), csrc/lstm_bwd.hip ----
+        sv, sv_keep = _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, ctx.attrs_all, ctx.win_all, o1_all, o2_all)
+        m, keep, _ = model._descriptor()
+        if not has_h2n:
+            m.Wn, m.bn = None, None
+        n_enc = sum(1 for d in decs if not d)
+        sw = BwdSweep()
+        sw.model, sw.saves = ctypes.pointer(m), ctypes.pointer(sv)
+        sw.S, sw.M, sw.B, sw.n_max, sw.n_enc, sw.pos_offset = S, M, idx.B, idx.n_max, n_enc, ctx.pos_offset
+        sw.nn_pool, sw.social_sparse, sw.directional_in = int(nn_pool), int(social and sparse_bwd), int(directional_in)
+        sw.h_override_step = -1
+        if ctx.noise_at is not None:
+            sw.h_override_step, sw.h_override = ctx.noise_at[0] - 1, ctx.noise_at[1].data_ptr()
+        sw.scene_start = idx.starts.data_ptr()
+        sw.d_rel = d_rel.data_ptr() if d_rel is not None else None
+        sw.d_pred = d_pred.data_ptr() if d_pred is not None else None
+        sw.wT_enc = wT['encoder'].data_ptr() if 'encoder' in wT else None
+        sw.wT_dec = wT['decoder'].data_ptr() if 'decoder' in wT else None
+        for li, t in enumerate(layT):
+            sw.layT[li] = t.data_ptr() if t is not None else None
+        sw.whT = whT.data_ptr() if whT is not None else None
+        sw.w_cell_major = ctx.w_cell_major.data_ptr() if sparse_bwd else None
+        if social or directional_in:
+            sw.row_base, sw.row_count = row_base.data_ptr(), row_count.data_ptr()
+        if social and sparse_bwd:
+            sw.cells_all, sw.ego_list, sw.ego_count = cells_all.data_ptr(), ego_list.data_ptr(), ego_count.data_ptr()
+        sw.dlin_all, sw.dG_all, sw.de_all = dlin_all.data_ptr(), dG_all.data_ptr(), de_all.data_ptr()
+        sw.dgoal_all = dgoal_all.data_ptr() if GD else None
+        for li, t in enumerate(dy_all):
+            sw.dy_all[li] = t.data_ptr()
+        sw.denc_all = denc_all.data_ptr() if social else None
+        sw.dnn_all = dnn_all.data_ptr() if nn_pool else None
+        sw.dvel_pool_all = dvel_pool_all.data_ptr() if directional_in else None
+        sw.grid_all = grid_all.data_ptr() if grid_all is not None else None
+        sw.dh, sw.dc = dh.data_ptr(), dc.data_ptr()
+        need = L.tnp_lstm_backward_scratch_bytes(ctypes.byref(sw))
+        scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+
+        def sweep(hi, lo):
+            if hi >= lo:
+                _lib.check(L.tnp_lstm_backward_sweep(ctypes.byref(sw), hi, lo, _lib.ptr(scratch), need, sp()), 'backward_sweep')
+
+        if ctx.noise_at is None:
+            sweep(S - 1, 0)
+        else:
+            s_noise, h_enc, ctx_act = ctx.noise_at
+            sweep(S - 1, s_noise)
+            # backward of adding_noise: dh is the gradient of [ReLU(W_ctx h + b_ctx) | z]
+            nc = ctx_act.shape[1]
+            dctx = torch.empty(M, nc, device=dev)
+            _lib.check(L.tnp_relu_mask(_lib.ptr(dh), H, _lib.ptr(ctx_act), nc, M, nc, _lib.ptr(dctx), nc, sp()), 'relu_mask')
+            grads['mlp_decoder_context.0.weight'] = _mm(dctx.t(), h_enc.t())
+            grads['mlp_decoder_context.0.bias'] = dctx.sum(0)
+            dh.copy_(_lin(dctx, T('mlp_decoder_context.0.weight')))
+            sweep(s_noise - 1, 0)
+        del keep, sv_keep
+        if GD:    # direction to the goal, the goal embedding's input (all steps at once)
+            gd = o2_all - ctx.goals[None]
+            nf = gd.norm(dim=2, keepdim=True)
+            gdir_all = torch.nan_to_num(torch.where(nf == 0, torch.zeros_like(gd), gd / nf)) * 4.0
+        d_obs = None
+        if ctx.input_grad:   # vel = o2 - o1 feeds the input embedding (x4) and the directional grid values
             emb_wT4 = torch.zeros(4, E - 2, device=dev)          # [W_emb^T ; 0 0] so that the GEMM's N is a multiple of 4
             emb_wT4[:2] = P['input_embedding.input_embeddings.0.weight'].detach().t()
-            dvel_pool = torch.empty(M, 2, device=dev)
-        dh_tot = torch.empty(M, H, device=dev)
-        dh_pass = torch.empty(M, H, device=dev)
-        dXH = torch.empty(M, I + H, device=dev)                # [dX | dG . W_hh]
-        dX = dXH[:, :I]
-        LDX = I + H                                           # leading dimension of dX
-        P0 = E + GD                                           # first pooled column of X
-
-        for s in range(S - 1, -1, -1):
-            o1, o2 = o1s[s], o2s[s]
-            pre = 'decoder' if decs[s] else 'encoder'
-            if ctx.noise_at is not None and s == ctx.noise_at[0] - 1:
-                # backward of adding_noise: dh is the gradient of [ReLU(W_ctx h + b_ctx) | z]
-                _, h_enc, ctx_act = ctx.noise_at
-                nc = ctx_act.shape[1]
-                dctx = torch.empty(M, nc, device=dev)
-                _lib.check(L.tnp_relu_mask(_lib.ptr(dh), H, _lib.ptr(ctx_act), nc, M, nc, _lib.ptr(dctx), nc, sp()), 'relu_mask')
-                grads['mlp_decoder_context.0.weight'] = _mm(dctx.t(), h_enc.t())
-                grads['mlp_decoder_context.0.bias'] = dctx.sum(0)
-                dh = _lin(dctx, T('mlp_decoder_context.0.weight'))
-            # ---- Hidden2Normal backward + gradient of the new hidden state ----
-            if has_h2n:
-                _lib.check(L.tnp_h2n_backward(_lib.ptr(h_out_of(s)), _lib.ptr(wn), _lib.ptr(bn),
-                                              _lib.ptr(d_rel[s]) if d_rel is not None else None,
-                                              _lib.ptr(d_pred[s + ctx.pos_offset]) if d_pred is not None else None,
-                                              _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(dh), M, H, _lib.ptr(dlin_all[s]),
-                                              _lib.ptr(dh_tot), sp()), 'tnp_h2n_backward')
-            else:
-                dh_tot.copy_(dh)
-            # ---- LSTMCell backward (absent rows pass the state gradient through) ----
-            dc_prev = torch.empty(M, H, device=dev)
-            _lib.check(L.tnp_lstm_cell_backward(_lib.ptr(gates_all[s]), _lib.ptr(c_all[s]), _lib.ptr(dh_tot), _lib.ptr(dc),
-                                                _lib.ptr(o1), _lib.ptr(o2), M, H, _lib.ptr(dG_all[s]), _lib.ptr(dc_prev),
-                                                _lib.ptr(dh_pass), sp()), 'tnp_lstm_cell_backward')
-            _lin(dG_all[s], wT[pre], out=dXH)                               # [dG . W_ih | dG . W_hh]
-            dh_prev = dXH[:, I:] + dh_pass
-            # ---- input / goal embedding backward (X holds the ReLU outputs) ----
-            Xs = X_all[s]
-            _lib.check(L.tnp_relu_mask(_lib.ptr(dX), LDX, _lib.ptr(Xs), I, M, E - 2, _lib.ptr(de_all[s]), E - 2, sp()), 'relu_mask')
-            if GD:
-                _lib.check(L.tnp_relu_mask(_off(dX, E), LDX, _off(Xs, E), I, M, GD - 2, _lib.ptr(dgoal_all[s]), GD - 2, sp()),
-                           'relu_mask')
-                gd = o2 - ctx.goals
-                nf = gd.norm(dim=1, keepdim=True)
-                gdir_all[s] = torch.nan_to_num(torch.where(nf == 0, torch.zeros_like(gd), gd / nf)) * 4.0
-            if nn_pool:   # the pooled part of X is the concatenated ReLU(Linear(attrs)) of the n neighbours
-                _lib.check(L.tnp_relu_mask(_off(dX, P0), LDX, _off(Xs, P0), I, M, pool.out_dim, _lib.ptr(dnn_all[s]),
-                                           pool.out_dim, sp()), 'relu_mask')
-            # ---- grid embedding MLP + scatter + social encoding backward ----
-            if pool is not None and not nn_pool:
-                o1c, o2c = o1.contiguous(), o2.contiguous()
-                enc = enc_all[s] if social else None
-                if not sparse_bwd:     # the dense grid is the only intermediate that is recomputed
-                    _lib.check(L.tnp_pool_grid_forward(tid, _lib.ptr(o1c), _lib.ptr(o2c), _lib.ptr(enc), C, _lib.ptr(idx.starts),
-                                                       idx.B, idx.n_max, G, C, cell, half_x, half_y, float(pool.constant),
-                                                       _lib.ptr(grid_all[s]), C * G * G, None, sp()), 'grid')
-                nl = len(layers)
-                # last layer: its ReLU output is the pooled part of X
-                Pdim = layers[-1].weight.shape[0]
-                _lib.check(L.tnp_relu_mask(_off(dX, P0), LDX, _off(Xs, P0), I, M, Pdim, _lib.ptr(dy_all[nl - 1][s]), Pdim, sp()),
-                           'relu_mask')
-                for li in range(nl - 1, 0, -1):
-                    d_in = _lin(dy_all[li][s], layT[li])                    # dy . W_li: gradient of layer li's input
-                    a_prev = act_all[li - 1][s]
-                    n_prev = a_prev.shape[1]
-                    _lib.check(L.tnp_relu_mask(_lib.ptr(d_in), n_prev, _lib.ptr(a_prev), n_prev, M, n_prev,
-                                               _lib.ptr(dy_all[li - 1][s]), n_prev, sp()), 'relu_mask')
-                if directional_in:
-                    _lin(dy_all[0][s], layT[0], out=dgrid)
-                    _lib.check(L.tnp_pool_pair_cells(_lib.ptr(o2c), _lib.ptr(row_base), _lib.ptr(row_count), M, idx.n_max, G,
-                                                     cell, half_x, half_y, _lib.ptr(cells), sp()), 'pair_cells')
-                    _lib.check(L.tnp_directional_scatter_backward(_lib.ptr(dgrid), C * G * G, _lib.ptr(cells), _lib.ptr(row_base),
-                                                                  _lib.ptr(row_count), _lib.ptr(o1c), _lib.ptr(o2c), M, idx.n_max,
-                                                                  G * G, _lib.ptr(dvel_pool), sp()), 'directional_scatter_backward')
-                if social and sparse_bwd:     # only the cells that hold a neighbour carry a gradient
-                    N1 = dy_all[0].shape[2]
-                    _lib.check(L.tnp_social_dgrid_cells(_lib.ptr(dy_all[0][s]), N1, _lib.ptr(ctx.w_cell_major), _lib.ptr(ego_list),
-                                                        _lib.ptr(ego_count), R, s, M, C, ncell, N1, _lib.ptr(dcell), sp()),
-                               'dgrid_cells')
-                    _lib.check(L.tnp_social_scatter_backward_cells(_lib.ptr(dcell), _lib.ptr(cells_all[s]), _lib.ptr(row_base),
-                                                                   _lib.ptr(row_count), M, idx.n_max, C, ncell,
-                                                                   _lib.ptr(denc_all[s]), sp()), 'scatter_backward_cells')
-                elif social:
-                    _lib.check(L.tnp_pool_pair_cells(_lib.ptr(o2c), _lib.ptr(row_base), _lib.ptr(row_count), M, idx.n_max, G,
-                                                     cell, half_x, half_y, _lib.ptr(cells), sp()), 'pair_cells')
-                    _lin(dy_all[0][s], layT[0], out=dgrid)                  # gradient of the dense grid
-                    _lib.check(L.tnp_social_scatter_backward(_lib.ptr(dgrid), C * G * G, _lib.ptr(cells), _lib.ptr(row_base),
-                                                             _lib.ptr(row_count), M, idx.n_max, C, G * G,
-                                                             _lib.ptr(denc_all[s]), sp()), 'scatter_backward')
-                if social:
-                    dh_prev += _lin(denc_all[s], whT)
-            if ctx.input_grad:   # vel = o2 - o1 feeds the input embedding (x4) and the directional grid values
-                dvel = _lin(de_all[s], emb_wT4)[:, :2] * 4.0
-                if directional_in:
-                    dvel = dvel + dvel_pool
-                d_obs[s + 1] += dvel
-                d_obs[s] -= dvel
-            dh, dc = dh_prev, dc_prev
+            dvel = _lin(de_all.reshape(S * M, E - 2), emb_wT4)[:, :2].reshape(S, M, 2) * 4.0
+            if directional_in:
+                dvel = dvel + dvel_pool_all
+            d_obs = torch.zeros(ctx.T_obs, M, 2, device=dev)
+            d_obs[1:S + 1] += dvel
+            d_obs[0:S] -= dvel
 
         # ---- deferred weight gradients: one GEMM per parameter over the stacked steps ----
         def wgrad(name, dy, x, bias_name):
@@ -363,7 +344,7 @@ class SequenceFn(torch.autograd.Function):
                 wgrad(pre + '.weight_ih', dG_all[lo:hi], X_all[lo:hi], pre + '.bias_ih')
                 wgrad(pre + '.weight_hh', dG_all[lo:hi], h_prev_all[lo:hi], None)
                 grads[pre + '.bias_hh'] = grads[pre + '.bias_ih'].clone()
-        vel_all = torch.nan_to_num(torch.stack(o2s, dim=0) - torch.stack(o1s, dim=0)) * 4.0
+        vel_all = torch.nan_to_num(o2_all - o1_all) * 4.0
         wgrad('input_embedding.input_embeddings.0.weight', de_all, vel_all, 'input_embedding.input_embeddings.0.bias')
         if GD:
             wgrad('goal_embedding.input_embeddings.0.weight', dgoal_all, gdir_all, 'goal_embedding.input_embeddings.0.bias')
