@@ -358,6 +358,12 @@ TNP_API int tnp_sparse_hits_build(const int16_t *winners, const int32_t *row_bas
                                   int32_t *list, int32_t *count, void *stream);
 TNP_API int tnp_sparse_wgrad(const float *dy, int ldy, const float *enc, int lde, const int32_t *list, const int32_t *count,
                              int R, int C, int ncell, int N1, float *dw_cell_major, void *stream);
+/* Weight gradient of a Linear over the stacked steps: dw[Mo, No] = dy[K, Mo]^T @ x[K, No] (+ dbias[Mo] = column sums of
+ * dy, NULL to skip) -- what autograd accumulates for weight / bias over the steps of LSTM.forward.  Both operands are
+ * read as stored (no transposes), K is split across workgroups and reduced in a fixed order (csrc/gemm_wgrad.hip). */
+TNP_API size_t tnp_wgrad_workspace_bytes(int Mo, int No, int K);
+TNP_API int tnp_wgrad(const float *dy, int ld_dy, const float *x, int ld_x, int K, int Mo, int No, float *dw, int ld_dw,
+                      float *dbias, void *workspace, size_t workspace_bytes, void *stream);
 /* out [cols, rows] = in [rows, cols]^T (LDS-tiled; operands of the weight-gradient GEMMs) */
 TNP_API int tnp_transpose(const float *in, int ld_in, int rows, int cols, float *out, int ld_out, void *stream);
 /* gradient of the directional grid's values (v_j - v_i, lstm/gridbased_pooling.py:118-143) with respect to the tracks'

@@ -152,3 +152,31 @@ def test_sparse_first_layer_backward_equals_dense_backward():
         a, b = grads[True][n], grads[False][n]
         scale = max(1e-6, float(b.abs().max()))
         assert float((a - b).abs().max()) / scale < 2e-5, n
+
+
+@pytest.mark.parametrize('K,Mo,No', [(1000, 5, 128), (777, 62, 2), (4099, 512, 320), (38912, 256, 288), (33, 130, 70),
+                                     (2048, 16, 128)])
+def test_wgrad_split_k_matches_fp64(K, Mo, No):
+    """tnp_wgrad (dy^T x with K split across workgroups + bias column sums) against an fp64 product, ragged shapes,
+    strided operands; two runs are bit-identical (fixed reduction order)."""
+    from trajnetplusplusbaselines_amd import _lib
+    g = torch.Generator().manual_seed(K + Mo)
+    dy_full = torch.randn(K, Mo + 3, generator=g).cuda()
+    x_full = torch.randn(K, No + 5, generator=g).cuda()
+    dy, x = dy_full[:, 1:Mo + 1], x_full[:, 2:No + 2]
+    L = _lib.lib()
+    nbytes = L.tnp_wgrad_workspace_bytes(Mo, No, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    outs = []
+    for _ in range(2):
+        dw = torch.full((Mo, No), float('nan'), device='cuda')
+        db = torch.full((Mo,), float('nan'), device='cuda')
+        _lib.check(L.tnp_wgrad(_lib.ptr(dy), dy.stride(0), _lib.ptr(x), x.stride(0), K, Mo, No, _lib.ptr(dw), No, _lib.ptr(db),
+                               _lib.ptr(ws), nbytes, _lib.stream_ptr()), 'tnp_wgrad')
+        outs.append((dw.clone(), db.clone()))
+    want = dy.double().t() @ x.double()
+    scale = float(want.abs().max())
+    assert float((outs[0][0].double() - want).abs().max()) / scale < 2e-6
+    wb = dy.double().sum(0)
+    assert float((outs[0][1].double() - wb).abs().max()) / float(wb.abs().max()) < 2e-6
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT_DIR = os.path.join(PKG, 'lib')
 OUT = os.path.join(OUT_DIR, 'libtrajnet_hip.so')
-SOURCES = ['gemm_f32_mfma.hip', 'pool_grid.hip', 'pool_embed_sparse.hip', 'pool_nongrid.hip', 'lstm_seq.hip', 'lstm_bwd.hip', 'loss.hip',
+SOURCES = ['gemm_f32_mfma.hip', 'gemm_wgrad.hip', 'pool_grid.hip', 'pool_embed_sparse.hip', 'pool_nongrid.hip', 'lstm_seq.hip', 'lstm_bwd.hip', 'loss.hip',
            'classical.hip']
 HEADERS = ['tnp_internal.h', 'classical_core.h', os.path.join('..', '..', 'include', 'trajnet_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-fvisibility=hidden',

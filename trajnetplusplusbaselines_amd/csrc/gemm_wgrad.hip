@@ -1,0 +1,140 @@
+// Weight-gradient GEMM of the training sweep (gfx950 only):   dW[Mo, No] = dY[K, Mo]^T @ X[K, No],  K = steps * tracks.
+//
+// The reference gets these from autograd (one small GEMM per step, accumulated); here every parameter has ONE
+// contraction over the stacked steps (lstm/training.py), i.e. a small output (<= 512 x 1024) and a very long K
+// (38 912 rows at config 2).  The forward GEMM kernel (gemm_f32_mfma.hip) wants K-contiguous operands and tiles M x N
+// only, which left these launches on 80 of 256 CUs after two LDS-tiled transposes.  This kernel
+// * reads both operands as they lie in HBM (row k of dY / X is contiguous): lane l of a wave loads
+//   dY[k + l/32][i0 + l%32] -- exactly the v_mfma_f32_32x32x2_f32 operand layout, 128-byte coalesced, no LDS, no
+//   barriers, no transposes;
+// * splits K across workgroups (grid.y) so that ~2 workgroups per CU stream independent K ranges; every wave owns a
+//   64 x 64 output block (four accumulators, one operand load per MFMA), a workgroup 128 x 128;
+// * writes per-split partial tiles and reduces them in a fixed order (deterministic, no atomics); the bias gradient
+//   (column sums of dY) rides along on the A operand.
+// Exact fp32 products and fp32 accumulation, like the forward kernel.
+#include "tnp_internal.h"
+
+namespace tnp {
+
+typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WG_U = 8;   // k-pairs per unrolled iteration (16 rows of K)
+
+__global__ void __launch_bounds__(256) wgrad_tn_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                                       int ldb, int Mo, int No, int K, int kchunk,
+                                                       float *__restrict__ part, float *__restrict__ bias_part) {
+    const int regions_n = (No + 127) >> 7;
+    const int rm = blockIdx.x / regions_n, rn = blockIdx.x - rm * regions_n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kh = lane >> 5;
+    const int i0 = rm * 128 + (wave & 1) * 64, j0 = rn * 128 + (wave >> 1) * 64;
+    if (i0 >= Mo || j0 >= No) return;           // no barriers in this kernel: idle waves just leave
+    const bool m1 = i0 + 32 < Mo, n1 = j0 + 32 < No;
+    const int kb = blockIdx.y * kchunk, ke = min(K, kb + kchunk);
+    const int ia0 = min(i0 + li, Mo - 1), ia1 = min(i0 + 32 + li, Mo - 1);
+    const int jb0 = min(j0 + li, No - 1), jb1 = min(j0 + 32 + li, No - 1);
+    wg_f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+    const bool want_bias = bias_part != nullptr && rn == 0 && (wave >> 1) == 0;
+    float bs0 = 0.f, bs1 = 0.f;
+    for (int k = kb; k < ke; k += 2 * WG_U) {
+        float a0[WG_U], a1[WG_U], b0[WG_U], b1[WG_U];
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) {
+            const int kk = k + 2 * u + kh;
+            const bool ok = kk < ke;
+            const size_t row = (size_t)(ok ? kk : ke - 1);
+            const float *ar = A + row * lda, *br = B + row * ldb;
+            float va0 = ar[ia0], vb0 = br[jb0];
+            float va1 = m1 ? ar[ia1] : 0.f, vb1 = n1 ? br[jb1] : 0.f;
+            a0[u] = ok ? va0 : 0.f; a1[u] = ok ? va1 : 0.f;
+            b0[u] = ok ? vb0 : 0.f; b1[u] = ok ? vb1 : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) {
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc00, 0, 0, 0);
+            if (n1) acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc01, 0, 0, 0);
+            if (m1) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc10, 0, 0, 0);
+            if (m1 && n1) acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc11, 0, 0, 0);
+            bs0 += a0[u]; bs1 += a1[u];
+        }
+    }
+    float *P = part + (size_t)blockIdx.y * Mo * No;
+    auto store = [&](const wg_f32x16 &acc, int ib, int jb) {
+        const int col = jb + li;
+        if (col >= No) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = ib + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row < Mo) P[(size_t)row * No + col] = acc[r];
+        }
+    };
+    store(acc00, i0, j0);
+    if (n1) store(acc01, i0, j0 + 32);
+    if (m1) store(acc10, i0 + 32, j0);
+    if (m1 && n1) store(acc11, i0 + 32, j0 + 32);
+    if (want_bias) {
+        bs0 += __shfl_xor(bs0, 32);
+        bs1 += __shfl_xor(bs1, 32);
+        float *bp = bias_part + (size_t)blockIdx.y * Mo;
+        if (kh == 0) {
+            if (i0 + li < Mo) bp[i0 + li] = bs0;
+            if (m1 && i0 + 32 + li < Mo) bp[i0 + 32 + li] = bs1;
+        }
+    }
+}
+
+// out[e] = sum over the splits of part[s][e], ascending s
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ part, int SK, long n, int cols, float *__restrict__ out,
+                                                           int ldo) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float acc = part[e];
+    for (int s = 1; s < SK; ++s) acc += part[(size_t)s * n + e];
+    out[(e / cols) * ldo + (e % cols)] = acc;
+}
+
+static void wgrad_plan(int Mo, int No, int K, int &regions, int &SK, int &kchunk) {
+    regions = ((Mo + 127) / 128) * ((No + 127) / 128);
+    int want = (512 + regions - 1) / regions;
+    if (want > 128) want = 128;
+    const int maxsk = (K + 255) / 256;
+    if (want > maxsk) want = maxsk;
+    if (want < 1) want = 1;
+    kchunk = (K + want - 1) / want;
+    kchunk = (kchunk + 2 * WG_U - 1) / (2 * WG_U) * (2 * WG_U);
+    SK = (K + kchunk - 1) / kchunk;
+}
+
+}  // namespace tnp
+
+extern "C" TNP_API size_t tnp_wgrad_workspace_bytes(int Mo, int No, int K) {
+    if (Mo <= 0 || No <= 0 || K <= 0) return 0;
+    int regions, SK, kchunk;
+    tnp::wgrad_plan(Mo, No, K, regions, SK, kchunk);
+    return ((size_t)SK * Mo * No + (size_t)SK * Mo) * sizeof(float);
+}
+
+extern "C" TNP_API int tnp_wgrad(const float *dy, int ld_dy, const float *x, int ld_x, int K, int Mo, int No, float *dw, int ld_dw,
+                                 float *dbias, void *workspace, size_t workspace_bytes, void *stream) {
+    if (Mo <= 0 || No <= 0) return 0;
+    if (K <= 0) TNP_FAIL(-1, "tnp_wgrad: K = %d", K);
+    int regions, SK, kchunk;
+    tnp::wgrad_plan(Mo, No, K, regions, SK, kchunk);
+    const size_t need = ((size_t)SK * Mo * No + (size_t)SK * Mo) * sizeof(float);
+    if (!workspace || workspace_bytes < need) TNP_FAIL(-1, "tnp_wgrad: workspace too small (need %zu bytes, got %zu)", need, workspace_bytes);
+    float *part = (float *)workspace, *bpart = part + (size_t)SK * Mo * No;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tnp::wgrad_tn_kernel, dim3(regions, SK), dim3(256), 0, s, dy, ld_dy, x, ld_x, Mo, No, K, kchunk, part,
+                       dbias ? bpart : nullptr);
+    TNP_HIP(hipGetLastError());
+    const long n = (long)Mo * No;
+    hipLaunchKernelGGL(tnp::wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, SK, n, No, dw, ld_dw);
+    TNP_HIP(hipGetLastError());
+    if (dbias) {
+        hipLaunchKernelGGL(tnp::wgrad_reduce_kernel, dim3((unsigned)((Mo + 255) / 256)), dim3(256), 0, s, bpart, SK, (long)Mo, Mo, dbias,
+                           Mo);
+        TNP_HIP(hipGetLastError());
+    }
+    return 0;
+}

@@ -326,11 +326,22 @@ class SequenceFn(torch.autograd.Function):
             d_obs[0:S] -= dvel
 
         # ---- deferred weight gradients: one GEMM per parameter over the stacked steps ----
+        wg_ws = [None]
+
         def wgrad(name, dy, x, bias_name):
+            # dW = dy^T x over the stacked steps, operands as stored, K split across workgroups (csrc/gemm_wgrad.hip)
             dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
-            grads[name] = _lib.linear_forward(_transpose(dy2), _transpose(x2), None)
+            K, Mo, No = dy2.shape[0], dy2.shape[1], x2.shape[1]
+            nbytes = L.tnp_wgrad_workspace_bytes(Mo, No, K)
+            if wg_ws[0] is None or wg_ws[0].numel() < nbytes:
+                wg_ws[0] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            dw = torch.empty(Mo, No, device=dev)
+            db = torch.empty(Mo, device=dev) if bias_name is not None else None
+            _lib.check(L.tnp_wgrad(_lib.ptr(dy2), dy2.stride(0), _lib.ptr(x2), x2.stride(0), K, Mo, No, _lib.ptr(dw), No,
+                                   _lib.ptr(db), _lib.ptr(wg_ws[0]), nbytes, sp()), 'tnp_wgrad')
+            grads[name] = dw
             if bias_name is not None:
-                grads[bias_name] = dy2.sum(0)
+                grads[bias_name] = db
 
         h_out_all, h_prev_all = h_all[1:], h_all[:-1]
         if ctx.noise_at is not None:     # the last encoder step's output is the hidden state BEFORE the noise was added
