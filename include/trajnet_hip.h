@@ -216,8 +216,10 @@ TNP_API int tnp_lstm_forward(const tnp_lstm_model *model, const float *observed,
  * ----------------------------------------------------------------------------------------- */
 typedef struct tnp_lstm_extras {
     const float *W_ctx, *b_ctx;   /* mlp_decoder_context.0 */
-    const float *noise;           /* [noise_dim], one vector shared by all tracks */
+    const float *noise;           /* [noise_dim], one vector shared by all tracks (or [groups, noise_dim], below) */
     int32_t noise_dim;            /* 0 = no noise interface */
+    int32_t noise_group_tracks;   /* 0: one vector; g > 0: tracks [i*g, (i+1)*g) carry vector i -- k generator samples
+                                     batched as k replicas of the scenes (sgan/sgan.py:78-100 runs them one by one) */
     float *h_final;               /* optional out [M,H] */
 } tnp_lstm_extras;
 TNP_API int tnp_lstm_forward_ex(const tnp_lstm_model *model, const float *observed, int T_obs, int M,

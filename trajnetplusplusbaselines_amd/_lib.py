@@ -41,7 +41,8 @@ class LstmModel(ctypes.Structure):
 
 class LstmExtras(ctypes.Structure):
     """mirror of ``struct tnp_lstm_extras``"""
-    _fields_ = [('W_ctx', _fp), ('b_ctx', _fp), ('noise', _fp), ('noise_dim', ctypes.c_int32), ('h_final', _fp)]
+    _fields_ = [('W_ctx', _fp), ('b_ctx', _fp), ('noise', _fp), ('noise_dim', ctypes.c_int32), ('noise_group_tracks', ctypes.c_int32),
+                ('h_final', _fp)]
 
 
 _LIB = None

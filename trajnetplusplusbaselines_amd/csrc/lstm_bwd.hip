@@ -133,7 +133,8 @@ __global__ void __launch_bounds__(256) directional_scatter_backward_kernel(const
                                                                            const float *__restrict__ obs1,
                                                                            const float *__restrict__ obs2, int M, int n_max,
                                                                            int ncell, float *__restrict__ dvel) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per track t: the lanes take the partners of t's scene, then a fixed shuffle tree (deterministic)
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= M) return;
     const int lo = row_base[t], ns = row_count[t], tt = t - lo;
     auto finite_vel = [&](int r) {
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(256) directional_scatter_backward_kernel(const
     };
     float ax = 0.0f, ay = 0.0f;
     if (finite_vel(t)) {
-        for (int i = lo; i < lo + ns; ++i) {
+        for (int i = lo + lane; i < lo + ns; i += 64) {
             if (i == t || !finite_vel(i)) continue;
             const int c1 = cells[(size_t)i * n_max + tt];
             if (c1 >= 0) { ax += dgrid[(size_t)i * ldg + c1]; ay += dgrid[(size_t)i * ldg + ncell + c1]; }
@@ -150,8 +151,9 @@ __global__ void __launch_bounds__(256) directional_scatter_backward_kernel(const
             if (c2 >= 0) { ax -= dgrid[(size_t)t * ldg + c2]; ay -= dgrid[(size_t)t * ldg + ncell + c2]; }
         }
     }
-    dvel[2 * t] = ax;
-    dvel[2 * t + 1] = ay;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { ax += __shfl_xor(ax, off); ay += __shfl_xor(ay, off); }
+    if (lane == 0) { dvel[2 * t] = ax; dvel[2 * t + 1] = ay; }
 }
 
 // out[c][r] = in[r][c]: 64x64 tiles through LDS (row stride 65 floats: conflict-free on both sides), coalesced 256-byte
@@ -479,7 +481,7 @@ extern "C" TNP_API int tnp_directional_scatter_backward(const float *dgrid, int 
                                                         const float *obs1, const float *obs2, int M, int n_max, int ncell,
                                                         float *dvel, void *stream) {
     if (M <= 0) return 0;
-    hipLaunchKernelGGL(tnp::directional_scatter_backward_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(tnp::directional_scatter_backward_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        dgrid, ldg, cells, row_base, row_count, obs1, obs2, M, n_max, ncell, dvel);
     TNP_HIP(hipGetLastError());
     return 0;

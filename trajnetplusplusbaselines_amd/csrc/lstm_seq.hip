@@ -509,11 +509,12 @@ static void fill_prep_common(PrepArgs &p, const tnp_lstm_model *md, const Worksp
 }
 
 // h[:, H-nd:H] = z (one noise vector shared by all tracks, sgan/sgan.py:213-216)
-__global__ void noise_broadcast_kernel(float *h, int M, int H, int nd, const float *z) {
+// group > 0: tracks [g*group, (g+1)*group) carry noise vector g (several generator samples batched as replicated scenes)
+__global__ void noise_broadcast_kernel(float *h, int M, int H, int nd, const float *z, int group) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= M * nd) return;
     const int m = q / nd, k = q - m * nd;
-    h[(size_t)m * H + (H - nd) + k] = z[k];
+    h[(size_t)m * H + (H - nd) + k] = z[(group > 0 ? (m / group) * nd : 0) + k];
 }
 
 }  // namespace tnp
@@ -555,7 +556,7 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
     if (M <= 0 || B <= 0) return 0;
     if (md->goal_flag && !goals) TNP_FAIL(-1, "goal_flag set but goals == NULL");
     const bool noisy = ex && ex->noise_dim > 0;
-    if (noisy && (ex->noise_dim >= md->H || !ex->W_ctx || !ex->b_ctx || !ex->noise))
+    if (noisy && (ex->noise_dim >= md->H || !ex->W_ctx || !ex->b_ctx || !ex->noise || ex->noise_group_tracks < 0))
         TNP_FAIL(-1, "tnp_lstm_forward_ex: bad noise interface (noise_dim %d)", ex->noise_dim);
     Workspace w;
     plan_workspace(md, M, workspace, w);
@@ -651,7 +652,7 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
             if (rc) return rc;
             const int tot = M * ex->noise_dim;
             hipLaunchKernelGGL(noise_broadcast_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, noisy, M, H,
-                               ex->noise_dim, ex->noise);
+                               ex->noise_dim, ex->noise, ex->noise_group_tracks);
             TNP_HIP(hipGetLastError());
             if (!sv) cur ^= 1;
             hcur = noisy;

@@ -249,7 +249,12 @@ class LSTM(torch.nn.Module):
         if noise is not None:
             w_ctx, b_ctx, noise = _lib.f32c(w_ctx.detach(), dev), _lib.f32c(b_ctx.detach(), dev), _lib.f32c(noise, dev)
             ex.W_ctx, ex.b_ctx, ex.noise = _lib.ptr(w_ctx), _lib.ptr(b_ctx), _lib.ptr(noise)
-            ex.noise_dim = int(noise.numel())
+            ex.noise_dim = int(noise.shape[-1])
+            groups = noise.numel() // ex.noise_dim       # [k, noise_dim]: k samples batched as k replicas of the scenes
+            if groups > 1:
+                if M % groups:
+                    raise ValueError('%d noise vectors for %d tracks' % (groups, M))
+                ex.noise_group_tracks = M // groups
         if want_h_final:
             h_final = torch.empty(M, self.hidden_dim, dtype=torch.float32, device=dev)
             ex.h_final = _lib.ptr(h_final)

@@ -152,10 +152,17 @@ class SequenceFn(torch.autograd.Function):
             pd = dict(zip([n for n, _ in model.named_parameters()], params))
             wc = _lib.f32c(pd['mlp_decoder_context.0.weight'].detach(), dev)
             bc = _lib.f32c(pd['mlp_decoder_context.0.bias'].detach(), dev)
-            z = _lib.f32c(noise, dev).reshape(-1)
+            z = _lib.f32c(noise, dev)
+            nd = int(z.shape[-1])
+            groups = z.numel() // nd                 # [k, noise_dim]: k samples batched as k replicas of the scenes
+            z = z.reshape(-1)
             h_enc = torch.empty(M, H, device=dev)
             sv.h_clean = h_enc.data_ptr()
-            ex.W_ctx, ex.b_ctx, ex.noise, ex.noise_dim = _lib.ptr(wc), _lib.ptr(bc), _lib.ptr(z), int(z.numel())
+            ex.W_ctx, ex.b_ctx, ex.noise, ex.noise_dim = _lib.ptr(wc), _lib.ptr(bc), _lib.ptr(z), nd
+            if groups > 1:
+                if M % groups:
+                    raise ValueError('%d noise vectors for %d tracks' % (groups, M))
+                ex.noise_group_tracks = M // groups
         # the whole sequence (encoder + decoder steps, feedback of the predicted positions) is one driver call
         _lib.check(L.tnp_lstm_forward_train(
             ctypes.byref(m), _lib.ptr(observed), T_obs, M, _lib.ptr(goals_t), _lib.ptr(idx.starts), _lib.ptr(idx.primary),
@@ -163,7 +170,7 @@ class SequenceFn(torch.autograd.Function):
             ctypes.byref(ex), ctypes.byref(sv), _lib.stream_ptr()), 'tnp_lstm_forward_train')
         if noise is not None:
             s_noise = T_obs - 1
-            ctx.noise_at = (s_noise, h_enc, h_all[s_noise][:, :H - int(z.numel())].contiguous())
+            ctx.noise_at = (s_noise, h_enc, h_all[s_noise][:, :H - nd].contiguous())
         decs = [0] * (T_obs - 1) + [1] * T_dec
         del keep
         ctx.model, ctx.idx, ctx.goals = model, idx, goals_t

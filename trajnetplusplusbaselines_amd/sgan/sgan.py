@@ -77,6 +77,35 @@ class LSTMGenerator(LSTM):
                                           noise=noise)
         return rel, pred
 
+    def sample_k(self, observed, goals, batch_split, prediction_truth=None, n_predict=None, k=1):
+        """k independent samples (the k `generator(...)` calls of reference sgan/sgan.py:94-100) as ONE sequence over k
+        replicas of the scenes, replica i carrying noise vector i: scenes never interact, so the results equal the
+        one-by-one calls, with k times the tracks per kernel launch.  Noise is drawn in the order the k calls draw it."""
+        if k == 1 or self.no_noise or not _scene_local(self.pool):
+            outs = [self.forward(observed, goals, batch_split, prediction_truth, n_predict) for _ in range(k)]
+            return [o[0] for o in outs], [o[1] for o in outs]
+        noise = torch.stack([get_noise((self.noise_dim,), self.noise_type, device='cpu') for _ in range(k)], dim=0)
+        if isinstance(prediction_truth, (list, tuple)):
+            prediction_truth = torch.stack(list(prediction_truth), dim=0)
+        rel, pred = self.forward(observed.repeat(1, k, 1), goals.repeat(k, 1) if goals is not None else None,
+                                 _replicate_scenes(batch_split, k),
+                                 prediction_truth.repeat(1, k, 1) if prediction_truth is not None else None, n_predict,
+                                 noise=noise)
+        return list(rel.chunk(k, dim=1)), list(pred.chunk(k, dim=1))
+
+
+def _replicate_scenes(batch_split, k):
+    """batch_split of k copies of the batch laid side by side along the track axis"""
+    split = torch.as_tensor(batch_split, dtype=torch.int64).cpu()
+    M = int(split[-1])
+    return torch.cat([split[:1]] + [split[1:] + i * M for i in range(k)])
+
+
+def _scene_local(pool):
+    """interaction modules whose output for a scene does not depend on the other scenes of the batch (TrajectronPooling
+    sums over the whole batch, a reference quirk) -- only those may be batched as replicated scenes"""
+    return pool is None or type(pool).__name__ == 'GridBasedPooling'
+
 
 class LSTMDiscriminator(LSTM):
     def __init__(self, embedding_dim=64, hidden_dim=128, pool=None, pool_to_input=True, goal_dim=None, goal_flag=False):
@@ -120,6 +149,19 @@ class LSTMDiscriminator(LSTM):
                 x = _lib.linear_forward(x, layer.weight.detach(), layer.bias.detach(), relu=True)
         return x
 
+    def score_pair(self, observed, real, fake, goals, batch_split):
+        """(scores_real, scores_fake) = (self(observed, real, ...), self(observed, fake, ...)) of reference
+        sgan/sgan.py:109-110 as one encoder run over 2 replicas of the scenes (the classifier acts row by row)."""
+        if real.shape != fake.shape or not _scene_local(self.pool):
+            return self.forward(observed, real, goals, batch_split), self.forward(observed, fake, goals, batch_split)
+        dev = self.encoder.weight_ih.device
+        obs = observed.to(dev, torch.float32)
+        pred2 = torch.cat([real.to(dev, torch.float32), fake.to(dev, torch.float32)], dim=1)
+        scores = self.forward(obs.repeat(1, 2, 1), pred2, goals.repeat(2, 1) if goals is not None else None,
+                              _replicate_scenes(batch_split, 2))
+        B = scores.shape[0] // 2
+        return scores[:B], scores[B:]
+
 
 class SGAN(torch.nn.Module):
     def __init__(self, generator=None, discriminator=None, k=1, d_steps=1, g_steps=1):
@@ -130,20 +172,37 @@ class SGAN(torch.nn.Module):
         self.discriminator = discriminator if discriminator is not None else LSTMDiscriminator()
         self.d_steps = d_steps
         self.k = k
+        #: run the k generator samples / the real + fake discriminator passes as replicated scenes of one sequence
+        self.batch_samples = True
+        #: 'd'-type steps run the generator without an autograd graph (its gradients are never applied on such a step)
+        self.skip_generator_graph_on_d = True
 
     def forward(self, observed, goals, batch_split, prediction_truth=None, n_predict=None, step_type='g',
                 pred_length=12):
         """reference sgan/sgan.py:78-132: k generator samples, then real / fake discriminator scores."""
-        rel_pred_list, pred_list = [], []
-        for _ in range(self.k):
-            rel_pred_scene, pred_scene = self.generator(observed, goals, batch_split, prediction_truth, n_predict)
-            rel_pred_list.append(rel_pred_scene)
-            pred_list.append(pred_scene)
-            if step_type == 'd':
-                break
+        n_samples = 1 if step_type == 'd' else self.k           # the reference breaks out of its loop on a 'd' step
+        # a discriminator step only updates the discriminator (sgan/trainer.py:286-300 steps d_optimizer): its generator
+        # sample needs no autograd graph (the reference builds one and throws the generator's gradients away)
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not (step_type == 'd' and self.skip_generator_graph_on_d)):
+            if self.batch_samples:
+                rel_pred_list, pred_list = self.generator.sample_k(observed, goals, batch_split, prediction_truth,
+                                                                   n_predict, n_samples)
+            else:
+                rel_pred_list, pred_list = [], []
+                for _ in range(n_samples):
+                    rel_pred_scene, pred_scene = self.generator(observed, goals, batch_split, prediction_truth, n_predict)
+                    rel_pred_list.append(rel_pred_scene)
+                    pred_list.append(pred_scene)
+        pred_scene = pred_list[-1]
         if self.d_steps and (prediction_truth is not None):
-            scores_real = self.discriminator(observed, prediction_truth, goals, batch_split)
-            scores_fake = self.discriminator(observed, pred_scene[-pred_length:], goals, batch_split)
+            if isinstance(prediction_truth, (list, tuple)):
+                prediction_truth = torch.stack(list(prediction_truth), dim=0)
+            if self.batch_samples:
+                scores_real, scores_fake = self.discriminator.score_pair(observed, prediction_truth,
+                                                                         pred_scene[-pred_length:], goals, batch_split)
+            else:
+                scores_real = self.discriminator(observed, prediction_truth, goals, batch_split)
+                scores_fake = self.discriminator(observed, pred_scene[-pred_length:], goals, batch_split)
             return rel_pred_list, pred_list, scores_real, scores_fake
         return rel_pred_list, pred_list, None, None
 
