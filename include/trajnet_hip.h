@@ -318,6 +318,13 @@ typedef struct tnp_bwd_sweep {
     float *dvel_pool_all;            /* directional_in: [S,M,2] */
     float *grid_all;                 /* dense first-layer weight gradient: [S,M,dims[0]] recomputed grids (else NULL) */
     float *dh, *dc;                  /* [M,H] in: gradient of the state after step s_hi; out: of the state before s_lo */
+    /* TNP_POOL_HIDDENMLP (HiddenStateMLPPooling): layT[0] = out_projection.weight^T [mlp_dim, P], whT =
+     * hidden_embedding.0.weight^T [H, mlp_dim_hidden]; dy_all[0] [S,M,P] gradient of the interaction vector, denc_all
+     * [S,M,mlp_dim_hidden] of the hidden embedding's pre-activation, hm_G_all [S,M,ms+mv] / hm_R_all [S,M,ms+mv,2]
+     * routed gradients and winning inputs of the spatial | velocity embeddings (tnp_pool_hiddenmlp_backward);
+     * saves->act_all[0] = pooled [S,M,mlp_dim], saves->enc_all = hidden embedding pre-activations */
+    int32_t hidden_mlp;
+    float *hm_G_all, *hm_R_all;
 } tnp_bwd_sweep;
 TNP_API size_t tnp_lstm_backward_scratch_bytes(const tnp_bwd_sweep *sweep);
 TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *sweep, int s_hi, int s_lo, void *scratch, size_t scratch_bytes,
@@ -366,6 +373,20 @@ TNP_API int tnp_sparse_wgrad(const float *dy, int ldy, const float *enc, int lde
 TNP_API size_t tnp_wgrad_workspace_bytes(int Mo, int No, int K);
 TNP_API int tnp_wgrad(const float *dy, int ld_dy, const float *x, int ld_x, int K, int Mo, int No, float *dw, int ld_dw,
                       float *dbias, void *workspace, size_t workspace_bytes, void *stream);
+/* Backward of HiddenStateMLPPooling's max-pool (lstm/non_gridbased_pooling.py:196-239 under autograd): d_pooled [M, ldp]
+ * (gradient of the max-pooled [spatial | hidden | velocity] vector) is routed to the winning slot of every (ego,
+ * dimension): G [M, ms+mv] and R [M, ms+mv, 2] (routed gradient and the winner's input of the two Linear(2 -> dim)
+ * embeddings -- tnp_colsum_prod turns them into weight / bias gradients), d_hidden_emb_pre [M, mh] (gradient of the
+ * hidden embedding's pre-activation, gathered per track); winner_scratch [M, mh] int32.
+ * tnp_colsum_prod: dW[k, c] = sum_rows G[row, k] R[row, k, c], db[k] = sum_rows G[row, k]. */
+TNP_API int tnp_pool_hiddenmlp_backward(const float *obs1, const float *obs2, const float *hidden_emb_pre, int ldh,
+                                        const int32_t *scene_start, const int32_t *row_base, const int32_t *row_count, int B,
+                                        int M, int ms, int mv, int mh, const float *W_spatial, const float *b_spatial,
+                                        const float *W_vel, const float *b_vel, const float *d_pooled, int ldp, float *G,
+                                        float *R, float *d_hidden_emb_pre, int32_t *winner_scratch, void *stream);
+TNP_API size_t tnp_colsum_prod_workspace_bytes(long rows, int cols);
+TNP_API int tnp_colsum_prod(const float *G, const float *R, long rows, int cols, float *dW, float *db, void *workspace,
+                            size_t workspace_bytes, void *stream);
 /* out [cols, rows] = in [rows, cols]^T (LDS-tiled; operands of the weight-gradient GEMMs) */
 TNP_API int tnp_transpose(const float *in, int ld_in, int rows, int cols, float *out, int ld_out, void *stream);
 /* gradient of the directional grid's values (v_j - v_i, lstm/gridbased_pooling.py:118-143) with respect to the tracks'

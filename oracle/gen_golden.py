@@ -297,6 +297,33 @@ def grad_case(ref):
     print('grad_cases.npz')
 
 
+def grad_nongrid_case(ref):
+    """grad_case for the non-grid interaction modules that train on the HIP path (tests/golden/grad_cases_nongrid.npz)."""
+    out = {}
+    import trajnetbaselines.lstm.non_gridbased_pooling as ng
+    for kind in ('hiddenstatemlp',):
+        torch.manual_seed({'hiddenstatemlp': 45}[kind])
+        pool = ng.HiddenStateMLPPooling(hidden_dim=128, mlp_dim=96, mlp_dim_spatial=32, mlp_dim_vel=32, out_dim=32)
+        model = ref.LSTM(pool=pool).train()
+        xy, split = synth.ragged_crowd(4, 2, 8, seed=52)
+        M = xy.shape[1]
+        observed, truth = xy[:9].clone(), xy[9:20].clone()
+        targets = xy[9:21] - xy[8:20]
+        rel, pred = model(observed, torch.zeros(M, 2), split, truth)
+        crit = ref.PredictionLoss()
+        loss = crit(rel[-12:], targets, split) * 8 + 0.1 * torch.nan_to_num(pred[-12:, split[:-1]]).pow(2).mean()
+        loss.backward()
+        pre = kind + '_'
+        out[pre + 'xy'], out[pre + 'split'] = xy.numpy(), split.numpy()
+        out[pre + 'loss'] = np.float32(loss.item())
+        for k, v in model.state_dict().items():
+            out[pre + 'sd_' + k] = v.numpy().copy()
+        for k, p in model.named_parameters():
+            out[pre + 'grad_' + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'grad_cases_nongrid.npz'), **out)
+    print('grad_cases_nongrid.npz')
+
+
 def train_curve_case(ref):
     """Loss trajectory of the reference over 6 optimisation steps of Trainer.train_batch's arithmetic
     (lstm/trainer.py:229-269: teacher-forced forward, PredictionLoss * batch_size, backward, Adam lr 1e-3 wd 1e-4
@@ -494,6 +521,8 @@ def real_cases(ref):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_import.import_reference()
+    if '--only-grad-nongrid' in sys.argv:
+        return grad_nongrid_case(ref)
     if '--only-sgantrain' in sys.argv:
         return sgan_train_case(ref)
     sgan_train_case(ref)
@@ -511,6 +540,7 @@ def main():
     if '--only-real' in sys.argv:
         return real_cases(ref)
     real_cases(ref)
+    grad_nongrid_case(ref)
     if '--only-grad' in sys.argv:
         return grad_case(ref)
     grad_case(ref)

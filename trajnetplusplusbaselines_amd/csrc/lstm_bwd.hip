@@ -434,8 +434,8 @@ __global__ void __launch_bounds__(256) state_grad_combine_kernel(const float *__
 }
 
 struct SweepScratch {
-    float *dh_tot, *dh_pass, *dxh, *dc_alt, *d_in, *tmp_h, *dgrid, *dcell;
-    int32_t *cells;
+    float *dh_tot, *dh_pass, *dxh, *dc_alt, *d_in, *tmp_h, *dgrid, *dcell, *d_pooled;
+    int32_t *cells, *widx;
     size_t bytes;
 };
 
@@ -458,7 +458,10 @@ static void plan_sweep(const tnp_bwd_sweep *a, void *base, SweepScratch &w) {
     size_t maxw = 0;
     if (grid) for (int l = 1; l < md->n_layers; ++l) maxw = maxw > (size_t)md->dims[l] ? maxw : (size_t)md->dims[l];
     w.d_in = (float *)take(M * maxw * 4);
-    w.tmp_h = (float *)take(social ? M * H * 4 : 0);
+    const bool hm = a->hidden_mlp != 0;
+    w.tmp_h = (float *)take((social || hm) ? M * H * 4 : 0);
+    w.d_pooled = (float *)take(hm ? M * (size_t)(md->dims[0] + md->dims[1] + md->dims[2]) * 4 : 0);
+    w.widx = (int32_t *)take(hm ? M * (size_t)md->dims[2] * 4 : 0);
     const bool dense0 = grid && ((social && !a->social_sparse) || a->directional_in);
     w.dgrid = (float *)take(dense0 ? M * (size_t)md->dims[0] * 4 : 0);
     w.cells = (int32_t *)take(dense0 ? M * (size_t)a->n_max * 4 : 0);
@@ -606,7 +609,8 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
     if (s_hi >= S || s_lo < 0 || s_lo > s_hi) TNP_FAIL(-1, "tnp_lstm_backward_sweep: steps %d..%d outside 0..%d", s_hi, s_lo, S - 1);
     const bool grid = md->pool_type >= TNP_POOL_OCCUPANCY && md->pool_type <= TNP_POOL_SOCIAL && !a->nn_pool;
     const bool social = grid && md->pool_type == TNP_POOL_SOCIAL;
-    if (md->pool_type != TNP_POOL_NONE && !grid && !a->nn_pool)
+    const bool hm = a->hidden_mlp != 0 && md->pool_type == TNP_POOL_HIDDENMLP;
+    if (md->pool_type != TNP_POOL_NONE && !grid && !a->nn_pool && !hm)
         TNP_FAIL(-1, "tnp_lstm_backward_sweep: pool type %d has no backward", md->pool_type);
     if ((md->variant >> 17) & 1) TNP_FAIL(-1, "tnp_lstm_backward_sweep: pool_to_input=False has no backward");
     tnp::SweepScratch w;
@@ -686,6 +690,21 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
                                                        ncell, denc, stream));
                 }
                 TNP_RC(tnp_linear_forward(denc, C, a->whT, C, nullptr, w.tmp_h, H, M, H, C, 0, 0, stream));
+                extra = w.tmp_h;
+            }
+        }
+        if (hm) {   // HiddenStateMLPPooling: out_projection (linear) <- max-pool routing <- embeddings
+            const int ms = md->dims[0], mv = md->dims[1], mh = md->dims[2], D = ms + mh + mv, GDm = ms + mv;
+            float *dP = a->dy_all[0] + r * Pw;
+            TNP_HIP(hipMemcpy2DAsync(dP, (size_t)Pw * 4, w.dxh + P0, (size_t)LDX * 4, (size_t)Pw * 4, M, hipMemcpyDeviceToDevice, s));
+            TNP_RC(tnp_linear_forward(dP, Pw, a->layT[0], Pw, nullptr, w.d_pooled, D, M, D, Pw, 0, 0, stream));
+            float *denc = mh > 0 ? a->denc_all + r * mh : nullptr;
+            TNP_RC(tnp_pool_hiddenmlp_backward(o1, o2, mh > 0 ? sv->enc_all + r * mh : nullptr, mh, a->scene_start, a->row_base,
+                                               a->row_count, a->B, M, ms, mv, mh, md->Wp[0], md->bp[0], md->Wp[1], md->bp[1],
+                                               w.d_pooled, D, a->hm_G_all + r * GDm, a->hm_R_all + r * GDm * 2, denc, w.widx,
+                                               stream));
+            if (mh > 0) {
+                TNP_RC(tnp_linear_forward(denc, mh, a->whT, mh, nullptr, w.tmp_h, H, M, H, mh, 0, 0, stream));
                 extra = w.tmp_h;
             }
         }

@@ -119,6 +119,115 @@ __global__ void __launch_bounds__(256) pool_hiddenmlp_kernel(const float *__rest
     }
 }
 
+// ---- backward of HiddenStateMLPPooling's max-pool (training) -----------------------------------------------------
+// torch.max routes the gradient of pooled[i, k] to the slot that attained the maximum; the ReLU in front of it passes
+// it on only where the winner's pre-activation is positive.  One thread per pooled dimension k recomputes the forward
+// of its (ego, k) pairs and writes
+//   spatial / velocity parts: G[i, k'] = routed gradient, R[i, k', 0:2] = the winning slot's input (relative position /
+//                             4 x relative velocity), from which the Linear(2 -> dim) gradients are column sums;
+//   hidden part:              widx[i, k'] = scene-local winner (or -1: inactive), consumed by the gather kernel below.
+__global__ void __launch_bounds__(256) pool_hiddenmlp_backward_kernel(const float *__restrict__ obs1, const float *__restrict__ obs2,
+                                                                      const float *__restrict__ henc, int ldh,
+                                                                      const int32_t *__restrict__ scene_start, int ms, int mv, int mh,
+                                                                      const float *__restrict__ Ws, const float *__restrict__ bs,
+                                                                      const float *__restrict__ Wv, const float *__restrict__ bv,
+                                                                      const float *__restrict__ dpool, int ldp,
+                                                                      float *__restrict__ G, float *__restrict__ R,
+                                                                      int32_t *__restrict__ widx) {
+    const int lo = scene_start[blockIdx.x], hi = scene_start[blockIdx.x + 1];
+    const int D = ms + mh + mv, GD = ms + mv;
+    for (int k = threadIdx.x; k < D; k += blockDim.x) {
+        const int part = k < ms ? 0 : (k < ms + mh ? 1 : 2);
+        float w0 = 0.0f, w1 = 0.0f, b0 = 0.0f;
+        if (part == 0) { w0 = Ws[2 * k]; w1 = Ws[2 * k + 1]; b0 = bs[k]; }
+        if (part == 2) { const int q = k - ms - mh; w0 = Wv[2 * q]; w1 = Wv[2 * q + 1]; b0 = bv[q]; }
+        for (int i = lo + blockIdx.y; i < hi; i += gridDim.y) {
+            const float xi = obs2[2 * i], yi = obs2[2 * i + 1];
+            const float vxi = xi - obs1[2 * i], vyi = yi - obs1[2 * i + 1];
+            float best = -INFINITY, brx = 0.0f, bry = 0.0f;
+            int bj = -1;
+            for (int j = lo; j < hi; ++j) {
+                float e, rx = 0.0f, ry = 0.0f;
+                if (part == 0) {
+                    rx = obs2[2 * j] - xi; ry = obs2[2 * j + 1] - yi;
+                    if (rx != rx || ry != ry) e = -100.0f;
+                    else { e = fmaf(ry, w1, fmaf(rx, w0, b0)); e = e > 0.0f ? e : 0.0f; }
+                } else if (part == 1) {
+                    e = henc[(size_t)j * ldh + (k - ms)];
+                    e = e > 0.0f ? e : 0.0f;
+                } else {
+                    rx = ((obs2[2 * j] - obs1[2 * j]) - vxi) * 4.0f;
+                    ry = ((obs2[2 * j + 1] - obs1[2 * j + 1]) - vyi) * 4.0f;
+                    if (rx != rx || ry != ry) e = -100.0f;
+                    else { e = fmaf(ry, w1, fmaf(rx, w0, b0)); e = e > 0.0f ? e : 0.0f; }
+                }
+                if (e > best) { best = e; bj = j; brx = rx; bry = ry; }   // first maximal slot, as torch.max
+            }
+            const bool active = best > 0.0f;     // ReLU output 0 (or the -100 fill): nothing flows to the parameters
+            const float g = active ? dpool[(size_t)i * ldp + k] : 0.0f;
+            if (part == 1) {
+                widx[(size_t)i * mh + (k - ms)] = active ? (bj - lo) : -1;
+            } else {
+                const int kk = part == 0 ? k : (k - mh);
+                G[(size_t)i * GD + kk] = g;
+                R[((size_t)i * GD + kk) * 2] = active ? brx : 0.0f;
+                R[((size_t)i * GD + kk) * 2 + 1] = active ? bry : 0.0f;
+            }
+        }
+    }
+}
+
+// d(hidden embedding pre-activation)[j, k'] = sum over the egos i of j's scene that picked j for dimension k' of dpool[i, ms+k']
+// one wave per track j: lanes = (ego slice, k'), fixed combination order
+__global__ void __launch_bounds__(256) pool_hiddenmlp_gather_kernel(const int32_t *__restrict__ widx, const float *__restrict__ dpool,
+                                                                    int ldp, const int32_t *__restrict__ row_base,
+                                                                    const int32_t *__restrict__ row_count, int M, int ms, int mh,
+                                                                    float *__restrict__ denc) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= M) return;
+    const int lo = row_base[j], ns = row_count[j], jj = j - lo;
+    for (int k = lane; k < mh; k += 64) {
+        float acc = 0.0f;
+        for (int i = lo; i < lo + ns; ++i)
+            if (widx[(size_t)i * mh + k] == jj) acc += dpool[(size_t)i * ldp + ms + k];
+        denc[(size_t)j * mh + k] = acc;
+    }
+}
+
+// dW[k, c] = sum_rows G[row, k] * R[row, k, c] (c = 0, 1), db[k] = sum_rows G[row, k]: gradients of a Linear(2 -> cols)
+// whose input differs per output unit (the max-pool's winner).  Two deterministic stages: row chunks, then chunks.
+constexpr int CS_ROWS = 2048;
+__global__ void __launch_bounds__(256) colsum_prod_kernel(const float *__restrict__ G, const float *__restrict__ R, long rows, int cols,
+                                                          float *__restrict__ part) {
+    __shared__ float red[4][64][3];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+    float a0 = 0.0f, a1 = 0.0f, ab = 0.0f;
+    if (c < cols)
+        for (long r = r0 + sub; r < r1; r += 4) {
+            const float g = G[r * cols + c];
+            a0 = fmaf(g, R[(r * cols + c) * 2], a0);
+            a1 = fmaf(g, R[(r * cols + c) * 2 + 1], a1);
+            ab += g;
+        }
+    red[sub][threadIdx.x & 63][0] = a0; red[sub][threadIdx.x & 63][1] = a1; red[sub][threadIdx.x & 63][2] = ab;
+    __syncthreads();
+    if (sub == 0 && c < cols) {
+        const int l = threadIdx.x;
+        for (int q = 0; q < 3; ++q)
+            part[((size_t)blockIdx.y * cols + c) * 3 + q] = (red[0][l][q] + red[1][l][q]) + (red[2][l][q] + red[3][l][q]);
+    }
+}
+__global__ void __launch_bounds__(256) colsum_reduce_kernel(const float *__restrict__ part, int nchunks, int cols, float *__restrict__ dW,
+                                                            float *__restrict__ db) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= cols * 3) return;
+    float acc = 0.0f;
+    for (int ch = 0; ch < nchunks; ++ch) acc += part[(size_t)ch * cols * 3 + e];
+    const int c = e / 3, q = e - c * 3;
+    if (q < 2) dW[c * 2 + q] = acc; else db[c] = acc;
+}
+
 int launch_pool_nn(const float *obs1, const float *obs2, const int32_t *scene_start, int B, int n_sel, int in_dim,
                    const float *W, const float *bias, int d, float *out, int ldo, hipStream_t s, float *attrs) {
     if (B <= 0) return 0;
@@ -408,4 +517,46 @@ extern "C" TNP_API int tnp_pool_attn_pair(const float *obs1, const float *obs2, 
 extern "C" TNP_API int tnp_pool_traj_forward(const float *obs1, const float *obs2, int M, const float *W, const float *bias,
                                              int P, float *out, int ldo, double *scratch4, void *stream) {
     return tnp::launch_pool_traj(obs1, obs2, M, W, bias, P, out, ldo, scratch4, (hipStream_t)stream);
+}
+
+extern "C" TNP_API int tnp_pool_hiddenmlp_backward(const float *obs1, const float *obs2, const float *hidden_emb_pre, int ldh,
+                                                   const int32_t *scene_start, const int32_t *row_base,
+                                                   const int32_t *row_count, int B, int M, int ms, int mv, int mh,
+                                                   const float *W_spatial, const float *b_spatial, const float *W_vel,
+                                                   const float *b_vel, const float *d_pooled, int ldp, float *G, float *R,
+                                                   float *d_hidden_emb_pre, int32_t *winner_scratch, void *stream) {
+    if (B <= 0 || M <= 0) return 0;
+    if (mh > 0 && (!hidden_emb_pre || !d_hidden_emb_pre || !winner_scratch))
+        TNP_FAIL(-1, "tnp_pool_hiddenmlp_backward: hidden-embedding buffers missing");
+    const int D = ms + mh + mv;
+    const int threads = D <= 64 ? 64 : (D <= 128 ? 128 : 256);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tnp::pool_hiddenmlp_backward_kernel, dim3(B, 8), dim3(threads), 0, s, obs1, obs2, hidden_emb_pre, ldh,
+                       scene_start, ms, mv, mh, W_spatial, b_spatial, W_vel, b_vel, d_pooled, ldp, G, R, winner_scratch);
+    TNP_HIP(hipGetLastError());
+    if (mh > 0) {
+        hipLaunchKernelGGL(tnp::pool_hiddenmlp_gather_kernel, dim3((M + 3) / 4), dim3(256), 0, s, winner_scratch, d_pooled, ldp,
+                           row_base, row_count, M, ms, mh, d_hidden_emb_pre);
+        TNP_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" TNP_API size_t tnp_colsum_prod_workspace_bytes(long rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return (size_t)((rows + tnp::CS_ROWS - 1) / tnp::CS_ROWS) * cols * 3 * sizeof(float);
+}
+
+extern "C" TNP_API int tnp_colsum_prod(const float *G, const float *R, long rows, int cols, float *dW, float *db, void *workspace,
+                                       size_t workspace_bytes, void *stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    const int nchunks = (int)((rows + tnp::CS_ROWS - 1) / tnp::CS_ROWS);
+    if (!workspace || workspace_bytes < (size_t)nchunks * cols * 3 * sizeof(float)) TNP_FAIL(-1, "tnp_colsum_prod: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tnp::colsum_prod_kernel, dim3((cols + 63) / 64, nchunks), dim3(256), 0, s, G, R, rows, cols, (float *)workspace);
+    TNP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(tnp::colsum_reduce_kernel, dim3((cols * 3 + 255) / 256), dim3(256), 0, s, (const float *)workspace, nchunks, cols,
+                       dW, db);
+    TNP_HIP(hipGetLastError());
+    return 0;
 }

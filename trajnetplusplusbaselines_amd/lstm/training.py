@@ -74,7 +74,8 @@ class BwdSweep(ctypes.Structure):
                 ('dG_all', ctypes.c_void_p), ('de_all', ctypes.c_void_p), ('dgoal_all', ctypes.c_void_p),
                 ('dy_all', ctypes.c_void_p * 3), ('denc_all', ctypes.c_void_p), ('dnn_all', ctypes.c_void_p),
                 ('dvel_pool_all', ctypes.c_void_p), ('grid_all', ctypes.c_void_p), ('dh', ctypes.c_void_p),
-                ('dc', ctypes.c_void_p)]
+                ('dc', ctypes.c_void_p), ('hidden_mlp', ctypes.c_int32), ('hm_G_all', ctypes.c_void_p),
+                ('hm_R_all', ctypes.c_void_p)]
 
 
 def _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, win_all, o1_all, o2_all):
@@ -123,7 +124,8 @@ class SequenceFn(torch.autograd.Function):
         ws, need = model._workspace(m, M, idx.B, dev)
         I = model.encoder.weight_ih.shape[1]
         nn_pool = pool is not None and type(pool).__name__ == 'NearestNeighborMLP'
-        layers = pool.embedding_layers() if (pool is not None and not nn_pool) else []
+        hm_pool = pool is not None and type(pool).__name__ == 'HiddenStateMLPPooling'
+        layers = pool.embedding_layers() if (pool is not None and not nn_pool and not hm_pool) else []
         if len(layers) > 3:
             raise NotImplementedError('embedding MLPs deeper than three layers')
         # per-step slices of buffers allocated once per sequence
@@ -133,11 +135,14 @@ class SequenceFn(torch.autograd.Function):
         gates_all = torch.empty(S, M, 4 * H, device=dev)
         act_all = [torch.empty(S, M, lin.weight.shape[0], device=dev) for lin in layers[:-1]]
         enc_all = torch.empty(S, M, pool.pooling_dim, device=dev) \
-            if (pool is not None and not nn_pool and pool.type_ == 'social') else None
+            if (pool is not None and not nn_pool and not hm_pool and pool.type_ == 'social') else None
+        if hm_pool:    # the max-pooled vector (out_projection's input) and the hidden embedding's pre-activation
+            act_all = [torch.empty(S, M, pool.mlp_dim, device=dev)]
+            enc_all = torch.empty(S, M, pool.mlp_dim_hidden, device=dev) if pool.mlp_dim_hidden else None
         attrs_all = torch.empty(S, M, pool.n * pool.input_dim, device=dev) if nn_pool else None
         # sparse first embedding layer: keep every step's winner table for the sparse backward
         win_all = None
-        if enc_all is not None and opts.get('sparse_backward', getattr(model, 'sparse_backward', True)) and layers[0].weight.shape[0] % 64 == 0 \
+        if enc_all is not None and not hm_pool and opts.get('sparse_backward', getattr(model, 'sparse_backward', True)) and layers[0].weight.shape[0] % 64 == 0 \
                 and layers[0].weight.shape[0] * 64 + 4096 <= (160 * 1024) // ((pool.pooling_dim + 15) // 16) \
                 and L.tnp_lstm_sparse_first_layer(ctypes.byref(m), M) == 1:
             win_all = torch.empty(S, M, pool.n * pool.n, dtype=torch.int16, device=dev)
@@ -176,6 +181,7 @@ class SequenceFn(torch.autograd.Function):
         ctx.model, ctx.idx, ctx.goals = model, idx, goals_t
         ctx.saved = (h_all, c_all, X_all, gates_all, act_all, enc_all, decs)
         ctx.attrs_all = attrs_all
+        ctx.hm_pool = hm_pool
         ctx.obs_all = (o1_all, o2_all)
         ctx.win_all = win_all
         ctx.w_cell_major = model._cell_major_weight(layers[0].weight, pool) if win_all is not None else None
@@ -210,18 +216,27 @@ class SequenceFn(torch.autograd.Function):
         has_h2n = 'hidden2normal.linear.weight' in P            # the S-GAN discriminator has no output head
         o1_all, o2_all = ctx.obs_all
         nn_pool = ctx.attrs_all is not None                      # NearestNeighborMLP: only its embedding has parameters
-        layers = pool.embedding_layers() if (pool is not None and not nn_pool) else []
+        hm_pool = ctx.hm_pool                                    # HiddenStateMLPPooling
+        grid_pool = pool is not None and not nn_pool and not hm_pool
+        layers = pool.embedding_layers() if grid_pool else []
         lay_names = ['pool.embedding.%d' % i for i, mod in enumerate(pool.embedding) if isinstance(mod, torch.nn.Linear)] \
-            if (pool is not None and not nn_pool) else []
-        social = pool is not None and not nn_pool and pool.type_ == 'social'
+            if grid_pool else []
+        social = grid_pool and pool.type_ == 'social'
         dnn_all = torch.empty(S, M, pool.out_dim, device=dev) if nn_pool else None
-        directional_in = ctx.input_grad and pool is not None and not nn_pool and pool.type_ == 'directional'
-        if ctx.input_grad and nn_pool:
-            raise NotImplementedError('position gradients through NearestNeighborMLP')
+        directional_in = ctx.input_grad and grid_pool and pool.type_ == 'directional'
+        if ctx.input_grad and (nn_pool or hm_pool):
+            raise NotImplementedError('position gradients through %s' % type(pool).__name__)
         sparse_bwd = ctx.win_all is not None      # first layer's gradients from the winner tables (csrc/lstm_bwd.hip)
         layT = [T(n + '.weight') if (li > 0 or ((social or directional_in) and not sparse_bwd)) else None
                 for li, n in enumerate(lay_names)]
         whT = T('pool.hidden_dim_encoding.weight') if social else None
+        hm_G_all = hm_R_all = None
+        if hm_pool:
+            ms, mv, mh = pool.mlp_dim_spatial, pool.mlp_dim_vel, pool.mlp_dim_hidden
+            layT = [T('pool.out_projection.weight')]
+            whT = T('pool.hidden_embedding.0.weight') if mh else None
+            hm_G_all = torch.empty(S, M, ms + mv, device=dev)
+            hm_R_all = torch.empty(S, M, ms + mv, 2, device=dev)
 
         # per-step operands of the deferred weight-gradient GEMMs
         dlin_all = torch.empty(S, M, 5, device=dev)
@@ -232,7 +247,13 @@ class SequenceFn(torch.autograd.Function):
         dy_all = [torch.empty(S, M, lin.weight.shape[0], device=dev) for lin in layers]
         denc_all = torch.empty(S, M, pool.pooling_dim, device=dev) if social else None
         grid_all = None
-        if pool is not None and not nn_pool:
+        if hm_pool:
+            dy_all = [torch.empty(S, M, pool.out_dim, device=dev)]          # gradient of the interaction vector
+            denc_all = torch.empty(S, M, mh, device=dev) if mh else None
+            sizes = (idx.starts[1:] - idx.starts[:-1]).long()
+            row_base = torch.repeat_interleave(idx.starts[:-1].long(), sizes).to(torch.int32)
+            row_count = torch.repeat_interleave(sizes, sizes).to(torch.int32)
+        if grid_pool:
             G, cell, half_x, half_y = pool._geometry()
             C = pool.pooling_dim
             grid_all = torch.empty(S, M, C * G * G, device=dev) if not sparse_bwd else None
@@ -283,15 +304,17 @@ class SequenceFn(torch.autograd.Function):
             sw.layT[li] = t.data_ptr() if t is not None else None
         sw.whT = whT.data_ptr() if whT is not None else None
         sw.w_cell_major = ctx.w_cell_major.data_ptr() if sparse_bwd else None
-        if social or directional_in:
+        if social or directional_in or hm_pool:
             sw.row_base, sw.row_count = row_base.data_ptr(), row_count.data_ptr()
+        if hm_pool:
+            sw.hidden_mlp, sw.hm_G_all, sw.hm_R_all = 1, hm_G_all.data_ptr(), hm_R_all.data_ptr()
         if social and sparse_bwd:
             sw.cells_all, sw.ego_list, sw.ego_count = cells_all.data_ptr(), ego_list.data_ptr(), ego_count.data_ptr()
         sw.dlin_all, sw.dG_all, sw.de_all = dlin_all.data_ptr(), dG_all.data_ptr(), de_all.data_ptr()
         sw.dgoal_all = dgoal_all.data_ptr() if GD else None
         for li, t in enumerate(dy_all):
             sw.dy_all[li] = t.data_ptr()
-        sw.denc_all = denc_all.data_ptr() if social else None
+        sw.denc_all = denc_all.data_ptr() if denc_all is not None else None
         sw.dnn_all = dnn_all.data_ptr() if nn_pool else None
         sw.dvel_pool_all = dvel_pool_all.data_ptr() if directional_in else None
         sw.grid_all = grid_all.data_ptr() if grid_all is not None else None
@@ -382,6 +405,20 @@ class SequenceFn(torch.autograd.Function):
                 grads[name + '.bias'] = dy_all[0].reshape(-1, N1).sum(0)
                 continue
             wgrad(name + '.weight', dy_all[li], grid_all if li == 0 else act_all[li - 1], name + '.bias')
+        if hm_pool:
+            wgrad('pool.out_projection.weight', dy_all[0], act_all[0], 'pool.out_projection.bias')
+            if mh:
+                wgrad('pool.hidden_embedding.0.weight', denc_all, h_prev_all, 'pool.hidden_embedding.0.bias')
+            # Linear(2 -> dim) embeddings behind the max-pool: per output unit the input is the winning slot's
+            rows, cols = S * M, ms + mv
+            nb = L.tnp_colsum_prod_workspace_bytes(rows, cols)
+            cws = torch.empty(nb, dtype=torch.uint8, device=dev)
+            dW2, db2 = torch.empty(cols, 2, device=dev), torch.empty(cols, device=dev)
+            _lib.check(L.tnp_colsum_prod(_lib.ptr(hm_G_all), _lib.ptr(hm_R_all), rows, cols, _lib.ptr(dW2), _lib.ptr(db2),
+                                         _lib.ptr(cws), nb, sp()), 'colsum_prod')
+            grads['pool.spatial_embedding.0.weight'], grads['pool.spatial_embedding.0.bias'] = dW2[:ms], db2[:ms]
+            if mv:
+                grads['pool.vel_embedding.0.weight'], grads['pool.vel_embedding.0.bias'] = dW2[ms:], db2[ms:]
         if nn_pool:       # rows = (step, track, neighbour slot)
             d = pool.out_dim // pool.n
             wgrad('pool.embedding.0.weight', dnn_all.reshape(-1, d), ctx.attrs_all.reshape(-1, pool.input_dim),
