@@ -325,6 +325,13 @@ typedef struct tnp_bwd_sweep {
      * saves->act_all[0] = pooled [S,M,mlp_dim], saves->enc_all = hidden embedding pre-activations */
     int32_t hidden_mlp;
     float *hm_G_all, *hm_R_all;
+    /* TNP_POOL_ATTNMLP (AttentionMLPPooling, folded maps in model->Wx / bx): layT[0] = Wfin^T [mlp_dim, P], whT as above,
+     * at_WuT [mlp_dim, mlp_dim+4] = Wx[1]^T, at_WqT [mlp_dim, mlp_dim] = Wx[0]^T; stacked outputs for the weight
+     * gradients: dy_all[0] [S,M,P], denc_all, at_eself_all / at_q_all / at_dq_all / at_ebar_all [S,M,mlp_dim],
+     * at_du_all [S,M,mlp_dim+4], at_A_all [S,M,ms+mv,3] */
+    int32_t attention;
+    const float *at_WuT, *at_WqT;
+    float *at_eself_all, *at_q_all, *at_dq_all, *at_ebar_all, *at_du_all, *at_A_all;
 } tnp_bwd_sweep;
 TNP_API size_t tnp_lstm_backward_scratch_bytes(const tnp_bwd_sweep *sweep);
 TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *sweep, int s_hi, int s_lo, void *scratch, size_t scratch_bytes,
@@ -378,7 +385,26 @@ TNP_API int tnp_wgrad(const float *dy, int ld_dy, const float *x, int ld_x, int 
  * dimension): G [M, ms+mv] and R [M, ms+mv, 2] (routed gradient and the winner's input of the two Linear(2 -> dim)
  * embeddings -- tnp_colsum_prod turns them into weight / bias gradients), d_hidden_emb_pre [M, mh] (gradient of the
  * hidden embedding's pre-activation, gathered per track); winner_scratch [M, mh] int32.
- * tnp_colsum_prod: dW[k, c] = sum_rows G[row, k] R[row, k, c], db[k] = sum_rows G[row, k]. */
+ * tnp_colsum_prod: dW[k, c] = sum_rows G[row, k] R[row, k, c], db[k] = sum_rows G[row, k]; with G == NULL, R is
+ * [rows, cols, 3] = per-row (sum g r_x, sum g r_y, sum g) and the three planes are summed over the rows.
+ *
+ * Backward of AttentionMLPPooling's pair kernel (lstm/non_gridbased_pooling.py:297-351 under autograd, linear maps folded
+ * as in tnp_lstm_model.Wx): from d_ebar [M, ldd] (gradient of sum_j a_ij e_ij) and u [M, ldu]
+ *   tnp_pool_attn_pair_backward: du [M, ldu] (gradient of u, column D = the bias term), A3 [M, ms+mv, 3] (per ego and
+ *       spatial | velocity unit: sum over the slots of g r_x, g r_y, g), dEh [M, n_max, mh] (gradient of every slot's
+ *       hidden embedding as seen by ego i), ebar [M, lde] (recomputed forward output);
+ *   tnp_pool_attn_self_backward: de_self [M, ldd] (gradient of the ego's own embedding through the query) is added to
+ *       A3's bias plane and, with dEh gathered per track, gives d_hidden_emb_pre [M, mh]; dself_scratch [M, mh]. */
+TNP_API int tnp_pool_attn_pair_backward(const float *obs1, const float *obs2, const float *hidden_emb_pre, int ldh,
+                                        const int32_t *scene_start, int B, int n_max, int ms, int mv, int mh,
+                                        const float *W_spatial, const float *b_spatial, const float *W_vel, const float *b_vel,
+                                        float fill, const float *u, int ldu, const float *d_ebar, int ldd, float *du, float *A3,
+                                        float *dEh, float *ebar, int lde, void *stream);
+TNP_API int tnp_pool_attn_self_backward(const float *obs1, const float *obs2, const float *hidden_emb_pre, int ldh,
+                                        const int32_t *row_base, const int32_t *row_count, int M, int n_max, int ms, int mv,
+                                        int mh, const float *b_spatial, const float *b_vel, const float *de_self, int ldd,
+                                        const float *dEh, float *A3, float *dself_scratch, float *d_hidden_emb_pre,
+                                        void *stream);
 TNP_API int tnp_pool_hiddenmlp_backward(const float *obs1, const float *obs2, const float *hidden_emb_pre, int ldh,
                                         const int32_t *scene_start, const int32_t *row_base, const int32_t *row_count, int B,
                                         int M, int ms, int mv, int mh, const float *W_spatial, const float *b_spatial,

@@ -182,13 +182,16 @@ def test_wgrad_split_k_matches_fp64(K, Mo, No):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
-def test_hiddenstatemlp_gradients_match_reference_autograd():
+@pytest.mark.parametrize('kind', ['hiddenstatemlp', 'attentionmlp'])
+def test_nongrid_gradients_match_reference_autograd(kind):
     """Training through HiddenStateMLPPooling (max-pool routing, Linear(2 -> dim) embeddings behind it, hidden embedding,
-    out_projection) against the reference's autograd on the same weights and batch (grad_cases_nongrid.npz)."""
-    from trajnetplusplusbaselines_amd.lstm import LSTM, HiddenStateMLPPooling, PredictionLoss
+    out_projection) and AttentionMLPPooling (softmax attention over the slots with the linear maps folded, gradients
+    un-folded to wq / wk / wv / in_proj / out_proj / out_projection) against the reference's autograd on the same weights
+    and batch (grad_cases_nongrid.npz)."""
+    from trajnetplusplusbaselines_amd.lstm import LSTM, HiddenStateMLPPooling, AttentionMLPPooling, PredictionLoss
     G = np.load(os.path.join(helpers.GOLDEN, 'grad_cases_nongrid.npz'))
-    kind = 'hiddenstatemlp'
-    pool = HiddenStateMLPPooling(hidden_dim=128, mlp_dim=96, mlp_dim_spatial=32, mlp_dim_vel=32, out_dim=32)
+    cls = HiddenStateMLPPooling if kind == 'hiddenstatemlp' else AttentionMLPPooling
+    pool = cls(hidden_dim=128, mlp_dim=96, mlp_dim_spatial=32, mlp_dim_vel=32, out_dim=32)
     model = LSTM(pool=pool)
     pre = kind + '_sd_'
     model.load_state_dict({k[len(pre):]: torch.tensor(G[k]) for k in G.files if k.startswith(pre)})
@@ -210,4 +213,4 @@ def test_hiddenstatemlp_gradients_match_reference_autograd():
         err = float(np.abs(p.grad.cpu().numpy() - want).max()) / scale
         worst = max(worst, err)
         assert err < 2e-3, '%s: relative error %.2e (scale %.2e)' % (name, err, scale)
-    print('hiddenstatemlp worst relative gradient error %.2e' % worst)
+    print(kind, 'worst relative gradient error %.2e' % worst)

@@ -127,7 +127,7 @@ def test_gpu_full_size_vs_oracle(kind):
 @pytest.mark.gpu
 def test_training_through_nongrid_module_raises():
     import torch
-    model = build_amd('attentionmlp').train()   # NearestNeighborMLP and HiddenStateMLPPooling train (tests/test_gpu_training.py)
+    model = build_amd('nn_lstm').train()   # the stateless modules train (tests/test_gpu_training.py), the stateful encoders not yet
     xy, split = torch.tensor(GOLD['nn_lin_xy']), torch.tensor(GOLD['nn_lin_split'])
     with pytest.raises(NotImplementedError):
         model(xy[:9], torch.zeros(xy.shape[1], 2), split, prediction_truth=xy[9:20].clone())

@@ -123,6 +123,11 @@ def lib():
     L.tnp_colsum_prod_workspace_bytes.restype = ctypes.c_size_t
     L.tnp_colsum_prod_workspace_bytes.argtypes = [ctypes.c_long, ctypes.c_int]
     L.tnp_colsum_prod.argtypes = [_fp, _fp, ctypes.c_long, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t, _fp]
+    L.tnp_pool_attn_pair_backward.argtypes = [_fp, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, ctypes.c_float, _fp, ctypes.c_int,
+                                              _fp, ctypes.c_int, _fp, _fp, _fp, _fp, ctypes.c_int, _fp]
+    L.tnp_pool_attn_self_backward.argtypes = [_fp, _fp, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, _fp, _fp, _fp, _fp, _fp]
     L.tnp_transpose.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]
     L.tnp_directional_scatter_backward.argtypes = [_fp, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, _fp, _fp]

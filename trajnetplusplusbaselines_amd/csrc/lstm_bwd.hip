@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(256) state_grad_combine_kernel(const float *__
 }
 
 struct SweepScratch {
-    float *dh_tot, *dh_pass, *dxh, *dc_alt, *d_in, *tmp_h, *dgrid, *dcell, *d_pooled;
+    float *dh_tot, *dh_pass, *dxh, *dc_alt, *d_in, *tmp_h, *dgrid, *dcell, *d_pooled, *at_u, *at_deh, *at_dself;
     int32_t *cells, *widx;
     size_t bytes;
 };
@@ -459,8 +459,12 @@ static void plan_sweep(const tnp_bwd_sweep *a, void *base, SweepScratch &w) {
     if (grid) for (int l = 1; l < md->n_layers; ++l) maxw = maxw > (size_t)md->dims[l] ? maxw : (size_t)md->dims[l];
     w.d_in = (float *)take(M * maxw * 4);
     const bool hm = a->hidden_mlp != 0;
-    w.tmp_h = (float *)take((social || hm) ? M * H * 4 : 0);
-    w.d_pooled = (float *)take(hm ? M * (size_t)(md->dims[0] + md->dims[1] + md->dims[2]) * 4 : 0);
+    const bool at = a->attention != 0;
+    w.tmp_h = (float *)take((social || hm || at) ? M * H * 4 : 0);
+    w.d_pooled = (float *)take((hm || at) ? M * (size_t)(md->dims[0] + md->dims[1] + md->dims[2]) * 4 : 0);
+    w.at_u = (float *)take(at ? M * (size_t)(md->dims[0] + md->dims[1] + md->dims[2] + 4) * 4 : 0);
+    w.at_deh = (float *)take(at ? M * (size_t)a->n_max * md->dims[2] * 4 : 0);
+    w.at_dself = (float *)take(at ? M * (size_t)md->dims[2] * 4 : 0);
     w.widx = (int32_t *)take(hm ? M * (size_t)md->dims[2] * 4 : 0);
     const bool dense0 = grid && ((social && !a->social_sparse) || a->directional_in);
     w.dgrid = (float *)take(dense0 ? M * (size_t)md->dims[0] * 4 : 0);
@@ -610,7 +614,8 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
     const bool grid = md->pool_type >= TNP_POOL_OCCUPANCY && md->pool_type <= TNP_POOL_SOCIAL && !a->nn_pool;
     const bool social = grid && md->pool_type == TNP_POOL_SOCIAL;
     const bool hm = a->hidden_mlp != 0 && md->pool_type == TNP_POOL_HIDDENMLP;
-    if (md->pool_type != TNP_POOL_NONE && !grid && !a->nn_pool && !hm)
+    const bool at = a->attention != 0 && md->pool_type == TNP_POOL_ATTNMLP;
+    if (md->pool_type != TNP_POOL_NONE && !grid && !a->nn_pool && !hm && !at)
         TNP_FAIL(-1, "tnp_lstm_backward_sweep: pool type %d has no backward", md->pool_type);
     if ((md->variant >> 17) & 1) TNP_FAIL(-1, "tnp_lstm_backward_sweep: pool_to_input=False has no backward");
     tnp::SweepScratch w;
@@ -702,6 +707,32 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
             TNP_RC(tnp_pool_hiddenmlp_backward(o1, o2, mh > 0 ? sv->enc_all + r * mh : nullptr, mh, a->scene_start, a->row_base,
                                                a->row_count, a->B, M, ms, mv, mh, md->Wp[0], md->bp[0], md->Wp[1], md->bp[1],
                                                w.d_pooled, D, a->hm_G_all + r * GDm, a->hm_R_all + r * GDm * 2, denc, w.widx,
+                                               stream));
+            if (mh > 0) {
+                TNP_RC(tnp_linear_forward(denc, mh, a->whT, mh, nullptr, w.tmp_h, H, M, H, mh, 0, 0, stream));
+                extra = w.tmp_h;
+            }
+        }
+        if (at) {   // AttentionMLPPooling: Wfin (linear) <- softmax attention over the slots <- embeddings, query path
+            const int ms = md->dims[0], mv = md->dims[1], mh = md->dims[2], D = ms + mh + mv, GDm = ms + mv, LU = D + 4;
+            float *dP = a->dy_all[0] + r * Pw;
+            TNP_HIP(hipMemcpy2DAsync(dP, (size_t)Pw * 4, w.dxh + P0, (size_t)LDX * 4, (size_t)Pw * 4, M, hipMemcpyDeviceToDevice, s));
+            TNP_RC(tnp_linear_forward(dP, Pw, a->layT[0], Pw, nullptr, w.d_pooled, D, M, D, Pw, 0, 0, stream));       // d ebar
+            const float *hpre = mh > 0 ? sv->enc_all + r * mh : nullptr;
+            float *es = a->at_eself_all + r * D, *qs = a->at_q_all + r * D;
+            TNP_RC(tnp_pool_attn_self(o1, o2, hpre, mh, 1, M, ms, mv, mh, md->bp[0], md->bp[1], md->constant, es, D, stream));
+            TNP_RC(tnp_linear_forward(es, D, md->Wx[0], D, md->bx[0], qs, D, M, D, D, 0, 0, stream));                  // q
+            TNP_RC(tnp_linear_forward(qs, D, md->Wx[1], D, nullptr, w.at_u, LU, M, LU, D, 0, 0, stream));              // u
+            float *dus = a->at_du_all + r * LU;
+            TNP_RC(tnp_pool_attn_pair_backward(o1, o2, hpre, mh, a->scene_start, a->B, a->n_max, ms, mv, mh, md->Wp[0], md->bp[0],
+                                               md->Wp[1], md->bp[1], md->constant, w.at_u, LU, w.d_pooled, D, dus,
+                                               a->at_A_all + r * GDm * 3, w.at_deh, a->at_ebar_all + r * D, D, stream));
+            float *dqs = a->at_dq_all + r * D;
+            TNP_RC(tnp_linear_forward(dus, LU, a->at_WuT, LU, nullptr, dqs, D, M, D, LU, 0, 0, stream));               // dq = Wu^T du
+            TNP_RC(tnp_linear_forward(dqs, D, a->at_WqT, D, nullptr, w.d_pooled, D, M, D, D, 0, 0, stream));           // de_self
+            float *denc = mh > 0 ? a->denc_all + r * mh : nullptr;
+            TNP_RC(tnp_pool_attn_self_backward(o1, o2, hpre, mh, a->row_base, a->row_count, M, a->n_max, ms, mv, mh, md->bp[0],
+                                               md->bp[1], w.d_pooled, D, w.at_deh, a->at_A_all + r * GDm * 3, w.at_dself, denc,
                                                stream));
             if (mh > 0) {
                 TNP_RC(tnp_linear_forward(denc, mh, a->whT, mh, nullptr, w.tmp_h, H, M, H, mh, 0, 0, stream));

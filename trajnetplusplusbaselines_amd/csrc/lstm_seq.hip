@@ -547,7 +547,7 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
     hipStream_t s = (hipStream_t)stream;
     int rc = validate_model(md);
     if (rc) return rc;
-    if (sv && (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ || md->pool_type == TNP_POOL_ATTNMLP))
+    if (sv && (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ))
         TNP_FAIL(-1, "tnp_lstm_forward_train: stateful interaction encoders are inference-only");
     if (sv && (!sv->h_all || !sv->c_all || !sv->X_all || !sv->gates_all || !sv->obs1_all || !sv->obs2_all))
         TNP_FAIL(-1, "tnp_lstm_forward_train: h_all, c_all, X_all, gates_all, obs1_all, obs2_all are required");
@@ -587,7 +587,7 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
             const size_t r = (size_t)st * M;
             w.X = sv->X_all + r * w.I;
             w.pdst = w.to_hidden ? w.hplus : (md->pool_type != TNP_POOL_NONE ? w.X + (w.I - md->P) : nullptr);
-            if (sv->act_all[0])    // grid MLP: first hidden layer; HiddenStateMLPPooling: the max-pooled vector
+            if (sv->act_all[0] && md->pool_type != TNP_POOL_ATTNMLP)   // grid MLP: first hidden layer; HiddenStateMLPPooling: the max-pooled vector
                 w.y[0] = sv->act_all[0] + r * (md->pool_type == TNP_POOL_HIDDENMLP ? md->dims[0] + md->dims[1] + md->dims[2]
                                                                                   : md->dims[1]);
             if (sv->act_all[1]) w.y[1] = sv->act_all[1] + r * md->dims[2];

@@ -203,13 +203,21 @@ __global__ void __launch_bounds__(256) colsum_prod_kernel(const float *__restric
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
     const long r0 = (long)blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
     float a0 = 0.0f, a1 = 0.0f, ab = 0.0f;
-    if (c < cols)
-        for (long r = r0 + sub; r < r1; r += 4) {
-            const float g = G[r * cols + c];
-            a0 = fmaf(g, R[(r * cols + c) * 2], a0);
-            a1 = fmaf(g, R[(r * cols + c) * 2 + 1], a1);
-            ab += g;
+    if (c < cols) {
+        if (G) {
+            for (long r = r0 + sub; r < r1; r += 4) {
+                const float g = G[r * cols + c];
+                a0 = fmaf(g, R[(r * cols + c) * 2], a0);
+                a1 = fmaf(g, R[(r * cols + c) * 2 + 1], a1);
+                ab += g;
+            }
+        } else {   // R = [rows, cols, 3]: per-row sums already formed (attention: every slot contributes)
+            for (long r = r0 + sub; r < r1; r += 4) {
+                const float *p = R + (r * cols + c) * 3;
+                a0 += p[0]; a1 += p[1]; ab += p[2];
+            }
         }
+    }
     red[sub][threadIdx.x & 63][0] = a0; red[sub][threadIdx.x & 63][1] = a1; red[sub][threadIdx.x & 63][2] = ab;
     __syncthreads();
     if (sub == 0 && c < cols) {
@@ -397,6 +405,190 @@ __global__ void __launch_bounds__(64) pool_attn_pair_kernel(const float *__restr
     }
 }
 
+// ---- backward of the attention pair kernel (training) --------------------------------------------------------------
+// Given debar_i = d(loss)/d(sum_j a_ij e_ij) and u_i, one wave per ego recomputes the scores and softmax weights and
+// propagates:  da_j = debar . e_ij,  dscore_j = a_j (da_j - sum_l a_l da_l),  de_ij = a_j debar + dscore_j/sqrt(D) u_i[0:D],
+//   du_i[0:D] = sum_j dscore_j/sqrt(D) e_ij,  du_i[D] = sum_j dscore_j/sqrt(D)   (padded slots included: constants).
+// de_ij is consumed on the spot: the spatial / velocity units (Linear(2 -> dim) + ReLU on the pair's relative position /
+// 4 x relative velocity) accumulate A[i, k] = (sum_j g r_x, sum_j g r_y, sum_j g) with g = de_ij[k] where the unit is
+// active; the hidden-state units write dEh[i, slot j, k'] for the per-track gather.  ebar_i is written again (stacked
+// operand of the folded value / output projections' weight gradients).
+__global__ void __launch_bounds__(64) pool_attn_pair_backward_kernel(const float *__restrict__ obs1, const float *__restrict__ obs2,
+                                                                     const float *__restrict__ henc, int ldh,
+                                                                     const int32_t *__restrict__ scene_start, int n_max, int ms,
+                                                                     int mv, int mh, const float *__restrict__ Ws,
+                                                                     const float *__restrict__ bs, const float *__restrict__ Wv,
+                                                                     const float *__restrict__ bv, float fill,
+                                                                     const float *__restrict__ u, int ldu,
+                                                                     const float *__restrict__ debar, int ldd,
+                                                                     float *__restrict__ du, float *__restrict__ A3,
+                                                                     float *__restrict__ dEh, float *__restrict__ ebar, int lde) {
+    extern __shared__ float att_sc[];                      // [2][n_scene]: softmax weights, then da
+    const int lo = scene_start[blockIdx.x], hi = scene_start[blockIdx.x + 1], ns = hi - lo;
+    float *att_a = att_sc, *att_da = att_sc + n_max;
+    const int D = ms + mh + mv, GD = ms + mv, lane = threadIdx.x;
+    const float scale = 1.0f / sqrtf((float)D);
+    const int npad = n_max - ns;
+    float w0[ATT_MAXD_PER_LANE], w1[ATT_MAXD_PER_LANE], b0[ATT_MAXD_PER_LANE];
+#pragma unroll
+    for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) {
+        const int k = lane + 64 * t;
+        w0[t] = w1[t] = b0[t] = 0.0f;
+        if (k < ms) { w0[t] = Ws[2 * k]; w1[t] = Ws[2 * k + 1]; b0[t] = bs[k]; }
+        else if (k >= ms + mh && k < D) { const int q = k - ms - mh; w0[t] = Wv[2 * q]; w1[t] = Wv[2 * q + 1]; b0[t] = bv[q]; }
+    }
+    auto wave_sum = [&](float v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        return v;
+    };
+    for (int i = lo + blockIdx.y; i < hi; i += gridDim.y) {
+        const float xi = obs2[2 * i], yi = obs2[2 * i + 1];
+        const float vxi = xi - obs1[2 * i], vyi = yi - obs1[2 * i + 1];
+        float ui[ATT_MAXD_PER_LANE], db[ATT_MAXD_PER_LANE], ep[ATT_MAXD_PER_LANE];
+#pragma unroll
+        for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) {
+            const int k = lane + 64 * t;
+            ui[t] = k < D ? u[(size_t)i * ldu + k] : 0.0f;
+            db[t] = k < D ? debar[(size_t)i * ldd + k] : 0.0f;
+            ep[t] = (k < D && !(k >= ms && k < ms + mh)) ? fill : 0.0f;     // embedding of a padded slot
+        }
+        const float ci = u[(size_t)i * ldu + D];
+        // embedding of slot j and, for the spatial / velocity units, the inputs and whether the unit passes a gradient
+        auto embed = [&](int j, float (&e)[ATT_MAXD_PER_LANE], float (&rx)[ATT_MAXD_PER_LANE], float (&ry)[ATT_MAXD_PER_LANE]) {
+            const float xj = obs2[2 * j], yj = obs2[2 * j + 1];
+            const float vxj = xj - obs1[2 * j], vyj = yj - obs1[2 * j + 1];
+#pragma unroll
+            for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) {
+                const int k = lane + 64 * t;
+                float h = 0.0f;
+                rx[t] = 0.0f; ry[t] = 0.0f;
+                if (k >= ms && k < ms + mh) { h = henc[(size_t)j * ldh + (k - ms)]; h = h > 0.0f ? h : 0.0f; }
+                else if (k < ms) { rx[t] = xj - xi; ry[t] = yj - yi; }
+                else if (k < D) { rx[t] = (vxj - vxi) * 4.0f; ry[t] = (vyj - vyi) * 4.0f; }
+                e[t] = k < D ? attn_embed(k, ms, mh, fill, xi, yi, vxi, vyi, xj, yj, vxj, vyj, h, w0[t], w1[t], b0[t]) : 0.0f;
+            }
+        };
+        // pass 1: scores -> softmax weights
+        float mx = -INFINITY;
+        for (int j = lo; j < hi; ++j) {
+            float e[ATT_MAXD_PER_LANE], rx[ATT_MAXD_PER_LANE], ry[ATT_MAXD_PER_LANE];
+            embed(j, e, rx, ry);
+            float part = 0.0f, pd = 0.0f;
+#pragma unroll
+            for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) { part = fmaf(ui[t], e[t], part); pd = fmaf(db[t], e[t], pd); }
+            const float sj = (wave_sum(part) + ci) * scale;
+            const float daj = wave_sum(pd);
+            if (lane == 0) { att_a[j - lo] = sj; att_da[j - lo] = daj; }
+            mx = fmaxf(mx, sj);
+        }
+        float s_pad = 0.0f, da_pad = 0.0f;
+        if (npad > 0) {
+            float part = 0.0f, pd = 0.0f;
+#pragma unroll
+            for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) { part = fmaf(ui[t], ep[t], part); pd = fmaf(db[t], ep[t], pd); }
+            s_pad = (wave_sum(part) + ci) * scale;
+            da_pad = wave_sum(pd);
+            mx = fmaxf(mx, s_pad);
+        }
+        __syncthreads();
+        float den = 0.0f, dot = 0.0f;
+        for (int j = 0; j < ns; ++j) { const float a = expf(att_a[j] - mx); den += a; dot = fmaf(a, att_da[j], dot); }
+        float a_pad = 0.0f;
+        if (npad > 0) { a_pad = expf(s_pad - mx); den += a_pad * (float)npad; dot = fmaf(a_pad * (float)npad, da_pad, dot); }
+        const float inv = 1.0f / den;
+        dot *= inv;                                         // sum_l a_l da_l
+        // pass 2: propagate
+        float dul[ATT_MAXD_PER_LANE] = {0.0f, 0.0f, 0.0f, 0.0f}, eb[ATT_MAXD_PER_LANE] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float a0[ATT_MAXD_PER_LANE] = {0.0f, 0.0f, 0.0f, 0.0f}, a1[ATT_MAXD_PER_LANE] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float ab[ATT_MAXD_PER_LANE] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float du_c = 0.0f;
+        for (int j = lo; j < hi; ++j) {
+            float e[ATT_MAXD_PER_LANE], rx[ATT_MAXD_PER_LANE], ry[ATT_MAXD_PER_LANE];
+            embed(j, e, rx, ry);
+            const float a = expf(att_a[j - lo] - mx) * inv;
+            const float ds = a * (att_da[j - lo] - dot) * scale;
+            du_c += ds;
+#pragma unroll
+            for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) {
+                const int k = lane + 64 * t;
+                if (k >= D) continue;
+                eb[t] = fmaf(a, e[t], eb[t]);
+                dul[t] = fmaf(ds, e[t], dul[t]);
+                const float de = fmaf(a, db[t], ds * ui[t]);
+                if (k >= ms && k < ms + mh) {
+                    dEh[((size_t)i * n_max + (j - lo)) * mh + (k - ms)] = de;
+                } else if (e[t] > 0.0f && rx[t] == rx[t] && ry[t] == ry[t]) {   // active unit of a present pair (fill <= 0)
+                    a0[t] = fmaf(de, rx[t], a0[t]);
+                    a1[t] = fmaf(de, ry[t], a1[t]);
+                    ab[t] += de;
+                }
+            }
+        }
+        if (npad > 0) {
+            const float a = a_pad * inv;
+            const float ds = a * (da_pad - dot) * scale * (float)npad;
+            du_c += ds;
+#pragma unroll
+            for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) { eb[t] = fmaf(a * (float)npad, ep[t], eb[t]); dul[t] = fmaf(ds, ep[t], dul[t]); }
+        }
+#pragma unroll
+        for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) {
+            const int k = lane + 64 * t;
+            if (k >= D) continue;
+            du[(size_t)i * ldu + k] = dul[t];
+            ebar[(size_t)i * lde + k] = eb[t];
+            if (!(k >= ms && k < ms + mh)) {
+                const int kk = k < ms ? k : k - mh;
+                float *o = A3 + ((size_t)i * GD + kk) * 3;
+                o[0] = a0[t]; o[1] = a1[t]; o[2] = ab[t];
+            }
+        }
+        if (lane == 0) {
+            du[(size_t)i * ldu + D] = du_c;
+            for (int q = D + 1; q < ldu; ++q) du[(size_t)i * ldu + q] = 0.0f;
+        }
+        __syncthreads();
+    }
+}
+
+// the ego's own slot also feeds the query: de_self = Wq^T dq is routed through e_ii (relative position / velocity 0 ->
+// only the biases of the spatial / velocity units, and the ego's own hidden embedding)
+__global__ void __launch_bounds__(256) pool_attn_self_backward_kernel(const float *__restrict__ obs1, const float *__restrict__ obs2,
+                                                                      int M, int ms, int mv, int mh, const float *__restrict__ bs,
+                                                                      const float *__restrict__ bv, const float *__restrict__ de_self,
+                                                                      int ldd, float *__restrict__ A3, float *__restrict__ dself_h) {
+    const int D = ms + mh + mv, GD = ms + mv;
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)M * D) return;
+    const int i = (int)(q / D), k = (int)(q - (long)i * D);
+    const float g = de_self[(size_t)i * ldd + k];
+    if (k >= ms && k < ms + mh) { dself_h[(size_t)i * mh + (k - ms)] = g; return; }
+    const float xi = obs2[2 * i], yi = obs2[2 * i + 1];
+    const float vxi = xi - obs1[2 * i], vyi = yi - obs1[2 * i + 1];
+    bool ok;
+    float b;
+    if (k < ms) { ok = (xi == xi) && (yi == yi); b = bs[k]; }
+    else { ok = (vxi == vxi) && (vyi == vyi); b = bv[k - ms - mh]; }
+    if (ok && b > 0.0f) A3[((size_t)i * GD + (k < ms ? k : k - mh)) * 3 + 2] += g;
+}
+
+// d(hidden embedding pre-activation)[j, k'] = relu'( henc_pre[j, k'] ) * ( dself_h[j, k'] + sum over the egos i of j's
+// scene of dEh[i, slot of j, k'] ); one wave per track, ascending ego order
+__global__ void __launch_bounds__(256) pool_attn_gather_kernel(const float *__restrict__ dEh, const float *__restrict__ dself_h,
+                                                               const float *__restrict__ henc_pre, int ldh,
+                                                               const int32_t *__restrict__ row_base, const int32_t *__restrict__ row_count,
+                                                               int M, int n_max, int mh, float *__restrict__ denc) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= M) return;
+    const int lo = row_base[j], ns = row_count[j], jj = j - lo;
+    for (int k = lane; k < mh; k += 64) {
+        float acc = dself_h[(size_t)j * mh + k];
+        for (int i = lo; i < lo + ns; ++i) acc += dEh[((size_t)i * n_max + jj) * mh + k];
+        denc[(size_t)j * mh + k] = henc_pre[(size_t)j * ldh + k] > 0.0f ? acc : 0.0f;
+    }
+}
+
 int launch_pool_attn_self(const float *obs1, const float *obs2, const float *henc, int ldh, int henc_relu, int M, int ms,
                           int mv, int mh, const float *bs, const float *bv, float fill, float *e_self, int lde,
                           hipStream_t s) {
@@ -558,5 +750,42 @@ extern "C" TNP_API int tnp_colsum_prod(const float *G, const float *R, long rows
     hipLaunchKernelGGL(tnp::colsum_reduce_kernel, dim3((cols * 3 + 255) / 256), dim3(256), 0, s, (const float *)workspace, nchunks, cols,
                        dW, db);
     TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" TNP_API int tnp_pool_attn_pair_backward(const float *obs1, const float *obs2, const float *hidden_emb_pre, int ldh,
+                                                   const int32_t *scene_start, int B, int n_max, int ms, int mv, int mh,
+                                                   const float *W_spatial, const float *b_spatial, const float *W_vel,
+                                                   const float *b_vel, float fill, const float *u, int ldu, const float *d_ebar,
+                                                   int ldd, float *du, float *A3, float *dEh, float *ebar, int lde, void *stream) {
+    if (B <= 0) return 0;
+    const int D = ms + mh + mv;
+    if (D > 64 * tnp::ATT_MAXD_PER_LANE) TNP_FAIL(-1, "AttentionMLPPooling: mlp_dim %d > %d", D, 64 * tnp::ATT_MAXD_PER_LANE);
+    if (n_max < 1 || (size_t)n_max * 8 > 60000) TNP_FAIL(-1, "AttentionMLPPooling: n_max %d out of range", n_max);
+    if (ldu < D + 1) TNP_FAIL(-1, "tnp_pool_attn_pair_backward: ldu %d < mlp_dim + 1", ldu);
+    hipLaunchKernelGGL(tnp::pool_attn_pair_backward_kernel, dim3(B, 16), dim3(64), (size_t)n_max * 2 * sizeof(float),
+                       (hipStream_t)stream, obs1, obs2, hidden_emb_pre, ldh, scene_start, n_max, ms, mv, mh, W_spatial, b_spatial,
+                       W_vel, b_vel, fill, u, ldu, d_ebar, ldd, du, A3, dEh, ebar, lde);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" TNP_API int tnp_pool_attn_self_backward(const float *obs1, const float *obs2, const float *hidden_emb_pre, int ldh,
+                                                   const int32_t *row_base, const int32_t *row_count, int M, int n_max, int ms,
+                                                   int mv, int mh, const float *b_spatial, const float *b_vel,
+                                                   const float *de_self, int ldd, const float *dEh, float *A3, float *dself_scratch,
+                                                   float *d_hidden_emb_pre, void *stream) {
+    if (M <= 0) return 0;
+    const int D = ms + mh + mv;
+    const long total = (long)M * D;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tnp::pool_attn_self_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, obs1, obs2, M, ms,
+                       mv, mh, b_spatial, b_vel, de_self, ldd, A3, dself_scratch);
+    TNP_HIP(hipGetLastError());
+    if (mh > 0) {
+        hipLaunchKernelGGL(tnp::pool_attn_gather_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dEh, dself_scratch, hidden_emb_pre, ldh,
+                           row_base, row_count, M, n_max, mh, d_hidden_emb_pre);
+        TNP_HIP(hipGetLastError());
+    }
     return 0;
 }

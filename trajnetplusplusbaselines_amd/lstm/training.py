@@ -75,7 +75,63 @@ class BwdSweep(ctypes.Structure):
                 ('dy_all', ctypes.c_void_p * 3), ('denc_all', ctypes.c_void_p), ('dnn_all', ctypes.c_void_p),
                 ('dvel_pool_all', ctypes.c_void_p), ('grid_all', ctypes.c_void_p), ('dh', ctypes.c_void_p),
                 ('dc', ctypes.c_void_p), ('hidden_mlp', ctypes.c_int32), ('hm_G_all', ctypes.c_void_p),
-                ('hm_R_all', ctypes.c_void_p)]
+                ('hm_R_all', ctypes.c_void_p), ('attention', ctypes.c_int32), ('at_WuT', ctypes.c_void_p),
+                ('at_WqT', ctypes.c_void_p), ('at_eself_all', ctypes.c_void_p), ('at_q_all', ctypes.c_void_p),
+                ('at_dq_all', ctypes.c_void_p), ('at_ebar_all', ctypes.c_void_p), ('at_du_all', ctypes.c_void_p),
+                ('at_A_all', ctypes.c_void_p)]
+
+
+def _attention_param_grads(pool, P, grads, wgrad, dout_all, bufs, denc_all, h_prev_all, rows, L, dev, sp):
+    """Parameter gradients of AttentionMLPPooling from the stacked operands of the sweep.  The kernels work with the
+    folded maps (q = Wq_eff e + bq, u = [Wk_eff^T q ; bk . q], out = wop (wo (Win_v (wv ebar) + b_v) + bo) + bop); the
+    chain rule back to wq / wk / wv / in_proj / out_proj / out_projection is a handful of [rows, D] GEMMs."""
+    ms, mv, mh, D = pool.mlp_dim_spatial, pool.mlp_dim_vel, pool.mlp_dim_hidden, pool.mlp_dim
+    g = lambda n: P['pool.' + n].detach()
+    wq, wk, wv = g('wq.weight'), g('wk.weight'), g('wv.weight')
+    w_in, b_in = g('multihead_attn.in_proj_weight'), g('multihead_attn.in_proj_bias')
+    wo, bo = g('multihead_attn.out_proj.weight'), g('multihead_attn.out_proj.bias')
+    wop = g('out_projection.weight')
+    flat = lambda t: t.reshape(rows, -1)
+    eself, q, dq, ebar, du = (flat(bufs[k]) for k in ('eself', 'q', 'dq', 'ebar', 'du'))
+    dout = flat(dout_all)
+    tmp = {}
+
+    def wg(dy, x, with_bias):       # (dy^T x, column sums of dy) through the shared split-K kernel
+        wgrad('_t', dy, x, '_b' if with_bias else None)
+        return grads.pop('_t'), (grads.pop('_b') if with_bias else None)
+    # query / key paths
+    dwq_eff, dbq = wg(dq, eself, True)                                   # q = Wq_eff e_self + bq
+    dwk_eff, _ = wg(q, du[:, :D], False)                                 # u[0:D] = Wk_eff^T q
+    dbk, _ = wg(du[:, D:D + 1], q, False)                                # u[D] = bk . q
+    # value / output path, recomputed forward intermediates
+    t1 = _lib.linear_forward(ebar, wv, None)
+    t2 = _lib.linear_forward(t1, w_in[2 * D:].contiguous(), b_in[2 * D:].contiguous())
+    t3 = _lib.linear_forward(t2, wo, bo)
+    dt3 = _lib.linear_forward(dout, wop.t().contiguous(), None)
+    dt2 = _lib.linear_forward(dt3, wo.t().contiguous(), None)
+    dt1 = _lib.linear_forward(dt2, w_in[2 * D:].t().contiguous(), None)
+    grads['pool.out_projection.weight'], grads['pool.out_projection.bias'] = wg(dout, t3, True)
+    grads['pool.multihead_attn.out_proj.weight'], grads['pool.multihead_attn.out_proj.bias'] = wg(dt3, t2, True)
+    dwin_v, db_v = wg(dt2, t1, True)
+    grads['pool.wv.weight'], _ = wg(dt1, ebar, False)
+    # un-fold: Wq_eff = Win_q wq, Wk_eff = Win_k wk
+    grads['pool.multihead_attn.in_proj_weight'] = torch.cat([dwq_eff @ wq.t(), dwk_eff @ wk.t(), dwin_v], dim=0)
+    grads['pool.multihead_attn.in_proj_bias'] = torch.cat([dbq, dbk.reshape(-1), db_v], dim=0)
+    grads['pool.wq.weight'] = w_in[:D].t() @ dwq_eff
+    grads['pool.wk.weight'] = w_in[D:2 * D].t() @ dwk_eff
+    # embeddings behind the attention
+    if mh:
+        wgrad('pool.hidden_embedding.0.weight', denc_all, h_prev_all, 'pool.hidden_embedding.0.bias')
+    cols = ms + mv
+    nb = L.tnp_colsum_prod_workspace_bytes(rows, cols)
+    cws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    dW2, db2 = torch.empty(cols, 2, device=dev), torch.empty(cols, device=dev)
+    _lib.check(L.tnp_colsum_prod(None, _lib.ptr(bufs['A']), rows, cols, _lib.ptr(dW2), _lib.ptr(db2), _lib.ptr(cws), nb, sp()),
+               'colsum')
+    grads['pool.spatial_embedding.0.weight'], grads['pool.spatial_embedding.0.bias'] = dW2[:ms], db2[:ms]
+    if mv:
+        grads['pool.vel_embedding.0.weight'], grads['pool.vel_embedding.0.bias'] = dW2[ms:], db2[ms:]
+    del tmp
 
 
 def _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, win_all, o1_all, o2_all):
@@ -125,7 +181,8 @@ class SequenceFn(torch.autograd.Function):
         I = model.encoder.weight_ih.shape[1]
         nn_pool = pool is not None and type(pool).__name__ == 'NearestNeighborMLP'
         hm_pool = pool is not None and type(pool).__name__ == 'HiddenStateMLPPooling'
-        layers = pool.embedding_layers() if (pool is not None and not nn_pool and not hm_pool) else []
+        at_pool = pool is not None and type(pool).__name__ == 'AttentionMLPPooling'
+        layers = pool.embedding_layers() if (pool is not None and not (nn_pool or hm_pool or at_pool)) else []
         if len(layers) > 3:
             raise NotImplementedError('embedding MLPs deeper than three layers')
         # per-step slices of buffers allocated once per sequence
@@ -135,14 +192,15 @@ class SequenceFn(torch.autograd.Function):
         gates_all = torch.empty(S, M, 4 * H, device=dev)
         act_all = [torch.empty(S, M, lin.weight.shape[0], device=dev) for lin in layers[:-1]]
         enc_all = torch.empty(S, M, pool.pooling_dim, device=dev) \
-            if (pool is not None and not nn_pool and not hm_pool and pool.type_ == 'social') else None
+            if (pool is not None and not (nn_pool or hm_pool or at_pool) and pool.type_ == 'social') else None
         if hm_pool:    # the max-pooled vector (out_projection's input) and the hidden embedding's pre-activation
             act_all = [torch.empty(S, M, pool.mlp_dim, device=dev)]
+        if hm_pool or at_pool:
             enc_all = torch.empty(S, M, pool.mlp_dim_hidden, device=dev) if pool.mlp_dim_hidden else None
         attrs_all = torch.empty(S, M, pool.n * pool.input_dim, device=dev) if nn_pool else None
         # sparse first embedding layer: keep every step's winner table for the sparse backward
         win_all = None
-        if enc_all is not None and not hm_pool and opts.get('sparse_backward', getattr(model, 'sparse_backward', True)) and layers[0].weight.shape[0] % 64 == 0 \
+        if enc_all is not None and not (hm_pool or at_pool) and opts.get('sparse_backward', getattr(model, 'sparse_backward', True)) and layers[0].weight.shape[0] % 64 == 0 \
                 and layers[0].weight.shape[0] * 64 + 4096 <= (160 * 1024) // ((pool.pooling_dim + 15) // 16) \
                 and L.tnp_lstm_sparse_first_layer(ctypes.byref(m), M) == 1:
             win_all = torch.empty(S, M, pool.n * pool.n, dtype=torch.int16, device=dev)
@@ -181,7 +239,7 @@ class SequenceFn(torch.autograd.Function):
         ctx.model, ctx.idx, ctx.goals = model, idx, goals_t
         ctx.saved = (h_all, c_all, X_all, gates_all, act_all, enc_all, decs)
         ctx.attrs_all = attrs_all
-        ctx.hm_pool = hm_pool
+        ctx.hm_pool, ctx.at_pool = hm_pool, at_pool
         ctx.obs_all = (o1_all, o2_all)
         ctx.win_all = win_all
         ctx.w_cell_major = model._cell_major_weight(layers[0].weight, pool) if win_all is not None else None
@@ -216,15 +274,15 @@ class SequenceFn(torch.autograd.Function):
         has_h2n = 'hidden2normal.linear.weight' in P            # the S-GAN discriminator has no output head
         o1_all, o2_all = ctx.obs_all
         nn_pool = ctx.attrs_all is not None                      # NearestNeighborMLP: only its embedding has parameters
-        hm_pool = ctx.hm_pool                                    # HiddenStateMLPPooling
-        grid_pool = pool is not None and not nn_pool and not hm_pool
+        hm_pool, at_pool = ctx.hm_pool, ctx.at_pool              # HiddenStateMLPPooling, AttentionMLPPooling
+        grid_pool = pool is not None and not (nn_pool or hm_pool or at_pool)
         layers = pool.embedding_layers() if grid_pool else []
         lay_names = ['pool.embedding.%d' % i for i, mod in enumerate(pool.embedding) if isinstance(mod, torch.nn.Linear)] \
             if grid_pool else []
         social = grid_pool and pool.type_ == 'social'
         dnn_all = torch.empty(S, M, pool.out_dim, device=dev) if nn_pool else None
         directional_in = ctx.input_grad and grid_pool and pool.type_ == 'directional'
-        if ctx.input_grad and (nn_pool or hm_pool):
+        if ctx.input_grad and (nn_pool or hm_pool or at_pool):
             raise NotImplementedError('position gradients through %s' % type(pool).__name__)
         sparse_bwd = ctx.win_all is not None      # first layer's gradients from the winner tables (csrc/lstm_bwd.hip)
         layT = [T(n + '.weight') if (li > 0 or ((social or directional_in) and not sparse_bwd)) else None
@@ -238,6 +296,17 @@ class SequenceFn(torch.autograd.Function):
             hm_G_all = torch.empty(S, M, ms + mv, device=dev)
             hm_R_all = torch.empty(S, M, ms + mv, 2, device=dev)
 
+        at_bufs = None
+        if at_pool:   # linear maps around the softmax folded as in the forward (AttentionMLPPooling.folded)
+            ms, mv, mh, D = pool.mlp_dim_spatial, pool.mlp_dim_vel, pool.mlp_dim_hidden, pool.mlp_dim
+            wq_eff, bq_f, wu_f, wfin, bfin = pool.folded()
+            layT = [wfin.t().contiguous()]
+            whT = T('pool.hidden_embedding.0.weight') if mh else None
+            at_wuT, at_wqT = wu_f.t().contiguous(), wq_eff.t().contiguous()
+            at_bufs = dict(eself=torch.empty(S, M, D, device=dev), q=torch.empty(S, M, D, device=dev),
+                           dq=torch.empty(S, M, D, device=dev), ebar=torch.empty(S, M, D, device=dev),
+                           du=torch.empty(S, M, D + 4, device=dev), A=torch.empty(S, M, ms + mv, 3, device=dev))
+
         # per-step operands of the deferred weight-gradient GEMMs
         dlin_all = torch.empty(S, M, 5, device=dev)
         dG_all = torch.empty(S, M, 4 * H, device=dev)
@@ -247,7 +316,7 @@ class SequenceFn(torch.autograd.Function):
         dy_all = [torch.empty(S, M, lin.weight.shape[0], device=dev) for lin in layers]
         denc_all = torch.empty(S, M, pool.pooling_dim, device=dev) if social else None
         grid_all = None
-        if hm_pool:
+        if hm_pool or at_pool:
             dy_all = [torch.empty(S, M, pool.out_dim, device=dev)]          # gradient of the interaction vector
             denc_all = torch.empty(S, M, mh, device=dev) if mh else None
             sizes = (idx.starts[1:] - idx.starts[:-1]).long()
@@ -304,8 +373,12 @@ class SequenceFn(torch.autograd.Function):
             sw.layT[li] = t.data_ptr() if t is not None else None
         sw.whT = whT.data_ptr() if whT is not None else None
         sw.w_cell_major = ctx.w_cell_major.data_ptr() if sparse_bwd else None
-        if social or directional_in or hm_pool:
+        if social or directional_in or hm_pool or at_pool:
             sw.row_base, sw.row_count = row_base.data_ptr(), row_count.data_ptr()
+        if at_pool:
+            sw.attention, sw.at_WuT, sw.at_WqT = 1, at_wuT.data_ptr(), at_wqT.data_ptr()
+            sw.at_eself_all, sw.at_q_all, sw.at_dq_all = (at_bufs[k].data_ptr() for k in ('eself', 'q', 'dq'))
+            sw.at_ebar_all, sw.at_du_all, sw.at_A_all = (at_bufs[k].data_ptr() for k in ('ebar', 'du', 'A'))
         if hm_pool:
             sw.hidden_mlp, sw.hm_G_all, sw.hm_R_all = 1, hm_G_all.data_ptr(), hm_R_all.data_ptr()
         if social and sparse_bwd:
@@ -405,6 +478,8 @@ class SequenceFn(torch.autograd.Function):
                 grads[name + '.bias'] = dy_all[0].reshape(-1, N1).sum(0)
                 continue
             wgrad(name + '.weight', dy_all[li], grid_all if li == 0 else act_all[li - 1], name + '.bias')
+        if at_pool:
+            _attention_param_grads(pool, P, grads, wgrad, dy_all[0], at_bufs, denc_all, h_prev_all, S * M, L, dev, sp)
         if hm_pool:
             wgrad('pool.out_projection.weight', dy_all[0], act_all[0], 'pool.out_projection.bias')
             if mh:
