@@ -283,6 +283,10 @@ typedef struct tnp_train_saves {
     int16_t *winners_all;
     float *obs1_all, *obs2_all;
     float *h_clean;
+    /* TNP_POOL_NNLSTM / TNP_POOL_TRAJ (stateful interaction encoders): pool_lstm state before step s and after the last
+     * one ph_all / pc_all [steps+1, M, Hp], its post-activation gates pgates_all [steps, M, 4Hp]; act_all[0] holds the
+     * pool_lstm's input features [steps, M, P]; traj_in_all [steps, M, 8] the Trajectron embedding's inputs */
+    float *ph_all, *pc_all, *pgates_all, *traj_in_all;
 } tnp_train_saves;
 TNP_API int tnp_lstm_forward_train(const tnp_lstm_model *model, const float *observed, int T_obs, int M, const float *goals,
                                    const int32_t *scene_start, const uint8_t *primary_flag, int B, int n_max,
@@ -332,6 +336,14 @@ typedef struct tnp_bwd_sweep {
     int32_t attention;
     const float *at_WuT, *at_WqT;
     float *at_eself_all, *at_q_all, *at_dq_all, *at_ebar_all, *at_du_all, *at_A_all;
+    /* TNP_POOL_NNLSTM / TNP_POOL_TRAJ (BPTT through the interaction encoder's pool_lstm, whose state the reference
+     * carries across steps without detaching): st_pwT [P+Hp, 4Hp] = [pool_lstm.weight_ih^T ; weight_hh^T], st_h2pT
+     * [Hp, P] = hidden2pool.weight^T, st_zeros [M,2] any finite buffer (the pool_lstm updates every track);
+     * stacked outputs dy_all[0] [S,M,P] (gradient of the interaction vector), st_dG_all [S,M,4Hp], st_dfeat_all
+     * [S,M,P] (gradient of the embedding's pre-activation); st_dph / st_dpc [M,Hp] in/out like dh / dc */
+    int32_t stateful;
+    const float *st_pwT, *st_h2pT, *st_zeros;
+    float *st_dG_all, *st_dfeat_all, *st_dph, *st_dpc;
 } tnp_bwd_sweep;
 TNP_API size_t tnp_lstm_backward_scratch_bytes(const tnp_bwd_sweep *sweep);
 TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *sweep, int s_hi, int s_lo, void *scratch, size_t scratch_bytes,

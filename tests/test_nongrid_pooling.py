@@ -125,9 +125,6 @@ def test_gpu_full_size_vs_oracle(kind):
 
 
 @pytest.mark.gpu
-def test_training_through_nongrid_module_raises():
+def test_contract_errors():
     import torch
-    model = build_amd('nn_lstm').train()   # the stateless modules train (tests/test_gpu_training.py), the stateful encoders not yet
-    xy, split = torch.tensor(GOLD['nn_lin_xy']), torch.tensor(GOLD['nn_lin_split'])
-    with pytest.raises(NotImplementedError):
-        model(xy[:9], torch.zeros(xy.shape[1], 2), split, prediction_truth=xy[9:20].clone())
+    model = build_amd('nn_lstm').train()   # all five modules train (tests/test_gpu_training.py)

@@ -435,6 +435,7 @@ __global__ void __launch_bounds__(256) state_grad_combine_kernel(const float *__
 
 struct SweepScratch {
     float *dh_tot, *dh_pass, *dxh, *dc_alt, *d_in, *tmp_h, *dgrid, *dcell, *d_pooled, *at_u, *at_deh, *at_dself;
+    float *st_tot, *st_pass, *st_dxh, *st_dc_alt;
     int32_t *cells, *widx;
     size_t bytes;
 };
@@ -465,6 +466,12 @@ static void plan_sweep(const tnp_bwd_sweep *a, void *base, SweepScratch &w) {
     w.at_u = (float *)take(at ? M * (size_t)(md->dims[0] + md->dims[1] + md->dims[2] + 4) * 4 : 0);
     w.at_deh = (float *)take(at ? M * (size_t)a->n_max * md->dims[2] * 4 : 0);
     w.at_dself = (float *)take(at ? M * (size_t)md->dims[2] * 4 : 0);
+    const bool stf = a->stateful != 0;
+    const size_t Hp = stf ? (size_t)md->dims[0] : 0;
+    w.st_tot = (float *)take(M * Hp * 4);
+    w.st_pass = (float *)take(M * Hp * 4);
+    w.st_dxh = (float *)take(stf ? M * ((size_t)md->P + Hp) * 4 : 0);
+    w.st_dc_alt = (float *)take(M * Hp * 4);
     w.widx = (int32_t *)take(hm ? M * (size_t)md->dims[2] * 4 : 0);
     const bool dense0 = grid && ((social && !a->social_sparse) || a->directional_in);
     w.dgrid = (float *)take(dense0 ? M * (size_t)md->dims[0] * 4 : 0);
@@ -615,7 +622,8 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
     const bool social = grid && md->pool_type == TNP_POOL_SOCIAL;
     const bool hm = a->hidden_mlp != 0 && md->pool_type == TNP_POOL_HIDDENMLP;
     const bool at = a->attention != 0 && md->pool_type == TNP_POOL_ATTNMLP;
-    if (md->pool_type != TNP_POOL_NONE && !grid && !a->nn_pool && !hm && !at)
+    const bool stf = a->stateful != 0 && (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ);
+    if (md->pool_type != TNP_POOL_NONE && !grid && !a->nn_pool && !hm && !at && !stf)
         TNP_FAIL(-1, "tnp_lstm_backward_sweep: pool type %d has no backward", md->pool_type);
     if ((md->variant >> 17) & 1) TNP_FAIL(-1, "tnp_lstm_backward_sweep: pool_to_input=False has no backward");
     tnp::SweepScratch w;
@@ -629,6 +637,7 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
     const size_t MH = (size_t)M * H;
     const int nl = md->n_layers, ncell = md->n * md->n, C = md->C;
     float *dc_cur = a->dc, *dc_nxt = w.dc_alt;
+    float *dpc_cur = a->st_dpc, *dpc_nxt = w.st_dc_alt;
     for (int st = s_hi; st >= s_lo; --st) {
         const size_t r = (size_t)st * M;
         const float *o1 = sv->obs1_all + r * 2, *o2 = sv->obs2_all + r * 2;
@@ -713,6 +722,26 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
                 extra = w.tmp_h;
             }
         }
+        if (stf) {   // NearestNeighborLSTM / TrajectronPooling: hidden2pool (linear) <- pool_lstm (BPTT) <- embedding
+            const int Hp = md->dims[0], LP = Pw + Hp;
+            const size_t MHp = (size_t)M * Hp;
+            float *dP = a->dy_all[0] + r * Pw;
+            TNP_HIP(hipMemcpy2DAsync(dP, (size_t)Pw * 4, w.dxh + P0, (size_t)LDX * 4, (size_t)Pw * 4, M, hipMemcpyDeviceToDevice, s));
+            // gradient of the encoder's new hidden state: through hidden2pool + what the next step handed back
+            TNP_RC(tnp_linear_forward(dP, Pw, a->st_h2pT, Pw, nullptr, w.st_pass, Hp, M, Hp, Pw, 0, 0, stream));
+            hipLaunchKernelGGL(tnp::state_grad_combine_kernel, dim3((unsigned)((MHp + 255) / 256)), dim3(256), 0, s, w.st_pass, Hp,
+                               a->st_dph, nullptr, M, Hp, w.st_tot);
+            TNP_HIP(hipGetLastError());
+            float *dGp = a->st_dG_all + r * 4 * Hp;
+            TNP_RC(tnp_lstm_cell_backward(sv->pgates_all + r * 4 * Hp, sv->pc_all + (size_t)st * MHp, w.st_tot, dpc_cur, a->st_zeros,
+                                          a->st_zeros, M, Hp, dGp, dpc_nxt, w.st_pass, stream));
+            TNP_RC(tnp_linear_forward(dGp, 4 * Hp, a->st_pwT, 4 * Hp, nullptr, w.st_dxh, LP, M, LP, 4 * Hp, 0, 0, stream));
+            TNP_RC(tnp_relu_mask(w.st_dxh, LP, sv->act_all[0] + r * Pw, Pw, M, Pw, a->st_dfeat_all + r * Pw, Pw, stream));
+            hipLaunchKernelGGL(tnp::state_grad_combine_kernel, dim3((unsigned)((MHp + 255) / 256)), dim3(256), 0, s, w.st_dxh + Pw, LP,
+                               w.st_pass, nullptr, M, Hp, a->st_dph);       // st_pass == 0: every track is updated
+            TNP_HIP(hipGetLastError());
+            float *t2 = dpc_cur; dpc_cur = dpc_nxt; dpc_nxt = t2;
+        }
         if (at) {   // AttentionMLPPooling: Wfin (linear) <- softmax attention over the slots <- embeddings, query path
             const int ms = md->dims[0], mv = md->dims[1], mh = md->dims[2], D = ms + mh + mv, GDm = ms + mv, LU = D + 4;
             float *dP = a->dy_all[0] + r * Pw;
@@ -745,5 +774,7 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
         float *t = dc_cur; dc_cur = dc_nxt; dc_nxt = t;
     }
     if (dc_cur != a->dc) TNP_HIP(hipMemcpyAsync(a->dc, dc_cur, MH * 4, hipMemcpyDeviceToDevice, s));
+    if (stf && dpc_cur != a->st_dpc)
+        TNP_HIP(hipMemcpyAsync(a->st_dpc, dpc_cur, (size_t)M * md->dims[0] * 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }

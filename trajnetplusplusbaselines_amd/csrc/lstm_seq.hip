@@ -247,6 +247,7 @@ struct Workspace {
     int pld;
     float *gates_save;   // training: post-activation gates of the step
     float *nn_attrs_save;
+    float *pc_out, *pgates_save, *traj_in_save;   // stateful interaction encoders under tnp_lstm_forward_train
     size_t bytes;
 };
 
@@ -298,6 +299,7 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     w.pld = w.to_hidden ? md->H : w.I;
     w.gates_save = nullptr;
     w.nn_attrs_save = nullptr;
+    w.pc_out = nullptr; w.pgates_save = nullptr; w.traj_in_save = nullptr;
     if (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ) {
         const int Hp = md->dims[0];
         w.ph[0] = (float *)take((size_t)M * Hp * 4);
@@ -387,9 +389,10 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
         const int Hp = md->dims[0];
         int rc;
         if (md->pool_type == TNP_POOL_NNLSTM)
-            rc = launch_pool_nn(w.obs1, w.obs2, scene_start, B, md->n, 4, md->Wp[0], md->bp[0], md->P / md->n, w.y[0], md->P, s);
+            rc = launch_pool_nn(w.obs1, w.obs2, scene_start, B, md->n, 4, md->Wp[0], md->bp[0], md->P / md->n, w.y[0], md->P, s,
+                                w.nn_attrs_save);
         else
-            rc = launch_pool_traj(w.obs1, w.obs2, M, md->Wp[0], md->bp[0], md->P, w.y[0], md->P, w.scratch, s);
+            rc = launch_pool_traj(w.obs1, w.obs2, M, md->Wp[0], md->bp[0], md->P, w.y[0], md->P, w.scratch, s, w.traj_in_save);
         if (rc) return rc;
         GemmArgs g;
         memset(&g, 0, sizeof(g));
@@ -398,7 +401,8 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
         g.B1 = md->Wx[0]; g.ldb1 = md->P; g.B2 = md->Wx[1]; g.ldb2 = Hp;
         g.bias1 = md->bx[0]; g.bias2 = md->bx[1];
         g.M = M; g.N = 4 * Hp; g.H = Hp;
-        g.h_in = w.ph[w.pcur]; g.h_out = w.ph[w.pcur ^ 1]; g.c_in = w.pc; g.c_out = w.pc; g.mask = w.ones;
+        g.h_in = w.ph[w.pcur]; g.h_out = w.ph[w.pcur ^ 1]; g.c_in = w.pc; g.c_out = w.pc_out ? w.pc_out : w.pc; g.mask = w.ones;
+        g.gates_out = w.pgates_save;
         rc = launch_lstm_gates(g, 0, s);
         if (rc) return rc;
         w.pcur ^= 1;
@@ -547,8 +551,9 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
     hipStream_t s = (hipStream_t)stream;
     int rc = validate_model(md);
     if (rc) return rc;
-    if (sv && (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ))
-        TNP_FAIL(-1, "tnp_lstm_forward_train: stateful interaction encoders are inference-only");
+    const bool stateful = md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ;
+    if (sv && stateful && (!sv->ph_all || !sv->pc_all || !sv->pgates_all || !sv->act_all[0]))
+        TNP_FAIL(-1, "tnp_lstm_forward_train: stateful interaction encoders need ph_all, pc_all, pgates_all, act_all[0]");
     if (sv && (!sv->h_all || !sv->c_all || !sv->X_all || !sv->gates_all || !sv->obs1_all || !sv->obs2_all))
         TNP_FAIL(-1, "tnp_lstm_forward_train: h_all, c_all, X_all, gates_all, obs1_all, obs2_all are required");
     if (T_obs < 2) TNP_FAIL(-1, "need at least 2 observed frames (got %d)", T_obs);
@@ -571,8 +576,8 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
     TNP_HIP(hipMemsetAsync(hcur, 0, MH * 4, s));  // lstm.py:207-210
     TNP_HIP(hipMemsetAsync(sv ? sv->c_all : w.c, 0, MH * 4, s));
     if (w.ph[0]) {  // pool.reset() (lstm/lstm.py:213-216): zero interaction-encoder state, all tracks "present"
-        TNP_HIP(hipMemsetAsync(w.ph[0], 0, (size_t)M * md->dims[0] * 4, s));
-        TNP_HIP(hipMemsetAsync(w.pc, 0, (size_t)M * md->dims[0] * 4, s));
+        TNP_HIP(hipMemsetAsync((sv && stateful) ? sv->ph_all : w.ph[0], 0, (size_t)M * md->dims[0] * 4, s));
+        TNP_HIP(hipMemsetAsync((sv && stateful) ? sv->pc_all : w.pc, 0, (size_t)M * md->dims[0] * 4, s));
         TNP_HIP(hipMemsetAsync(w.ones, 1, (size_t)M, s));
     }
     int npos = 0, nnorm = 0, cur = 0;
@@ -589,11 +594,18 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
             w.pdst = w.to_hidden ? w.hplus : (md->pool_type != TNP_POOL_NONE ? w.X + (w.I - md->P) : nullptr);
             if (sv->act_all[0] && md->pool_type != TNP_POOL_ATTNMLP)   // grid MLP: first hidden layer; HiddenStateMLPPooling: the max-pooled vector
                 w.y[0] = sv->act_all[0] + r * (md->pool_type == TNP_POOL_HIDDENMLP ? md->dims[0] + md->dims[1] + md->dims[2]
-                                                                                  : md->dims[1]);
+                                               : (stateful ? md->P : md->dims[1]));          // stateful: the pool_lstm's input features
+            if (stateful) {   // interaction-encoder state before / after every step, its gates, the embedding's inputs
+                const size_t MHp = (size_t)M * md->dims[0];
+                w.ph[0] = sv->ph_all + (size_t)st * MHp; w.ph[1] = sv->ph_all + (size_t)(st + 1) * MHp; w.pcur = 0;
+                w.pc = sv->pc_all + (size_t)st * MHp; w.pc_out = sv->pc_all + (size_t)(st + 1) * MHp;
+                w.pgates_save = sv->pgates_all + r * 4 * md->dims[0];
+                w.traj_in_save = sv->traj_in_all ? sv->traj_in_all + r * 8 : nullptr;
+            }
             if (sv->act_all[1]) w.y[1] = sv->act_all[1] + r * md->dims[2];
             if (sv->enc_all) w.enc = sv->enc_all + r * md->C;
             w.gates_save = sv->gates_all + r * 4 * H;
-            w.nn_attrs_save = sv->nn_attrs_all ? sv->nn_attrs_all + r * md->n * md->C : nullptr;
+            w.nn_attrs_save = sv->nn_attrs_all ? sv->nn_attrs_all + r * md->n * (md->pool_type == TNP_POOL_NNLSTM ? 4 : md->C) : nullptr;
             if (sv->winners_all && w.sparse) w.winners = sv->winners_all + r * md->n * md->n;
             w.obs1 = sv->obs1_all + r * 2;
             w.obs2 = sv->obs2_all + r * 2;

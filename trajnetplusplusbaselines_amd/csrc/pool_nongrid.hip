@@ -643,32 +643,37 @@ __global__ void __launch_bounds__(256) traj_total_kernel(const float *__restrict
 __global__ void __launch_bounds__(256) traj_feature_kernel(const float *__restrict__ obs1, const float *__restrict__ obs2,
                                                            int M, const double *__restrict__ total,
                                                            const float *__restrict__ W, const float *__restrict__ bias,
-                                                           int P, float *__restrict__ out, int ldo) {
+                                                           int P, float *__restrict__ out, int ldo,
+                                                           float *__restrict__ inputs) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= M * P) return;
     const int i = q / P, o = q - i * P;
     const float x = obs2[2 * i], y = obs2[2 * i + 1];
     const float vx = x - obs1[2 * i], vy = y - obs1[2 * i + 1];
     float r = 0.0f;
+    float in[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (x == x && y == y && vx == vx && vy == vy) {
-        const float in[8] = {x, y, vx, vy, (float)(total[0] - (double)x), (float)(total[1] - (double)y),
-                             (float)(total[2] - (double)vx), (float)(total[3] - (double)vy)};
+        in[0] = x; in[1] = y; in[2] = vx; in[3] = vy;
+        in[4] = (float)(total[0] - (double)x); in[5] = (float)(total[1] - (double)y);
+        in[6] = (float)(total[2] - (double)vx); in[7] = (float)(total[3] - (double)vy);
         float acc = bias[o];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc = fmaf(in[c], W[o * 8 + c], acc);
         r = acc > 0.0f ? acc : 0.0f;
     }
     out[(size_t)i * ldo + o] = r;
+    if (inputs && o == 0)   // training: the embedding's input rows (zero for invisible tracks, whose feature row is zero)
+        for (int c = 0; c < 8; ++c) inputs[(size_t)i * 8 + c] = in[c];
 }
 
 int launch_pool_traj(const float *obs1, const float *obs2, int M, const float *W, const float *bias, int P, float *out,
-                     int ldo, double *scratch4, hipStream_t s) {
+                     int ldo, double *scratch4, hipStream_t s, float *inputs) {
     if (M <= 0) return 0;
     if (!scratch4) TNP_FAIL(-1, "TrajectronPooling: scratch (4 doubles) missing");
     hipLaunchKernelGGL(traj_total_kernel, dim3(1), dim3(256), 0, s, obs1, obs2, M, scratch4);
     const long tot = (long)M * P;
     hipLaunchKernelGGL(traj_feature_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, obs1, obs2, M, scratch4, W,
-                       bias, P, out, ldo);
+                       bias, P, out, ldo, inputs);
     TNP_HIP(hipGetLastError());
     return 0;
 }

@@ -79,7 +79,7 @@ int launch_pool_attn_pair(const float *obs1, const float *obs2, const float *hen
                           float *ebar, int lde, hipStream_t s);
 
 int launch_pool_traj(const float *obs1, const float *obs2, int M, const float *W, const float *bias, int P, float *out,
-                     int ldo, double *scratch4, hipStream_t s);
+                     int ldo, double *scratch4, hipStream_t s, float *inputs = nullptr);
 
 // ---- profiling hook -------------------------------------------------------------------------
 enum { PROF_GEMM1 = 0, PROF_ALL_GEMM = 1 };

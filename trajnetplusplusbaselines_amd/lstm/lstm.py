@@ -218,7 +218,8 @@ class LSTM(torch.nn.Module):
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # training: same kernels step by step + an explicit backward sweep (lstm/training.py)
             trainable_pool = hasattr(self.pool, 'embedding_layers') or \
-                type(self.pool).__name__ in ('NearestNeighborMLP', 'HiddenStateMLPPooling', 'AttentionMLPPooling')
+                type(self.pool).__name__ in ('NearestNeighborMLP', 'HiddenStateMLPPooling', 'AttentionMLPPooling',
+                                             'NearestNeighborLSTM', 'TrajectronPooling')
             if self.pool is not None and (not trainable_pool or not self.pool_to_input):
                 raise NotImplementedError('training (backward) through %s%s is not available on the MI355X path yet; '
                                           'use model.eval() / torch.no_grad() for inference'

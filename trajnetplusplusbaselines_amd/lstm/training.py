@@ -57,7 +57,8 @@ class TrainSaves(ctypes.Structure):
     _fields_ = [('h_all', ctypes.c_void_p), ('c_all', ctypes.c_void_p), ('X_all', ctypes.c_void_p),
                 ('act_all', ctypes.c_void_p * 2), ('gates_all', ctypes.c_void_p), ('enc_all', ctypes.c_void_p),
                 ('nn_attrs_all', ctypes.c_void_p), ('winners_all', ctypes.c_void_p), ('obs1_all', ctypes.c_void_p),
-                ('obs2_all', ctypes.c_void_p), ('h_clean', ctypes.c_void_p)]
+                ('obs2_all', ctypes.c_void_p), ('h_clean', ctypes.c_void_p), ('ph_all', ctypes.c_void_p),
+                ('pc_all', ctypes.c_void_p), ('pgates_all', ctypes.c_void_p), ('traj_in_all', ctypes.c_void_p)]
 
 
 class BwdSweep(ctypes.Structure):
@@ -78,7 +79,9 @@ class BwdSweep(ctypes.Structure):
                 ('hm_R_all', ctypes.c_void_p), ('attention', ctypes.c_int32), ('at_WuT', ctypes.c_void_p),
                 ('at_WqT', ctypes.c_void_p), ('at_eself_all', ctypes.c_void_p), ('at_q_all', ctypes.c_void_p),
                 ('at_dq_all', ctypes.c_void_p), ('at_ebar_all', ctypes.c_void_p), ('at_du_all', ctypes.c_void_p),
-                ('at_A_all', ctypes.c_void_p)]
+                ('at_A_all', ctypes.c_void_p), ('stateful', ctypes.c_int32), ('st_pwT', ctypes.c_void_p),
+                ('st_h2pT', ctypes.c_void_p), ('st_zeros', ctypes.c_void_p), ('st_dG_all', ctypes.c_void_p),
+                ('st_dfeat_all', ctypes.c_void_p), ('st_dph', ctypes.c_void_p), ('st_dpc', ctypes.c_void_p)]
 
 
 def _attention_param_grads(pool, P, grads, wgrad, dout_all, bufs, denc_all, h_prev_all, rows, L, dev, sp):
@@ -134,8 +137,11 @@ def _attention_param_grads(pool, P, grads, wgrad, dout_all, bufs, denc_all, h_pr
     del tmp
 
 
-def _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, win_all, o1_all, o2_all):
+def _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, win_all, o1_all, o2_all, st=None):
     sv = TrainSaves()
+    if st is not None:    # stateful interaction encoders
+        sv.ph_all, sv.pc_all, sv.pgates_all = st['ph'].data_ptr(), st['pc'].data_ptr(), st['pgates'].data_ptr()
+        sv.traj_in_all = st['traj_in'].data_ptr() if st.get('traj_in') is not None else None
     sv.h_all, sv.c_all, sv.X_all, sv.gates_all = h_all.data_ptr(), c_all.data_ptr(), X_all.data_ptr(), gates_all.data_ptr()
     for li, a in enumerate(act_all):
         sv.act_all[li] = a.data_ptr()
@@ -143,7 +149,7 @@ def _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, wi
     sv.nn_attrs_all = attrs_all.data_ptr() if attrs_all is not None else None
     sv.winners_all = win_all.data_ptr() if win_all is not None else None
     sv.obs1_all, sv.obs2_all = o1_all.data_ptr(), o2_all.data_ptr()
-    return sv, (h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, win_all, o1_all, o2_all)
+    return sv, (h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, win_all, o1_all, o2_all, st)
 
 
 class SequenceFn(torch.autograd.Function):
@@ -182,7 +188,8 @@ class SequenceFn(torch.autograd.Function):
         nn_pool = pool is not None and type(pool).__name__ == 'NearestNeighborMLP'
         hm_pool = pool is not None and type(pool).__name__ == 'HiddenStateMLPPooling'
         at_pool = pool is not None and type(pool).__name__ == 'AttentionMLPPooling'
-        layers = pool.embedding_layers() if (pool is not None and not (nn_pool or hm_pool or at_pool)) else []
+        st_pool = pool is not None and type(pool).__name__ in ('NearestNeighborLSTM', 'TrajectronPooling')
+        layers = pool.embedding_layers() if (pool is not None and not (nn_pool or hm_pool or at_pool or st_pool)) else []
         if len(layers) > 3:
             raise NotImplementedError('embedding MLPs deeper than three layers')
         # per-step slices of buffers allocated once per sequence
@@ -192,12 +199,21 @@ class SequenceFn(torch.autograd.Function):
         gates_all = torch.empty(S, M, 4 * H, device=dev)
         act_all = [torch.empty(S, M, lin.weight.shape[0], device=dev) for lin in layers[:-1]]
         enc_all = torch.empty(S, M, pool.pooling_dim, device=dev) \
-            if (pool is not None and not (nn_pool or hm_pool or at_pool) and pool.type_ == 'social') else None
+            if (pool is not None and not (nn_pool or hm_pool or at_pool or st_pool) and pool.type_ == 'social') else None
         if hm_pool:    # the max-pooled vector (out_projection's input) and the hidden embedding's pre-activation
             act_all = [torch.empty(S, M, pool.mlp_dim, device=dev)]
         if hm_pool or at_pool:
             enc_all = torch.empty(S, M, pool.mlp_dim_hidden, device=dev) if pool.mlp_dim_hidden else None
         attrs_all = torch.empty(S, M, pool.n * pool.input_dim, device=dev) if nn_pool else None
+        st_saves = None
+        if st_pool:   # BPTT through the interaction encoder's own LSTM: its features, states and gates of every step
+            Hp, nn_lstm = pool.hidden_dim, type(pool).__name__ == 'NearestNeighborLSTM'
+            act_all = [torch.empty(S, M, pool.out_dim, device=dev)]
+            st_saves = dict(ph=torch.empty(S + 1, M, Hp, device=dev), pc=torch.empty(S + 1, M, Hp, device=dev),
+                            pgates=torch.empty(S, M, 4 * Hp, device=dev),
+                            traj_in=None if nn_lstm else torch.empty(S, M, 8, device=dev))
+            if nn_lstm:
+                attrs_all = torch.empty(S, M, pool.n * 4, device=dev)
         # sparse first embedding layer: keep every step's winner table for the sparse backward
         win_all = None
         if enc_all is not None and not (hm_pool or at_pool) and opts.get('sparse_backward', getattr(model, 'sparse_backward', True)) and layers[0].weight.shape[0] % 64 == 0 \
@@ -208,7 +224,7 @@ class SequenceFn(torch.autograd.Function):
         o1_all = torch.empty(S, M, 2, device=dev)
         o2_all = torch.empty(S, M, 2, device=dev)
         pos_all = torch.empty(S + (1 if T_obs == 2 else 0), M, 2, device=dev)
-        sv, sv_keep = _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, win_all, o1_all, o2_all)
+        sv, sv_keep = _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, win_all, o1_all, o2_all, st_saves)
         ex = _lib.LstmExtras()
         ctx.noise_at = None
         if noise is not None:        # adding_noise (sgan/sgan.py:200-221): h <- [ReLU(W_ctx h + b_ctx) | z]
@@ -239,7 +255,7 @@ class SequenceFn(torch.autograd.Function):
         ctx.model, ctx.idx, ctx.goals = model, idx, goals_t
         ctx.saved = (h_all, c_all, X_all, gates_all, act_all, enc_all, decs)
         ctx.attrs_all = attrs_all
-        ctx.hm_pool, ctx.at_pool = hm_pool, at_pool
+        ctx.hm_pool, ctx.at_pool, ctx.st_saves = hm_pool, at_pool, st_saves
         ctx.obs_all = (o1_all, o2_all)
         ctx.win_all = win_all
         ctx.w_cell_major = model._cell_major_weight(layers[0].weight, pool) if win_all is not None else None
@@ -273,16 +289,18 @@ class SequenceFn(torch.autograd.Function):
               for pre in set('decoder' if d else 'encoder' for d in decs)}
         has_h2n = 'hidden2normal.linear.weight' in P            # the S-GAN discriminator has no output head
         o1_all, o2_all = ctx.obs_all
-        nn_pool = ctx.attrs_all is not None                      # NearestNeighborMLP: only its embedding has parameters
+        st_saves = ctx.st_saves                                  # NearestNeighborLSTM / TrajectronPooling
+        st_pool = st_saves is not None
+        nn_pool = ctx.attrs_all is not None and not st_pool      # NearestNeighborMLP: only its embedding has parameters
         hm_pool, at_pool = ctx.hm_pool, ctx.at_pool              # HiddenStateMLPPooling, AttentionMLPPooling
-        grid_pool = pool is not None and not (nn_pool or hm_pool or at_pool)
+        grid_pool = pool is not None and not (nn_pool or hm_pool or at_pool or st_pool)
         layers = pool.embedding_layers() if grid_pool else []
         lay_names = ['pool.embedding.%d' % i for i, mod in enumerate(pool.embedding) if isinstance(mod, torch.nn.Linear)] \
             if grid_pool else []
         social = grid_pool and pool.type_ == 'social'
         dnn_all = torch.empty(S, M, pool.out_dim, device=dev) if nn_pool else None
         directional_in = ctx.input_grad and grid_pool and pool.type_ == 'directional'
-        if ctx.input_grad and (nn_pool or hm_pool or at_pool):
+        if ctx.input_grad and (nn_pool or hm_pool or at_pool or st_pool):
             raise NotImplementedError('position gradients through %s' % type(pool).__name__)
         sparse_bwd = ctx.win_all is not None      # first layer's gradients from the winner tables (csrc/lstm_bwd.hip)
         layT = [T(n + '.weight') if (li > 0 or ((social or directional_in) and not sparse_bwd)) else None
@@ -296,6 +314,13 @@ class SequenceFn(torch.autograd.Function):
             hm_G_all = torch.empty(S, M, ms + mv, device=dev)
             hm_R_all = torch.empty(S, M, ms + mv, 2, device=dev)
 
+        st_bufs = None
+        if st_pool:
+            Hp = pool.hidden_dim
+            st_bufs = dict(pwT=torch.cat([T('pool.pool_lstm.weight_ih'), T('pool.pool_lstm.weight_hh')], dim=0),
+                           h2pT=T('pool.hidden2pool.weight'), zeros=torch.zeros(M, 2, device=dev),
+                           dG=torch.empty(S, M, 4 * Hp, device=dev), dfeat=torch.empty(S, M, pool.out_dim, device=dev),
+                           dph=torch.zeros(M, Hp, device=dev), dpc=torch.zeros(M, Hp, device=dev))
         at_bufs = None
         if at_pool:   # linear maps around the softmax folded as in the forward (AttentionMLPPooling.folded)
             ms, mv, mh, D = pool.mlp_dim_spatial, pool.mlp_dim_vel, pool.mlp_dim_hidden, pool.mlp_dim
@@ -316,8 +341,10 @@ class SequenceFn(torch.autograd.Function):
         dy_all = [torch.empty(S, M, lin.weight.shape[0], device=dev) for lin in layers]
         denc_all = torch.empty(S, M, pool.pooling_dim, device=dev) if social else None
         grid_all = None
-        if hm_pool or at_pool:
+        if st_pool:
             dy_all = [torch.empty(S, M, pool.out_dim, device=dev)]          # gradient of the interaction vector
+        if hm_pool or at_pool:
+            dy_all = [torch.empty(S, M, pool.out_dim, device=dev)]
             denc_all = torch.empty(S, M, mh, device=dev) if mh else None
             sizes = (idx.starts[1:] - idx.starts[:-1]).long()
             row_base = torch.repeat_interleave(idx.starts[:-1].long(), sizes).to(torch.int32)
@@ -352,7 +379,8 @@ class SequenceFn(torch.autograd.Function):
         dvel_pool_all = torch.empty(S, M, 2, device=dev) if directional_in else None
 
         # ---- the reverse sweep: one driver call (two around the S-GAN noise hook), csrc/lstm_bwd.hip ----
-        sv, sv_keep = _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, ctx.attrs_all, ctx.win_all, o1_all, o2_all)
+        sv, sv_keep = _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, ctx.attrs_all, ctx.win_all, o1_all, o2_all,
+                                   st_saves)
         m, keep, _ = model._descriptor()
         if not has_h2n:
             m.Wn, m.bn = None, None
@@ -375,6 +403,10 @@ class SequenceFn(torch.autograd.Function):
         sw.w_cell_major = ctx.w_cell_major.data_ptr() if sparse_bwd else None
         if social or directional_in or hm_pool or at_pool:
             sw.row_base, sw.row_count = row_base.data_ptr(), row_count.data_ptr()
+        if st_pool:
+            sw.stateful = 1
+            sw.st_pwT, sw.st_h2pT, sw.st_zeros = (st_bufs[k].data_ptr() for k in ('pwT', 'h2pT', 'zeros'))
+            sw.st_dG_all, sw.st_dfeat_all, sw.st_dph, sw.st_dpc = (st_bufs[k].data_ptr() for k in ('dG', 'dfeat', 'dph', 'dpc'))
         if at_pool:
             sw.attention, sw.at_WuT, sw.at_WqT = 1, at_wuT.data_ptr(), at_wqT.data_ptr()
             sw.at_eself_all, sw.at_q_all, sw.at_dq_all = (at_bufs[k].data_ptr() for k in ('eself', 'q', 'dq'))
@@ -478,6 +510,17 @@ class SequenceFn(torch.autograd.Function):
                 grads[name + '.bias'] = dy_all[0].reshape(-1, N1).sum(0)
                 continue
             wgrad(name + '.weight', dy_all[li], grid_all if li == 0 else act_all[li - 1], name + '.bias')
+        if st_pool:
+            ph_all = st_saves['ph']
+            wgrad('pool.hidden2pool.weight', dy_all[0], ph_all[1:], 'pool.hidden2pool.bias')
+            wgrad('pool.pool_lstm.weight_ih', st_bufs['dG'], act_all[0], 'pool.pool_lstm.bias_ih')
+            wgrad('pool.pool_lstm.weight_hh', st_bufs['dG'], ph_all[:-1], None)
+            grads['pool.pool_lstm.bias_hh'] = grads['pool.pool_lstm.bias_ih'].clone()
+            if st_saves['traj_in'] is None:     # NearestNeighborLSTM: rows = (step, track, neighbour slot)
+                d = pool.out_dim // pool.n
+                wgrad('pool.embedding.0.weight', st_bufs['dfeat'].reshape(-1, d), ctx.attrs_all.reshape(-1, 4), 'pool.embedding.0.bias')
+            else:
+                wgrad('pool.embedding.0.weight', st_bufs['dfeat'], st_saves['traj_in'], 'pool.embedding.0.bias')
         if at_pool:
             _attention_param_grads(pool, P, grads, wgrad, dy_all[0], at_bufs, denc_all, h_prev_all, S * M, L, dev, sp)
         if hm_pool:
