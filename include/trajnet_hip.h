@@ -287,6 +287,7 @@ typedef struct tnp_train_saves {
      * one ph_all / pc_all [steps+1, M, Hp], its post-activation gates pgates_all [steps, M, 4Hp]; act_all[0] holds the
      * pool_lstm's input features [steps, M, P]; traj_in_all [steps, M, 8] the Trajectron embedding's inputs */
     float *ph_all, *pc_all, *pgates_all, *traj_in_all;
+    float *pvec_all;   /* LSTM(pool_to_input=False): [steps, M, H] interaction vector before it is added to the hidden state */
 } tnp_train_saves;
 TNP_API int tnp_lstm_forward_train(const tnp_lstm_model *model, const float *observed, int T_obs, int M, const float *goals,
                                    const int32_t *scene_start, const uint8_t *primary_flag, int B, int n_max,

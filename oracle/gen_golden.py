@@ -301,16 +301,19 @@ def grad_nongrid_case(ref):
     """grad_case for the non-grid interaction modules that train on the HIP path (tests/golden/grad_cases_nongrid.npz)."""
     out = {}
     import trajnetbaselines.lstm.non_gridbased_pooling as ng
-    for kind in ('hiddenstatemlp', 'attentionmlp', 'nn_lstm', 'traj_pool'):
-        torch.manual_seed({'hiddenstatemlp': 45, 'attentionmlp': 46, 'nn_lstm': 47, 'traj_pool': 48}[kind])
+    for kind in ('hiddenstatemlp', 'attentionmlp', 'nn_lstm', 'traj_pool', 'addhidden'):
+        torch.manual_seed({'hiddenstatemlp': 45, 'attentionmlp': 46, 'nn_lstm': 47, 'traj_pool': 48, 'addhidden': 49}[kind])
         if kind in ('hiddenstatemlp', 'attentionmlp'):
             cls = ng.HiddenStateMLPPooling if kind == 'hiddenstatemlp' else ng.AttentionMLPPooling
             pool = cls(hidden_dim=128, mlp_dim=96, mlp_dim_spatial=32, mlp_dim_vel=32, out_dim=32)
         elif kind == 'nn_lstm':
             pool = ng.NearestNeighborLSTM(n=4, hidden_dim=64, out_dim=32)
-        else:
+        elif kind == 'traj_pool':
             pool = ng.TrajectronPooling(hidden_dim=64, out_dim=32)
-        model = ref.LSTM(pool=pool).train()
+        else:   # LSTM(pool_to_input=False): the interaction vector (out_dim == hidden_dim) is added to the hidden state
+            pool = ref.GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=8, out_dim=128,
+                                        embedding_arch='two_layer', layer_dims=[128], latent_dim=8)
+        model = ref.LSTM(pool=pool, pool_to_input=(kind != 'addhidden')).train()
         xy, split = synth.ragged_crowd(4, 2, 8, seed=52)
         M = xy.shape[1]
         observed, truth = xy[:9].clone(), xy[9:20].clone()

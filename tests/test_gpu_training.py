@@ -182,7 +182,7 @@ def test_wgrad_split_k_matches_fp64(K, Mo, No):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize('kind', ['hiddenstatemlp', 'attentionmlp', 'nn_lstm', 'traj_pool'])
+@pytest.mark.parametrize('kind', ['hiddenstatemlp', 'attentionmlp', 'nn_lstm', 'traj_pool', 'addhidden'])
 def test_nongrid_gradients_match_reference_autograd(kind):
     """Training through HiddenStateMLPPooling (max-pool routing, Linear(2 -> dim) embeddings behind it, hidden embedding,
     out_projection) and AttentionMLPPooling (softmax attention over the slots with the linear maps folded, gradients
@@ -196,9 +196,13 @@ def test_nongrid_gradients_match_reference_autograd(kind):
         pool = cls(hidden_dim=128, mlp_dim=96, mlp_dim_spatial=32, mlp_dim_vel=32, out_dim=32)
     elif kind == 'nn_lstm':     # BPTT through the interaction encoder's own pool_lstm
         pool = NearestNeighborLSTM(n=4, hidden_dim=64, out_dim=32)
-    else:
+    elif kind == 'traj_pool':
         pool = TrajectronPooling(hidden_dim=64, out_dim=32)
-    model = LSTM(pool=pool)
+    else:   # LSTM(pool_to_input=False): the interaction vector is added to the hidden state (lstm/lstm.py:150-151)
+        from trajnetplusplusbaselines_amd.lstm import GridBasedPooling
+        pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=8, out_dim=128,
+                                embedding_arch='two_layer', layer_dims=[128], latent_dim=8)
+    model = LSTM(pool=pool, pool_to_input=(kind != 'addhidden'))
     pre = kind + '_sd_'
     model.load_state_dict({k[len(pre):]: torch.tensor(G[k]) for k in G.files if k.startswith(pre)})
     model = model.cuda().train()

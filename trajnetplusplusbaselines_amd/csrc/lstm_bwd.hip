@@ -445,7 +445,8 @@ static void plan_sweep(const tnp_bwd_sweep *a, void *base, SweepScratch &w) {
     const size_t M = (size_t)a->M, H = md->H;
     const bool grid = md->pool_type >= TNP_POOL_OCCUPANCY && md->pool_type <= TNP_POOL_SOCIAL && !a->nn_pool;
     const bool social = grid && md->pool_type == TNP_POOL_SOCIAL;
-    const size_t I = (size_t)md->E + (md->goal_flag ? md->goal_dim : 0) + (md->pool_type != TNP_POOL_NONE ? md->P : 0);
+    const bool to_hidden = md->pool_type != TNP_POOL_NONE && ((md->variant >> 17) & 1);
+    const size_t I = (size_t)md->E + (md->goal_flag ? md->goal_dim : 0) + ((md->pool_type != TNP_POOL_NONE && !to_hidden) ? md->P : 0);
     size_t off = 0;
     auto take = [&](size_t bytes) {
         void *p = base ? (char *)base + off : nullptr;
@@ -625,7 +626,8 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
     const bool stf = a->stateful != 0 && (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ);
     if (md->pool_type != TNP_POOL_NONE && !grid && !a->nn_pool && !hm && !at && !stf)
         TNP_FAIL(-1, "tnp_lstm_backward_sweep: pool type %d has no backward", md->pool_type);
-    if ((md->variant >> 17) & 1) TNP_FAIL(-1, "tnp_lstm_backward_sweep: pool_to_input=False has no backward");
+    const bool to_hidden = md->pool_type != TNP_POOL_NONE && ((md->variant >> 17) & 1);   // LSTM(pool_to_input=False)
+    if (to_hidden && !sv->pvec_all) TNP_FAIL(-1, "tnp_lstm_backward_sweep: pool_to_input=False needs saves->pvec_all");
     tnp::SweepScratch w;
     tnp::plan_sweep(a, scratch, w);
     if (!scratch || scratch_bytes < w.bytes)
@@ -633,7 +635,7 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
     hipStream_t s = (hipStream_t)stream;
     const int GD = md->goal_flag ? md->goal_dim : 0;
     const int Pw = md->pool_type != TNP_POOL_NONE ? md->P : 0;
-    const int I = E + GD + Pw, LDX = I + H, P0 = E + GD;
+    const int I = E + GD + (to_hidden ? 0 : Pw), LDX = I + H, P0 = E + GD;
     const size_t MH = (size_t)M * H;
     const int nl = md->n_layers, ncell = md->n * md->n, C = md->C;
     float *dc_cur = a->dc, *dc_nxt = w.dc_alt;
@@ -659,9 +661,14 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
         TNP_RC(tnp_linear_forward(dG, 4 * H, wT, 4 * H, nullptr, w.dxh, LDX, M, LDX, 4 * H, 0, 0, stream));   // [dG.W_ih | dG.W_hh]
         // ---- input / goal embedding backward (X holds the ReLU outputs) ----
         const float *Xs = sv->X_all + r * I;
+        // gradient and forward value of the interaction vector: pooled columns of X, or (pool_to_input=False) the vector
+        // that was added to the hidden operand -- its gradient is the hidden operand's
+        const float *pgrad = to_hidden ? w.dxh + I : w.dxh + P0;
+        const float *pact = to_hidden ? sv->pvec_all + r * H : Xs + P0;
+        const int pact_ld = to_hidden ? H : I;
         TNP_RC(tnp_relu_mask(w.dxh, LDX, Xs, I, M, E - 2, a->de_all + r * (E - 2), E - 2, stream));
         if (GD) TNP_RC(tnp_relu_mask(w.dxh + E, LDX, Xs + E, I, M, GD - 2, a->dgoal_all + r * (GD - 2), GD - 2, stream));
-        if (a->nn_pool) TNP_RC(tnp_relu_mask(w.dxh + P0, LDX, Xs + P0, I, M, Pw, a->dnn_all + r * Pw, Pw, stream));
+        if (a->nn_pool) TNP_RC(tnp_relu_mask(pgrad, LDX, pact, pact_ld, M, Pw, a->dnn_all + r * Pw, Pw, stream));
         // ---- grid embedding MLP + scatter + social encoding backward ----
         const float *extra = nullptr;
         if (grid) {
@@ -671,7 +678,7 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
                                              a->grid_all + r * md->dims[0], md->dims[0], nullptr, stream));
             }
             // last layer: its ReLU output is the pooled part of X
-            TNP_RC(tnp_relu_mask(w.dxh + P0, LDX, Xs + P0, I, M, Pw, a->dy_all[nl - 1] + r * Pw, Pw, stream));
+            TNP_RC(tnp_relu_mask(pgrad, LDX, pact, pact_ld, M, Pw, a->dy_all[nl - 1] + r * Pw, Pw, stream));
             for (int l = nl - 1; l >= 1; --l) {
                 const int n_out = md->dims[l + 1], n_in = md->dims[l];
                 TNP_RC(tnp_linear_forward(a->dy_all[l] + r * n_out, n_out, a->layT[l], n_out, nullptr, w.d_in, n_in, M, n_in, n_out,
@@ -710,7 +717,7 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
         if (hm) {   // HiddenStateMLPPooling: out_projection (linear) <- max-pool routing <- embeddings
             const int ms = md->dims[0], mv = md->dims[1], mh = md->dims[2], D = ms + mh + mv, GDm = ms + mv;
             float *dP = a->dy_all[0] + r * Pw;
-            TNP_HIP(hipMemcpy2DAsync(dP, (size_t)Pw * 4, w.dxh + P0, (size_t)LDX * 4, (size_t)Pw * 4, M, hipMemcpyDeviceToDevice, s));
+            TNP_HIP(hipMemcpy2DAsync(dP, (size_t)Pw * 4, pgrad, (size_t)LDX * 4, (size_t)Pw * 4, M, hipMemcpyDeviceToDevice, s));
             TNP_RC(tnp_linear_forward(dP, Pw, a->layT[0], Pw, nullptr, w.d_pooled, D, M, D, Pw, 0, 0, stream));
             float *denc = mh > 0 ? a->denc_all + r * mh : nullptr;
             TNP_RC(tnp_pool_hiddenmlp_backward(o1, o2, mh > 0 ? sv->enc_all + r * mh : nullptr, mh, a->scene_start, a->row_base,
@@ -726,7 +733,7 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
             const int Hp = md->dims[0], LP = Pw + Hp;
             const size_t MHp = (size_t)M * Hp;
             float *dP = a->dy_all[0] + r * Pw;
-            TNP_HIP(hipMemcpy2DAsync(dP, (size_t)Pw * 4, w.dxh + P0, (size_t)LDX * 4, (size_t)Pw * 4, M, hipMemcpyDeviceToDevice, s));
+            TNP_HIP(hipMemcpy2DAsync(dP, (size_t)Pw * 4, pgrad, (size_t)LDX * 4, (size_t)Pw * 4, M, hipMemcpyDeviceToDevice, s));
             // gradient of the encoder's new hidden state: through hidden2pool + what the next step handed back
             TNP_RC(tnp_linear_forward(dP, Pw, a->st_h2pT, Pw, nullptr, w.st_pass, Hp, M, Hp, Pw, 0, 0, stream));
             hipLaunchKernelGGL(tnp::state_grad_combine_kernel, dim3((unsigned)((MHp + 255) / 256)), dim3(256), 0, s, w.st_pass, Hp,
@@ -745,7 +752,7 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
         if (at) {   // AttentionMLPPooling: Wfin (linear) <- softmax attention over the slots <- embeddings, query path
             const int ms = md->dims[0], mv = md->dims[1], mh = md->dims[2], D = ms + mh + mv, GDm = ms + mv, LU = D + 4;
             float *dP = a->dy_all[0] + r * Pw;
-            TNP_HIP(hipMemcpy2DAsync(dP, (size_t)Pw * 4, w.dxh + P0, (size_t)LDX * 4, (size_t)Pw * 4, M, hipMemcpyDeviceToDevice, s));
+            TNP_HIP(hipMemcpy2DAsync(dP, (size_t)Pw * 4, pgrad, (size_t)LDX * 4, (size_t)Pw * 4, M, hipMemcpyDeviceToDevice, s));
             TNP_RC(tnp_linear_forward(dP, Pw, a->layT[0], Pw, nullptr, w.d_pooled, D, M, D, Pw, 0, 0, stream));       // d ebar
             const float *hpre = mh > 0 ? sv->enc_all + r * mh : nullptr;
             float *es = a->at_eself_all + r * D, *qs = a->at_q_all + r * D;

@@ -248,6 +248,7 @@ struct Workspace {
     float *gates_save;   // training: post-activation gates of the step
     float *nn_attrs_save;
     float *pc_out, *pgates_save, *traj_in_save;   // stateful interaction encoders under tnp_lstm_forward_train
+    float *pvec_save;                             // pool_to_input=False: the interaction vector before it is added to h
     size_t bytes;
 };
 
@@ -299,7 +300,7 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     w.pld = w.to_hidden ? md->H : w.I;
     w.gates_save = nullptr;
     w.nn_attrs_save = nullptr;
-    w.pc_out = nullptr; w.pgates_save = nullptr; w.traj_in_save = nullptr;
+    w.pc_out = nullptr; w.pgates_save = nullptr; w.traj_in_save = nullptr; w.pvec_save = nullptr;
     if (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ) {
         const int Hp = md->dims[0];
         w.ph[0] = (float *)take((size_t)M * Hp * 4);
@@ -481,6 +482,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
     memset(&g, 0, sizeof(g));
     if (w.to_hidden) {   // hplus = h_in + pooled (rows of absent tracks are never used: their state is copied through)
         const long tot4 = (long)M * H / 4;
+        if (w.pvec_save) TNP_HIP(hipMemcpyAsync(w.pvec_save, w.hplus, (size_t)M * H * 4, hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((tot4 + 255) / 256)), dim3(256), 0, s, w.hplus, h_in, tot4);
         TNP_HIP(hipGetLastError());
     }
@@ -554,6 +556,8 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
     const bool stateful = md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ;
     if (sv && stateful && (!sv->ph_all || !sv->pc_all || !sv->pgates_all || !sv->act_all[0]))
         TNP_FAIL(-1, "tnp_lstm_forward_train: stateful interaction encoders need ph_all, pc_all, pgates_all, act_all[0]");
+    if (sv && md->pool_type != TNP_POOL_NONE && ((md->variant >> 17) & 1) && !sv->pvec_all)
+        TNP_FAIL(-1, "tnp_lstm_forward_train: pool_to_input=False needs pvec_all");
     if (sv && (!sv->h_all || !sv->c_all || !sv->X_all || !sv->gates_all || !sv->obs1_all || !sv->obs2_all))
         TNP_FAIL(-1, "tnp_lstm_forward_train: h_all, c_all, X_all, gates_all, obs1_all, obs2_all are required");
     if (T_obs < 2) TNP_FAIL(-1, "need at least 2 observed frames (got %d)", T_obs);
@@ -607,6 +611,7 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
             w.gates_save = sv->gates_all + r * 4 * H;
             w.nn_attrs_save = sv->nn_attrs_all ? sv->nn_attrs_all + r * md->n * (md->pool_type == TNP_POOL_NNLSTM ? 4 : md->C) : nullptr;
             if (sv->winners_all && w.sparse) w.winners = sv->winners_all + r * md->n * md->n;
+            w.pvec_save = (w.to_hidden && sv->pvec_all) ? sv->pvec_all + r * H : nullptr;
             w.obs1 = sv->obs1_all + r * 2;
             w.obs2 = sv->obs2_all + r * 2;
         }

@@ -220,10 +220,9 @@ class LSTM(torch.nn.Module):
             trainable_pool = hasattr(self.pool, 'embedding_layers') or \
                 type(self.pool).__name__ in ('NearestNeighborMLP', 'HiddenStateMLPPooling', 'AttentionMLPPooling',
                                              'NearestNeighborLSTM', 'TrajectronPooling')
-            if self.pool is not None and (not trainable_pool or not self.pool_to_input):
-                raise NotImplementedError('training (backward) through %s%s is not available on the MI355X path yet; '
-                                          'use model.eval() / torch.no_grad() for inference'
-                                          % (type(self.pool).__name__, '' if self.pool_to_input else ' with pool_to_input=False'))
+            if self.pool is not None and not trainable_pool:
+                raise NotImplementedError('training (backward) through %s is not available on the MI355X path yet; '
+                                          'use model.eval() / torch.no_grad() for inference' % type(self.pool).__name__)
             from .training import run_sequence_with_grad
             rel_pred, pred, _ = run_sequence_with_grad(self, observed, goals, batch_split, prediction_truth, T_dec)
             return rel_pred, pred

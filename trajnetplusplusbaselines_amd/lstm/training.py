@@ -58,7 +58,8 @@ class TrainSaves(ctypes.Structure):
                 ('act_all', ctypes.c_void_p * 2), ('gates_all', ctypes.c_void_p), ('enc_all', ctypes.c_void_p),
                 ('nn_attrs_all', ctypes.c_void_p), ('winners_all', ctypes.c_void_p), ('obs1_all', ctypes.c_void_p),
                 ('obs2_all', ctypes.c_void_p), ('h_clean', ctypes.c_void_p), ('ph_all', ctypes.c_void_p),
-                ('pc_all', ctypes.c_void_p), ('pgates_all', ctypes.c_void_p), ('traj_in_all', ctypes.c_void_p)]
+                ('pc_all', ctypes.c_void_p), ('pgates_all', ctypes.c_void_p), ('traj_in_all', ctypes.c_void_p),
+                ('pvec_all', ctypes.c_void_p)]
 
 
 class BwdSweep(ctypes.Structure):
@@ -139,7 +140,9 @@ def _attention_param_grads(pool, P, grads, wgrad, dout_all, bufs, denc_all, h_pr
 
 def _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, win_all, o1_all, o2_all, st=None):
     sv = TrainSaves()
-    if st is not None:    # stateful interaction encoders
+    if st is not None and st.get('pvec') is not None:     # pool_to_input=False
+        sv.pvec_all = st['pvec'].data_ptr()
+    if st is not None and st.get('ph') is not None:    # stateful interaction encoders
         sv.ph_all, sv.pc_all, sv.pgates_all = st['ph'].data_ptr(), st['pc'].data_ptr(), st['pgates'].data_ptr()
         sv.traj_in_all = st['traj_in'].data_ptr() if st.get('traj_in') is not None else None
     sv.h_all, sv.c_all, sv.X_all, sv.gates_all = h_all.data_ptr(), c_all.data_ptr(), X_all.data_ptr(), gates_all.data_ptr()
@@ -224,6 +227,8 @@ class SequenceFn(torch.autograd.Function):
         o1_all = torch.empty(S, M, 2, device=dev)
         o2_all = torch.empty(S, M, 2, device=dev)
         pos_all = torch.empty(S + (1 if T_obs == 2 else 0), M, 2, device=dev)
+        if pool is not None and not model.pool_to_input:   # the interaction vector before it is added to the hidden state
+            st_saves = dict(st_saves or {}, pvec=torch.empty(S, M, H, device=dev))
         sv, sv_keep = _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, win_all, o1_all, o2_all, st_saves)
         ex = _lib.LstmExtras()
         ctx.noise_at = None
@@ -290,7 +295,7 @@ class SequenceFn(torch.autograd.Function):
         has_h2n = 'hidden2normal.linear.weight' in P            # the S-GAN discriminator has no output head
         o1_all, o2_all = ctx.obs_all
         st_saves = ctx.st_saves                                  # NearestNeighborLSTM / TrajectronPooling
-        st_pool = st_saves is not None
+        st_pool = st_saves is not None and st_saves.get('ph') is not None
         nn_pool = ctx.attrs_all is not None and not st_pool      # NearestNeighborMLP: only its embedding has parameters
         hm_pool, at_pool = ctx.hm_pool, ctx.at_pool              # HiddenStateMLPPooling, AttentionMLPPooling
         grid_pool = pool is not None and not (nn_pool or hm_pool or at_pool or st_pool)
@@ -485,10 +490,14 @@ class SequenceFn(torch.autograd.Function):
         if has_h2n:
             wgrad('hidden2normal.linear.weight', dlin_all, h_out_all, 'hidden2normal.linear.bias')
         n_enc = sum(1 for d in decs if not d)
+        # hidden operand of the LSTMCell: h, or h + interaction vector for LSTM(pool_to_input=False)
+        hid_all = h_prev_all
+        if ctx.st_saves is not None and ctx.st_saves.get('pvec') is not None:
+            hid_all = torch.nan_to_num(h_prev_all + ctx.st_saves['pvec'])
         for pre, lo, hi in (('encoder', 0, n_enc), ('decoder', n_enc, S)):
             if hi > lo:
                 wgrad(pre + '.weight_ih', dG_all[lo:hi], X_all[lo:hi], pre + '.bias_ih')
-                wgrad(pre + '.weight_hh', dG_all[lo:hi], h_prev_all[lo:hi], None)
+                wgrad(pre + '.weight_hh', dG_all[lo:hi], hid_all[lo:hi], None)
                 grads[pre + '.bias_hh'] = grads[pre + '.bias_ih'].clone()
         vel_all = torch.nan_to_num(o2_all - o1_all) * 4.0
         wgrad('input_embedding.input_embeddings.0.weight', de_all, vel_all, 'input_embedding.input_embeddings.0.bias')
