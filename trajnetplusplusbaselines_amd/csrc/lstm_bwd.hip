@@ -344,21 +344,26 @@ __global__ void __launch_bounds__(256) hits_compact_kernel(const int32_t *__rest
 }
 
 // dW'[c][ch][n] = sum over the hits (r, e) of cell c of  dy1[r, n] * enc[e, ch]   (all steps of the sweep at once)
-// One wave per (cell, 64 output columns); the hit list and the encodings are wave-uniform (scalar loads), the dy1 rows
-// are 256-byte coalesced reads; hits in list order -> deterministic.
+// One workgroup per (cell, 64 output columns); its four waves take the hits k = 4*g + wave of every group of four
+// batches (a wave's hit loop is a chain of dependent scalar + vector loads, so the list is split four ways) and the four
+// partial tiles are combined through LDS in a fixed order -> deterministic.  The hit list and the encodings are
+// wave-uniform (scalar loads), the dy1 rows are 256-byte coalesced reads.
 template <int C>
-__global__ void __launch_bounds__(64) sparse_wgrad_kernel(const float *__restrict__ dy, int ldy,
-                                                          const float *__restrict__ enc, int lde,
-                                                          const int2 *__restrict__ list, const int32_t *__restrict__ count,
-                                                          int R, int N1, float *__restrict__ dWc) {
-    const int c = blockIdx.x, n = blockIdx.y * 64 + threadIdx.x;
+__global__ void __launch_bounds__(256) sparse_wgrad_kernel(const float *__restrict__ dy, int ldy,
+                                                           const float *__restrict__ enc, int lde,
+                                                           const int2 *__restrict__ list, const int32_t *__restrict__ count,
+                                                           int R, int N1, float *__restrict__ dWc) {
+    __shared__ float red[3][C][64];
+    const int c = blockIdx.x, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.y * 64 + lane;
     const int cnt = count[c];
     const int2 *L = list + (size_t)c * R;
     float acc[C];
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) acc[ch] = 0.0f;
-    int k = 0;
-    for (; k + 4 <= cnt; k += 4) {
+    int k = wave * 4;
+    for (; k + 4 <= cnt; k += 16) {
         const int2 h0 = L[k], h1 = L[k + 1], h2 = L[k + 2], h3 = L[k + 3];
         const float d0 = dy[(size_t)h0.x * ldy + n], d1 = dy[(size_t)h1.x * ldy + n];
         const float d2 = dy[(size_t)h2.x * ldy + n], d3 = dy[(size_t)h3.x * ldy + n];
@@ -368,15 +373,23 @@ __global__ void __launch_bounds__(64) sparse_wgrad_kernel(const float *__restric
         for (int ch = 0; ch < C; ++ch)
             acc[ch] = fmaf(d3, e3[ch], fmaf(d2, e2[ch], fmaf(d1, e1[ch], fmaf(d0, e0[ch], acc[ch]))));
     }
-    for (; k < cnt; ++k) {
-        const int2 h = L[k];
+    for (int kk = k; kk < cnt && kk < k + 4; ++kk) {   // ragged last batch (if it falls to this wave)
+        const int2 h = L[kk];
         const float d = dy[(size_t)h.x * ldy + n];
         const float *e = enc + (size_t)h.y * lde;
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) acc[ch] = fmaf(d, e[ch], acc[ch]);
     }
+    if (wave > 0) {
 #pragma unroll
-    for (int ch = 0; ch < C; ++ch) dWc[((size_t)c * C + ch) * N1 + n] = acc[ch];
+        for (int ch = 0; ch < C; ++ch) red[wave - 1][ch][lane] = acc[ch];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch)
+            dWc[((size_t)c * C + ch) * N1 + n] = (acc[ch] + red[0][ch][lane]) + (red[1][ch][lane] + red[2][ch][lane]);
+    }
 }
 
 static int launch_hit_lists(bool occ, const void *table, const int32_t *row_base, int R, int M, int ncell, int seg,
@@ -415,7 +428,7 @@ static int launch_dgrid_cells(const float *dy, int ldy, const float *Wc, const i
 template <int C>
 static int launch_sparse_wgrad(const float *dy, int ldy, const float *enc, int lde, const int2 *list, const int32_t *count, int R,
                                int ncell, int N1, float *dWc, hipStream_t s) {
-    hipLaunchKernelGGL(sparse_wgrad_kernel<C>, dim3(ncell, N1 / 64), dim3(64), 0, s, dy, ldy, enc, lde, list, count, R, N1, dWc);
+    hipLaunchKernelGGL(sparse_wgrad_kernel<C>, dim3(ncell, N1 / 64), dim3(256), 0, s, dy, ldy, enc, lde, list, count, R, N1, dWc);
     TNP_HIP(hipGetLastError());
     return 0;
 }
