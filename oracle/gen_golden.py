@@ -481,6 +481,48 @@ def sgan_train_case(ref):
     print('sgan_train_case.npz', out['d_loss'], out['g_loss'], out['d_scores_fake'].ravel())
 
 
+def sgan_train_goals_case(ref):
+    """One generator step of S-GAN training with goals (goal_flag) in generator and discriminator, directional pooling:
+    tests/golden/sgan_train_goals.npz."""
+    import random
+    import types
+    import trajnetbaselines.sgan.sgan as ref_sgan
+    import trajnetbaselines.sgan.trainer as ref_tr
+    import trajnetbaselines.lstm.loss as ref_loss
+    torch.manual_seed(31)
+    mk = lambda: ref.GridBasedPooling(type_='directional', hidden_dim=128, cell_side=0.6, n=12, out_dim=64,
+                                      embedding_arch='one_layer')
+    gen = ref_sgan.LSTMGenerator(pool=mk(), noise_dim=16, goal_flag=True, goal_dim=64)
+    disc = ref_sgan.LSTMDiscriminator(pool=mk(), goal_flag=True, goal_dim=64)
+    model = ref_sgan.SGAN(generator=gen, discriminator=disc, k=2, d_steps=1, g_steps=1).train()
+    with torch.no_grad():
+        last = [mod for mod in disc.real_classifier if isinstance(mod, torch.nn.Linear)][-1]
+        last.bias.fill_(0.5)
+    out = {}
+    for k, v in model.state_dict().items():
+        out['sd_' + k] = v.numpy().copy()
+    xy, split = synth.ragged_crowd(4, 2, 7, seed=35)
+    M = xy.shape[1]
+    goals = torch.nan_to_num(xy[20]) + 0.5 * torch.randn(M, 2)
+    out.update(xy=xy.numpy(), split=split.numpy(), goals=goals.numpy())
+    fake_self = types.SimpleNamespace(model=model, criterion=ref_loss.PredictionLoss(keep_batch_dim=True), pred_length=12)
+    fake_self.variety_loss = lambda *a: ref_tr.Trainer.variety_loss(fake_self, *a)
+    targets = xy[9:21] - xy[8:20]
+    model.zero_grad()
+    torch.manual_seed(44)
+    random.seed(10)
+    rel, outs, s_real, s_fake = model(xy[:9].clone(), goals, split, xy[9:21].clone(), step_type='g', pred_length=12)
+    loss = ref_tr.Trainer.loss_criterion(fake_self, rel, targets, split, s_fake, s_real, 'g')
+    loss.backward()
+    out['g_loss'] = np.float64(loss.item())
+    out['g_scores_real'] = s_real.detach().numpy()
+    out['g_scores_fake'] = s_fake.detach().numpy()
+    for k, p in model.named_parameters():
+        out['g_grad_' + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'sgan_train_goals.npz'), **out)
+    print('sgan_train_goals.npz', out['g_loss'], out['g_scores_fake'].ravel())
+
+
 def sgan_train_social_case(ref):
     """One generator step of S-GAN training with SOCIAL pooling in generator and discriminator (gradient from the scores
     through the discriminator's input positions into the generator): tests/golden/sgan_train_social.npz."""
@@ -574,8 +616,11 @@ def main():
     ref = ref_import.import_reference()
     if '--only-grad-nongrid' in sys.argv:
         return grad_nongrid_case(ref)
+    if '--only-sgangoals' in sys.argv:
+        return sgan_train_goals_case(ref)
     if '--only-sgansocial' in sys.argv:
         return sgan_train_social_case(ref)
+    sgan_train_goals_case(ref)
     sgan_train_social_case(ref)
     if '--only-sgantrain' in sys.argv:
         return sgan_train_case(ref)

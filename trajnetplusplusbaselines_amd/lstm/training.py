@@ -173,8 +173,8 @@ class SequenceFn(torch.autograd.Function):
         opts = opts or {}
         noise = opts.get('noise')
         ctx.input_grad = bool(opts.get('input_grad')) and observed.requires_grad
-        if ctx.input_grad and (model.goal_flag or T_dec != 0):
-            raise NotImplementedError('gradients with respect to the observed positions: encoder-only runs without goals')
+        if ctx.input_grad and T_dec != 0:
+            raise NotImplementedError('gradients with respect to the observed positions: encoder-only runs')
         observed = _lib.f32c(observed.detach(), dev)
         truth = _lib.f32c(truth.detach(), dev) if truth is not None else None
         goals_t = _lib.f32c(goals.detach(), dev) if (goals is not None and model.goal_flag) else None
@@ -464,6 +464,13 @@ class SequenceFn(torch.autograd.Function):
             d_obs = torch.zeros(ctx.T_obs, M, 2, device=dev)
             d_obs[1:S + 1] += dvel
             d_obs[0:S] -= dvel
+            if GD:   # the goal embedding sees the unit vector from the goal to the current position (lstm/lstm.py:132-139)
+                goal_wT4 = torch.zeros(4, GD - 2, device=dev)
+                goal_wT4[:2] = P['goal_embedding.input_embeddings.0.weight'].detach().t()
+                du = _lin(dgoal_all.reshape(S * M, GD - 2), goal_wT4)[:, :2].reshape(S, M, 2) * 4.0
+                unit = gdir_all / 4.0
+                d_o2 = (du - unit * (unit * du).sum(dim=2, keepdim=True)) / nf
+                d_obs[1:S + 1] += torch.where(torch.isfinite(d_o2) & (nf > 0), d_o2, torch.zeros_like(d_o2))
 
         # ---- deferred weight gradients: one GEMM per parameter over the stacked steps ----
         wg_ws = [None]
