@@ -333,6 +333,31 @@ def grad_nongrid_case(ref):
     print('grad_cases_nongrid.npz')
 
 
+def grad_short_case(ref):
+    """Gradients in the two corner modes of LSTM.forward: two observed frames (positions pre-seeded, lstm/lstm.py:222-223)
+    and free-running decoding (n_predict, every track fed its own detached prediction) -- tests/golden/grad_short.npz."""
+    out = {}
+    torch.manual_seed(57)
+    pool = ref.GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=8, out_dim=64,
+                                embedding_arch='two_layer', layer_dims=[128], latent_dim=8)
+    model = ref.LSTM(pool=pool).train()
+    xy, split = synth.ragged_crowd(4, 1, 7, seed=58)
+    M = xy.shape[1]
+    rel, pred = model(xy[:2].clone(), torch.zeros(M, 2), split, n_predict=6)
+    prim = split[:-1]
+    loss = rel[-6:, prim, :2].pow(2).sum() + 0.3 * torch.nan_to_num(pred[-6:, prim]).pow(2).mean() + rel[-6:, prim, 2:].sum()
+    loss.backward()
+    out['xy'], out['split'] = xy.numpy(), split.numpy()
+    out['loss'] = np.float32(loss.item())
+    out['rel'], out['pred'] = rel.detach().numpy(), pred.detach().numpy()
+    for k, v in model.state_dict().items():
+        out['sd_' + k] = v.numpy().copy()
+    for k, p in model.named_parameters():
+        out['grad_' + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'grad_short.npz'), **out)
+    print('grad_short.npz', loss.item())
+
+
 def train_curve_case(ref):
     """Loss trajectory of the reference over 6 optimisation steps of Trainer.train_batch's arithmetic
     (lstm/trainer.py:229-269: teacher-forced forward, PredictionLoss * batch_size, backward, Adam lr 1e-3 wd 1e-4
@@ -616,6 +641,9 @@ def main():
     ref = ref_import.import_reference()
     if '--only-grad-nongrid' in sys.argv:
         return grad_nongrid_case(ref)
+    if '--only-grad-short' in sys.argv:
+        return grad_short_case(ref)
+    grad_short_case(ref)
     if '--only-sgangoals' in sys.argv:
         return sgan_train_goals_case(ref)
     if '--only-sgansocial' in sys.argv:
