@@ -249,6 +249,8 @@ struct Workspace {
     float *nn_attrs_save;
     float *pc_out, *pgates_save, *traj_in_save;   // stateful interaction encoders under tnp_lstm_forward_train
     float *pvec_save;                             // pool_to_input=False: the interaction vector before it is added to h
+    int32_t *row_end;                             // sparse path: one past the last row of every row's scene
+    int fuse_grid, save_winners;                  // winner tile built inside the sparse kernel; table wanted by the caller
     size_t bytes;
 };
 
@@ -287,10 +289,15 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     w.mask = (uint8_t *)take((size_t)M);
     w.sparse = grid_pool && md->pool_type == TNP_POOL_SOCIAL && md->Wp0_cell_major != nullptr && md->constant == 0.0f &&
                ((md->variant >> 16) & 1) == 0 && sparse_supported(md->C, md->dims[1], md->n * md->n) && (w.I % 4 == 0);
-    w.winners = nullptr; w.row_base = nullptr; w.partial = nullptr;
+    w.winners = nullptr; w.row_base = nullptr; w.partial = nullptr; w.row_end = nullptr; w.fuse_grid = 0; w.save_winners = 0;
     if (w.sparse) {
         w.winners = (int16_t *)take((size_t)M * md->n * md->n * sizeof(int16_t));
         w.row_base = (int32_t *)take((size_t)M * sizeof(int32_t));
+        w.row_end = (int32_t *)take((size_t)M * sizeof(int32_t));
+        // default kernel variant only (bits 0-15 of `variant` select measurement variants that read the winner table)
+        w.fuse_grid = (md->variant & 0xFFFF) == 0 && sparse_fuses_grid(md->n * md->n, 32767) &&
+                      (size_t)M * md->C * sizeof(float) < ((size_t)1 << 32) && getenv("TNP_SPARSE_VARIANT") == nullptr &&
+                      getenv("TNP_NO_GRID_FUSION") == nullptr;
         const size_t pb = sparse_partial_bytes(M, md->dims[1], md->n * md->n);
         if (pb) w.partial = (float *)take(pb);
     }
@@ -443,7 +450,8 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
         ga.B = B; ga.n_max = n_max; ga.type = md->pool_type; ga.n = md->n; ga.C = md->C;
         ga.cell = md->cell; ga.half_x = md->half_x; ga.half_y = md->half_y; ga.constant = md->constant;
         ga.grid = w.sparse ? nullptr : w.grid; ga.ldg = w.ldg; ga.winners = w.sparse ? w.winners : nullptr;
-        int rc = launch_grid(ga, s);
+        const bool fused_grid = w.sparse && w.fuse_grid && n_max <= 32767;
+        int rc = fused_grid ? 0 : launch_grid(ga, s);
         if (rc) return rc;
         const float *src = w.grid;
         int lds = w.ldg;
@@ -453,8 +461,13 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
             float *dst = last ? w.pdst : w.y[0];
             const int ldo = last ? w.pld : md->dims[1];
             prof_before(PROF_GEMM1, s);
+            SparseGridFuse fg;
+            fg.obs2 = w.obs2; fg.row_end = w.row_end; fg.n_max = n_max; fg.G = md->n;
+            fg.cell = md->cell; fg.half_x = md->half_x; fg.half_y = md->half_y;
+            fg.winners_out = w.save_winners ? w.winners : nullptr;
             rc = launch_pool_embed_sparse(w.winners, w.enc, md->C, w.row_base, md->Wp0_cell_major, md->bp[0], M,
-                                          md->n * md->n, md->C, md->dims[1], 1, dst, ldo, w.partial, s);
+                                          md->n * md->n, md->C, md->dims[1], 1, dst, ldo, w.partial, s,
+                                          fused_grid ? &fg : nullptr);
             prof_after(PROF_GEMM1, s);
             if (rc) return rc;
             src = dst; lds = ldo; l0 = 1;
@@ -573,7 +586,7 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
         TNP_FAIL(-1, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
     const size_t F = (size_t)M * 2;
     const int H = md->H;
-    if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s); if (rc) return rc; }
+    if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s, w.row_end); if (rc) return rc; }
     const size_t MH = (size_t)M * H;
     // training: the states of all steps stay in the caller's [steps + 1, M, H] buffers instead of the ping-pong pair
     float *hcur = sv ? sv->h_all : w.h[0];
@@ -610,7 +623,7 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
             if (sv->enc_all) w.enc = sv->enc_all + r * md->C;
             w.gates_save = sv->gates_all + r * 4 * H;
             w.nn_attrs_save = sv->nn_attrs_all ? sv->nn_attrs_all + r * md->n * (md->pool_type == TNP_POOL_NNLSTM ? 4 : md->C) : nullptr;
-            if (sv->winners_all && w.sparse) w.winners = sv->winners_all + r * md->n * md->n;
+            if (sv->winners_all && w.sparse) { w.winners = sv->winners_all + r * md->n * md->n; w.save_winners = 1; }
             w.pvec_save = (w.to_hidden && sv->pvec_all) ? sv->pvec_all + r * H : nullptr;
             w.obs1 = sv->obs1_all + r * 2;
             w.obs2 = sv->obs2_all + r * 2;
@@ -744,9 +757,9 @@ static int lstm_step_impl(const tnp_lstm_model *md, int decoder, const float *h_
         if (sv->enc) w.enc = sv->enc;
         w.gates_save = sv->gates;
         w.nn_attrs_save = sv->nn_attrs;
-        if (sv->winners && w.sparse) w.winners = sv->winners;
+        if (sv->winners && w.sparse) { w.winners = sv->winners; w.save_winners = 1; }
     }
-    if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s); if (rc) return rc; }
+    if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s, w.row_end); if (rc) return rc; }
     PrepArgs p;
     fill_prep_common(p, md, w, M);
     p.h = h_in; p.goals = goals;

@@ -46,6 +46,12 @@ struct SparseArgs {
     float *out;              // S == 1: [M][ldo] final (bias + relu applied); S > 1: partial [S][M][N1]
     int ldo;
     int relu;
+    // fused grid build (cell-split kernel, FG): the winner tile is computed from the positions instead of read
+    const float *obs2;           // [M][2] current positions (NaN = absent)
+    const int32_t *row_end;      // [M] one past the last row of the row's scene
+    int n_max, G;                // padded slot count of the reference (cell-0 clobber rule), cells per side
+    float cell, half_x, half_y;
+    int16_t *winners_out;        // optional [M][ncell]: the winner table for the training backward
 };
 
 // SP_EQ ego groups x 4 column sets = SP_EQ*4 waves per workgroup.  Wave (q, cs) owns the accumulator entries
@@ -231,16 +237,19 @@ __global__ void __launch_bounds__(256) sparse_reduce_kernel(const float *partial
     }
 }
 
-__global__ void row_base_kernel(const int32_t *scene_start, int B, int32_t *row_base) {
+__global__ void row_base_kernel(const int32_t *scene_start, int B, int32_t *row_base, int32_t *row_end) {
     const int s = blockIdx.x;
     if (s >= B) return;
     const int lo = scene_start[s], hi = scene_start[s + 1];
-    for (int r = lo + threadIdx.x; r < hi; r += blockDim.x) row_base[r] = lo;
+    for (int r = lo + threadIdx.x; r < hi; r += blockDim.x) {
+        row_base[r] = lo;
+        if (row_end) row_end[r] = hi;
+    }
 }
 
-int launch_row_base(const int32_t *scene_start, int B, int32_t *row_base, hipStream_t s) {
+int launch_row_base(const int32_t *scene_start, int B, int32_t *row_base, hipStream_t s, int32_t *row_end) {
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(row_base_kernel, dim3(B), dim3(64), 0, s, scene_start, B, row_base);
+    hipLaunchKernelGGL(row_base_kernel, dim3(B), dim3(64), 0, s, scene_start, B, row_base, row_end);
     TNP_HIP(hipGetLastError());
     return 0;
 }
@@ -284,7 +293,7 @@ __device__ __forceinline__ void sload_row(typename SRow<C>::type &v, const float
 // ABL: measurement only (4 = no weight loads, 8 = no hits).
 // TE egos x 8192/TE columns per workgroup.  TE = 64 (experiment, TNP_SPARSE_VARIANT 6/7): half the weight stream, 8 waves,
 // winner tile stored as int8 (needs n_max <= 127).
-template <int C, int PF, int U, bool SASM, int ABL = 0, int TE = TL_TE, typename WT = int16_t>
+template <int C, int PF, int U, bool SASM, int ABL = 0, int TE = TL_TE, typename WT = int16_t, bool FG = false>
 __global__ void __launch_bounds__(64 * TL_NQ * (8192 / TE / 64)) pool_embed_cellsplit_kernel(const SparseArgs a) {
     constexpr int OB = 8192 / TE, NCS = OB / 64;
     constexpr int NQ = TL_NQ, WLS = TE + (sizeof(WT) == 1 ? 4 : 2), NTH = 64 * NQ * NCS;
@@ -300,12 +309,54 @@ __global__ void __launch_bounds__(64 * TL_NQ * (8192 / TE / 64)) pool_embed_cell
     const unsigned ocu = (unsigned)(o < a.N1 ? o : a.N1 - 1);
 
     float *accl = acc + (size_t)q * TE * OB + cs * 64 + lane;
+    if constexpr (FG) {
+        // Winner tile straight from the positions (what grid_build_kernel computes, pool_grid.hip: the reference's exact
+        // fp32 cell arithmetic, LDS integer max on key = 2*j + in_range = "last writer in ascending j wins", cell-0
+        // clobber by out-of-range / absent / padded neighbours).  One wave per ego, lanes over the neighbours of its
+        // scene; the int32 keys live in the (not yet zeroed) accumulator space.  The four column-set workgroups of a tile
+        // repeat this (32 x 31 pairs): cheaper than a kernel launch and the winner table's HBM round trip.
+        int *wkey = reinterpret_cast<int *>(acc);                                 // [TE][ncell]
+        for (int idx = tid; idx < TE * a.ncell; idx += NTH) wkey[idx] = -1;
+        __syncthreads();
+        const float fG = (float)a.G;
+        for (int e = wave; e < TE; e += NTH / 64) {
+            const int row = row0 + e;
+            if (row >= a.M) continue;
+            const int lo = a.row_base[row], ns = a.row_end[row] - lo, ki = row - lo;
+            float2 pi = reinterpret_cast<const float2 *>(a.obs2)[row];
+            if (pi.x != pi.x || pi.y != pi.y) { pi.x = -500.0f; pi.y = -500.0f; }
+            int *wk = wkey + e * a.ncell;
+            for (int j = lane; j < ns; j += 64) {
+                if (j == ki) continue;
+                float2 pj = reinterpret_cast<const float2 *>(a.obs2)[lo + j];
+                if (pj.x != pj.x || pj.y != pj.y) { pj.x = -500.0f; pj.y = -500.0f; }
+                const float ox = __fadd_rn(__fdiv_rn(__fsub_rn(pj.x, pi.x), a.cell), a.half_x);
+                const float oy = __fadd_rn(__fdiv_rn(__fsub_rn(pj.y, pi.y), a.cell), a.half_y);
+                const bool inr = !(ox < 0.0f) && !(ox >= fG) && !(oy < 0.0f) && !(oy >= fG);
+                const int cellid = inr ? ((int)ox * a.G + (int)oy) : 0;
+                atomicMax(&wk[cellid], 2 * j + (inr ? 1 : 0));
+            }
+            if (ns < a.n_max && lane == 0) atomicMax(&wk[0], 2 * (a.n_max - 1));
+        }
+        __syncthreads();
+        for (int idx = tid; idx < TE * a.ncell; idx += NTH) {
+            const int e = idx / a.ncell, c = idx - e * a.ncell;
+            const int row = row0 + e;
+            const int k = wkey[idx];
+            const WT v = (row < a.M && k >= 0 && (k & 1)) ? (WT)(k >> 1) : (WT)-1;
+            wl[c * WLS + e] = v;
+            if (a.winners_out && ob == 0 && row < a.M) a.winners_out[(size_t)row * a.ncell + c] = (int16_t)v;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int e = 0; e < TE; ++e) accl[e * OB] = 0.0f;
-    for (int idx = tid; idx < TE * a.ncell; idx += NTH) {
-        const int e = idx / a.ncell, c = idx - e * a.ncell;
-        const int row = row0 + e;
-        wl[c * WLS + e] = row < a.M ? (WT)a.winners[(size_t)row * a.ncell + c] : (WT)-1;
+    if constexpr (!FG) {
+        for (int idx = tid; idx < TE * a.ncell; idx += NTH) {
+            const int e = idx / a.ncell, c = idx - e * a.ncell;
+            const int row = row0 + e;
+            wl[c * WLS + e] = row < a.M ? (WT)a.winners[(size_t)row * a.ncell + c] : (WT)-1;
+        }
     }
     const int rb = a.row_base[min(row0 + (lane & (TE - 1)), a.M - 1)];
     __syncthreads();
@@ -479,9 +530,11 @@ size_t sparse_partial_bytes(int M, int N1, int ncell) {
     return S > 1 ? (size_t)S * M * N1 * sizeof(float) : 0;
 }
 
+bool sparse_fuses_grid(int ncell, int n_max) { return ncell <= TL_MAXCELL_LDS && n_max <= 32767; }
+
 int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, const int32_t *row_base,
                              const float *Wp, const float *bias, int M, int ncell, int C, int N1, int relu,
-                             float *out, int ldo, float *partial, hipStream_t s) {
+                             float *out, int ldo, float *partial, hipStream_t s, const SparseGridFuse *fg) {
     if (M <= 0) return 0;
     if (!sparse_supported(C, N1, ncell)) TNP_FAIL(-1, "sparse pooling embedding: unsupported C=%d N1=%d", C, N1);
     // TNP_SPARSE_VARIANT (measurement, tools/sparse_sweep.sh): 0 default; 1 = one hit in flight; 2 = compiler-
@@ -491,6 +544,7 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
     SparseArgs a;
     a.winners = winners; a.enc = enc; a.ldv = ldv; a.row_base = row_base; a.Wp = Wp; a.bias = bias;
     a.M = M; a.ncell = ncell; a.C = C; a.N1 = N1; a.relu = relu; a.ldo = ldo;
+    a.obs2 = nullptr; a.row_end = nullptr; a.n_max = 0; a.G = 0; a.cell = 1.0f; a.half_x = a.half_y = 0.0f; a.winners_out = nullptr;
     if (ncell <= TL_MAXCELL_LDS && (sp_variant == 6 || sp_variant == 7) && C == 16) {
         // experiment: 64-ego tiles (assumes n_max <= 127: int8 winner tile)
         a.out = out;
@@ -511,6 +565,17 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
         const int cblocks = a.ego_tiles * a.out_blocks;
         // the lean path addresses neighbour rows with a 32-bit byte offset
         const bool lean = (size_t)M * ldv * sizeof(float) < ((size_t)1 << 32) && sp_variant != 2;
+        if (fg && lean && sp_variant == 0) {   // winner tile computed in the kernel: no grid kernel, no winner table
+            a.obs2 = fg->obs2; a.row_end = fg->row_end; a.n_max = fg->n_max; a.G = fg->G;
+            a.cell = fg->cell; a.half_x = fg->half_x; a.half_y = fg->half_y; a.winners_out = fg->winners_out;
+#define CS_LAUNCH_FG(CC) { static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
+        pool_embed_cellsplit_kernel<CC, 2, 2, true, 0, TL_TE, int16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((pool_embed_cellsplit_kernel<CC, 2, 2, true, 0, TL_TE, int16_t, true>), dim3(cblocks), dim3(1024), csmem, s, a); }
+            if (C == 4) CS_LAUNCH_FG(4) else if (C == 8) CS_LAUNCH_FG(8) else if (C == 16) CS_LAUNCH_FG(16) else CS_LAUNCH_FG(32)
+            TNP_HIP(hipGetLastError());
+            return 0;
+        }
+        if (fg) TNP_FAIL(-1, "sparse pooling embedding: fused grid build needs the default kernel variant");
 #define CS_LAUNCH(CC, UU, SA, ABLM) { static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
         pool_embed_cellsplit_kernel<CC, 2, UU, SA, ABLM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
         hipLaunchKernelGGL((pool_embed_cellsplit_kernel<CC, 2, UU, SA, ABLM>), dim3(cblocks), dim3(1024), csmem, s, a); }

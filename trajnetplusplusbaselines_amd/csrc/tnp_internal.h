@@ -58,10 +58,15 @@ int launch_grid(const GridArgs &a, hipStream_t s);
 // ---- sparse pooling embedding (first MLP layer on the winner table) ---------------------------
 bool sparse_supported(int C, int N1, int ncell);
 size_t sparse_partial_bytes(int M, int N1, int ncell);
-int launch_row_base(const int32_t *scene_start, int B, int32_t *row_base, hipStream_t s);
+int launch_row_base(const int32_t *scene_start, int B, int32_t *row_base, hipStream_t s, int32_t *row_end = nullptr);
+// optional: build the winner tile inside the cell-split kernel from the positions (no grid kernel, no winner table)
+struct SparseGridFuse {
+    const float *obs2; const int32_t *row_end; int n_max, G; float cell, half_x, half_y; int16_t *winners_out;
+};
+bool sparse_fuses_grid(int ncell, int n_max);
 int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, const int32_t *row_base,
                              const float *Wp, const float *bias, int M, int ncell, int C, int N1, int relu,
-                             float *out, int ldo, float *partial, hipStream_t s);
+                             float *out, int ldo, float *partial, hipStream_t s, const SparseGridFuse *fg = nullptr);
 
 // ---- non-grid interaction modules (pool_nongrid.hip) -----------------------------------------
 int launch_pool_nn(const float *obs1, const float *obs2, const int32_t *scene_start, int B, int n_sel, int in_dim,
