@@ -250,7 +250,7 @@ def main():
                 # bound for the first embedding layer"); the kernel runs on the fp32 VALU, whose peak equals the
                 # fp32 MFMA peak on CDNA4 (157.3 TFLOP/s)
                 flops = 2.0 * M * (cfg['agents'] - 1) * model.pool.pooling_dim * N0
-                kname = ('pool_embed_cellsplit_kernel (pool.embedding.0 on the winner table: '
+                kname = ('pool_embed_cellsplit_kernel (winner tile from the positions + pool.embedding.0 on it: '
                          '%d egos x <=%d occupied cells x %d values -> %d)' % (M, cfg['agents'] - 1,
                                                                               model.pool.pooling_dim, N0))
             else:
@@ -275,10 +275,10 @@ def main():
                     if t is not None:
                         roof['traffic'] = t['bytes']
                         roof['traffic_detail'] = t
-                        # compulsory bytes of the layer: weights + winner table / grid + values + output
+                        # compulsory bytes of the layer: weights + output + (sparse: positions and per-track values, the
+                        # winner tile is built in LDS; dense: the grid)
                         roof['compulsory_bytes'] = float(N0 * K0 * 4 + M * N0 * 4 +
-                                                         (M * cfg['n'] * cfg['n'] * 2 + M * model.pool.pooling_dim * 4 if sparse
-                                                          else M * K0 * 4))
+                                                         (M * 8 + M * model.pool.pooling_dim * 4 if sparse else M * K0 * 4))
 
     if args.train and is_sgan:
         workload_mode = 'S-GAN training: one discriminator step + one generator step (k=3, Adam)'
