@@ -62,6 +62,15 @@ class TrainSaves(ctypes.Structure):
                 ('pvec_all', ctypes.c_void_p)]
 
 
+def _pool_kind(pool):
+    """which backward the interaction module needs"""
+    name = type(pool).__name__
+    if pool is None:
+        return 'none'
+    return {'NearestNeighborMLP': 'nn', 'HiddenStateMLPPooling': 'hiddenmlp', 'AttentionMLPPooling': 'attention',
+            'NearestNeighborLSTM': 'stateful', 'TrajectronPooling': 'stateful'}.get(name, 'grid')
+
+
 class BwdSweep(ctypes.Structure):
     """mirror of ``struct tnp_bwd_sweep`` (include/trajnet_hip.h)"""
     _fields_ = [('model', ctypes.POINTER(_lib.LstmModel)), ('saves', ctypes.POINTER(TrainSaves)),
@@ -180,7 +189,6 @@ class SequenceFn(torch.autograd.Function):
         goals_t = _lib.f32c(goals.detach(), dev) if (goals is not None and model.goal_flag) else None
         T_obs, M = observed.size(0), observed.size(1)
         idx = _lib.SceneIndex.get(batch_split, dev)
-        prim = idx.starts[:-1].long()
         H = model.hidden_dim
         pool = model.pool
         S = (T_obs - 1) + T_dec
@@ -188,11 +196,9 @@ class SequenceFn(torch.autograd.Function):
         m, keep, _ = model._descriptor()
         ws, need = model._workspace(m, M, idx.B, dev)
         I = model.encoder.weight_ih.shape[1]
-        nn_pool = pool is not None and type(pool).__name__ == 'NearestNeighborMLP'
-        hm_pool = pool is not None and type(pool).__name__ == 'HiddenStateMLPPooling'
-        at_pool = pool is not None and type(pool).__name__ == 'AttentionMLPPooling'
-        st_pool = pool is not None and type(pool).__name__ in ('NearestNeighborLSTM', 'TrajectronPooling')
-        layers = pool.embedding_layers() if (pool is not None and not (nn_pool or hm_pool or at_pool or st_pool)) else []
+        kind = _pool_kind(pool)
+        nn_pool, hm_pool, at_pool, st_pool = kind == 'nn', kind == 'hiddenmlp', kind == 'attention', kind == 'stateful'
+        layers = pool.embedding_layers() if kind == 'grid' else []
         if len(layers) > 3:
             raise NotImplementedError('embedding MLPs deeper than three layers')
         # per-step slices of buffers allocated once per sequence
@@ -201,8 +207,7 @@ class SequenceFn(torch.autograd.Function):
         X_all = torch.empty(S, M, I, device=dev)
         gates_all = torch.empty(S, M, 4 * H, device=dev)
         act_all = [torch.empty(S, M, lin.weight.shape[0], device=dev) for lin in layers[:-1]]
-        enc_all = torch.empty(S, M, pool.pooling_dim, device=dev) \
-            if (pool is not None and not (nn_pool or hm_pool or at_pool or st_pool) and pool.type_ == 'social') else None
+        enc_all = torch.empty(S, M, pool.pooling_dim, device=dev) if (kind == 'grid' and pool.type_ == 'social') else None
         if hm_pool:    # the max-pooled vector (out_projection's input) and the hidden embedding's pre-activation
             act_all = [torch.empty(S, M, pool.mlp_dim, device=dev)]
         if hm_pool or at_pool:
@@ -219,10 +224,11 @@ class SequenceFn(torch.autograd.Function):
                 attrs_all = torch.empty(S, M, pool.n * 4, device=dev)
         # sparse first embedding layer: keep every step's winner table for the sparse backward
         win_all = None
-        if enc_all is not None and not (hm_pool or at_pool) and opts.get('sparse_backward', getattr(model, 'sparse_backward', True)) and layers[0].weight.shape[0] % 64 == 0 \
-                and layers[0].weight.shape[0] * 64 + 4096 <= (160 * 1024) // ((pool.pooling_dim + 15) // 16) \
-                and L.tnp_lstm_sparse_first_layer(ctypes.byref(m), M) == 1:
-            win_all = torch.empty(S, M, pool.n * pool.n, dtype=torch.int16, device=dev)
+        if kind == 'grid' and pool.type_ == 'social' and opts.get('sparse_backward', getattr(model, 'sparse_backward', True)):
+            n1 = layers[0].weight.shape[0]
+            lds_ok = n1 * 64 + 4096 <= (160 * 1024) // ((pool.pooling_dim + 15) // 16)    # tnp_social_dgrid_cells' weight block
+            if n1 % 64 == 0 and lds_ok and L.tnp_lstm_sparse_first_layer(ctypes.byref(m), M) == 1:
+                win_all = torch.empty(S, M, pool.n * pool.n, dtype=torch.int16, device=dev)
         normals = torch.empty(S, M, 5, device=dev)
         o1_all = torch.empty(S, M, 2, device=dev)
         o2_all = torch.empty(S, M, 2, device=dev)
