@@ -346,6 +346,9 @@ typedef struct tnp_bwd_sweep {
     const float *st_pwT, *st_h2pT, *st_zeros;
     float *st_dG_all, *st_dfeat_all, *st_dph, *st_dpc;
 } tnp_bwd_sweep;
+/* sizeof() of the structs of this header as the library was compiled (which: 0 tnp_lstm_model, 1 tnp_lstm_extras,
+ * 2 tnp_step_saves, 3 tnp_train_saves, 4 tnp_bwd_sweep; 0 for any other value) -- lets a binding check its mirrors */
+TNP_API size_t tnp_abi_sizeof(int which);
 TNP_API size_t tnp_lstm_backward_scratch_bytes(const tnp_bwd_sweep *sweep);
 TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *sweep, int s_hi, int s_lo, void *scratch, size_t scratch_bytes,
                                     void *stream);

@@ -87,3 +87,15 @@ def test_paths_to_xy_and_center_scene_roundtrip():
     d = c[8, 0] - c[7, 0]
     assert abs(d[0]) < 1e-12 and d[1] > 0
     assert np.allclose(trajdata.inverse_scene(c, rot, center), full)
+
+
+def test_ctypes_mirrors_have_the_c_struct_sizes():
+    """The ctypes Structures of the host layer mirror the C structs of include/trajnet_hip.h field by field; a field added
+    on one side only changes the size (or shifts every later pointer), which this catches without a GPU."""
+    import ctypes
+    from trajnetplusplusbaselines_amd.lstm import training
+    L = _lib.lib()
+    mirrors = [_lib.LstmModel, _lib.LstmExtras, training.StepSaves, training.TrainSaves, training.BwdSweep]
+    for which, cls in enumerate(mirrors):
+        assert L.tnp_abi_sizeof(which) == ctypes.sizeof(cls), cls.__name__
+    assert L.tnp_abi_sizeof(99) == 0

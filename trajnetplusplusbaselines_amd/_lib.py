@@ -84,6 +84,8 @@ def lib():
     L.tnp_lstm_forward_train.argtypes = [ctypes.POINTER(LstmModel), _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp,
                                          ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t,
                                          ctypes.POINTER(LstmExtras), _fp, _fp]
+    L.tnp_abi_sizeof.restype = ctypes.c_size_t
+    L.tnp_abi_sizeof.argtypes = [ctypes.c_int]
     L.tnp_lstm_backward_scratch_bytes.restype = ctypes.c_size_t
     L.tnp_lstm_backward_scratch_bytes.argtypes = [_fp]
     L.tnp_lstm_backward_sweep.argtypes = [_fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_size_t, _fp]

@@ -798,3 +798,14 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
         TNP_HIP(hipMemcpyAsync(a->st_dpc, dpc_cur, (size_t)M * md->dims[0] * 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }
+
+extern "C" TNP_API size_t tnp_abi_sizeof(int which) {
+    switch (which) {
+        case 0: return sizeof(tnp_lstm_model);
+        case 1: return sizeof(tnp_lstm_extras);
+        case 2: return sizeof(tnp_step_saves);
+        case 3: return sizeof(tnp_train_saves);
+        case 4: return sizeof(tnp_bwd_sweep);
+        default: return 0;
+    }
+}
