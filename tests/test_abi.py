@@ -99,3 +99,24 @@ def test_ctypes_mirrors_have_the_c_struct_sizes():
     for which, cls in enumerate(mirrors):
         assert L.tnp_abi_sizeof(which) == ctypes.sizeof(cls), cls.__name__
     assert L.tnp_abi_sizeof(99) == 0
+
+
+def test_scene_replication_and_pool_kinds():
+    """host helpers of the batched S-GAN samples and of the training sweep (no GPU needed)"""
+    from trajnetplusplusbaselines_amd.sgan.sgan import _replicate_scenes, _scene_local
+    from trajnetplusplusbaselines_amd.lstm.training import _pool_kind
+    from trajnetplusplusbaselines_amd.lstm import (NearestNeighborMLP, HiddenStateMLPPooling, AttentionMLPPooling,
+                                                   NearestNeighborLSTM, TrajectronPooling)
+    split = torch.tensor([0, 3, 4, 9])
+    assert _replicate_scenes(split, 1).tolist() == [0, 3, 4, 9]
+    assert _replicate_scenes(split, 3).tolist() == [0, 3, 4, 9, 12, 13, 18, 21, 22, 27]
+    assert _replicate_scenes([0, 2], 2).tolist() == [0, 2, 4]
+    grid = GridBasedPooling(type_='directional', n=4, out_dim=16)
+    assert _scene_local(None) and _scene_local(grid) and not _scene_local(TrajectronPooling(hidden_dim=32, out_dim=8))
+    kinds = {None: 'none', grid: 'grid', NearestNeighborMLP(n=2, out_dim=8): 'nn',
+             HiddenStateMLPPooling(hidden_dim=32, mlp_dim=48, mlp_dim_spatial=16, mlp_dim_vel=16, out_dim=8): 'hiddenmlp',
+             AttentionMLPPooling(hidden_dim=32, mlp_dim=48, mlp_dim_spatial=16, mlp_dim_vel=16, out_dim=8): 'attention',
+             NearestNeighborLSTM(n=2, hidden_dim=32, out_dim=8): 'stateful',
+             TrajectronPooling(hidden_dim=32, out_dim=8): 'stateful'}
+    for pool, kind in kinds.items():
+        assert _pool_kind(pool) == kind
