@@ -444,11 +444,16 @@ TNP_API int tnp_directional_scatter_backward(const float *dgrid, int ldg, const 
  *           mean over the two coordinates)
  *   inputs [T,M,5], targets [T,M,2]; out: [1] mean (keep_batch_dim = 0) or [B] per-scene mean over time;
  *   values_ws: T*B floats of scratch.
+ * tnp_primary_loss_backward: d_inputs [T,M,5] = d(out)/d(inputs) . grad_out (grad_out [1] or [B] as `out`); analytic
+ *   derivatives of the expressions above, rows of non-primaries are zero -- what loss.backward() hands to LSTM.forward.
  * tnp_collision_loss_forward = CollisionLoss (:138-162) over predictions [T,M,ld] (first two columns), out [1].
  * ----------------------------------------------------------------------------------------- */
 TNP_API int tnp_primary_loss_forward(int mode, const float *inputs, const float *targets, const int32_t *scene_start,
                              int B, int T, int M, float background_rate, int keep_batch_dim, float scale,
                              float *values_ws, float *out, void *stream);
+TNP_API int tnp_primary_loss_backward(int mode, const float *inputs, const float *targets, const int32_t *scene_start,
+                              int B, int T, int M, float background_rate, int keep_batch_dim, float scale,
+                              const float *grad_out, float *d_inputs, void *stream);
 TNP_API int tnp_collision_loss_forward(const float *predictions, int ld, const int32_t *scene_start, int B, int T,
                                int M, float col_wt, float col_distance, float *partial_ws, float *out, void *stream);
 

@@ -114,3 +114,35 @@ def test_variety_loss_matches_reference():
     targets = (xy[9:21] - xy[8:20]).cuda()
     got = variety_loss(PredictionLoss(keep_batch_dim=True), rel, targets, split)
     np.testing.assert_allclose(float(got), float(z['variety_loss']), rtol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode,keep', [(0, False), (0, True), (1, False), (1, True)])
+def test_fused_loss_backward_matches_the_tensor_expression(mode, keep):
+    """tnp_primary_loss_backward (analytic derivatives, one launch) against autograd through the tensor restatement of
+    lstm/loss.py:23-91, with scalar and per-scene upstream gradients"""
+    from trajnetplusplusbaselines_amd.lstm import loss as L
+    g = torch.Generator().manual_seed(3 + mode)
+    T, sizes = 12, [5, 1, 9, 3]
+    split = torch.tensor([0] + list(np.cumsum(sizes)))
+    M = int(split[-1])
+    raw = torch.randn(T, M, 5, generator=g)
+    inputs = torch.cat([raw[..., :2], 0.01 + 0.2 * torch.sigmoid(raw[..., 2:4]), 0.7 * torch.sigmoid(raw[..., 4:])], dim=2).cuda()
+    targets = (raw[..., :2] + 0.1 * torch.randn(T, M, 2, generator=g)).cuda()
+    weights = torch.rand(len(sizes), generator=g).cuda()
+    grads = []
+    for fn in (L._PrimaryLossFn.apply, None):
+        x = inputs.clone().requires_grad_(True)
+        if fn is not None:
+            out = fn(x, targets, split, mode, 0.2, keep, 1.5)
+        else:
+            out = L._primary_loss_autograd(mode, x, targets, split, 0.2, keep, 1.5)
+        ((out * weights).sum() if keep else out * 0.7).backward()
+        grads.append((out.detach().clone(), x.grad.clone()))
+    assert torch.allclose(grads[0][0], grads[1][0], rtol=2e-5, atol=1e-6)
+    scale = float(grads[1][1].abs().max())
+    assert float((grads[0][1] - grads[1][1]).abs().max()) < 2e-5 * scale
+    prim = split[:-1].cuda()
+    mask = torch.ones(M, dtype=torch.bool, device='cuda')
+    mask[prim] = False
+    assert float(grads[0][1][:, mask].abs().max()) == 0.0      # only the primaries carry a gradient

@@ -144,6 +144,8 @@ def lib():
     L.tnp_pool_embed_sparse_forward.argtypes = [_fp, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp,
                                                 ctypes.c_size_t, _fp]
+    L.tnp_primary_loss_backward.argtypes = [ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_float, ctypes.c_int, ctypes.c_float, _fp, _fp, _fp]
     L.tnp_primary_loss_forward.argtypes = [ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_float, ctypes.c_int, ctypes.c_float, _fp, _fp, _fp]
     L.tnp_collision_loss_forward.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -38,6 +38,44 @@ __global__ void loss_values_kernel(int mode, const float *inputs, const float *t
     values[idx] = v;
 }
 
+// d(out)/d(inputs) of tnp_primary_loss_forward times the upstream gradient: one lane per (step, scene) writes the five
+// derivatives of its primary (all other rows of d_inputs stay zero).  Analytic derivatives of
+//   -log(0.01 + b N(x | mu, 3, 3, 0) + (0.99 - b) N(x | mu, s1, s2, rho))   with a = n1/s1, c = n2/s2, q = 1 - rho^2:
+//   dlnN/dmu1 = (a - rho c)/(q s1),  dlnN/ds1 = (a^2 - rho a c)/(q s1) - 1/s1,  dlnN/drho = (a c q - rho z)/q^2 + rho/q
+__global__ void loss_backward_kernel(int mode, const float *inputs, const float *targets, const int32_t *scene_start, int B,
+                                     int T, int M, float bg, int per_scene, float scale, const float *grad_out,
+                                     float *d_inputs) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * B) return;
+    const int t = idx / B, s = idx - t * B;
+    const int m = scene_start[s];
+    const float *in = inputs + ((size_t)t * M + m) * 5;
+    const float *tg = targets + ((size_t)t * M + m) * 2;
+    const float w = per_scene ? grad_out[s] * scale / (float)T : grad_out[0] * scale / (float)(T * B);
+    float d[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (mode == 0) {
+        const float n1 = tg[0] - in[0], n2 = tg[1] - in[1];
+        const float s1 = in[2], s2 = in[3], r = in[4];
+        const float g1 = gaussian_2d_dev(in[0], in[1], 3.0f, 3.0f, 0.0f, tg[0], tg[1]);
+        const float g2 = gaussian_2d_dev(in[0], in[1], s1, s2, r, tg[0], tg[1]);
+        const float D = 0.01f + bg * g1 + (0.99f - bg) * g2;
+        const float a = n1 / s1, c = n2 / s2, q = 1.0f - r * r;
+        const float z = a * a + c * c - 2.0f * r * a * c;
+        const float k1 = bg * g1 / D, k2 = (0.99f - bg) * g2 / D;
+        d[0] = -(k1 * n1 / 9.0f + k2 * (a - r * c) / (q * s1));
+        d[1] = -(k1 * n2 / 9.0f + k2 * (c - r * a) / (q * s2));
+        d[2] = -k2 * ((a * a - r * a * c) / (q * s1) - 1.0f / s1);
+        d[3] = -k2 * ((c * c - r * a * c) / (q * s2) - 1.0f / s2);
+        d[4] = -k2 * ((a * c * q - r * z) / (q * q) + r / q);
+    } else {
+        d[0] = 2.0f * (in[0] - tg[0]);
+        d[1] = 2.0f * (in[1] - tg[1]);
+    }
+    float *o = d_inputs + ((size_t)t * M + m) * 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) o[k] = w * d[k];
+}
+
 // out[s] = scale * mean_t values[t*B+s]   (keep_batch_dim)   or   out[0] = scale * mean over everything
 __global__ void __launch_bounds__(256) loss_reduce_kernel(const float *values, int B, int T, int per_scene, float scale,
                                                           float *out) {
@@ -113,6 +151,22 @@ extern "C" TNP_API int tnp_primary_loss_forward(int mode, const float *inputs, c
     TNP_HIP(hipGetLastError());
     hipLaunchKernelGGL(tnp::loss_reduce_kernel, dim3(keep_batch_dim ? B : 1), dim3(256), 0, s, values_ws, B, T,
                        keep_batch_dim, scale, out);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" TNP_API int tnp_primary_loss_backward(int mode, const float *inputs, const float *targets,
+                                                 const int32_t *scene_start, int B, int T, int M, float background_rate,
+                                                 int keep_batch_dim, float scale, const float *grad_out, float *d_inputs,
+                                                 void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (mode != 0 && mode != 1) TNP_FAIL(-1, "tnp_primary_loss_backward: mode must be 0 (NLL) or 1 (L2)");
+    if (T <= 0 || M <= 0) return 0;
+    TNP_HIP(hipMemsetAsync(d_inputs, 0, (size_t)T * M * 5 * sizeof(float), s));
+    if (B <= 0) return 0;
+    const int n = T * B;
+    hipLaunchKernelGGL(tnp::loss_backward_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mode, inputs, targets, scene_start, B,
+                       T, M, background_rate, keep_batch_dim, scale, grad_out, d_inputs);
     TNP_HIP(hipGetLastError());
     return 0;
 }

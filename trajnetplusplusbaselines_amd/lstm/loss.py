@@ -1,5 +1,5 @@
 """Losses of the reference's lstm/loss.py (same class names and call signatures), evaluated on the primaries of a
-batch by csrc/loss.hip.  Forward values only in this round (the backward arrives with the training kernels)."""
+batch by csrc/loss.hip: forward values and, on the training path, the analytic backward (tnp_primary_loss_backward)."""
 import math
 
 import torch
@@ -34,10 +34,42 @@ def _primary_loss_autograd(mode, inputs, targets, batch_split, background_rate, 
     return (sq.mean(dim=0).mean(dim=1) if keep_batch_dim else sq.mean()) * (scale * 2.0)
 
 
+class _PrimaryLossFn(torch.autograd.Function):
+    """loss = tnp_primary_loss_forward(inputs, ...); d(loss)/d(inputs) by tnp_primary_loss_backward: two launches each
+    instead of the ~60 elementwise kernels of the tensor expression above."""
+
+    @staticmethod
+    def forward(ctx, inputs, targets, batch_split, mode, background_rate, keep_batch_dim, scale):
+        dev = inputs.device
+        inp = _lib.f32c(inputs.detach())
+        tgt = _lib.f32c(targets.detach(), dev)
+        T, M = inp.size(0), inp.size(1)
+        idx = _lib.SceneIndex.get(batch_split, dev)
+        out = torch.empty(idx.B if keep_batch_dim else 1, dtype=torch.float32, device=dev)
+        ws = torch.empty(T * idx.B, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().tnp_primary_loss_forward(mode, _lib.ptr(inp), _lib.ptr(tgt), _lib.ptr(idx.starts), idx.B, T, M,
+                                                       float(background_rate), int(keep_batch_dim), float(scale),
+                                                       _lib.ptr(ws), _lib.ptr(out), _lib.stream_ptr()),
+                   'tnp_primary_loss_forward')
+        ctx.args = (inp, tgt, idx, mode, float(background_rate), int(keep_batch_dim), float(scale))
+        return out if keep_batch_dim else out[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        inp, tgt, idx, mode, bg, keep, scale = ctx.args
+        T, M = inp.size(0), inp.size(1)
+        g = _lib.f32c(grad_out.detach(), inp.device).reshape(-1)
+        d_inputs = torch.empty(T, M, 5, dtype=torch.float32, device=inp.device)
+        _lib.check(_lib.lib().tnp_primary_loss_backward(mode, _lib.ptr(inp), _lib.ptr(tgt), _lib.ptr(idx.starts), idx.B, T, M, bg,
+                                                        keep, scale, _lib.ptr(g), _lib.ptr(d_inputs), _lib.stream_ptr()),
+                   'tnp_primary_loss_backward')
+        return d_inputs, None, None, None, None, None, None
+
+
 def _primary_loss(mode, inputs, targets, batch_split, background_rate, keep_batch_dim, scale):
     _lib.require_device(inputs, 'inputs')
     if inputs.requires_grad and torch.is_grad_enabled():
-        return _primary_loss_autograd(mode, inputs, targets, batch_split, background_rate, keep_batch_dim, scale)
+        return _PrimaryLossFn.apply(inputs, targets, batch_split, mode, background_rate, keep_batch_dim, scale)
     dev = inputs.device
     inputs = _lib.f32c(inputs.detach())
     targets = _lib.f32c(targets.detach(), dev)
