@@ -215,6 +215,9 @@ class SceneIndex(object):
             raise ValueError('batch_split must start at 0')
         self.n_max = int(sizes.max()) if self.B > 0 else 0
         self.starts = split.to(torch.int32).to(device)
+        # first row / size of every row's scene (training backward): built on the host, one copy, no device-side sync later
+        self.row_base = torch.repeat_interleave(split[:-1], sizes).to(torch.int32).to(device)
+        self.row_count = torch.repeat_interleave(sizes, sizes).to(torch.int32).to(device)
         self.primary = torch.empty(max(self.M, 1), dtype=torch.uint8, device=device)
         check(lib().tnp_mark_primaries(ptr(self.starts), self.B, self.M, ptr(self.primary), stream_ptr()),
               'tnp_mark_primaries')

@@ -357,17 +357,13 @@ class SequenceFn(torch.autograd.Function):
         if hm_pool or at_pool:
             dy_all = [torch.empty(S, M, pool.out_dim, device=dev)]
             denc_all = torch.empty(S, M, mh, device=dev) if mh else None
-            sizes = (idx.starts[1:] - idx.starts[:-1]).long()
-            row_base = torch.repeat_interleave(idx.starts[:-1].long(), sizes).to(torch.int32)
-            row_count = torch.repeat_interleave(sizes, sizes).to(torch.int32)
+            row_base, row_count = idx.row_base, idx.row_count
         if grid_pool:
             G, cell, half_x, half_y = pool._geometry()
             C = pool.pooling_dim
             grid_all = torch.empty(S, M, C * G * G, device=dev) if not sparse_bwd else None
             if social or directional_in:
-                sizes = (idx.starts[1:] - idx.starts[:-1]).long()
-                row_base = torch.repeat_interleave(idx.starts[:-1].long(), sizes).to(torch.int32)
-                row_count = torch.repeat_interleave(sizes, sizes).to(torch.int32)
+                row_base, row_count = idx.row_base, idx.row_count
                 if sparse_bwd:
                     # pair cells of every step in one launch, then per (step, cell) the egos with a neighbour in that cell
                     R, ncell = S * M, G * G

@@ -138,12 +138,11 @@ class LSTMDiscriminator(LSTM):
             from ..lstm.training import run_sequence_with_grad
             frames = torch.cat([observed.to(dev, torch.float32), prediction.to(dev, torch.float32)], dim=0)
             _, _, h = run_sequence_with_grad(self, frames, goals, batch_split, None, 0, {'input_grad': True})
-            split = torch.as_tensor(batch_split, dtype=torch.int64).to(dev)
-            return self.real_classifier(h[split[:-1]])
+            prim = _lib.SceneIndex.get(batch_split, dev).starts[:-1].long()   # cached on the device: no host sync
+            return self.real_classifier(h[prim])
         frames = torch.cat([_lib.f32c(observed, dev), _lib.f32c(prediction, dev)], dim=0)
         _, _, h = self._run_sequence(frames, goals, batch_split, None, 0, want_h_final=True)
-        split = torch.as_tensor(batch_split, dtype=torch.int64).to(dev)
-        x = h[split[:-1]]
+        x = h[_lib.SceneIndex.get(batch_split, dev).starts[:-1].long()]
         for layer in self.real_classifier:
             if isinstance(layer, nn.Linear):
                 x = _lib.linear_forward(x, layer.weight.detach(), layer.bias.detach(), relu=True)
