@@ -253,3 +253,21 @@ def test_two_frame_free_running_gradients_match_reference():
         scale = max(1e-6, float(np.abs(want).max()))
         err = float(np.abs(p.grad.cpu().numpy() - want).max()) / scale
         assert err < 2e-3, '%s: relative error %.2e (scale %.2e)' % (name, err, scale)
+
+
+def test_training_step_is_bitwise_reproducible():
+    """Every reduction of the training path has a fixed order (split-K partial tiles, per-cell hit lists, gathers per
+    track, LDS integer max for the winners): two runs from the same weights give bit-identical gradients."""
+    from trajnetplusplusbaselines_amd.lstm import PredictionLoss
+    grads = []
+    for _ in range(2):
+        model = build('social')
+        xy, split = torch.tensor(GOLD['social_xy']), torch.tensor(GOLD['social_split'])
+        M = xy.shape[1]
+        targets = (xy[9:21] - xy[8:20]).cuda()
+        rel, pred = model(xy[:9].clone(), torch.zeros(M, 2), split, xy[9:20].clone())
+        (PredictionLoss()(rel[-12:], targets, split) * 8).backward()
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys()
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n
