@@ -355,6 +355,11 @@ TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *sweep, int s_hi, int s_
 TNP_API int tnp_h2n_backward(const float *h_out, const float *Wn, const float *bn, const float *d_normal,
                              const float *d_pos, const float *obs1, const float *obs2, const float *dh_in, int M, int H,
                              float *dlin, float *dh_tot, void *stream);
+/* tnp_h2n_backward followed by tnp_lstm_cell_backward in one launch (dh_tot stays in registers) */
+TNP_API int tnp_h2n_cell_backward(const float *h_out, const float *Wn, const float *bn, const float *d_normal,
+                                  const float *d_pos, const float *obs1, const float *obs2, const float *dh_in,
+                                  const float *gates, const float *c_prev, const float *dc, int M, int H, float *dlin,
+                                  float *dG, float *dc_prev, float *dh_pass, void *stream);
 TNP_API int tnp_lstm_cell_backward(const float *gates, const float *c_prev, const float *dh_tot, const float *dc,
                                    const float *obs1, const float *obs2, int M, int H, float *dG, float *dc_prev,
                                    float *dh_pass, void *stream);

@@ -62,6 +62,83 @@ __global__ void __launch_bounds__(64) h2n_backward_kernel(const float *__restric
     }
 }
 
+// h2n_backward_kernel + lstm_cell_backward_kernel in one launch: the wave that forms dh_tot[m, :] applies the LSTMCell
+// derivatives to it right away (same expressions as the two kernels, no dh_tot round trip)
+__global__ void __launch_bounds__(64) h2n_cell_backward_kernel(const float *__restrict__ h_out, const float *__restrict__ Wn,
+                                                          const float *__restrict__ bn, const float *__restrict__ d_normal,
+                                                          const float *__restrict__ d_pos, const float *__restrict__ obs1,
+                                                          const float *__restrict__ obs2, const float *__restrict__ dh_in,
+                                                          int M, int H, float *__restrict__ dlin,
+                                                          const float *__restrict__ gates, const float *__restrict__ c_prev,
+                                                          const float *__restrict__ dc, float *__restrict__ dG,
+                                                          float *__restrict__ dc_prev, float *__restrict__ dh_pass) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    if (m >= M) return;
+    const float a = obs1[2 * m], b = obs2[2 * m];
+    const bool present = (a == a) && (b == b);                       // lstm/lstm.py:118
+    float dl[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (present) {
+        // Linear output of Hidden2Normal (needed for the sigmoid derivatives): 5 dot products over H
+        float lin[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (int k = lane; k < H; k += 64) {
+            const float hv = h_out[(size_t)m * H + k];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) lin[q] = fmaf(hv, Wn[q * H + k], lin[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) lin[q] += __shfl_xor(lin[q], off, 64);
+            lin[q] += bn[q];
+        }
+        float dn[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            float v = d_normal ? d_normal[(size_t)m * 5 + q] : 0.0f;
+            if (v != v) v = 0.0f;                                    // NaN rows of absent tracks carry no gradient
+            dn[q] = v;
+        }
+        if (d_pos) {                                                // positions = obs2 + normal[:, :2]
+            float px = d_pos[2 * m], py = d_pos[2 * m + 1];
+            dn[0] += (px == px) ? px : 0.0f;
+            dn[1] += (py == py) ? py : 0.0f;
+        }
+        const float s2 = sigm(lin[2]), s3 = sigm(lin[3]), s4 = sigm(lin[4]);
+        dl[0] = dn[0]; dl[1] = dn[1];
+        dl[2] = dn[2] * 0.2f * s2 * (1.0f - s2);
+        dl[3] = dn[3] * 0.2f * s3 * (1.0f - s3);
+        dl[4] = dn[4] * 0.7f * s4 * (1.0f - s4);
+    }
+    if (lane < 5) dlin[(size_t)m * 5 + lane] = dl[lane];
+    for (int k = lane; k < H; k += 64) {
+        float acc = dh_in[(size_t)m * H + k];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc = fmaf(dl[q], Wn[q * H + k], acc);
+        const size_t q = (size_t)m * H + k;
+        float *g = dG + (size_t)m * 4 * H + k;
+        const float dcv = dc[q];
+        if (present) {
+            const float *gs = gates + (size_t)m * 4 * H + k;
+            const float gi = gs[0], gf = gs[H], gg = gs[2 * H], go = gs[3 * H];
+            const float cp = c_prev[q];
+            const float cn = gf * cp + gi * gg;
+            const float tc = tanhf(cn);
+            const float d_o = acc * tc;
+            const float dct = dcv + acc * go * (1.0f - tc * tc);
+            g[0] = dct * gg * gi * (1.0f - gi);
+            g[H] = dct * cp * gf * (1.0f - gf);
+            g[2 * H] = dct * gi * (1.0f - gg * gg);
+            g[3 * H] = d_o * go * (1.0f - go);
+            dc_prev[q] = dct * gf;
+            dh_pass[q] = 0.0f;
+        } else {  // state copied through: the gradient bypasses the cell
+            g[0] = 0.0f; g[H] = 0.0f; g[2 * H] = 0.0f; g[3 * H] = 0.0f;
+            dc_prev[q] = dcv;
+            dh_pass[q] = acc;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) lstm_cell_backward_kernel(const float *__restrict__ gates, const float *__restrict__ c_prev,
                                                                  const float *__restrict__ dh_tot, const float *__restrict__ dc,
                                                                  const float *__restrict__ obs1, const float *__restrict__ obs2,
@@ -438,16 +515,37 @@ static int launch_sparse_wgrad(const float *dy, int ldy, const float *enc, int l
 }
 
 // gradient of the previous hidden state: the W_hh part of the fused data-gradient GEMM + what bypassed the cell for
-// absent rows (+ the social encoding's contribution)
+// absent rows (+ the social encoding's contribution, either precomputed in `extra` or formed here as
+// denc[m, :] . Wh[:, k] with whT [H, C] -- a C-term dot per element instead of a GEMM launch)
 __global__ void __launch_bounds__(256) state_grad_combine_kernel(const float *__restrict__ dxh, int ld, const float *__restrict__ pass,
                                                                  const float *__restrict__ extra, int M, int H,
-                                                                 float *__restrict__ out) {
+                                                                 float *__restrict__ out, const float *__restrict__ denc = nullptr,
+                                                                 const float *__restrict__ whT = nullptr, int C = 0) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= (long)M * H) return;
     const int m = (int)(q / H), k = (int)(q - (long)m * H);
     float v = dxh[(size_t)m * ld + k] + pass[q];
     if (extra) v += extra[q];
+    if (denc) {
+        float acc = 0.0f;
+        for (int c = 0; c < C; ++c) acc = fmaf(denc[(size_t)m * C + c], whT[(size_t)k * C + c], acc);
+        v += acc;
+    }
     out[q] = v;
+}
+
+// The ReLU masks of one step's data gradient in one launch: input embedding, goal embedding and the (ReLU-output)
+// interaction vector.  Segment s of a row: out_s[m, c] = act_s[m, c] > 0 ? grad_s[m, c] : 0.
+struct MaskSeg { const float *grad; int ldg; const float *act; int lda; float *out; int n; };
+__global__ void __launch_bounds__(256) relu_mask3_kernel(MaskSeg s0, MaskSeg s1, MaskSeg s2, int M) {
+    const int W = s0.n + s1.n + s2.n;
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)M * W) return;
+    const int m = (int)(q / W);
+    int c = (int)(q - (long)m * W);
+    const MaskSeg *sg = &s0;
+    if (c >= s0.n) { c -= s0.n; sg = &s1; if (c >= s1.n) { c -= s1.n; sg = &s2; } }
+    sg->out[(size_t)m * sg->n + c] = sg->act[(size_t)m * sg->lda + c] > 0.0f ? sg->grad[(size_t)m * sg->ldg + c] : 0.0f;
 }
 
 struct SweepScratch {
@@ -525,6 +623,17 @@ extern "C" TNP_API int tnp_h2n_backward(const float *h_out, const float *Wn, con
     if (M <= 0) return 0;
     hipLaunchKernelGGL(tnp::h2n_backward_kernel, dim3(M), dim3(64), 0, (hipStream_t)stream, h_out, Wn, bn, d_normal, d_pos,
                        obs1, obs2, dh_in, M, H, dlin, dh_tot);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" TNP_API int tnp_h2n_cell_backward(const float *h_out, const float *Wn, const float *bn, const float *d_normal,
+                                             const float *d_pos, const float *obs1, const float *obs2, const float *dh_in,
+                                             const float *gates, const float *c_prev, const float *dc, int M, int H,
+                                             float *dlin, float *dG, float *dc_prev, float *dh_pass, void *stream) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(tnp::h2n_cell_backward_kernel, dim3(M), dim3(64), 0, (hipStream_t)stream, h_out, Wn, bn, d_normal, d_pos,
+                       obs1, obs2, dh_in, M, H, dlin, gates, c_prev, dc, dG, dc_prev, dh_pass);
     TNP_HIP(hipGetLastError());
     return 0;
 }
@@ -662,17 +771,17 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
         const float *o1 = sv->obs1_all + r * 2, *o2 = sv->obs2_all + r * 2;
         const float *h_out = (st == a->h_override_step) ? a->h_override : sv->h_all + (size_t)(st + 1) * MH;
         // ---- Hidden2Normal backward + gradient of the new hidden state ----
-        if (md->Wn) {
-            TNP_RC(tnp_h2n_backward(h_out, md->Wn, md->bn, a->d_rel ? a->d_rel + r * 5 : nullptr,
-                                    a->d_pred ? a->d_pred + (r + (size_t)a->pos_offset * M) * 2 : nullptr, o1, o2, a->dh, M, H,
-                                    a->dlin_all + r * 5, w.dh_tot, stream));
-        } else {
-            TNP_HIP(hipMemcpyAsync(w.dh_tot, a->dh, MH * 4, hipMemcpyDeviceToDevice, s));
-        }
-        // ---- LSTMCell backward (absent rows pass the state gradient through) ----
+        // ---- Hidden2Normal backward + LSTMCell backward (absent rows pass the state gradient through) ----
         float *dG = a->dG_all + r * 4 * H;
-        TNP_RC(tnp_lstm_cell_backward(sv->gates_all + r * 4 * H, sv->c_all + (size_t)st * MH, w.dh_tot, dc_cur, o1, o2, M, H, dG,
-                                      dc_nxt, w.dh_pass, stream));
+        if (md->Wn) {
+            TNP_RC(tnp_h2n_cell_backward(h_out, md->Wn, md->bn, a->d_rel ? a->d_rel + r * 5 : nullptr,
+                                         a->d_pred ? a->d_pred + (r + (size_t)a->pos_offset * M) * 2 : nullptr, o1, o2, a->dh,
+                                         sv->gates_all + r * 4 * H, sv->c_all + (size_t)st * MH, dc_cur, M, H, a->dlin_all + r * 5,
+                                         dG, dc_nxt, w.dh_pass, stream));
+        } else {   // no output head (S-GAN discriminator): the state gradient goes straight into the cell
+            TNP_RC(tnp_lstm_cell_backward(sv->gates_all + r * 4 * H, sv->c_all + (size_t)st * MH, a->dh, dc_cur, o1, o2, M, H, dG,
+                                          dc_nxt, w.dh_pass, stream));
+        }
         const float *wT = st >= a->n_enc ? a->wT_dec : a->wT_enc;
         if (!wT) TNP_FAIL(-1, "tnp_lstm_backward_sweep: transposed cell weights missing for step %d", st);
         TNP_RC(tnp_linear_forward(dG, 4 * H, wT, 4 * H, nullptr, w.dxh, LDX, M, LDX, 4 * H, 0, 0, stream));   // [dG.W_ih | dG.W_hh]
@@ -683,19 +792,24 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
         const float *pgrad = to_hidden ? w.dxh + I : w.dxh + P0;
         const float *pact = to_hidden ? sv->pvec_all + r * H : Xs + P0;
         const int pact_ld = to_hidden ? H : I;
-        TNP_RC(tnp_relu_mask(w.dxh, LDX, Xs, I, M, E - 2, a->de_all + r * (E - 2), E - 2, stream));
-        if (GD) TNP_RC(tnp_relu_mask(w.dxh + E, LDX, Xs + E, I, M, GD - 2, a->dgoal_all + r * (GD - 2), GD - 2, stream));
-        if (a->nn_pool) TNP_RC(tnp_relu_mask(pgrad, LDX, pact, pact_ld, M, Pw, a->dnn_all + r * Pw, Pw, stream));
+        {   // ReLU masks of the input / goal embedding and of a ReLU-output interaction vector, one launch
+            tnp::MaskSeg s0 = {w.dxh, LDX, Xs, I, a->de_all + r * (E - 2), E - 2};
+            tnp::MaskSeg s1 = {w.dxh + E, LDX, Xs + E, I, GD ? a->dgoal_all + r * (GD - 2) : nullptr, GD ? GD - 2 : 0};
+            float *pout = a->nn_pool ? a->dnn_all + r * Pw : (grid ? a->dy_all[md->n_layers - 1] + r * Pw : nullptr);
+            tnp::MaskSeg s2 = {pgrad, LDX, pact, pact_ld, pout, pout ? Pw : 0};
+            const long tot = (long)M * (s0.n + s1.n + s2.n);
+            hipLaunchKernelGGL(tnp::relu_mask3_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, s0, s1, s2, M);
+            TNP_HIP(hipGetLastError());
+        }
         // ---- grid embedding MLP + scatter + social encoding backward ----
-        const float *extra = nullptr;
+        const float *extra = nullptr, *social_denc = nullptr;
         if (grid) {
             if (a->grid_all) {   // the dense grid is the only intermediate that is recomputed
                 TNP_RC(tnp_pool_grid_forward(md->pool_type, o1, o2, social ? sv->enc_all + r * C : nullptr, C, a->scene_start, a->B,
                                              a->n_max, md->n, C, md->cell, md->half_x, md->half_y, md->constant,
                                              a->grid_all + r * md->dims[0], md->dims[0], nullptr, stream));
             }
-            // last layer: its ReLU output is the pooled part of X
-            TNP_RC(tnp_relu_mask(pgrad, LDX, pact, pact_ld, M, Pw, a->dy_all[nl - 1] + r * Pw, Pw, stream));
+            // (last layer: its ReLU output is the pooled part of X, masked above)
             for (int l = nl - 1; l >= 1; --l) {
                 const int n_out = md->dims[l + 1], n_in = md->dims[l];
                 TNP_RC(tnp_linear_forward(a->dy_all[l] + r * n_out, n_out, a->layT[l], n_out, nullptr, w.d_in, n_in, M, n_in, n_out,
@@ -727,8 +841,7 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
                     TNP_RC(tnp_social_scatter_backward(w.dgrid, md->dims[0], w.cells, a->row_base, a->row_count, M, a->n_max, C,
                                                        ncell, denc, stream));
                 }
-                TNP_RC(tnp_linear_forward(denc, C, a->whT, C, nullptr, w.tmp_h, H, M, H, C, 0, 0, stream));
-                extra = w.tmp_h;
+                social_denc = denc;     // its contribution to dh (denc . Wh) is formed inside the combine kernel
             }
         }
         if (hm) {   // HiddenStateMLPPooling: out_projection (linear) <- max-pool routing <- embeddings
@@ -793,7 +906,7 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
             }
         }
         hipLaunchKernelGGL(tnp::state_grad_combine_kernel, dim3((unsigned)((MH + 255) / 256)), dim3(256), 0, s, w.dxh + I, LDX,
-                           w.dh_pass, extra, M, H, a->dh);
+                           w.dh_pass, extra, M, H, a->dh, social_denc, a->whT, C);
         TNP_HIP(hipGetLastError());
         float *t = dc_cur; dc_cur = dc_nxt; dc_nxt = t;
     }
