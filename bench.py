@@ -87,6 +87,20 @@ def cpu_baseline(cfg, xy, split, budget_s=20.0):
                 seconds_per_forward=best)
 
 
+def cpu_baseline_classical(st, pos, vel, goals, speed, obs, z, starts, agents, scenes_sample, scenes_total):
+    """cpu_baseline leg of the classical rollouts (tools/bench_classical.py, BASELINE config 5): the oracle's host
+    execution of the same arithmetic (OpenMP over scenes) on a bounded sample of scenes, extrapolated to the full batch."""
+    from oracle import oracle
+    n, A, scale = scenes_sample, agents, scenes_total / float(scenes_sample)
+    cpu = {}
+    t0 = time.perf_counter(); oracle.sf_rollout(st[:n * A], starts[:n + 1]); cpu['socialforce'] = (time.perf_counter() - t0) * scale
+    t0 = time.perf_counter()
+    oracle.orca_rollout(pos[:n * A], vel[:n * A], goals[:n * A], speed[:n * A], 1.3 * speed[:n * A], starts[:n + 1])
+    cpu['orca'] = (time.perf_counter() - t0) * scale
+    t0 = time.perf_counter(); oracle.kalman_predict(obs[:n * A], z[:n * A]); cpu['kalman'] = (time.perf_counter() - t0) * scale
+    return cpu
+
+
 def under_profiler():
     """True when this process already runs under rocprofv3 / a rocprofiler tool (no nested PMC child runs then)."""
     if any(k.startswith(('ROCPROF', 'ROCPROFILER', 'ROCP_')) for k in os.environ):

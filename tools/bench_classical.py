@@ -3,7 +3,7 @@ to the host execution of the same arithmetic (oracle, OpenMP over scenes) on a b
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import oracle
+import bench
 from trajnetplusplusbaselines_amd.classical import socialforce, orca, kalman
 from tests.test_classical import crowd
 
@@ -26,11 +26,8 @@ res = {}
 res['socialforce'] = timeit(lambda: socialforce.rollout_batch(st, sizes))
 res['orca'] = timeit(lambda: orca.rollout_batch(pos, vel, speed, goals, sizes))
 res['kalman'] = timeit(lambda: kalman.predict_batch(obs, 12, noise=z))
-sub = 128   # scenes of the CPU sample
-cpu = {}
-t0 = time.perf_counter(); oracle.sf_rollout(st[:sub * A], starts[:sub + 1]); cpu['socialforce'] = (time.perf_counter() - t0) * S / sub
-t0 = time.perf_counter(); oracle.orca_rollout(pos[:sub * A], vel[:sub * A], goals[:sub * A], speed[:sub * A], 1.3 * speed[:sub * A], starts[:sub + 1]); cpu['orca'] = (time.perf_counter() - t0) * S / sub
-t0 = time.perf_counter(); oracle.kalman_predict(obs[:sub * A], z[:sub * A]); cpu['kalman'] = (time.perf_counter() - t0) * S / sub
+sub = 128   # scenes of the CPU sample (bench.py's cpu_baseline leg runs the oracle)
+cpu = bench.cpu_baseline_classical(st, pos, vel, goals, speed, obs, z, starts, A, sub, S)
 for k in res:
     print(json.dumps(dict(predictor=k, scenes=S, agents=A, gpu_seconds_incl_pcie=round(res[k], 4),
                           gpu_scene_steps_per_s=round(S * 21 / res[k]), cpu_port_seconds_extrapolated=round(cpu[k], 2),
