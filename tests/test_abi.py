@@ -2,6 +2,7 @@
 declares, the host classes mirror the reference's constructor / state_dict contract, and the
 product path fails loudly without a GPU (no CPU fallback)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -120,3 +121,22 @@ def test_scene_replication_and_pool_kinds():
              TrajectronPooling(hidden_dim=32, out_dim=8): 'stateful'}
     for pool, kind in kinds.items():
         assert _pool_kind(pool) == kind
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/trajnet_hip.h compiles as C99, a C program links against libtrajnet_hip.so and the host-only entry points
+    answer without a GPU (tests/c/abi_smoke.c)."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, 'trajnetplusplusbaselines_amd', 'lib')
+    _lib.lib()                                      # builds the library if needed
+    exe = str(tmp_path / 'abi_smoke')
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(root, 'include'),
+                    os.path.join(root, 'tests', 'c', 'abi_smoke.c'), '-o', exe, '-L', libdir, '-ltrajnet_hip',
+                    '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib'], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith('ok abi')
