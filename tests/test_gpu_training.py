@@ -116,10 +116,12 @@ def test_training_curve_matches_reference():
     print('losses', losses, 'ref', z['losses'].tolist(), 'dADE %.2e dFDE %.2e' % (np.abs(a0 - a1).max(), np.abs(f0 - f1).max()))
 
 
-def test_sparse_first_layer_backward_equals_dense_backward():
-    """The social first-layer gradients computed from the winner tables (tnp_social_dgrid_sparse, tnp_sparse_wgrad)
-    equal the dense GEMM backward on a crowd with duplicates, empty cells and ragged scenes; the golden social case
-    above runs the sparse form against the reference's autograd."""
+@pytest.mark.parametrize('latent_dim,n,layer', [(16, 12, 192), (4, 8, 64), (8, 16, 128), (32, 6, 256)])
+def test_sparse_first_layer_backward_equals_dense_backward(latent_dim, n, layer):
+    """The social first-layer gradients computed from the winner tables (tnp_social_dgrid_cells, tnp_sparse_wgrad)
+    equal the dense GEMM backward on a crowd with duplicates, empty cells and ragged scenes, for every channel count
+    the sparse kernels are instantiated for (C = 32 runs two 16-channel MFMA blocks); the golden social case above runs
+    the sparse form against the reference's autograd."""
     import ctypes
     from trajnetplusplusbaselines_amd import _lib
     from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling, PredictionLoss
@@ -136,8 +138,8 @@ def test_sparse_first_layer_backward_equals_dense_backward():
     grads = {}
     for sparse in (True, False):
         torch.manual_seed(3)
-        pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.5, n=12, out_dim=64,
-                                embedding_arch='two_layer', layer_dims=[192], latent_dim=16)
+        pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.5, n=n, out_dim=64,
+                                embedding_arch='two_layer', layer_dims=[layer], latent_dim=latent_dim)
         model = LSTM(pool=pool).cuda().train()
         model.sparse_backward = sparse
         m, keep, _ = model._descriptor()
