@@ -273,3 +273,56 @@ def test_training_step_is_bitwise_reproducible():
     assert grads[0].keys() == grads[1].keys()
     for n in grads[0]:
         assert torch.equal(grads[0][n], grads[1][n]), n
+
+
+def test_step_train_saves_equal_the_sequence_drivers_first_step():
+    """tnp_lstm_step_train (one step with saves, the per-step form of the training forward) leaves exactly what
+    tnp_lstm_forward_train leaves for the first step of the sequence: state, LSTMCell input, activations, gates,
+    encodings, winner table -- bit for bit."""
+    import ctypes
+    from trajnetplusplusbaselines_amd import _lib
+    from trajnetplusplusbaselines_amd.lstm import training
+    model = build('social').eval()
+    xy, split = torch.tensor(GOLD['social_xy']).cuda(), torch.tensor(GOLD['social_split'])
+    M, H = xy.shape[1], model.hidden_dim
+    L = _lib.lib()
+    idx = _lib.SceneIndex.get(split, xy.device)
+    m, keep, dev = model._descriptor()
+    ws, need = model._workspace(m, M, idx.B, dev)
+    pool = model.pool
+    I = model.encoder.weight_ih.shape[1]
+    N1, ncell, C = pool.embedding_layers()[0].weight.shape[0], pool.n * pool.n, pool.pooling_dim
+    assert L.tnp_lstm_sparse_first_layer(ctypes.byref(m), M) == 1
+    # --- sequence driver: two observed frames = one encoder step
+    S = 1
+    bufs = dict(h=torch.empty(S + 1, M, H), c=torch.empty(S + 1, M, H), X=torch.empty(S, M, I), g=torch.empty(S, M, 4 * H),
+                a=torch.empty(S, M, N1), e=torch.empty(S, M, C), o1=torch.empty(S, M, 2), o2=torch.empty(S, M, 2))
+    bufs = {k: v.cuda() for k, v in bufs.items()}
+    win = torch.empty(S, M, ncell, dtype=torch.int16, device='cuda')
+    sv = training.TrainSaves()
+    sv.h_all, sv.c_all, sv.X_all, sv.gates_all = (bufs[k].data_ptr() for k in ('h', 'c', 'X', 'g'))
+    sv.act_all[0], sv.enc_all, sv.winners_all = bufs['a'].data_ptr(), bufs['e'].data_ptr(), win.data_ptr()
+    sv.obs1_all, sv.obs2_all = bufs['o1'].data_ptr(), bufs['o2'].data_ptr()
+    rel, pos = torch.empty(S, M, 5, device='cuda'), torch.empty(S + 1, M, 2, device='cuda')
+    ex = _lib.LstmExtras()
+    obs = xy[:2].contiguous()
+    _lib.check(L.tnp_lstm_forward_train(ctypes.byref(m), _lib.ptr(obs), 2, M, None, _lib.ptr(idx.starts), _lib.ptr(idx.primary),
+                                        idx.B, idx.n_max, None, 0, _lib.ptr(rel), _lib.ptr(pos), _lib.ptr(ws), need,
+                                        ctypes.byref(ex), ctypes.byref(sv), _lib.stream_ptr()), 'forward_train')
+    # --- the same step through the per-step entry point
+    h0, c0 = torch.zeros(M, H, device='cuda'), torch.zeros(M, H, device='cuda')
+    h1, c1, nrm = torch.empty(M, H, device='cuda'), torch.empty(M, H, device='cuda'), torch.empty(M, 5, device='cuda')
+    X1, g1, a1, e1 = (torch.empty_like(bufs[k][0]) for k in ('X', 'g', 'a', 'e'))
+    w1 = torch.empty(M, ncell, dtype=torch.int16, device='cuda')
+    ss = training.StepSaves()
+    ss.X, ss.gates, ss.enc, ss.winners = X1.data_ptr(), g1.data_ptr(), e1.data_ptr(), w1.data_ptr()
+    ss.act[0] = a1.data_ptr()
+    _lib.check(L.tnp_lstm_step_train(ctypes.byref(m), 0, _lib.ptr(h0), _lib.ptr(c0), _lib.ptr(obs[0]), _lib.ptr(obs[1]), None,
+                                     _lib.ptr(idx.starts), idx.B, M, idx.n_max, _lib.ptr(h1), _lib.ptr(c1), _lib.ptr(nrm),
+                                     ctypes.byref(ss), _lib.ptr(ws), need, _lib.stream_ptr()), 'step_train')
+    torch.cuda.synchronize()
+    nan_eq = lambda a, b: torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+    assert nan_eq(h1, bufs['h'][1]) and nan_eq(c1, bufs['c'][1]) and nan_eq(nrm, rel[0])
+    present = ~torch.isnan(obs[0, :, 0]) & ~torch.isnan(obs[1, :, 0])
+    assert torch.equal(X1[present], bufs['X'][0][present]) and torch.equal(g1[present], bufs['g'][0][present])
+    assert torch.equal(a1, bufs['a'][0]) and torch.equal(e1, bufs['e'][0]) and torch.equal(w1, win[0])
