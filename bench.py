@@ -17,6 +17,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -38,6 +39,8 @@ CONFIGS = {
     'sgan': dict(type_='directional', n=12, arch='one_layer', layer_dims=None, out_dim=256, scenes=32, agents=32,
                  name='S-GAN directional n=12 k=3 (generator x3 + discriminator x2)', sgan=True),
 }
+CONFIGS['classical'] = dict(classical=True, scenes=4096, agents=128,
+                            name='classical.socialforce + ORCA + Kalman batched rollouts (BASELINE config 5)')
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 
 
@@ -99,6 +102,75 @@ def cpu_baseline_classical(st, pos, vel, goals, speed, obs, z, starts, agents, s
     cpu['orca'] = (time.perf_counter() - t0) * scale
     t0 = time.perf_counter(); oracle.kalman_predict(obs[:n * A], z[:n * A]); cpu['kalman'] = (time.perf_counter() - t0) * scale
     return cpu
+
+
+def bench_classical(args, cfg, device):
+    """BASELINE config 5: social force, ORCA and Kalman rollouts of 4096 scenes x 128 agents (9 obs + 12 pred), inputs
+    resident in HBM, one "step" = all three predictors over the whole batch (one workgroup per scene, state in LDS).
+    Latency / LDS-bound scalar work per scene: no HBM or MFMA roofline applies (roofline: null)."""
+    S, A = cfg['scenes'], cfg['agents']
+    rng = np.random.RandomState(11)
+    M = S * A
+    pos = rng.rand(M, 2) * 8 - 4
+    vel = rng.randn(M, 2) * 0.6
+    goals = pos + vel * 4.8 + rng.randn(M, 2) * 0.2
+    speed = np.linalg.norm(vel, axis=1)
+    st = np.concatenate([pos, vel, goals], axis=1)
+    starts = np.arange(S + 1, dtype=np.int64) * A
+    t = np.arange(9)[None, :, None]
+    obs = pos[:, None, :] + vel[:, None, :] * 0.4 * (t - 8) + rng.randn(M, 9, 2) * 0.03
+    z = rng.standard_normal((M, 5, 13, 6))
+    dv = lambda a, dt: torch.tensor(np.ascontiguousarray(a, dtype=dt), device=device)
+    d = dict(st=dv(st, np.float64), starts=dv(starts, np.int32), pos=dv(pos, np.float32), vel=dv(vel, np.float32),
+             goals=dv(goals, np.float64), speed=dv(speed, np.float64), vmax=dv(1.3 * speed, np.float32), obs=dv(obs, np.float64),
+             z=dv(z, np.float64))
+    out_sf = torch.empty(12, M, 2, dtype=torch.float64, device=device)
+    out_orca = torch.empty(12, M, 2, dtype=torch.float32, device=device)
+    out_k = torch.empty(M, 13, 2, dtype=torch.float64, device=device)
+    L, P, sp = _lib.lib(), _lib.ptr, _lib.stream_ptr
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def step(timed=False):
+        if timed:
+            ev[0].record()
+        _lib.check(L.tnp_sf_rollout(P(d['st']), P(d['starts']), S, M, A, 12 * 8, 8, 0.5, 2.1, 0.3, 1.0 / 20, P(out_sf), sp()), 'sf')
+        if timed:
+            ev[1].record()
+        _lib.check(L.tnp_orca_rollout(P(d['pos']), P(d['vel']), P(d['goals']), P(d['speed']), P(d['vmax']), P(d['starts']), S, M, A,
+                                      8 * 12 + 1, 8, 1.0 / 20, 1.5, 10, 1.5, 0.4, P(out_orca), None, sp()), 'orca')
+        if timed:
+            ev[2].record()
+        _lib.check(L.tnp_kalman_predict(P(d['obs']), M, 9, 10, 13, 5, P(d['z']), 1e-5, 0.05 ** 2, P(out_k), sp()), 'kalman')
+        if timed:
+            ev[3].record()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    step(timed=True)
+    torch.cuda.synchronize()
+    per = {k: ev[i].elapsed_time(ev[i + 1]) for i, k in enumerate(('socialforce', 'orca', 'kalman'))}
+    out = {'metric': 'scene-steps/sec (9 obs + 12 pred)', 'value': S * 21 * args.steps / elapsed, 'unit': 'scene-steps/s',
+           'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64 (social force, Kalman) / f32 (ORCA)',
+           'data': 'synthetic',
+           'config': {'workload': '%s, %d scenes x %d agents; one step = all three predictors over the batch' % (cfg['name'], S, A),
+                      'ms_per_predictor': per,
+                      'scene_steps_per_s_per_predictor': {k: S * 21 / (v * 1e-3) for k, v in per.items()}},
+           'roofline': None, 'cpu_baseline': None}
+    if not args.no_cpu_baseline:
+        sub_n = 64
+        cpu = cpu_baseline_classical(st, pos, vel, goals, speed, obs, z, starts, A, sub_n, S)
+        tot = sum(cpu.values())
+        out['cpu_baseline'] = {'value': S * 21 / tot, 'unit': 'scene-steps/s', 'cores': os.cpu_count(), 'kind': 'port',
+                               'sample': '%d of %d scenes per predictor, extrapolated (oracle/classical_oracle.c, OpenMP over scenes)' % (sub_n, S),
+                               'seconds_per_predictor_extrapolated': cpu}
+    print(json.dumps(out))
 
 
 def under_profiler():
@@ -181,6 +253,10 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     cfg = CONFIGS[args.config]
+    if cfg.get('classical'):
+        if distributed:
+            raise SystemExit('--config classical is a single-GPU measurement')
+        return bench_classical(args, cfg, device)
     model = build_model(cfg, device)
     is_sgan = bool(cfg.get('sgan'))
     if not is_sgan:
