@@ -107,7 +107,6 @@ def _attention_param_grads(pool, P, grads, wgrad, dout_all, bufs, denc_all, h_pr
     flat = lambda t: t.reshape(rows, -1)
     eself, q, dq, ebar, du = (flat(bufs[k]) for k in ('eself', 'q', 'dq', 'ebar', 'du'))
     dout = flat(dout_all)
-    tmp = {}
 
     def wg(dy, x, with_bias):       # (dy^T x, column sums of dy) through the shared split-K kernel
         wgrad('_t', dy, x, '_b' if with_bias else None)
@@ -144,7 +143,6 @@ def _attention_param_grads(pool, P, grads, wgrad, dout_all, bufs, denc_all, h_pr
     grads['pool.spatial_embedding.0.weight'], grads['pool.spatial_embedding.0.bias'] = dW2[:ms], db2[:ms]
     if mv:
         grads['pool.vel_embedding.0.weight'], grads['pool.vel_embedding.0.bias'] = dW2[ms:], db2[ms:]
-    del tmp
 
 
 def _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, win_all, o1_all, o2_all, st=None):
@@ -283,7 +281,6 @@ class SequenceFn(torch.autograd.Function):
         h_all, c_all, X_all, gates_all, act_all, enc_all, decs = ctx.saved
         dev = h_all.device
         S, M, H, E = len(decs), idx.M, model.hidden_dim, model.embedding_dim
-        I = X_all.shape[2]
         pool = model.pool
         GD = model.goal_dim if model.goal_flag else 0
         L = _lib.lib()
@@ -335,7 +332,7 @@ class SequenceFn(torch.autograd.Function):
         at_bufs = None
         if at_pool:   # linear maps around the softmax folded as in the forward (AttentionMLPPooling.folded)
             ms, mv, mh, D = pool.mlp_dim_spatial, pool.mlp_dim_vel, pool.mlp_dim_hidden, pool.mlp_dim
-            wq_eff, bq_f, wu_f, wfin, bfin = pool.folded()
+            wq_eff, _, wu_f, wfin, _ = pool.folded()
             layT = [wfin.t().contiguous()]
             whT = T('pool.hidden_embedding.0.weight') if mh else None
             at_wuT, at_wqT = wu_f.t().contiguous(), wq_eff.t().contiguous()
