@@ -430,11 +430,20 @@ template <int C>
 __global__ void __launch_bounds__(256) sparse_wgrad_kernel(const float *__restrict__ dy, int ldy,
                                                            const float *__restrict__ enc, int lde,
                                                            const int2 *__restrict__ list, const int32_t *__restrict__ count,
-                                                           int R, int N1, float *__restrict__ dWc) {
+                                                           int R, int N1, int ncell, float *__restrict__ dWc) {
     __shared__ float red[3][C][64];
-    const int c = blockIdx.x, lane = threadIdx.x & 63;
+    // Workgroups b, b+8, ... share an XCD (and its L2).  A dy row is needed by every cell its ego occupies (~8), in the
+    // same 64-column chunk: all cells of a column chunk go to ONE XCD, so the row segment is fetched from HBM once per
+    // chunk instead of once per cell (the hit lists are sorted by row, the cells sweep the rows roughly together).
+    int c, chunk;
+    {
+        const int nchunk = N1 >> 6, bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+        if ((nchunk & 7) == 0) { chunk = xcd + 8 * (slot / ncell); c = slot - (slot / ncell) * ncell; }
+        else { chunk = bid / ncell; c = bid - chunk * ncell; }
+    }
+    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = blockIdx.y * 64 + lane;
+    const int n = chunk * 64 + lane;
     const int cnt = count[c];
     const int2 *L = list + (size_t)c * R;
     float acc[C];
@@ -509,7 +518,7 @@ static int launch_dgrid_cells(const float *dy, int ldy, const float *Wc, const i
 template <int C>
 static int launch_sparse_wgrad(const float *dy, int ldy, const float *enc, int lde, const int2 *list, const int32_t *count, int R,
                                int ncell, int N1, float *dWc, hipStream_t s) {
-    hipLaunchKernelGGL(sparse_wgrad_kernel<C>, dim3(ncell, N1 / 64), dim3(256), 0, s, dy, ldy, enc, lde, list, count, R, N1, dWc);
+    hipLaunchKernelGGL(sparse_wgrad_kernel<C>, dim3(ncell * (N1 / 64)), dim3(256), 0, s, dy, ldy, enc, lde, list, count, R, N1, ncell, dWc);
     TNP_HIP(hipGetLastError());
     return 0;
 }
