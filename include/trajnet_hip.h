@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNP_ABI_VERSION 3
+#define TNP_ABI_VERSION 4
 #define TNP_API __attribute__((visibility("default")))
 
 /* pooling types: GridBasedPooling(type_=...)  lstm/gridbased_pooling.py:16-19,55-66 */
@@ -58,16 +58,22 @@ TNP_API int tnp_mark_primaries(const int32_t *scene_start, int B, int M, uint8_t
  *   obs1, obs2   [rows,2]   previous / current positions, NaN = absent track
  *   values       [rows,ldv] social: hidden_dim_encoding(hidden) per track (C columns used)
  *   scene_start  [B+1]      rows of scene s are [scene_start[s], scene_start[s+1])
- *   n_max        number of slots the reference would pad every scene to (lstm/lstm.py:29);
- *                scenes with fewer tracks get the reference's padded-slot cell-0 clobber
+ *   n_max        width of the reference's padded [B, n_max, .] pooling tensors (lstm/lstm.py:29): the largest
+ *                entry of scene_slots, or -- with scene_slots == NULL -- the number of slots EVERY scene is
+ *                padded to (at least the largest scene; a sharded batch passes the global maximum)
+ *   scene_slots  [B] int32 or NULL: slots the reference pads scene s to (>= its track count).  The padded
+ *                slots are absent neighbours with the highest index, so a scene with scene_slots[s] > its
+ *                track count gets the reference's cell-0 clobber and a scene with
+ *                scene_slots[s] == its track count does not -- the latter is what one call per scene
+ *                (lstm/lstm.py:291, the evaluator) computes, the former what a ragged training batch does
  *   cell         float32(cell_side / pool_size); half_x/half_y = n/2 (front: half_y = 0)
  *   grid         [rows,ldg] out, feature = c*n*n + cell_x*n + cell_y   (may be NULL)
  *   winners      [rows,n*n] out, int16: scene-local index of the neighbour that owns the
  *                cell, -1 = background `constant`                       (may be NULL)
  * ----------------------------------------------------------------------------------------- */
 TNP_API int tnp_pool_grid_forward(int type, const float *obs1, const float *obs2, const float *values, int ldv,
-                          const int32_t *scene_start, int B, int n_max, int n, int C, float cell,
-                          float half_x, float half_y, float constant, float *grid, int ldg,
+                          const int32_t *scene_start, int B, int n_max, const int32_t *scene_slots, int n, int C,
+                          float cell, float half_x, float half_y, float constant, float *grid, int ldg,
                           int16_t *winners, void *stream);
 
 /* Cells of all ordered (ego, neighbour) pairs, for the backward pass of the grid scatter (autograd of
@@ -130,13 +136,14 @@ TNP_API int tnp_pool_traj_forward(const float *obs1, const float *obs2, int M, c
  *   tnp_pool_attn_self : e_self[i] = embedding of slot i relative to itself ([ReLU(b_spatial) | hidden_emb[i] |
  *                        ReLU(b_vel)], fill where the ego's position / velocity is NaN)            -> [M, D]
  *   tnp_pool_attn_pair : a_ij = softmax_j((u[i,0:D] . e_ij + u[i,D]) / sqrt(D)) over ALL n_max slots of the padded
- *                        scene (slots beyond the scene's tracks count as padded: fill / 0 / fill), ebar[i] = sum_j a_ij e_ij */
+ *                        scene (slots beyond the scene's tracks count as padded: fill / 0 / fill; scene_slots as for
+ *                        tnp_pool_grid_forward: per-scene slot counts, NULL = n_max), ebar[i] = sum_j a_ij e_ij */
 TNP_API int tnp_pool_attn_self(const float *obs1, const float *obs2, const float *hidden_emb, int ldh,
                                int hidden_emb_relu, int M, int ms, int mv, int mh, const float *b_spatial,
                                const float *b_vel, float fill, float *e_self, int lde, void *stream);
 TNP_API int tnp_pool_attn_pair(const float *obs1, const float *obs2, const float *hidden_emb, int ldh,
-                               int hidden_emb_relu, const int32_t *scene_start, int B, int n_max, int ms, int mv,
-                               int mh, const float *W_spatial, const float *b_spatial, const float *W_vel,
+                               int hidden_emb_relu, const int32_t *scene_start, int B, int n_max,
+                               const int32_t *scene_slots, int ms, int mv, int mh, const float *W_spatial, const float *b_spatial, const float *W_vel,
                                const float *b_vel, float fill, const float *u, int ldu, float *ebar, int lde,
                                void *stream);
 
@@ -195,7 +202,8 @@ TNP_API size_t tnp_lstm_workspace_bytes(const tnp_lstm_model *model, int M, int 
  * LSTM.forward (lstm/lstm.py:170-264): T_obs-1 encoder steps + T_dec decoder steps.
  *   observed    [T_obs,M,2]
  *   goals       [M,2] (read only when model->goal_flag)
- *   scene_start [B+1] int32, primary_flag [M] uint8 (tnp_mark_primaries), n_max
+ *   scene_start [B+1] int32, primary_flag [M] uint8 (tnp_mark_primaries), n_max / scene_slots as for
+ *               tnp_pool_grid_forward (NULL: every scene padded to n_max, the reference's batch semantics)
  *   truth       [T_dec,M,2] teacher-forcing frames (prediction_truth) or NULL = n_predict
  *               mode with T_dec = n_predict-1
  *   rel_pred    [T_obs-1+T_dec, M, 5] out (mu_x, mu_y, sigma_x, sigma_y, rho), NaN = absent
@@ -204,8 +212,8 @@ TNP_API size_t tnp_lstm_workspace_bytes(const tnp_lstm_model *model, int M, int 
  * ----------------------------------------------------------------------------------------- */
 TNP_API int tnp_lstm_forward(const tnp_lstm_model *model, const float *observed, int T_obs, int M,
                      const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
-                     int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
-                     void *workspace, size_t workspace_bytes, void *stream);
+                     int B, int n_max, const int32_t *scene_slots, const float *truth, int T_dec, float *rel_pred,
+                     float *pred, void *workspace, size_t workspace_bytes, void *stream);
 
 /* -------------------------------------------------------------------------------------------
  * Same sequence with the S-GAN hooks (sgan/sgan.py):
@@ -224,8 +232,9 @@ typedef struct tnp_lstm_extras {
 } tnp_lstm_extras;
 TNP_API int tnp_lstm_forward_ex(const tnp_lstm_model *model, const float *observed, int T_obs, int M,
                         const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
-                        int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
-                        void *workspace, size_t workspace_bytes, const tnp_lstm_extras *extras, void *stream);
+                        int B, int n_max, const int32_t *scene_slots, const float *truth, int T_dec, float *rel_pred,
+                        float *pred, void *workspace, size_t workspace_bytes, const tnp_lstm_extras *extras,
+                        void *stream);
 
 /* -------------------------------------------------------------------------------------------
  * LSTM.step (lstm/lstm.py:91-168) on dense state: one masked recurrent step.
@@ -236,8 +245,8 @@ TNP_API int tnp_lstm_forward_ex(const tnp_lstm_model *model, const float *observ
  * ----------------------------------------------------------------------------------------- */
 TNP_API int tnp_lstm_step(const tnp_lstm_model *model, int decoder, const float *h_in, const float *c_in,
                   const float *obs1, const float *obs2, const float *goals, const int32_t *scene_start,
-                  int B, int M, int n_max, float *h_out, float *c_out, float *normal, void *workspace,
-                  size_t workspace_bytes, void *stream);
+                  int B, int M, int n_max, const int32_t *scene_slots, float *h_out, float *c_out, float *normal,
+                  void *workspace, size_t workspace_bytes, void *stream);
 
 /* -------------------------------------------------------------------------------------------
  * Training support (loss.backward() through LSTM.forward, lstm/trainer.py:229-269).
@@ -267,9 +276,9 @@ typedef struct tnp_step_saves {
 } tnp_step_saves;
 TNP_API int tnp_lstm_step_train(const tnp_lstm_model *model, int decoder, const float *h_in, const float *c_in,
                                 const float *obs1, const float *obs2, const float *goals,
-                                const int32_t *scene_start, int B, int M, int n_max, float *h_out, float *c_out,
-                                float *normal, const tnp_step_saves *saves, void *workspace,
-                                size_t workspace_bytes, void *stream);
+                                const int32_t *scene_start, int B, int M, int n_max, const int32_t *scene_slots,
+                                float *h_out, float *c_out, float *normal, const tnp_step_saves *saves,
+                                void *workspace, size_t workspace_bytes, void *stream);
 /* Whole training forward in one call: tnp_lstm_forward_ex that leaves what the backward sweep needs in the caller's
  * buffers, all [steps = T_obs-1+T_dec] x M rows, contiguous: h_all / c_all [steps+1, M, H] (state before step s and
  * after the last one), X_all [steps, M, I] (LSTMCell input), act_all[l] (ReLU output of embedding layer l), gates_all
@@ -291,7 +300,7 @@ typedef struct tnp_train_saves {
 } tnp_train_saves;
 TNP_API int tnp_lstm_forward_train(const tnp_lstm_model *model, const float *observed, int T_obs, int M, const float *goals,
                                    const int32_t *scene_start, const uint8_t *primary_flag, int B, int n_max,
-                                   const float *truth, int T_dec, float *rel_pred, float *pred, void *workspace,
+                                   const int32_t *scene_slots, const float *truth, int T_dec, float *rel_pred, float *pred, void *workspace,
                                    size_t workspace_bytes, const tnp_lstm_extras *extras, const tnp_train_saves *saves,
                                    void *stream);
 /* The reverse sweep over steps s_hi .. s_lo (inclusive, descending) of a sequence run by tnp_lstm_forward_train: per step
@@ -310,6 +319,7 @@ typedef struct tnp_bwd_sweep {
     int32_t h_override_step;         /* step whose output state is h_override instead of h_all[step+1] (-1: none) */
     const float *h_override;
     const int32_t *scene_start;
+    const int32_t *scene_slots;      /* [B] or NULL, as handed to tnp_lstm_forward_train (AttentionMLPPooling's padded slots) */
     const float *d_rel, *d_pred;     /* upstream gradients [S,M,5] / [S+pos_offset,M,2], either may be NULL */
     const float *wT_enc, *wT_dec;    /* [I+H, 4H] = [W_ih^T ; W_hh^T] of the two cells (wT_dec NULL when no decoder step) */
     const float *layT[3];            /* W_l^T [in_l, out_l] of embedding layer l; l = 0 only for the dense first-layer paths */
@@ -417,9 +427,9 @@ TNP_API int tnp_wgrad(const float *dy, int ld_dy, const float *x, int ld_x, int 
  *   tnp_pool_attn_self_backward: de_self [M, ldd] (gradient of the ego's own embedding through the query) is added to
  *       A3's bias plane and, with dEh gathered per track, gives d_hidden_emb_pre [M, mh]; dself_scratch [M, mh]. */
 TNP_API int tnp_pool_attn_pair_backward(const float *obs1, const float *obs2, const float *hidden_emb_pre, int ldh,
-                                        const int32_t *scene_start, int B, int n_max, int ms, int mv, int mh,
-                                        const float *W_spatial, const float *b_spatial, const float *W_vel, const float *b_vel,
-                                        float fill, const float *u, int ldu, const float *d_ebar, int ldd, float *du, float *A3,
+                                        const int32_t *scene_start, int B, int n_max, const int32_t *scene_slots, int ms,
+                                        int mv, int mh, const float *W_spatial, const float *b_spatial, const float *W_vel,
+                                        const float *b_vel, float fill, const float *u, int ldu, const float *d_ebar, int ldd, float *du, float *A3,
                                         float *dEh, float *ebar, int lde, void *stream);
 TNP_API int tnp_pool_attn_self_backward(const float *obs1, const float *obs2, const float *hidden_emb_pre, int ldh,
                                         const int32_t *row_base, const int32_t *row_count, int M, int n_max, int ms, int mv,
@@ -452,6 +462,10 @@ TNP_API int tnp_directional_scatter_backward(const float *dgrid, int ldg, const 
  * tnp_primary_loss_backward: d_inputs [T,M,5] = d(out)/d(inputs) . grad_out (grad_out [1] or [B] as `out`); analytic
  *   derivatives of the expressions above, rows of non-primaries are zero -- what loss.backward() hands to LSTM.forward.
  * tnp_collision_loss_forward = CollisionLoss (:138-162) over predictions [T,M,ld] (first two columns), out [1].
+ * tnp_collision_loss_backward: d_predictions [T,M,ld] = d(out)/d(predictions) . grad_out[0] -- non-zero only in the
+ *   primaries' rows (the neighbours are detached, :155): -col_wt/col_distance * sum over the colliding neighbours of the
+ *   unit vector from the neighbour to the primary; NaN coordinates (overwritten with -1000 in place, :148) and
+ *   coincident points (torch.norm's subgradient) get zero.
  * ----------------------------------------------------------------------------------------- */
 TNP_API int tnp_primary_loss_forward(int mode, const float *inputs, const float *targets, const int32_t *scene_start,
                              int B, int T, int M, float background_rate, int keep_batch_dim, float scale,
@@ -461,6 +475,9 @@ TNP_API int tnp_primary_loss_backward(int mode, const float *inputs, const float
                               const float *grad_out, float *d_inputs, void *stream);
 TNP_API int tnp_collision_loss_forward(const float *predictions, int ld, const int32_t *scene_start, int B, int T,
                                int M, float col_wt, float col_distance, float *partial_ws, float *out, void *stream);
+TNP_API int tnp_collision_loss_backward(const float *predictions, int ld, const int32_t *scene_start, int B, int T,
+                                int M, float col_wt, float col_distance, const float *grad_out, float *d_predictions,
+                                void *stream);
 
 /* -------------------------------------------------------------------------------------------
  * Kernel timing hook for bench.py's roofline leg: when enabled, every launch of the dominant

@@ -274,6 +274,27 @@ def collision_loss(predictions, batch_split, col_wt=10.0, col_distance=0.2):
                                       ctypes.c_float(col_distance)))
 
 
+def collision_loss_grad(predictions, batch_split, col_wt=10.0, col_distance=0.2, grad_out=1.0):
+    """d CollisionLoss / d predictions as the reference's autograd gives it (lstm/loss.py:148-161): only the primaries'
+    rows, neighbours detached (:155); a coordinate that was NaN was overwritten in place with -1000 (:148) and carries no
+    gradient; torch.norm's subgradient at distance 0 is 0.  numpy float64 accumulation, float32 result."""
+    pred = np.asarray(predictions, dtype=np.float32)
+    split = np.asarray(batch_split, dtype=np.int64)
+    grad = np.zeros_like(pred)
+    live = ~np.isnan(pred[..., :2])
+    p = np.where(live, pred[..., :2], np.float32(-1000.0)).astype(np.float32)
+    for lo, hi in zip(split[:-1], split[1:]):
+        if lo + 1 >= hi:
+            continue
+        diff = p[:, lo:lo + 1] - p[:, lo + 1:hi]                      # [T, n, 2] float32 like torch
+        d = np.sqrt((diff * diff).sum(-1, dtype=np.float32)).astype(np.float32)
+        hit = (d <= np.float32(col_distance)) & (d > 0)
+        unit = np.where(hit[..., None], diff.astype(np.float64) / np.where(d > 0, d, 1.0)[..., None], 0.0)
+        g = -float(grad_out) * float(col_wt) / float(col_distance) * unit.sum(axis=1)
+        grad[:, lo, :2] = np.where(live[:, lo], g, 0.0)
+    return grad
+
+
 # --------------------------------------------------------------------------
 # classical predictors (oracle/classical_oracle.c; parity unpinned, see its header)
 # --------------------------------------------------------------------------

@@ -98,3 +98,31 @@ def ade_fde(pred, truth):
     """Average / final displacement error of the primaries' predicted path [T, B, 2] (metres)."""
     d = np.linalg.norm(np.asarray(pred, dtype=np.float64) - np.asarray(truth, dtype=np.float64), axis=-1)
     return d.mean(axis=0), d[-1]
+
+
+def primary_loss_autograd(mode, inputs, targets, batch_split, background_rate, keep_batch_dim, scale):
+    """Differentiable tensor restatement of PredictionLoss / L2Loss on the [T, B] primaries (reference lstm/loss.py:23-91,
+    :107-135) -- the checker for tnp_primary_loss_backward's analytic derivatives."""
+    import math
+    import torch
+
+    def gaussian_2d(p, x):
+        norm1, norm2 = x[:, 0] - p[:, 0], x[:, 1] - p[:, 1]
+        s1, s2, rho = p[:, 2], p[:, 3], p[:, 4]
+        s1s2 = s1 * s2
+        z = (norm1 / s1) ** 2 + (norm2 / s2) ** 2 - 2 * rho * norm1 * norm2 / s1s2
+        return torch.exp(-z / (2 * (1 - rho ** 2))) / (2 * math.pi * s1s2 * torch.sqrt(1 - rho ** 2))
+
+    dev = inputs.device
+    prim = torch.as_tensor(batch_split, dtype=torch.int64).to(dev)[:-1]
+    T, B = inputs.size(0), prim.numel()
+    inp = inputs[:, prim].reshape(-1, 5)
+    tgt = targets.detach().float().to(dev)[:, prim].reshape(-1, 2)
+    if mode == 0:
+        bg = inp.clone()
+        bg[:, 2], bg[:, 3], bg[:, 4] = 3.0, 3.0, 0.0
+        values = -torch.log(0.01 + background_rate * gaussian_2d(bg, tgt) + (0.99 - background_rate) * gaussian_2d(inp, tgt))
+        values = values.reshape(T, B)
+        return (values.mean(dim=0) if keep_batch_dim else values.mean()) * scale
+    sq = ((inp[:, :2] - tgt) ** 2).reshape(T, B, 2)
+    return (sq.mean(dim=0).mean(dim=1) if keep_batch_dim else sq.mean()) * (scale * 2.0)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 12
     for name in names:
         assert hasattr(L, name), name
-    assert L.tnp_abi_version() == _lib.ABI_VERSION == 3   # 2: tnp_lstm_model gained Wx / bx; 3: tnp_step_saves gained winners
+    assert L.tnp_abi_version() == _lib.ABI_VERSION == 4   # 2: tnp_lstm_model gained Wx / bx; 3: tnp_step_saves gained winners; 4: scene_slots
 
 
 def test_struct_layout_matches_header_size():

@@ -108,7 +108,7 @@ def test_ragged_scenes_padded_slot_clobber():
     o = torch.tensor(flat).cuda()
     st = torch.tensor(starts).cuda()
     _lib.check(_lib.lib().tnp_pool_grid_forward(_lib.POOL_OCCUPANCY, _lib.ptr(o), _lib.ptr(o), None, 0, _lib.ptr(st),
-                                                len(sizes), n_max, n, 1, 1.0, n / 2, n / 2, 0.0, _lib.ptr(grid),
+                                                len(sizes), n_max, None, n, 1, 1.0, n / 2, n / 2, 0.0, _lib.ptr(grid),
                                                 n * n, None, _lib.stream_ptr()), 'grid')
     got = grid.cpu().numpy()
     for s, ns in enumerate(sizes):

@@ -26,7 +26,7 @@ def run_sparse(obs1, obs2, enc, starts, n_max, n, cell_side, W, b, relu=True):
     winners = torch.empty(M, ncell, dtype=torch.int16, device=dev)
     L = _lib.lib()
     _lib.check(L.tnp_pool_grid_forward(_lib.POOL_SOCIAL, _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(e), C, _lib.ptr(st), B,
-                                       n_max, n, C, float(np.float32(cell_side)), n / 2, n / 2, 0.0, None, 0,
+                                       n_max, None, n, C, float(np.float32(cell_side)), n / 2, n / 2, 0.0, None, 0,
                                        _lib.ptr(winners), _lib.stream_ptr()), 'grid')
     row_base = torch.empty(M, dtype=torch.int32, device=dev)
     _lib.check(L.tnp_row_base(_lib.ptr(st), B, _lib.ptr(row_base), _lib.stream_ptr()), 'row_base')

@@ -136,7 +136,7 @@ def test_fused_loss_backward_matches_the_tensor_expression(mode, keep):
         if fn is not None:
             out = fn(x, targets, split, mode, 0.2, keep, 1.5)
         else:
-            out = L._primary_loss_autograd(mode, x, targets, split, 0.2, keep, 1.5)
+            out = helpers.primary_loss_autograd(mode, x, targets, split, 0.2, keep, 1.5)
         ((out * weights).sum() if keep else out * 0.7).backward()
         grads.append((out.detach().clone(), x.grad.clone()))
     assert torch.allclose(grads[0][0], grads[1][0], rtol=2e-5, atol=1e-6)
@@ -146,3 +146,43 @@ def test_fused_loss_backward_matches_the_tensor_expression(mode, keep):
     mask = torch.ones(M, dtype=torch.bool, device='cuda')
     mask[prim] = False
     assert float(grads[0][1][:, mask].abs().max()) == 0.0      # only the primaries carry a gradient
+
+
+COLG = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'collision_grad.npz'))
+COL_PARAMS = [(10.0, 0.2), (2.0, 0.5)]
+
+
+@pytest.mark.parametrize('k', range(int(COLG['num_cases'])))
+def test_oracle_collision_gradient_matches_reference_autograd(k):
+    """numpy restatement of d CollisionLoss / d positions vs the reference's autograd (oracle/gen_golden_r2.py)"""
+    pos, split = COLG['c%d_positions' % k], COLG['c%d_split' % k]
+    for cw, cd in COL_PARAMS:
+        tag = 'c%d_w%g_d%g_' % (k, cw, cd)
+        assert oracle.collision_loss(pos, split, cw, cd) == pytest.approx(float(COLG[tag + 'value']), rel=2e-5, abs=1e-6)
+        got = oracle.collision_loss_grad(pos, split, cw, cd, grad_out=0.7)
+        want = COLG[tag + 'grad']
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+        prim = np.zeros(pos.shape[1], dtype=bool)
+        prim[split[:-1]] = True
+        assert not want[:, ~prim].any()                       # the reference detaches the neighbours
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k', range(int(COLG['num_cases'])))
+def test_gpu_collision_gradient_matches_reference_autograd(k):
+    """tnp_collision_loss_backward through CollisionLoss's autograd Function vs the reference's gradients"""
+    from trajnetplusplusbaselines_amd.lstm import loss as L
+    pos, split = COLG['c%d_positions' % k], COLG['c%d_split' % k]
+    some = False
+    for cw, cd in COL_PARAMS:
+        tag = 'c%d_w%g_d%g_' % (k, cw, cd)
+        p = torch.tensor(pos).cuda().requires_grad_(True)
+        val = L.CollisionLoss(p * 1.0, torch.tensor(split), col_wt=cw, col_distance=cd)
+        assert float(val) == pytest.approx(float(COLG[tag + 'value']), rel=2e-5, abs=1e-6)
+        (val * 0.7).backward()
+        want = COLG[tag + 'grad']
+        got = p.grad.cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+        assert np.array_equal(got != 0, np.abs(want) > 0) or np.abs(got - want).max() < 1e-6
+        some |= bool(np.abs(want).max() > 0)
+    assert some or k == 2                                       # every case but the single-track one collides

@@ -15,7 +15,7 @@ Wcm = W.view(N1, C, ncell).permute(2, 1, 0).contiguous()
 L = _lib.lib()
 winners = torch.empty(M, ncell, dtype=torch.int16, device=dev)
 grid = torch.empty(M, C * ncell, device=dev)
-_lib.check(L.tnp_pool_grid_forward(2, _lib.ptr(obs1), _lib.ptr(obs2), _lib.ptr(enc), C, _lib.ptr(st), B, N, n, C, float(np.float32(0.6)), n / 2, n / 2, 0.0, _lib.ptr(grid), C * ncell, _lib.ptr(winners), _lib.stream_ptr()), 'grid')
+_lib.check(L.tnp_pool_grid_forward(2, _lib.ptr(obs1), _lib.ptr(obs2), _lib.ptr(enc), C, _lib.ptr(st), B, N, None, n, C, float(np.float32(0.6)), n / 2, n / 2, 0.0, _lib.ptr(grid), C * ncell, _lib.ptr(winners), _lib.stream_ptr()), 'grid')
 print('hits per ego', float((winners >= 0).sum()) / M)
 row_base = torch.empty(M, dtype=torch.int32, device=dev)
 L.tnp_row_base(_lib.ptr(st), B, _lib.ptr(row_base), _lib.stream_ptr())
@@ -27,4 +27,4 @@ us = time_fn(f, iters=20)
 ref = _lib.linear_forward(grid, W, b, relu=True)
 print('TNP_SPARSE_VARIANT', os.environ.get('TNP_SPARSE_VARIANT', '0'), 'sparse %.1f us' % us, 'max err vs dense %.2e' % (out - ref).abs().max().item(),
       'dense %.1f us' % time_fn(lambda: _lib.linear_forward(grid, W, b, relu=True, out=ref), iters=20),
-      'grid(winners only) %.1f us' % time_fn(lambda: L.tnp_pool_grid_forward(2, _lib.ptr(obs1), _lib.ptr(obs2), _lib.ptr(enc), C, _lib.ptr(st), B, N, n, C, float(np.float32(0.6)), n / 2, n / 2, 0.0, None, 0, _lib.ptr(winners), _lib.stream_ptr()), iters=20))
+      'grid(winners only) %.1f us' % time_fn(lambda: L.tnp_pool_grid_forward(2, _lib.ptr(obs1), _lib.ptr(obs2), _lib.ptr(enc), C, _lib.ptr(st), B, N, None, n, C, float(np.float32(0.6)), n / 2, n / 2, 0.0, None, 0, _lib.ptr(winners), _lib.stream_ptr()), iters=20))

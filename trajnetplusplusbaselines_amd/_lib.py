@@ -5,6 +5,7 @@ PyTorch is used only as plumbing here: device memory (tensor.data_ptr()), the cu
 torch.distributed.  Every entry point enqueues on ``torch.cuda.current_stream()`` and returns immediately.
 """
 import ctypes
+import numbers
 import os
 
 import torch
@@ -15,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'trajnet_hip.h')
 
 POOL_NONE, POOL_OCCUPANCY, POOL_DIRECTIONAL, POOL_SOCIAL = -1, 0, 1, 2
 POOL_NN, POOL_HIDDENMLP, POOL_ATTNMLP, POOL_NNLSTM, POOL_TRAJ = 4, 5, 6, 7, 8
-ABI_VERSION = 3   # TNP_ABI_VERSION of include/trajnet_hip.h this binding was written against
+ABI_VERSION = 4   # TNP_ABI_VERSION of include/trajnet_hip.h this binding was written against
 POOL_TYPES = {None: POOL_NONE, 'occupancy': POOL_OCCUPANCY, 'directional': POOL_DIRECTIONAL, 'social': POOL_SOCIAL}
 
 _fp = ctypes.c_void_p
@@ -71,18 +72,18 @@ def lib():
     L.tnp_lstm_workspace_bytes.restype = ctypes.c_size_t
     L.tnp_lstm_workspace_bytes.argtypes = [ctypes.POINTER(LstmModel), ctypes.c_int, ctypes.c_int]
     L.tnp_mark_primaries.argtypes = [_fp, ctypes.c_int, ctypes.c_int, _fp, _fp]
-    L.tnp_pool_grid_forward.argtypes = [ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
+    L.tnp_pool_grid_forward.argtypes = [ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, _fp,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, _fp, ctypes.c_int, _fp, _fp]
     L.tnp_linear_forward.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp]
     L.tnp_lstm_forward.argtypes = [ctypes.POINTER(LstmModel), _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp,
-                                   ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t, _fp]
+                                   ctypes.c_int, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t, _fp]
     L.tnp_lstm_forward_ex.argtypes = [ctypes.POINTER(LstmModel), _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp,
-                                      ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t,
+                                      ctypes.c_int, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t,
                                       ctypes.POINTER(LstmExtras), _fp]
     L.tnp_lstm_forward_train.argtypes = [ctypes.POINTER(LstmModel), _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp,
-                                         ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t,
+                                         ctypes.c_int, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t,
                                          ctypes.POINTER(LstmExtras), _fp, _fp]
     L.tnp_abi_sizeof.restype = ctypes.c_size_t
     L.tnp_abi_sizeof.argtypes = [ctypes.c_int]
@@ -90,7 +91,7 @@ def lib():
     L.tnp_lstm_backward_scratch_bytes.argtypes = [_fp]
     L.tnp_lstm_backward_sweep.argtypes = [_fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_size_t, _fp]
     L.tnp_lstm_step.argtypes = [ctypes.POINTER(LstmModel), ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
-                                ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, ctypes.c_size_t, _fp]
+                                ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, ctypes.c_size_t, _fp]
     L.tnp_profile_begin.argtypes = [ctypes.c_int]
     L.tnp_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     L.tnp_constant_velocity.argtypes = [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp]
@@ -100,7 +101,7 @@ def lib():
     L.tnp_pool_nn_forward.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, ctypes.c_int,
                                       _fp, ctypes.c_int, _fp]
     L.tnp_lstm_step_train.argtypes = [ctypes.POINTER(LstmModel), ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int,
-                                      ctypes.c_int, _fp, _fp, _fp, _fp, _fp, ctypes.c_size_t, _fp]
+                                      ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_size_t, _fp]
     L.tnp_h2n_backward.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]
     L.tnp_h2n_cell_backward.argtypes = [_fp] * 11 + [ctypes.c_int, ctypes.c_int] + [_fp] * 5
     L.tnp_lstm_cell_backward.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]
@@ -126,7 +127,7 @@ def lib():
     L.tnp_colsum_prod_workspace_bytes.restype = ctypes.c_size_t
     L.tnp_colsum_prod_workspace_bytes.argtypes = [ctypes.c_long, ctypes.c_int]
     L.tnp_colsum_prod.argtypes = [_fp, _fp, ctypes.c_long, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t, _fp]
-    L.tnp_pool_attn_pair_backward.argtypes = [_fp, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+    L.tnp_pool_attn_pair_backward.argtypes = [_fp, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, ctypes.c_float, _fp, ctypes.c_int,
                                               _fp, ctypes.c_int, _fp, _fp, _fp, _fp, ctypes.c_int, _fp]
     L.tnp_pool_attn_self_backward.argtypes = [_fp, _fp, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -137,7 +138,7 @@ def lib():
     L.tnp_pool_traj_forward.argtypes = [_fp, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp]
     L.tnp_pool_attn_self.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, _fp, _fp, ctypes.c_float, _fp, ctypes.c_int, _fp]
-    L.tnp_pool_attn_pair.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
+    L.tnp_pool_attn_pair.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, _fp,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, ctypes.c_float, _fp,
                                      ctypes.c_int, _fp, ctypes.c_int, _fp]
     L.tnp_pool_hiddenmlp_forward.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
@@ -151,6 +152,8 @@ def lib():
                                            ctypes.c_float, ctypes.c_int, ctypes.c_float, _fp, _fp, _fp]
     L.tnp_collision_loss_forward.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_float, ctypes.c_float, _fp, _fp, _fp]
+    L.tnp_collision_loss_backward.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_float, ctypes.c_float, _fp, _fp, _fp]
     L.tnp_sf_rollout.argtypes = [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _fp, _fp]
     L.tnp_orca_rollout.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -200,10 +203,21 @@ def f32c(t, device=None):
 
 
 class SceneIndex(object):
-    """int32 scene starts + per-track primary flags + the reference's padded slot count (lstm/lstm.py:29)."""
+    """int32 scene starts + per-track primary flags + the reference's padded slot counts (lstm/lstm.py:29).
+
+    ``pad_to`` says how many slots the reference would pad every scene to -- the padded slots are absent neighbours
+    with the highest index, which clobber cell (0, 0) of a grid and enter AttentionMLPPooling's
+    softmax:
+      None      the largest scene of THIS batch_split (what ``generate_pooling_inputs`` does for the batch it is given);
+      int       that many slots for every scene (>= the largest scene): a shard of a bigger batch passes the global
+                maximum, so the shard computes what the unsharded batch would;
+      'scene'   every scene on its own, no padded slots: what one reference call per scene computes (the evaluator,
+                lstm/lstm.py:291);
+      sequence  per-scene slot counts.
+    ``n_max`` is the largest slot count, ``slots`` the per-scene int32 device tensor (None = n_max for all)."""
     _cache = {}
 
-    def __init__(self, batch_split, device):
+    def __init__(self, batch_split, device, pad_to=None):
         split = batch_split.detach().to('cpu', torch.int64)
         if split.numel() < 2:
             raise ValueError('batch_split needs at least two entries')
@@ -215,6 +229,25 @@ class SceneIndex(object):
         if int(split[0]) != 0:
             raise ValueError('batch_split must start at 0')
         self.n_max = int(sizes.max()) if self.B > 0 else 0
+        self.slots = None
+        if isinstance(pad_to, numbers.Integral):
+            pad_to = int(pad_to)
+        if pad_to is not None:
+            if isinstance(pad_to, str):
+                if pad_to != 'scene':
+                    raise ValueError("pad_to must be None, an int, 'scene' or per-scene slot counts")
+                slots = sizes.clone()
+            elif isinstance(pad_to, int):
+                slots = torch.full_like(sizes, pad_to)
+            else:
+                slots = torch.as_tensor(pad_to, dtype=torch.int64).reshape(-1)
+                if slots.numel() != self.B:
+                    raise ValueError('pad_to has %d entries for %d scenes' % (slots.numel(), self.B))
+            if self.B > 0 and bool((slots < sizes).any()):
+                raise ValueError('pad_to is smaller than a scene: padded slot counts must be >= the track counts')
+            self.n_max = int(slots.max()) if self.B > 0 else 0
+            if not isinstance(pad_to, int):
+                self.slots = slots.to(torch.int32).to(device)
         self.starts = split.to(torch.int32).to(device)
         # first row / size of every row's scene (training backward): built on the host, one copy, no device-side sync later
         self.row_base = torch.repeat_interleave(split[:-1], sizes).to(torch.int32).to(device)
@@ -224,16 +257,20 @@ class SceneIndex(object):
               'tnp_mark_primaries')
 
     @classmethod
-    def get(cls, batch_split, device):
+    def get(cls, batch_split, device, pad_to=None):
         if isinstance(batch_split, (list, tuple)):
             batch_split = torch.tensor(batch_split, dtype=torch.int64)
         host = batch_split.detach().to('cpu', torch.int64)
-        key = (str(device), host.numpy().tobytes())
+        if isinstance(pad_to, numbers.Integral):
+            pad_to = int(pad_to)
+        if pad_to is not None and not isinstance(pad_to, (int, str)):
+            pad_to = tuple(int(v) for v in torch.as_tensor(pad_to).reshape(-1).tolist())
+        key = (str(device), host.numpy().tobytes(), pad_to)
         idx = cls._cache.get(key)
         if idx is None:
             if len(cls._cache) > 64:
                 cls._cache.clear()
-            idx = cls(host, device)
+            idx = cls(host, device, pad_to)
             cls._cache[key] = idx
         return idx
 

@@ -10,6 +10,7 @@ OUT_DIR = os.path.join(PKG, 'lib')
 OUT = os.path.join(OUT_DIR, 'libtrajnet_hip.so')
 SOURCES = ['gemm_f32_mfma.hip', 'gemm_wgrad.hip', 'pool_grid.hip', 'pool_embed_sparse.hip', 'pool_nongrid.hip', 'lstm_seq.hip', 'lstm_bwd.hip', 'loss.hip',
            'classical.hip']
+EXACT = ('classical.hip', 'pool_grid.hip')
 HEADERS = ['tnp_internal.h', 'classical_core.h', os.path.join('..', '..', 'include', 'trajnet_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-fvisibility=hidden',
          '-Wall', '-Wno-unused-function']
@@ -34,19 +35,23 @@ def build(force=False, verbose=False):
     if not (force or needs_build()):
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    objs = []
+    objs, cmds = [], []
     for src in SOURCES:
         path = os.path.join(HERE, src)
         if not os.path.exists(path):
             continue
         obj = os.path.join(OUT_DIR, os.path.splitext(src)[0] + '.o')
         # exact-arithmetic units (cell indexing, float64 / float32 simulators): no fma contraction
-        extra = ['-ffp-contract=off'] if src in ('classical.hip', 'pool_grid.hip') else []
+        extra = ['-ffp-contract=off'] if src in EXACT else []
         cmd = [hipcc()] + FLAGS + extra + ['-c', path, '-o', obj]
         if verbose:
             print(' '.join(cmd))
-        subprocess.check_call(cmd)
+        cmds.append(cmd)
         objs.append(obj)
+    # translation units are independent: compile them side by side
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 4)) as pool:
+        list(pool.map(subprocess.check_call, cmds))
     cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
     if verbose:
         print(' '.join(cmd))

@@ -125,6 +125,41 @@ __global__ void __launch_bounds__(256) collision_scene_kernel(const float *pred,
     if (tid == 0) partial[s] = col_wt * sh[0];
 }
 
+// Backward of CollisionLoss with respect to the primaries' predicted positions (autograd through lstm/loss.py:148-161:
+// the neighbours are detached, NaN coordinates were overwritten in place with -1000 so they carry no gradient, and
+// torch.norm's subgradient at distance 0 is 0):
+//   d loss / d p = -col_wt / col_distance * sum over colliding neighbours of (p - n) / |p - n|
+// One wave per (scene, frame): lanes stride over the neighbours, fixed-order butterfly reduction (bit-reproducible).
+__global__ void __launch_bounds__(64) collision_backward_kernel(const float *pred, int ld, const int32_t *scene_start, int T,
+                                                                int M, float col_wt, float col_distance,
+                                                                const float *grad_out, float *d_pred) {
+    const int s = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+    const int lo = scene_start[s], hi = scene_start[s + 1];
+    if (hi <= lo) return;
+    const float *pp = pred + ((size_t)t * M + lo) * ld;
+    float px = pp[0], py = pp[1];
+    const bool live_x = px == px, live_y = py == py;
+    if (!live_x) px = -1000.0f;
+    if (!live_y) py = -1000.0f;
+    float gx = 0.0f, gy = 0.0f;
+    for (int j = lo + 1 + lane; j < hi; j += 64) {
+        const float *pn = pred + ((size_t)t * M + j) * ld;
+        float nx = pn[0], ny = pn[1];
+        if (nx != nx) nx = -1000.0f;
+        if (ny != ny) ny = -1000.0f;
+        const float dx = px - nx, dy = py - ny;
+        const float d = sqrtf(dx * dx + dy * dy);
+        if (d <= col_distance && d > 0.0f) { gx += dx / d; gy += dy / d; }
+    }
+    for (int off = 32; off > 0; off >>= 1) { gx += __shfl_xor(gx, off); gy += __shfl_xor(gy, off); }
+    if (lane == 0) {
+        const float k = -grad_out[0] * col_wt / col_distance;
+        float *dp = d_pred + ((size_t)t * M + lo) * ld;
+        dp[0] = live_x ? k * gx : 0.0f;
+        dp[1] = live_y ? k * gy : 0.0f;
+    }
+}
+
 __global__ void __launch_bounds__(256) sum_kernel(const float *x, int n, float *out) {
     __shared__ float sh[256];
     const int tid = threadIdx.x;
@@ -180,6 +215,20 @@ extern "C" TNP_API int tnp_collision_loss_forward(const float *predictions, int 
                        col_distance, partial_ws);
     TNP_HIP(hipGetLastError());
     hipLaunchKernelGGL(tnp::sum_kernel, dim3(1), dim3(256), 0, s, partial_ws, B, out);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" TNP_API int tnp_collision_loss_backward(const float *predictions, int ld, const int32_t *scene_start, int B,
+                                                   int T, int M, float col_wt, float col_distance, const float *grad_out,
+                                                   float *d_predictions, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (T <= 0 || M <= 0) return 0;
+    if (ld < 2) TNP_FAIL(-1, "tnp_collision_loss_backward: ld %d < 2", ld);
+    TNP_HIP(hipMemsetAsync(d_predictions, 0, (size_t)T * M * ld * sizeof(float), s));
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(tnp::collision_backward_kernel, dim3(B, T), dim3(64), 0, s, predictions, ld, scene_start, T, M, col_wt,
+                       col_distance, grad_out, d_predictions);
     TNP_HIP(hipGetLastError());
     return 0;
 }

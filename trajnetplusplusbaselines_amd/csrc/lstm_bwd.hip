@@ -815,7 +815,7 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
         if (grid) {
             if (a->grid_all) {   // the dense grid is the only intermediate that is recomputed
                 TNP_RC(tnp_pool_grid_forward(md->pool_type, o1, o2, social ? sv->enc_all + r * C : nullptr, C, a->scene_start, a->B,
-                                             a->n_max, md->n, C, md->cell, md->half_x, md->half_y, md->constant,
+                                             a->n_max, a->scene_slots, md->n, C, md->cell, md->half_x, md->half_y, md->constant,
                                              a->grid_all + r * md->dims[0], md->dims[0], nullptr, stream));
             }
             // (last layer: its ReLU output is the pooled part of X, masked above)
@@ -899,7 +899,7 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
             TNP_RC(tnp_linear_forward(es, D, md->Wx[0], D, md->bx[0], qs, D, M, D, D, 0, 0, stream));                  // q
             TNP_RC(tnp_linear_forward(qs, D, md->Wx[1], D, nullptr, w.at_u, LU, M, LU, D, 0, 0, stream));              // u
             float *dus = a->at_du_all + r * LU;
-            TNP_RC(tnp_pool_attn_pair_backward(o1, o2, hpre, mh, a->scene_start, a->B, a->n_max, ms, mv, mh, md->Wp[0], md->bp[0],
+            TNP_RC(tnp_pool_attn_pair_backward(o1, o2, hpre, mh, a->scene_start, a->B, a->n_max, a->scene_slots, ms, mv, mh, md->Wp[0], md->bp[0],
                                                md->Wp[1], md->bp[1], md->constant, w.at_u, LU, w.d_pooled, D, dus,
                                                a->at_A_all + r * GDm * 3, w.at_deh, a->at_ebar_all + r * D, D, stream));
             float *dqs = a->at_dq_all + r * D;

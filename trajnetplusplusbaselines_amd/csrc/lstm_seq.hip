@@ -250,6 +250,7 @@ struct Workspace {
     float *pc_out, *pgates_save, *traj_in_save;   // stateful interaction encoders under tnp_lstm_forward_train
     float *pvec_save;                             // pool_to_input=False: the interaction vector before it is added to h
     int32_t *row_end;                             // sparse path: one past the last row of every row's scene
+    int32_t *row_padded;                          // sparse path: slots the reference pads the row's scene to
     int fuse_grid, save_winners;                  // winner tile built inside the sparse kernel; table wanted by the caller
     size_t bytes;
 };
@@ -289,11 +290,13 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     w.mask = (uint8_t *)take((size_t)M);
     w.sparse = grid_pool && md->pool_type == TNP_POOL_SOCIAL && md->Wp0_cell_major != nullptr && md->constant == 0.0f &&
                ((md->variant >> 16) & 1) == 0 && sparse_supported(md->C, md->dims[1], md->n * md->n) && (w.I % 4 == 0);
-    w.winners = nullptr; w.row_base = nullptr; w.partial = nullptr; w.row_end = nullptr; w.fuse_grid = 0; w.save_winners = 0;
+    w.winners = nullptr; w.row_base = nullptr; w.partial = nullptr; w.row_end = nullptr; w.row_padded = nullptr; w.fuse_grid = 0;
+    w.save_winners = 0;
     if (w.sparse) {
         w.winners = (int16_t *)take((size_t)M * md->n * md->n * sizeof(int16_t));
         w.row_base = (int32_t *)take((size_t)M * sizeof(int32_t));
         w.row_end = (int32_t *)take((size_t)M * sizeof(int32_t));
+        w.row_padded = (int32_t *)take((size_t)M * sizeof(int32_t));
         // default kernel variant only (bits 0-15 of `variant` select measurement variants that read the winner table)
         w.fuse_grid = (md->variant & 0xFFFF) == 0 && sparse_fuses_grid(md->n * md->n, 32767) &&
                       (size_t)M * md->C * sizeof(float) < ((size_t)1 << 32) && getenv("TNP_SPARSE_VARIANT") == nullptr &&
@@ -372,7 +375,7 @@ __global__ void add_rows_kernel(float *__restrict__ y, const float *__restrict__
 // pool + gates of one step; obs/mask/X[:,0:E+GD]/enc already prepared
 static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, const float *h_in, float *h_out,
                          const float *c_in, float *c_out, const int32_t *scene_start, int B, int M, int n_max,
-                         hipStream_t s) {
+                         const int32_t *scene_slots, hipStream_t s) {
     const int H = md->H;
     if (md->pool_type == TNP_POOL_NN) {          // NearestNeighborMLP straight into the pooled columns of X
         int rc = launch_pool_nn(w.obs1, w.obs2, scene_start, B, md->n, md->C, md->Wp[0], md->bp[0], md->P / md->n,
@@ -436,7 +439,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
         g.M = M; g.N = D + 4; g.C = w.y[0]; g.ldc = D + 4;
         rc = launch_linear(g, 0, s);
         if (rc) return rc;
-        rc = launch_pool_attn_pair(w.obs1, w.obs2, henc, mh, 1, scene_start, B, n_max, ms, mv, mh, md->Wp[0], md->bp[0],
+        rc = launch_pool_attn_pair(w.obs1, w.obs2, henc, mh, 1, scene_start, B, n_max, scene_slots, ms, mv, mh, md->Wp[0], md->bp[0],
                                    md->Wp[1], md->bp[1], md->constant, w.y[0], D + 4, w.y[1], D, s);
         if (rc) return rc;
         memset(&g, 0, sizeof(g));                      // pooled = Wfin ebar + bfin
@@ -447,7 +450,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
     } else if (md->pool_type != TNP_POOL_NONE) {
         GridArgs ga;
         ga.obs1 = w.obs1; ga.obs2 = w.obs2; ga.values = w.enc; ga.ldv = md->C; ga.scene_start = scene_start;
-        ga.B = B; ga.n_max = n_max; ga.type = md->pool_type; ga.n = md->n; ga.C = md->C;
+        ga.B = B; ga.n_max = n_max; ga.scene_slots = scene_slots; ga.type = md->pool_type; ga.n = md->n; ga.C = md->C;
         ga.cell = md->cell; ga.half_x = md->half_x; ga.half_y = md->half_y; ga.constant = md->constant;
         ga.grid = w.sparse ? nullptr : w.grid; ga.ldg = w.ldg; ga.winners = w.sparse ? w.winners : nullptr;
         const bool fused_grid = w.sparse && w.fuse_grid && n_max <= 32767;
@@ -462,7 +465,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
             const int ldo = last ? w.pld : md->dims[1];
             prof_before(PROF_GEMM1, s);
             SparseGridFuse fg;
-            fg.obs2 = w.obs2; fg.row_end = w.row_end; fg.n_max = n_max; fg.G = md->n;
+            fg.obs2 = w.obs2; fg.row_end = w.row_end; fg.row_padded = w.row_padded; fg.G = md->n;
             fg.cell = md->cell; fg.half_x = md->half_x; fg.half_y = md->half_y;
             fg.winners_out = w.save_winners ? w.winners : nullptr;
             rc = launch_pool_embed_sparse(w.winners, w.enc, md->C, w.row_base, md->Wp0_cell_major, md->bp[0], M,
@@ -560,8 +563,8 @@ extern "C" TNP_API int tnp_lstm_sparse_first_layer(const tnp_lstm_model *model, 
 
 static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, int T_obs, int M,
                              const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
-                             int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
-                             void *workspace, size_t workspace_bytes, const tnp_lstm_extras *ex,
+                             int B, int n_max, const int32_t *scene_slots, const float *truth, int T_dec, float *rel_pred,
+                             float *pred, void *workspace, size_t workspace_bytes, const tnp_lstm_extras *ex,
                              const tnp_train_saves *sv, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc = validate_model(md);
@@ -586,7 +589,7 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
         TNP_FAIL(-1, "workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
     const size_t F = (size_t)M * 2;
     const int H = md->H;
-    if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s, w.row_end); if (rc) return rc; }
+    if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s, w.row_end, w.row_padded, scene_slots, n_max); if (rc) return rc; }
     const size_t MH = (size_t)M * H;
     // training: the states of all steps stay in the caller's [steps + 1, M, H] buffers instead of the ping-pong pair
     float *hcur = sv ? sv->h_all : w.h[0];
@@ -698,7 +701,7 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
             float *hnext = sv ? sv->h_all + (size_t)(st + 1) * MH : w.h[cur ^ 1];
             const float *c_in = sv ? sv->c_all + (size_t)st * MH : w.c;
             float *c_out = sv ? sv->c_all + (size_t)(st + 1) * MH : w.c;
-            rc = run_step_body(md, decoder, w, hcur, hnext, c_in, c_out, scene_start, B, M, n_max, s);
+            rc = run_step_body(md, decoder, w, hcur, hnext, c_in, c_out, scene_start, B, M, n_max, scene_slots, s);
             if (rc) return rc;
             cur ^= 1;
             hcur = hnext;
@@ -710,35 +713,35 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
 
 extern "C" TNP_API int tnp_lstm_forward_train(const tnp_lstm_model *md, const float *observed, int T_obs, int M,
                                       const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
-                                      int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
-                                      void *workspace, size_t workspace_bytes, const tnp_lstm_extras *extras,
-                                      const tnp_train_saves *saves, void *stream) {
+                                      int B, int n_max, const int32_t *scene_slots, const float *truth, int T_dec,
+                                      float *rel_pred, float *pred, void *workspace, size_t workspace_bytes,
+                                      const tnp_lstm_extras *extras, const tnp_train_saves *saves, void *stream) {
     if (!saves) TNP_FAIL(-1, "tnp_lstm_forward_train: saves == NULL");
-    return lstm_forward_impl(md, observed, T_obs, M, goals, scene_start, primary_flag, B, n_max, truth, T_dec, rel_pred,
+    return lstm_forward_impl(md, observed, T_obs, M, goals, scene_start, primary_flag, B, n_max, scene_slots, truth, T_dec, rel_pred,
                              pred, workspace, workspace_bytes, extras, saves, stream);
 }
 
 extern "C" TNP_API int tnp_lstm_forward(const tnp_lstm_model *md, const float *observed, int T_obs, int M,
                                 const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
-                                int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
-                                void *workspace, size_t workspace_bytes, void *stream) {
-    return lstm_forward_impl(md, observed, T_obs, M, goals, scene_start, primary_flag, B, n_max, truth, T_dec, rel_pred,
+                                int B, int n_max, const int32_t *scene_slots, const float *truth, int T_dec, float *rel_pred,
+                                float *pred, void *workspace, size_t workspace_bytes, void *stream) {
+    return lstm_forward_impl(md, observed, T_obs, M, goals, scene_start, primary_flag, B, n_max, scene_slots, truth, T_dec, rel_pred,
                              pred, workspace, workspace_bytes, nullptr, nullptr, stream);
 }
 
 extern "C" TNP_API int tnp_lstm_forward_ex(const tnp_lstm_model *md, const float *observed, int T_obs, int M,
                                    const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
-                                   int B, int n_max, const float *truth, int T_dec, float *rel_pred, float *pred,
-                                   void *workspace, size_t workspace_bytes, const tnp_lstm_extras *extras,
+                                   int B, int n_max, const int32_t *scene_slots, const float *truth, int T_dec, float *rel_pred,
+                                   float *pred, void *workspace, size_t workspace_bytes, const tnp_lstm_extras *extras,
                                    void *stream) {
-    return lstm_forward_impl(md, observed, T_obs, M, goals, scene_start, primary_flag, B, n_max, truth, T_dec, rel_pred,
+    return lstm_forward_impl(md, observed, T_obs, M, goals, scene_start, primary_flag, B, n_max, scene_slots, truth, T_dec, rel_pred,
                              pred, workspace, workspace_bytes, extras, nullptr, stream);
 }
 
 static int lstm_step_impl(const tnp_lstm_model *md, int decoder, const float *h_in, const float *c_in,
                              const float *obs1, const float *obs2, const float *goals, const int32_t *scene_start,
-                             int B, int M, int n_max, float *h_out, float *c_out, float *normal, void *workspace,
-                             size_t workspace_bytes, const tnp_step_saves *sv, void *stream) {
+                             int B, int M, int n_max, const int32_t *scene_slots, float *h_out, float *c_out, float *normal,
+                             void *workspace, size_t workspace_bytes, const tnp_step_saves *sv, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc = validate_model(md);
     if (rc) return rc;
@@ -759,7 +762,7 @@ static int lstm_step_impl(const tnp_lstm_model *md, int decoder, const float *h_
         w.nn_attrs_save = sv->nn_attrs;
         if (sv->winners && w.sparse) { w.winners = sv->winners; w.save_winners = 1; }
     }
-    if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s, w.row_end); if (rc) return rc; }
+    if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s, w.row_end, w.row_padded, scene_slots, n_max); if (rc) return rc; }
     PrepArgs p;
     fill_prep_common(p, md, w, M);
     p.h = h_in; p.goals = goals;
@@ -769,7 +772,7 @@ static int lstm_step_impl(const tnp_lstm_model *md, int decoder, const float *h_
     p.primary = w.mask;  // any valid [M] byte buffer (unused: patch1 = patch2 = 0)
     rc = launch_prepare(p, s);
     if (rc) return rc;
-    rc = run_step_body(md, decoder, w, h_in, h_out, c_in, c_out, scene_start, B, M, n_max, s);
+    rc = run_step_body(md, decoder, w, h_in, h_out, c_in, c_out, scene_start, B, M, n_max, scene_slots, s);
     if (rc) return rc;
     // Hidden2Normal of the new state; positions are the caller's business in step mode
     PrepArgs q;
@@ -781,18 +784,18 @@ static int lstm_step_impl(const tnp_lstm_model *md, int decoder, const float *h_
 
 extern "C" TNP_API int tnp_lstm_step(const tnp_lstm_model *md, int decoder, const float *h_in, const float *c_in,
                              const float *obs1, const float *obs2, const float *goals, const int32_t *scene_start,
-                             int B, int M, int n_max, float *h_out, float *c_out, float *normal, void *workspace,
-                             size_t workspace_bytes, void *stream) {
-    return lstm_step_impl(md, decoder, h_in, c_in, obs1, obs2, goals, scene_start, B, M, n_max, h_out, c_out, normal,
+                             int B, int M, int n_max, const int32_t *scene_slots, float *h_out, float *c_out, float *normal,
+                             void *workspace, size_t workspace_bytes, void *stream) {
+    return lstm_step_impl(md, decoder, h_in, c_in, obs1, obs2, goals, scene_start, B, M, n_max, scene_slots, h_out, c_out, normal,
                           workspace, workspace_bytes, nullptr, stream);
 }
 
 extern "C" TNP_API int tnp_lstm_step_train(const tnp_lstm_model *md, int decoder, const float *h_in, const float *c_in,
                                    const float *obs1, const float *obs2, const float *goals,
-                                   const int32_t *scene_start, int B, int M, int n_max, float *h_out, float *c_out,
-                                   float *normal, const tnp_step_saves *saves, void *workspace,
+                                   const int32_t *scene_start, int B, int M, int n_max, const int32_t *scene_slots,
+                                   float *h_out, float *c_out, float *normal, const tnp_step_saves *saves, void *workspace,
                                    size_t workspace_bytes, void *stream) {
-    return lstm_step_impl(md, decoder, h_in, c_in, obs1, obs2, goals, scene_start, B, M, n_max, h_out, c_out, normal,
+    return lstm_step_impl(md, decoder, h_in, c_in, obs1, obs2, goals, scene_start, B, M, n_max, scene_slots, h_out, c_out, normal,
                           workspace, workspace_bytes, saves, stream);
 }
 

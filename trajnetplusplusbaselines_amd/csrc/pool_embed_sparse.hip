@@ -49,7 +49,8 @@ struct SparseArgs {
     // fused grid build (cell-split kernel, FG): the winner tile is computed from the positions instead of read
     const float *obs2;           // [M][2] current positions (NaN = absent)
     const int32_t *row_end;      // [M] one past the last row of the row's scene
-    int n_max, G;                // padded slot count of the reference (cell-0 clobber rule), cells per side
+    const int32_t *row_padded;   // [M] slots the reference pads the row's scene to (cell-0 clobber rule)
+    int G;                       // cells per side
     float cell, half_x, half_y;
     int16_t *winners_out;        // optional [M][ncell]: the winner table for the training backward
 };
@@ -237,19 +238,24 @@ __global__ void __launch_bounds__(256) sparse_reduce_kernel(const float *partial
     }
 }
 
-__global__ void row_base_kernel(const int32_t *scene_start, int B, int32_t *row_base, int32_t *row_end) {
+__global__ void row_base_kernel(const int32_t *scene_start, int B, int32_t *row_base, int32_t *row_end, int32_t *row_padded,
+                                const int32_t *scene_slots, int n_max) {
     const int s = blockIdx.x;
     if (s >= B) return;
     const int lo = scene_start[s], hi = scene_start[s + 1];
+    const int pad = scene_slots ? scene_slots[s] : n_max;
     for (int r = lo + threadIdx.x; r < hi; r += blockDim.x) {
         row_base[r] = lo;
         if (row_end) row_end[r] = hi;
+        if (row_padded) row_padded[r] = pad;
     }
 }
 
-int launch_row_base(const int32_t *scene_start, int B, int32_t *row_base, hipStream_t s, int32_t *row_end) {
+int launch_row_base(const int32_t *scene_start, int B, int32_t *row_base, hipStream_t s, int32_t *row_end, int32_t *row_padded,
+                    const int32_t *scene_slots, int n_max) {
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(row_base_kernel, dim3(B), dim3(64), 0, s, scene_start, B, row_base, row_end);
+    hipLaunchKernelGGL(row_base_kernel, dim3(B), dim3(64), 0, s, scene_start, B, row_base, row_end, row_padded, scene_slots,
+                       n_max);
     TNP_HIP(hipGetLastError());
     return 0;
 }
@@ -336,7 +342,8 @@ __global__ void __launch_bounds__(64 * TL_NQ * (8192 / TE / 64)) pool_embed_cell
                 const int cellid = inr ? ((int)ox * a.G + (int)oy) : 0;
                 atomicMax(&wk[cellid], 2 * j + (inr ? 1 : 0));
             }
-            if (ns < a.n_max && lane == 0) atomicMax(&wk[0], 2 * (a.n_max - 1));
+            const int pad = a.row_padded[row];
+            if (ns < pad && lane == 0) atomicMax(&wk[0], 2 * (pad - 1));
         }
         __syncthreads();
         for (int idx = tid; idx < TE * a.ncell; idx += NTH) {
@@ -544,7 +551,7 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
     SparseArgs a;
     a.winners = winners; a.enc = enc; a.ldv = ldv; a.row_base = row_base; a.Wp = Wp; a.bias = bias;
     a.M = M; a.ncell = ncell; a.C = C; a.N1 = N1; a.relu = relu; a.ldo = ldo;
-    a.obs2 = nullptr; a.row_end = nullptr; a.n_max = 0; a.G = 0; a.cell = 1.0f; a.half_x = a.half_y = 0.0f; a.winners_out = nullptr;
+    a.obs2 = nullptr; a.row_end = nullptr; a.row_padded = nullptr; a.G = 0; a.cell = 1.0f; a.half_x = a.half_y = 0.0f; a.winners_out = nullptr;
     if (ncell <= TL_MAXCELL_LDS && (sp_variant == 6 || sp_variant == 7) && C == 16) {
         // experiment: 64-ego tiles (assumes n_max <= 127: int8 winner tile)
         a.out = out;
@@ -566,7 +573,7 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
         // the lean path addresses neighbour rows with a 32-bit byte offset
         const bool lean = (size_t)M * ldv * sizeof(float) < ((size_t)1 << 32) && sp_variant != 2;
         if (fg && lean && sp_variant == 0) {   // winner tile computed in the kernel: no grid kernel, no winner table
-            a.obs2 = fg->obs2; a.row_end = fg->row_end; a.n_max = fg->n_max; a.G = fg->G;
+            a.obs2 = fg->obs2; a.row_end = fg->row_end; a.row_padded = fg->row_padded; a.G = fg->G;
             a.cell = fg->cell; a.half_x = fg->half_x; a.half_y = fg->half_y; a.winners_out = fg->winners_out;
 #define CS_LAUNCH_FG(CC) { static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
         pool_embed_cellsplit_kernel<CC, 2, 2, true, 0, TL_TE, int16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \

@@ -29,6 +29,7 @@ __global__ void __launch_bounds__(256) grid_build_kernel(const GridArgs a) {
     const int start = a.scene_start[s];
     const int ns = a.scene_start[s + 1] - start;
     const int ego0 = blockIdx.x * TNP_GRID_EGOS;
+    const int pad = a.scene_slots ? a.scene_slots[s] : a.n_max;   // slots the reference pads this scene to
     if (ego0 >= ns) return;  // uniform for the workgroup
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(256) grid_build_kernel(const GridArgs a) {
                 atomicMax(&win[cell], 2 * j + (inr ? 1 : 0));
             }
             // slots the reference pads this scene with (lstm/lstm.py:29-40): absent, highest j, cell 0
-            if (ns < a.n_max && lane == 0) atomicMax(&win[0], 2 * (a.n_max - 1));
+            if (ns < pad && lane == 0) atomicMax(&win[0], 2 * (pad - 1));
         }
         __syncthreads();
         if (active) {
@@ -196,14 +197,14 @@ extern "C" TNP_API int tnp_pool_pair_cells(const float *obs2, const int32_t *row
 }
 
 extern "C" TNP_API int tnp_pool_grid_forward(int type, const float *obs1, const float *obs2, const float *values, int ldv,
-                                     const int32_t *scene_start, int B, int n_max, int n, int C, float cell,
-                                     float half_x, float half_y, float constant, float *grid, int ldg,
+                                     const int32_t *scene_start, int B, int n_max, const int32_t *scene_slots, int n, int C,
+                                     float cell, float half_x, float half_y, float constant, float *grid, int ldg,
                                      int16_t *winners, void *stream) {
     if (type < TNP_POOL_OCCUPANCY || type > TNP_POOL_SOCIAL) TNP_FAIL(-1, "unknown pooling type %d", type);
     if (type == TNP_POOL_SOCIAL && values == nullptr) TNP_FAIL(-1, "social pooling needs per-track values");
     tnp::GridArgs a;
     a.obs1 = obs1; a.obs2 = obs2; a.values = values; a.ldv = ldv; a.scene_start = scene_start;
-    a.B = B; a.n_max = n_max; a.type = type; a.n = n; a.C = C;
+    a.B = B; a.n_max = n_max; a.scene_slots = scene_slots; a.type = type; a.n = n; a.C = C;
     a.cell = cell; a.half_x = half_x; a.half_y = half_y; a.constant = constant;
     a.grid = grid; a.ldg = ldg; a.winners = winners;
     return tnp::launch_grid(a, (hipStream_t)stream);

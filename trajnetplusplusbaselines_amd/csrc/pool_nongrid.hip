@@ -308,7 +308,8 @@ constexpr int ATT_MAXD_PER_LANE = 4;   // D <= 256
 // one wave per ego (blockIdx.x = scene, blockIdx.y strides over its egos); lane <-> dims lane, lane + 64, ...
 __global__ void __launch_bounds__(64) pool_attn_pair_kernel(const float *__restrict__ obs1, const float *__restrict__ obs2,
                                                             const float *__restrict__ henc, int ldh, int henc_relu,
-                                                            const int32_t *__restrict__ scene_start, int n_max, int ms,
+                                                            const int32_t *__restrict__ scene_start, int n_max,
+                                                            const int32_t *__restrict__ scene_slots, int ms,
                                                             int mv, int mh, const float *__restrict__ Ws,
                                                             const float *__restrict__ bs, const float *__restrict__ Wv,
                                                             const float *__restrict__ bv, float fill,
@@ -318,7 +319,7 @@ __global__ void __launch_bounds__(64) pool_attn_pair_kernel(const float *__restr
     const int lo = scene_start[blockIdx.x], hi = scene_start[blockIdx.x + 1];
     const int D = ms + mh + mv, lane = threadIdx.x;
     const float scale = 1.0f / sqrtf((float)D);
-    const int npad = n_max - (hi - lo);                    // virtual padded slots: [fill.., 0.., fill..]
+    const int npad = (scene_slots ? scene_slots[blockIdx.x] : n_max) - (hi - lo);   // virtual padded slots: [fill.., 0.., fill..]
     float w0[ATT_MAXD_PER_LANE], w1[ATT_MAXD_PER_LANE], b0[ATT_MAXD_PER_LANE];
 #pragma unroll
     for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) {
@@ -415,7 +416,8 @@ __global__ void __launch_bounds__(64) pool_attn_pair_kernel(const float *__restr
 // operand of the folded value / output projections' weight gradients).
 __global__ void __launch_bounds__(64) pool_attn_pair_backward_kernel(const float *__restrict__ obs1, const float *__restrict__ obs2,
                                                                      const float *__restrict__ henc, int ldh,
-                                                                     const int32_t *__restrict__ scene_start, int n_max, int ms,
+                                                                     const int32_t *__restrict__ scene_start, int n_max,
+                                                                     const int32_t *__restrict__ scene_slots, int ms,
                                                                      int mv, int mh, const float *__restrict__ Ws,
                                                                      const float *__restrict__ bs, const float *__restrict__ Wv,
                                                                      const float *__restrict__ bv, float fill,
@@ -428,7 +430,7 @@ __global__ void __launch_bounds__(64) pool_attn_pair_backward_kernel(const float
     float *att_a = att_sc, *att_da = att_sc + n_max;
     const int D = ms + mh + mv, GD = ms + mv, lane = threadIdx.x;
     const float scale = 1.0f / sqrtf((float)D);
-    const int npad = n_max - ns;
+    const int npad = (scene_slots ? scene_slots[blockIdx.x] : n_max) - ns;
     float w0[ATT_MAXD_PER_LANE], w1[ATT_MAXD_PER_LANE], b0[ATT_MAXD_PER_LANE];
 #pragma unroll
     for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) {
@@ -602,15 +604,15 @@ int launch_pool_attn_self(const float *obs1, const float *obs2, const float *hen
 }
 
 int launch_pool_attn_pair(const float *obs1, const float *obs2, const float *henc, int ldh, int henc_relu,
-                          const int32_t *scene_start, int B, int n_max, int ms, int mv, int mh, const float *Ws,
-                          const float *bs, const float *Wv, const float *bv, float fill, const float *u, int ldu,
-                          float *ebar, int lde, hipStream_t s) {
+                          const int32_t *scene_start, int B, int n_max, const int32_t *scene_slots, int ms, int mv, int mh,
+                          const float *Ws, const float *bs, const float *Wv, const float *bv, float fill, const float *u,
+                          int ldu, float *ebar, int lde, hipStream_t s) {
     if (B <= 0) return 0;
     const int D = ms + mh + mv;
     if (D > 64 * ATT_MAXD_PER_LANE) TNP_FAIL(-1, "AttentionMLPPooling: mlp_dim %d > %d", D, 64 * ATT_MAXD_PER_LANE);
     if (n_max < 1 || (size_t)n_max * 4 > 60000) TNP_FAIL(-1, "AttentionMLPPooling: n_max %d out of range", n_max);
     hipLaunchKernelGGL(pool_attn_pair_kernel, dim3(B, 16), dim3(64), (size_t)n_max * sizeof(float), s, obs1, obs2, henc, ldh,
-                       henc_relu, scene_start, n_max, ms, mv, mh, Ws, bs, Wv, bv, fill, u, ldu, ebar, lde);
+                       henc_relu, scene_start, n_max, scene_slots, ms, mv, mh, Ws, bs, Wv, bv, fill, u, ldu, ebar, lde);
     TNP_HIP(hipGetLastError());
     return 0;
 }
@@ -703,11 +705,12 @@ extern "C" TNP_API int tnp_pool_attn_self(const float *obs1, const float *obs2, 
 }
 
 extern "C" TNP_API int tnp_pool_attn_pair(const float *obs1, const float *obs2, const float *hidden_emb, int ldh,
-                                          int hidden_emb_relu, const int32_t *scene_start, int B, int n_max, int ms,
-                                          int mv, int mh, const float *W_spatial, const float *b_spatial,
+                                          int hidden_emb_relu, const int32_t *scene_start, int B, int n_max,
+                                          const int32_t *scene_slots, int ms, int mv, int mh, const float *W_spatial,
+                                          const float *b_spatial,
                                           const float *W_vel, const float *b_vel, float fill, const float *u, int ldu,
                                           float *ebar, int lde, void *stream) {
-    return tnp::launch_pool_attn_pair(obs1, obs2, hidden_emb, ldh, hidden_emb_relu, scene_start, B, n_max, ms, mv, mh,
+    return tnp::launch_pool_attn_pair(obs1, obs2, hidden_emb, ldh, hidden_emb_relu, scene_start, B, n_max, scene_slots, ms, mv, mh,
                                       W_spatial, b_spatial, W_vel, b_vel, fill, u, ldu, ebar, lde, (hipStream_t)stream);
 }
 
@@ -759,7 +762,8 @@ extern "C" TNP_API int tnp_colsum_prod(const float *G, const float *R, long rows
 }
 
 extern "C" TNP_API int tnp_pool_attn_pair_backward(const float *obs1, const float *obs2, const float *hidden_emb_pre, int ldh,
-                                                   const int32_t *scene_start, int B, int n_max, int ms, int mv, int mh,
+                                                   const int32_t *scene_start, int B, int n_max, const int32_t *scene_slots,
+                                                   int ms, int mv, int mh,
                                                    const float *W_spatial, const float *b_spatial, const float *W_vel,
                                                    const float *b_vel, float fill, const float *u, int ldu, const float *d_ebar,
                                                    int ldd, float *du, float *A3, float *dEh, float *ebar, int lde, void *stream) {
@@ -769,7 +773,7 @@ extern "C" TNP_API int tnp_pool_attn_pair_backward(const float *obs1, const floa
     if (n_max < 1 || (size_t)n_max * 8 > 60000) TNP_FAIL(-1, "AttentionMLPPooling: n_max %d out of range", n_max);
     if (ldu < D + 1) TNP_FAIL(-1, "tnp_pool_attn_pair_backward: ldu %d < mlp_dim + 1", ldu);
     hipLaunchKernelGGL(tnp::pool_attn_pair_backward_kernel, dim3(B, 16), dim3(64), (size_t)n_max * 2 * sizeof(float),
-                       (hipStream_t)stream, obs1, obs2, hidden_emb_pre, ldh, scene_start, n_max, ms, mv, mh, W_spatial, b_spatial,
+                       (hipStream_t)stream, obs1, obs2, hidden_emb_pre, ldh, scene_start, n_max, scene_slots, ms, mv, mh, W_spatial, b_spatial,
                        W_vel, b_vel, fill, u, ldu, d_ebar, ldd, du, A3, dEh, ebar, lde);
     TNP_HIP(hipGetLastError());
     return 0;

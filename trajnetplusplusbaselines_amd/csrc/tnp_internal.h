@@ -48,6 +48,7 @@ struct GridArgs {
     const float *values; int ldv;
     const int32_t *scene_start;
     int B, n_max, type, n, C;
+    const int32_t *scene_slots;   // [B] padded slot count per scene, NULL = n_max for every scene
     float cell, half_x, half_y, constant;
     float *grid; int ldg;
     int16_t *winners;
@@ -58,10 +59,11 @@ int launch_grid(const GridArgs &a, hipStream_t s);
 // ---- sparse pooling embedding (first MLP layer on the winner table) ---------------------------
 bool sparse_supported(int C, int N1, int ncell);
 size_t sparse_partial_bytes(int M, int N1, int ncell);
-int launch_row_base(const int32_t *scene_start, int B, int32_t *row_base, hipStream_t s, int32_t *row_end = nullptr);
+int launch_row_base(const int32_t *scene_start, int B, int32_t *row_base, hipStream_t s, int32_t *row_end = nullptr,
+                    int32_t *row_padded = nullptr, const int32_t *scene_slots = nullptr, int n_max = 0);
 // optional: build the winner tile inside the cell-split kernel from the positions (no grid kernel, no winner table)
 struct SparseGridFuse {
-    const float *obs2; const int32_t *row_end; int n_max, G; float cell, half_x, half_y; int16_t *winners_out;
+    const float *obs2; const int32_t *row_end; const int32_t *row_padded; int G; float cell, half_x, half_y; int16_t *winners_out;
 };
 bool sparse_fuses_grid(int ncell, int n_max);
 int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, const int32_t *row_base,
@@ -79,9 +81,9 @@ int launch_pool_attn_self(const float *obs1, const float *obs2, const float *hen
                           int mv, int mh, const float *bs, const float *bv, float fill, float *e_self, int lde,
                           hipStream_t s);
 int launch_pool_attn_pair(const float *obs1, const float *obs2, const float *henc, int ldh, int henc_relu,
-                          const int32_t *scene_start, int B, int n_max, int ms, int mv, int mh, const float *Ws,
-                          const float *bs, const float *Wv, const float *bv, float fill, const float *u, int ldu,
-                          float *ebar, int lde, hipStream_t s);
+                          const int32_t *scene_start, int B, int n_max, const int32_t *scene_slots, int ms, int mv, int mh,
+                          const float *Ws, const float *bs, const float *Wv, const float *bv, float fill, const float *u,
+                          int ldu, float *ebar, int lde, hipStream_t s);
 
 int launch_pool_traj(const float *obs1, const float *obs2, int M, const float *W, const float *bias, int P, float *out,
                      int ldo, double *scratch4, hipStream_t s, float *inputs = nullptr);

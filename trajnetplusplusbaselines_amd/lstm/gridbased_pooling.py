@@ -135,7 +135,7 @@ class GridBasedPooling(torch.nn.Module):
         vals = _lib.f32c(values, dev).reshape(B * N, -1) if values is not None else None
         _lib.check(_lib.lib().tnp_pool_grid_forward(
             type_id, _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(vals), vals.stride(0) if vals is not None else 0,
-            _lib.ptr(starts), B, N, G, C, cell, half_x, half_y, float(self.constant),
+            _lib.ptr(starts), B, N, None, G, C, cell, half_x, half_y, float(self.constant),
             _lib.ptr(grid), C * G * G, _lib.ptr(winners), _lib.stream_ptr()), 'tnp_pool_grid_forward')
         return grid, winners
 

@@ -1,42 +1,13 @@
 """Losses of the reference's lstm/loss.py (same class names and call signatures), evaluated on the primaries of a
 batch by csrc/loss.hip: forward values and, on the training path, the analytic backward (tnp_primary_loss_backward)."""
-import math
-
 import torch
 
 from .. import _lib
 
 
-def _gaussian_2d(p, x):
-    """differentiable restatement of lstm/loss.py:23-50 on device tensors (training path only)"""
-    norm1, norm2 = x[:, 0] - p[:, 0], x[:, 1] - p[:, 1]
-    s1, s2, rho = p[:, 2], p[:, 3], p[:, 4]
-    s1s2 = s1 * s2
-    z = (norm1 / s1) ** 2 + (norm2 / s2) ** 2 - 2 * rho * norm1 * norm2 / s1s2
-    return torch.exp(-z / (2 * (1 - rho ** 2))) / (2 * math.pi * s1s2 * torch.sqrt(1 - rho ** 2))
-
-
-def _primary_loss_autograd(mode, inputs, targets, batch_split, background_rate, keep_batch_dim, scale):
-    """Loss on the [T, B] primaries with autograd (tiny tensors; the heavy part of the backward is lstm/training.py)."""
-    dev = inputs.device
-    split = torch.as_tensor(batch_split, dtype=torch.int64).to(dev)
-    prim = split[:-1]
-    T, B = inputs.size(0), prim.numel()
-    inp = inputs[:, prim].reshape(-1, 5)
-    tgt = _lib.f32c(targets.detach(), dev)[:, prim].reshape(-1, 2)
-    if mode == 0:
-        bg = inp.clone()
-        bg[:, 2], bg[:, 3], bg[:, 4] = 3.0, 3.0, 0.0
-        values = -torch.log(0.01 + background_rate * _gaussian_2d(bg, tgt) + (0.99 - background_rate) * _gaussian_2d(inp, tgt))
-        values = values.reshape(T, B)
-        return (values.mean(dim=0) if keep_batch_dim else values.mean()) * scale
-    sq = ((inp[:, :2] - tgt) ** 2).reshape(T, B, 2)
-    return (sq.mean(dim=0).mean(dim=1) if keep_batch_dim else sq.mean()) * (scale * 2.0)
-
-
 class _PrimaryLossFn(torch.autograd.Function):
     """loss = tnp_primary_loss_forward(inputs, ...); d(loss)/d(inputs) by tnp_primary_loss_backward: two launches each
-    instead of the ~60 elementwise kernels of the tensor expression above."""
+    instead of the ~60 elementwise kernels of the same expression written with tensor ops."""
 
     @staticmethod
     def forward(ctx, inputs, targets, batch_split, mode, background_rate, keep_batch_dim, scale):
@@ -84,19 +55,47 @@ def _primary_loss(mode, inputs, targets, batch_split, background_rate, keep_batc
     return out if keep_batch_dim else out[0]
 
 
-def CollisionLoss(predictions, batch_split, col_wt=10.0, col_distance=0.2):
-    """Penalises primary predictions that come closer than col_distance to a neighbour (lstm/loss.py:138-162)."""
-    _lib.require_device(predictions, 'predictions')
-    dev = predictions.device
-    pred = _lib.f32c(predictions.detach())
+def _collision_forward(pred, idx, col_wt, col_distance):
     T, M, ld = pred.shape
-    idx = _lib.SceneIndex.get(batch_split, dev)
-    partial = torch.empty(idx.B, dtype=torch.float32, device=dev)
-    out = torch.empty(1, dtype=torch.float32, device=dev)
+    partial = torch.empty(idx.B, dtype=torch.float32, device=pred.device)
+    out = torch.empty(1, dtype=torch.float32, device=pred.device)
     _lib.check(_lib.lib().tnp_collision_loss_forward(_lib.ptr(pred), ld, _lib.ptr(idx.starts), idx.B, T, M, float(col_wt),
                                                      float(col_distance), _lib.ptr(partial), _lib.ptr(out),
                                                      _lib.stream_ptr()), 'tnp_collision_loss_forward')
     return out[0]
+
+
+class _CollisionLossFn(torch.autograd.Function):
+    """tnp_collision_loss_forward / tnp_collision_loss_backward: the penalty back-propagates into the primaries'
+    predicted positions (the neighbours are detached, reference lstm/loss.py:155)."""
+
+    @staticmethod
+    def forward(ctx, predictions, batch_split, col_wt, col_distance):
+        pred = _lib.f32c(predictions.detach())
+        idx = _lib.SceneIndex.get(batch_split, pred.device)
+        ctx.args = (pred, idx, float(col_wt), float(col_distance))
+        return _collision_forward(pred, idx, col_wt, col_distance)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        pred, idx, col_wt, col_distance = ctx.args
+        T, M, ld = pred.shape
+        g = _lib.f32c(grad_out.detach(), pred.device).reshape(-1)
+        d_pred = torch.empty_like(pred)
+        _lib.check(_lib.lib().tnp_collision_loss_backward(_lib.ptr(pred), ld, _lib.ptr(idx.starts), idx.B, T, M, col_wt,
+                                                          col_distance, _lib.ptr(g), _lib.ptr(d_pred), _lib.stream_ptr()),
+                   'tnp_collision_loss_backward')
+        return d_pred, None, None, None
+
+
+def CollisionLoss(predictions, batch_split, col_wt=10.0, col_distance=0.2):
+    """Penalises primary predictions that come closer than col_distance to a neighbour (lstm/loss.py:138-162).
+    Differentiable with respect to the primaries' positions, like the reference's."""
+    _lib.require_device(predictions, 'predictions')
+    if predictions.requires_grad and torch.is_grad_enabled():
+        return _CollisionLossFn.apply(predictions, batch_split, col_wt, col_distance)
+    pred = _lib.f32c(predictions.detach())
+    return _collision_forward(pred, _lib.SceneIndex.get(batch_split, pred.device), col_wt, col_distance)
 
 
 class PredictionLoss(torch.nn.Module):

@@ -179,9 +179,10 @@ class LSTM(torch.nn.Module):
         return self._ws, need
 
     # ---- one recurrent step (reference lstm/lstm.py:91-168) -------------------------------------------
-    def step(self, lstm, hidden_cell_state, obs1, obs2, goals, batch_split):
+    def step(self, lstm, hidden_cell_state, obs1, obs2, goals, batch_split, pad_to=None):
         """One masked step.  ``hidden_cell_state`` may be the reference's (list of [H] tensors, list of [H]
-        tensors) or a pair of dense [M,H] tensors; the same kind is returned, with ``normal`` [M,5]."""
+        tensors) or a pair of dense [M,H] tensors; the same kind is returned, with ``normal`` [M,5].
+        ``pad_to``: see ``forward``."""
         m, keep, dev = self._descriptor()
         was_list = isinstance(hidden_cell_state[0], (list, tuple))
         if was_list:
@@ -192,7 +193,7 @@ class LSTM(torch.nn.Module):
         h_in, c_in = _lib.f32c(h_in, dev), _lib.f32c(c_in, dev)
         obs1, obs2 = _lib.f32c(obs1, dev), _lib.f32c(obs2, dev)
         M = obs2.size(0)
-        idx = _lib.SceneIndex.get(batch_split, dev)
+        idx = _lib.SceneIndex.get(batch_split, dev, pad_to)
         if idx.M != M:
             raise ValueError('batch_split covers %d tracks, observations have %d' % (idx.M, M))
         goals_t = _lib.f32c(goals, dev) if (goals is not None and self.goal_flag) else None
@@ -202,15 +203,22 @@ class LSTM(torch.nn.Module):
         normal = torch.empty(M, 5, dtype=torch.float32, device=dev)
         _lib.check(_lib.lib().tnp_lstm_step(
             ctypes.byref(m), decoder, _lib.ptr(h_in), _lib.ptr(c_in), _lib.ptr(obs1), _lib.ptr(obs2),
-            _lib.ptr(goals_t), _lib.ptr(idx.starts), idx.B, M, idx.n_max, _lib.ptr(h_out), _lib.ptr(c_out),
+            _lib.ptr(goals_t), _lib.ptr(idx.starts), idx.B, M, idx.n_max, _lib.ptr(idx.slots), _lib.ptr(h_out), _lib.ptr(c_out),
             _lib.ptr(normal), _lib.ptr(ws), need, _lib.stream_ptr()), 'tnp_lstm_step')
         if was_list:
             return (list(h_out.unbind(0)), list(c_out.unbind(0))), normal
         return (h_out, c_out), normal
 
     # ---- whole sequence (reference lstm/lstm.py:170-264) ----------------------------------------------
-    def forward(self, observed, goals, batch_split, prediction_truth=None, n_predict=None):
-        """observed [T_obs,M,2], goals [M,2], batch_split [B+1] -> (rel_pred_scene [S,M,5], pred_scene [S,M,2])."""
+    def forward(self, observed, goals, batch_split, prediction_truth=None, n_predict=None, pad_to=None):
+        """observed [T_obs,M,2], goals [M,2], batch_split [B+1] -> (rel_pred_scene [S,M,5], pred_scene [S,M,2]).
+
+        ``pad_to`` (extension, keyword only in spirit) names the number of slots the reference would have padded the
+        scenes to (lstm/lstm.py:29: the padded, absent slots clobber cell (0, 0) of shorter scenes' grids and enter
+        AttentionMLPPooling's softmax).  None = the largest scene of this call, i.e. exactly what the reference does
+        with this batch; an int = the largest scene of the WHOLE batch when this call holds a shard of it (results then
+        equal the unsharded batch bit for bit); 'scene' = every scene unpadded, i.e. what one reference call per scene
+        gives (the evaluator); or per-scene slot counts.  See ``_lib.SceneIndex``."""
         assert ((prediction_truth is None) + (n_predict is None)) == 1
         if prediction_truth is not None and isinstance(prediction_truth, (list, tuple)):
             prediction_truth = torch.stack(list(prediction_truth), dim=0)
@@ -224,18 +232,19 @@ class LSTM(torch.nn.Module):
                 raise NotImplementedError('training (backward) through %s is not available on the MI355X path yet; '
                                           'use model.eval() / torch.no_grad() for inference' % type(self.pool).__name__)
             from .training import run_sequence_with_grad
-            rel_pred, pred, _ = run_sequence_with_grad(self, observed, goals, batch_split, prediction_truth, T_dec)
+            rel_pred, pred, _ = run_sequence_with_grad(self, observed, goals, batch_split, prediction_truth, T_dec,
+                                                       {'pad_to': pad_to} if pad_to is not None else None)
             return rel_pred, pred
-        rel_pred, pred, _ = self._run_sequence(observed, goals, batch_split, prediction_truth, T_dec)
+        rel_pred, pred, _ = self._run_sequence(observed, goals, batch_split, prediction_truth, T_dec, pad_to=pad_to)
         return rel_pred, pred
 
     def _run_sequence(self, observed, goals, batch_split, truth, T_dec, w_ctx=None, b_ctx=None, noise=None,
-                      want_h_final=False):
+                      want_h_final=False, pad_to=None):
         """tnp_lstm_forward(_ex): T_obs-1 encoder steps + T_dec decoder steps; optional S-GAN hooks."""
         m, keep, dev = self._descriptor()
         observed = _lib.f32c(observed, dev)
         T_obs, M = observed.size(0), observed.size(1)
-        idx = _lib.SceneIndex.get(batch_split, dev)
+        idx = _lib.SceneIndex.get(batch_split, dev, pad_to)
         if idx.M != M:
             raise ValueError('batch_split covers %d tracks, observed has %d' % (idx.M, M))
         truth = _lib.f32c(truth, dev) if truth is not None else None
@@ -261,7 +270,7 @@ class LSTM(torch.nn.Module):
             ex.h_final = _lib.ptr(h_final)
         _lib.check(_lib.lib().tnp_lstm_forward_ex(
             ctypes.byref(m), _lib.ptr(observed), T_obs, M, _lib.ptr(goals_t), _lib.ptr(idx.starts),
-            _lib.ptr(idx.primary), idx.B, idx.n_max, _lib.ptr(truth), T_dec, _lib.ptr(rel_pred), _lib.ptr(pred),
+            _lib.ptr(idx.primary), idx.B, idx.n_max, _lib.ptr(idx.slots), _lib.ptr(truth), T_dec, _lib.ptr(rel_pred), _lib.ptr(pred),
             _lib.ptr(ws), need, ctypes.byref(ex), _lib.stream_ptr()), 'tnp_lstm_forward')
         return rel_pred, pred, h_final
 
@@ -314,7 +323,9 @@ class LSTMPredictor(object):
         marking the primaries) instead of one call per scene per joblib worker (reference
         evaluator/trajnet_evaluator.py:61-75).  Returns a list (scene order) of the ``multimodal_outputs`` dicts
         ``__call__`` returns.  Scene preprocessing (paths_to_xy, center_scene) is per scene on the host, as in
-        the reference; scenes never interact (lstm/lstm.py:243-250), so the result equals the per-scene calls."""
+        the reference; scenes never interact (lstm/lstm.py:243-250) and the forward runs with ``pad_to='scene'`` (no padded
+        slots: a per-scene call has none, whereas the reference's ragged batch would clobber cell (0, 0) of the shorter
+        scenes' grids), so the result equals the per-scene calls."""
         self.model.eval()
         normalize = bool(getattr(args, 'normalize_scene', False))
         xys, goals, frames = [], [], []
@@ -337,7 +348,7 @@ class LSTMPredictor(object):
             goal = torch.tensor(np.concatenate(goals, axis=0), dtype=torch.float32)
             batch_split = torch.tensor(split, dtype=torch.int64)
             for num_p in range(modes):
-                _, output = self.model(obs, goal, batch_split, n_predict=n_predict)
+                _, output = self.model(obs, goal, batch_split, n_predict=n_predict, pad_to='scene')
                 output = output.cpu().numpy()
                 for s in range(len(xys)):
                     out = output[:, split[s]:split[s + 1]]

@@ -197,7 +197,7 @@ class AttentionMLPPooling(torch.nn.Module):
         u = _lib.linear_forward(q, wu, None)
         ebar = torch.empty(B * N, D, dtype=torch.float32, device=dev)
         starts = _padded_starts(B, N, dev)
-        _lib.check(L.tnp_pool_attn_pair(_lib.ptr(o1), _lib.ptr(o2), _lib.ptr(henc), mh, 0, _lib.ptr(starts), B, N, ms, mv, mh,
+        _lib.check(L.tnp_pool_attn_pair(_lib.ptr(o1), _lib.ptr(o2), _lib.ptr(henc), mh, 0, _lib.ptr(starts), B, N, None, ms, mv, mh,
                                         f(sp.weight), f(sp.bias), f(ve.weight) if ve is not None else None,
                                         f(ve.bias) if ve is not None else None, float(self.fill_value), _lib.ptr(u), D + 4,
                                         _lib.ptr(ebar), D, _lib.stream_ptr()), 'tnp_pool_attn_pair')

@@ -1,37 +1,74 @@
 """One optimisation step as the reference's Trainer.train_batch does it (lstm/trainer.py:229-269), plus its
-data-parallel form: scenes sharded over ranks, one bucketed gradient all-reduce (RCCL over xGMI on ROCm) per step."""
+data-parallel form: scenes sharded over ranks, gradients all-reduced (RCCL over xGMI on ROCm) once per step."""
+import random
+
 import torch
 
 from .. import parallel
 
 
 def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batch_split, obs_length=9, pred_length=12,
-                batch_size=None, group=None, n_global_scenes=None):
+                batch_size=None, group=None, n_global_scenes=None, pad_to=None, start_length=0, obs_dropout=False,
+                buckets=None):
     """batch_scene [obs+pred, M, 2] (NaN = absent), batch_scene_goal [M, 2], batch_split [B+1].
 
-    Single process: loss = criterion(rel_outputs[-pred_length:], targets, batch_split) * batch_size, backward, step
-    (lstm/trainer.py:252-267).  With a process group, `batch_scene` is this rank's shard of scenes: the loss is scaled
-    so that SUM-reduced gradients equal the single-process gradient (parallel.scale_loss_for_sharding), gradients are
-    all-reduced in one flattened bucket, and every rank applies the same optimizer step.  Returns the loss value."""
+    Single process: loss = criterion(rel_outputs[-pred_length:], targets, batch_split, primary_prediction) * batch_size,
+    backward, step (lstm/trainer.py:246-267; ``primary_prediction`` = the truth frames with the primaries' columns
+    replaced by the model's predictions, :258-260 -- what the auxiliary collision loss is evaluated on;
+    ``obs_dropout`` draws ``start_length`` like :246-247).
+
+    With a process group, `batch_scene` is this rank's shard of scenes (``parallel.shard_batch``): pass its
+    ``n_global_scenes`` and ``pad_to`` (the largest scene of the whole batch, so that padded-slot effects equal the
+    unsharded batch's).  The loss is scaled so that SUM-reduced gradients equal the single-process gradient
+    (parallel.scale_loss_for_sharding), gradients are all-reduced -- through ``buckets`` (parallel.GradBuckets: flat
+    persistent buffers, asynchronous launch) when given, else one flattened bucket -- and every rank applies the same
+    optimizer step.  A rank whose shard is empty (fewer scenes than ranks) back-propagates a zero-weighted one-track
+    dummy scene: it contributes zero gradients for exactly the parameters the other ranks have gradients for, so the
+    collectives line up.  Returns the loss value of this rank."""
     model.train()
     dev = next(model.parameters()).device
-    batch_scene = batch_scene.to(dev)
+    distributed = group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())
     split = torch.as_tensor(batch_split, dtype=torch.int64)
     n_local = split.numel() - 1
     batch_size = batch_size or n_local
-    observed = batch_scene[:obs_length].clone()
-    prediction_truth = batch_scene[obs_length:-1].clone()
+    if obs_dropout:
+        start_length = random.randint(0, obs_length - 2)
+    if buckets is not None:
+        buckets.zero()
+    else:
+        optimizer.zero_grad()
+    empty = n_local <= 0 or int(split[-1]) <= 0
+    if empty and not distributed:
+        raise ValueError('empty batch')
+    if empty:
+        t = torch.arange(obs_length + pred_length, dtype=torch.float32).view(-1, 1, 1)
+        batch_scene = (t * torch.tensor([0.1, 0.05])).expand(-1, 1, 2).contiguous()
+        batch_scene_goal, split, n_local = torch.zeros(1, 2), torch.tensor([0, 1]), 0
+    batch_scene = batch_scene.to(dev)
+    observed = batch_scene[start_length:obs_length].clone()
+    prediction_truth = batch_scene[obs_length:obs_length + pred_length - 1].clone()
     targets = batch_scene[obs_length:obs_length + pred_length] - batch_scene[obs_length - 1:obs_length + pred_length - 1]
-    rel_outputs, outputs = model(observed, batch_scene_goal, split, prediction_truth)
-    loss_mean = criterion(rel_outputs[-pred_length:], targets, split, outputs[-pred_length:]) \
-        if getattr(criterion, 'col_wt', 0) else criterion(rel_outputs[-pred_length:], targets, split)
-    if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+    rel_outputs, outputs = model(observed, batch_scene_goal, split, prediction_truth, pad_to=pad_to)
+    if getattr(criterion, 'col_wt', 0):
+        prim = split[:-1].to(dev)
+        primary_prediction = batch_scene[-pred_length:].clone()
+        primary_prediction[:, prim] = outputs[-pred_length:, prim]
+        loss_mean = criterion(rel_outputs[-pred_length:], targets, split, primary_prediction)
+    else:
+        loss_mean = criterion(rel_outputs[-pred_length:], targets, split)
+    if distributed:
+        if n_global_scenes is None and empty:
+            raise ValueError('an empty shard needs n_global_scenes')
         n_global = n_global_scenes if n_global_scenes is not None else n_local * torch.distributed.get_world_size(group)
-        loss = parallel.scale_loss_for_sharding(loss_mean, batch_size, n_local, n_global)
+        loss = parallel.scale_loss_for_sharding(loss_mean, batch_size, n_local, n_global)   # n_local == 0: weight 0
     else:
         loss = loss_mean * batch_size
-    optimizer.zero_grad()
     loss.backward()
-    parallel.allreduce_gradients(list(model.parameters()), group=group)
+    loss_value = loss.detach()
+    if buckets is not None:
+        buckets.launch_all()
+        buckets.wait()
+    elif distributed:
+        parallel.allreduce_gradients(list(model.parameters()), group=group)
     optimizer.step()
-    return float(loss.detach())
+    return float(loss_value)

@@ -77,7 +77,8 @@ class BwdSweep(ctypes.Structure):
                 ('S', ctypes.c_int32), ('M', ctypes.c_int32), ('B', ctypes.c_int32), ('n_max', ctypes.c_int32),
                 ('n_enc', ctypes.c_int32), ('pos_offset', ctypes.c_int32), ('nn_pool', ctypes.c_int32),
                 ('social_sparse', ctypes.c_int32), ('directional_in', ctypes.c_int32), ('h_override_step', ctypes.c_int32),
-                ('h_override', ctypes.c_void_p), ('scene_start', ctypes.c_void_p), ('d_rel', ctypes.c_void_p),
+                ('h_override', ctypes.c_void_p), ('scene_start', ctypes.c_void_p), ('scene_slots', ctypes.c_void_p),
+                ('d_rel', ctypes.c_void_p),
                 ('d_pred', ctypes.c_void_p), ('wT_enc', ctypes.c_void_p), ('wT_dec', ctypes.c_void_p),
                 ('layT', ctypes.c_void_p * 3), ('whT', ctypes.c_void_p), ('w_cell_major', ctypes.c_void_p),
                 ('row_base', ctypes.c_void_p), ('row_count', ctypes.c_void_p), ('cells_all', ctypes.c_void_p),
@@ -186,7 +187,7 @@ class SequenceFn(torch.autograd.Function):
         truth = _lib.f32c(truth.detach(), dev) if truth is not None else None
         goals_t = _lib.f32c(goals.detach(), dev) if (goals is not None and model.goal_flag) else None
         T_obs, M = observed.size(0), observed.size(1)
-        idx = _lib.SceneIndex.get(batch_split, dev)
+        idx = _lib.SceneIndex.get(batch_split, dev, opts.get('pad_to'))
         H = model.hidden_dim
         pool = model.pool
         S = (T_obs - 1) + T_dec
@@ -254,7 +255,7 @@ class SequenceFn(torch.autograd.Function):
         # the whole sequence (encoder + decoder steps, feedback of the predicted positions) is one driver call
         _lib.check(L.tnp_lstm_forward_train(
             ctypes.byref(m), _lib.ptr(observed), T_obs, M, _lib.ptr(goals_t), _lib.ptr(idx.starts), _lib.ptr(idx.primary),
-            idx.B, idx.n_max, _lib.ptr(truth), T_dec, _lib.ptr(normals), _lib.ptr(pos_all), _lib.ptr(ws), need,
+            idx.B, idx.n_max, _lib.ptr(idx.slots), _lib.ptr(truth), T_dec, _lib.ptr(normals), _lib.ptr(pos_all), _lib.ptr(ws), need,
             ctypes.byref(ex), ctypes.byref(sv), _lib.stream_ptr()), 'tnp_lstm_forward_train')
         if noise is not None:
             s_noise = T_obs - 1
@@ -397,6 +398,7 @@ class SequenceFn(torch.autograd.Function):
         if ctx.noise_at is not None:
             sw.h_override_step, sw.h_override = ctx.noise_at[0] - 1, ctx.noise_at[1].data_ptr()
         sw.scene_start = idx.starts.data_ptr()
+        sw.scene_slots = idx.slots.data_ptr() if idx.slots is not None else None
         sw.d_rel = d_rel.data_ptr() if d_rel is not None else None
         sw.d_pred = d_pred.data_ptr() if d_pred is not None else None
         sw.wT_enc = wT['encoder'].data_ptr() if 'encoder' in wT else None

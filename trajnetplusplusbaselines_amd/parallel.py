@@ -14,7 +14,9 @@ def shard_bounds(batch_split, rank, world_size, balance='pairs'):
     """Contiguous block of scenes for `rank`.  Returns (scene_lo, scene_hi).
 
     balance = 'scenes': equal scene counts; 'tracks': equal sum of tracks; 'pairs': equal sum of N^2
-    (the O(N^2) neighbour work), which is what matters for ragged batches."""
+    (the O(N^2) neighbour work), which is what matters for ragged batches.  A scene that straddles a target goes to
+    the earlier rank, and every rank gets at least one scene whenever there are at least `world_size` scenes (an
+    empty shard would leave its rank without a forward while the others wait in the all-reduce)."""
     split = torch.as_tensor(batch_split, dtype=torch.int64).cpu()
     n_scenes = split.numel() - 1
     if world_size <= 1:
@@ -28,19 +30,42 @@ def shard_bounds(batch_split, rank, world_size, balance='pairs'):
         w = sizes * sizes
     cum = torch.cumsum(w, 0)
     total = float(cum[-1]) if n_scenes else 0.0
-    # boundary r = first scene index whose cumulative weight exceeds r/world of the total
     bounds = [0]
     for r in range(1, world_size):
         target = total * r / world_size
-        idx = int(torch.searchsorted(cum, torch.tensor(target, dtype=torch.float64), right=False))
-        bounds.append(max(bounds[-1], min(idx + 1 if n_scenes and float(cum[min(idx, n_scenes - 1)]) <= target else idx, n_scenes)))
+        # first boundary whose prefix weight reaches the target: the straddling scene stays with the earlier rank
+        b = int(torch.searchsorted(cum, torch.tensor(target, dtype=torch.float64), right=False)) + 1 if n_scenes else 0
+        if n_scenes >= world_size:
+            b = max(b, bounds[-1] + 1)                      # at least one scene for rank r-1 ...
+            b = min(b, n_scenes - (world_size - r))         # ... and one left for every later rank
+        bounds.append(max(bounds[-1], min(b, n_scenes)))
     bounds.append(n_scenes)
     return bounds[rank], bounds[rank + 1]
 
 
+class Shard(tuple):
+    """(observed, goals, batch_split, prediction_truth, track_range) of one rank -- unpacks like the 5-tuple it used to be --
+    plus what the shard must know about the whole batch: ``pad_to`` (largest scene of the UNSHARDED batch: handed to
+    ``LSTM.forward(..., pad_to=)`` it makes the shard compute exactly what the reference computes for the whole batch,
+    whose scenes are all padded to that many slots, lstm/lstm.py:29), ``n_scenes_global`` and ``scene_range``."""
+
+    def __new__(cls, observed, goals, batch_split, prediction_truth, track_range, pad_to, n_scenes_global, scene_range):
+        self = super(Shard, cls).__new__(cls, (observed, goals, batch_split, prediction_truth, track_range))
+        self.pad_to, self.n_scenes_global, self.scene_range = pad_to, n_scenes_global, scene_range
+        return self
+
+    observed = property(lambda self: self[0])
+    goals = property(lambda self: self[1])
+    batch_split = property(lambda self: self[2])
+    prediction_truth = property(lambda self: self[3])
+    track_range = property(lambda self: self[4])
+    n_scenes = property(lambda self: self[2].numel() - 1)
+
+
 def shard_batch(observed, goals, batch_split, rank, world_size, prediction_truth=None, balance='pairs'):
     """Slice one batch (track-major tensors [T, M, 2] / [M, 2], batch_split [B+1]) to this rank's scenes and
-    rebase its batch_split.  Returns (observed, goals, batch_split, prediction_truth, (track_lo, track_hi))."""
+    rebase its batch_split.  Returns a ``Shard``: (observed, goals, batch_split, prediction_truth, (track_lo, track_hi))
+    with ``.pad_to`` / ``.n_scenes_global`` / ``.scene_range``."""
     split = torch.as_tensor(batch_split, dtype=torch.int64).cpu()
     lo, hi = shard_bounds(split, rank, world_size, balance)
     t_lo, t_hi = int(split[lo]), int(split[hi])
@@ -48,7 +73,9 @@ def shard_batch(observed, goals, batch_split, rank, world_size, prediction_truth
     obs = observed[:, t_lo:t_hi]
     g = goals[t_lo:t_hi] if goals is not None else None
     truth = prediction_truth[:, t_lo:t_hi] if prediction_truth is not None else None
-    return obs, g, local_split, truth, (t_lo, t_hi)
+    n_scenes = split.numel() - 1
+    pad_to = int((split[1:] - split[:-1]).max()) if n_scenes > 0 else 0
+    return Shard(obs, g, local_split, truth, (t_lo, t_hi), pad_to, n_scenes, (lo, hi))
 
 
 def gather_tracks(local, n_tracks_total, track_range, group=None):
@@ -80,8 +107,10 @@ def scale_loss_for_sharding(loss_mean_local, nominal_batch_size, n_local_scenes,
 
 def allreduce_gradients(parameters, group=None, bucket_bytes=32 << 20):
     """One flattened SUM all-reduce per bucket (parameters with grad None -- e.g. the unused goal embedding,
-    lstm/lstm.py:75 -- are skipped consistently on every rank).  Social-LSTM is 19.7 MB of fp32 gradients:
-    a single bucket, latency-bound on xGMI, so fewer larger messages is the right shape."""
+    lstm/lstm.py:75 -- are skipped, consistently on every rank: ranks run the same model, and a rank whose shard is empty
+    back-propagates a zero-weighted dummy scene, lstm/train_step.py).  Social-LSTM is 19.7 MB of fp32 gradients: a single
+    bucket, latency-bound on xGMI, so fewer larger messages is the right shape.  Prefer ``GradBuckets`` on the training
+    path: persistent flat buffers, no concatenation or copy-back, asynchronous launch."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return 0
     grads = [p.grad for p in parameters if p.grad is not None]
@@ -106,6 +135,79 @@ def allreduce_gradients(parameters, group=None, bucket_bytes=32 << 20):
             flush()
     flush()
     return n_msgs
+
+
+class GradBuckets(object):
+    """Persistent flat gradient storage for data-parallel training: every trained parameter's ``.grad`` is a view into
+    one of a few flat fp32 buffers (``bucket_bytes`` each, parameters in REVERSE registration order), so a bucket is
+    all-reduced in place -- no ``torch.cat``, no copy-back -- with ``async_op=True``: on ROCm the collective runs on
+    RCCL's own stream over xGMI while the compute stream carries on (the next bucket's launch, the optimizer's
+    bookkeeping), and ``wait()`` only makes the compute stream wait for it (no host synchronisation).
+
+    The buffers are laid out by ``attach()`` after the first backward: parameters that received no gradient (the goal
+    embedding of a model without goals, lstm/lstm.py:75) stay out, keep ``grad is None`` and are skipped by the
+    optimizer exactly as in the reference -- the same set on every rank, since ranks run the same model.  From then on
+    gradients are zeroed in place (``zero()``), never set to None, so the views stay attached across steps."""
+
+    def __init__(self, parameters, group=None, bucket_bytes=8 << 20):
+        self.group = group
+        self.params = [p for p in parameters if p.requires_grad]
+        self.bucket_bytes = bucket_bytes
+        self.buckets = []       # (flat tensor, [params])
+        self.attached = False
+        self._pending = []
+
+    def attach(self):
+        cur, size = [], 0
+        for p in reversed(self.params):
+            if p.grad is None:
+                continue
+            cur.append(p)
+            size += p.numel() * 4
+            if size >= self.bucket_bytes:
+                self._close(cur)
+                cur, size = [], 0
+        if cur:
+            self._close(cur)
+        self.attached = True
+
+    def _close(self, params):
+        dev = params[0].device
+        flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+        off = 0
+        for p in params:
+            view = flat[off:off + p.numel()].view_as(p)
+            view.copy_(p.grad)
+            p.grad = view
+            off += p.numel()
+        self.buckets.append((flat, list(params)))
+
+    def zero(self):
+        if not self.attached:
+            for p in self.params:
+                p.grad = None
+            return
+        for flat, _ in self.buckets:
+            flat.zero_()
+
+    def active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def launch_all(self):
+        """Start the SUM all-reduce of every bucket (gradients enqueued on the current stream); returns the count."""
+        if not self.attached:
+            self.attach()
+        if not self.active():
+            return 0
+        for flat, _ in self.buckets:
+            self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return len(self.buckets)
+
+    def wait(self):
+        """The current stream waits for the launched collectives (no host block on ROCm / RCCL)."""
+        for work in self._pending:
+            work.wait()
+        self._pending = []
 
 
 def max_over_ranks(value, device=None, group=None):
