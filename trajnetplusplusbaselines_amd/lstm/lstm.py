@@ -63,6 +63,16 @@ class LSTM(torch.nn.Module):
         self._ws = None
         self._cell_major = None  # (key, tensor): cell-major copy of pool.embedding[0].weight
 
+    # device-side caches (workspace, re-laid-out weight copies): rebuilt lazily, never pickled / deep-copied
+    _CACHES = ('_ws', '_cell_major', '_dummy_head')
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._CACHES:
+            if k in state:
+                state[k] = None
+        return state
+
     # ---- descriptor / workspace ---------------------------------------------------------------------
     def _decoder_cell(self):
         return self.decoder

@@ -142,10 +142,15 @@ class AttentionMLPPooling(torch.nn.Module):
         self.wv = torch.nn.Linear(self.mlp_dim, self.mlp_dim, bias=False)
         self.multihead_attn = torch.nn.MultiheadAttention(embed_dim=self.mlp_dim, num_heads=1)
         self.out_projection = torch.nn.Linear(self.mlp_dim, self.out_dim)
-        self._folded = None
+        self._folded = None     # cache of the folded attention maps: rebuilt lazily, not pickled
 
     def reset(self, num_tracks, max_num_neigh, device):
         self.track_mask = None
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['_folded'] = None
+        return state
 
     def folded(self):
         """(Wq [D,D], bq [D], Wu [D+4,D], Wfin [P,D], bfin [P]) on the parameters' device, recomputed when a parameter
