@@ -7,8 +7,13 @@
 One "step" = one LSTM.forward (8 encoder + 11 decoder recurrent steps = 21 frames) over one batch of synthetic
 scenes per GPU (scenes are independent -> pure data-parallel sharding, no collective on the inference data path;
 weak scaling).  Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline     : the dominant kernel (first pooling-embedding GEMM on the fp32 matrix cores) timed with HIP
-                 events on the launch stream over a repeat of the timed region,
+  roofline     : the dominant kernel (first pooling-embedding layer) timed with HIP events on the launch stream over a
+                 repeat of the timed region; `frac` against SURVEY 8(d)'s (A-1)-cell bound and `frac_on_hits` against the
+                 occupied cells actually present in the batch (counted on the host from the positions every step ran on),
+  training     : the same model's optimisation step (Trainer.train_batch: forward + backward + Adam) on the same shard,
+                 timed the same way right after the inference region; at N > 1 it includes the gradient all-reduce over
+                 RCCL (parallel.GradBuckets: flat buckets, asynchronous launch) -- the part of the 1 -> 8 GPU curve
+                 that can fail to scale (skip with --no-train),
   cpu_baseline : the CPU oracle (a C port of the reference algorithm, OpenMP over tracks) timed on this host.
 """
 import argparse
@@ -87,7 +92,43 @@ def cpu_baseline(cfg, xy, split, budget_s=20.0):
     return dict(value=scenes * 21 / best, unit='scene-steps/s', cores=threads, kind='port',
                 sample='%d full forwards of the same %d-scene batch (best of %d), oracle/trajnet_oracle.c with '
                        'OpenMP over tracks' % (reps + 1, scenes, reps + 1),
-                seconds_per_forward=best)
+                seconds_per_forward=best,
+                note='kind "port": the Python reference cannot travel to the GPU box (/root/reference does not exist '
+                     'there), so this is the oracle\'s C restatement.  It is SLOWER than the reference itself: the '
+                     'reference (PyTorch CPU, 8 vCPUs of the build container) measured 605 scene-steps/s inference and 152 '
+                     'per optimisation step while surveying (BASELINE.md section 2) -- use that figure for like-for-like ratios.',
+                reference_python_scene_steps_per_s=605.0, reference_python_cores=8)
+
+
+def occupied_cells_per_step(observed, pred, split, n, cell_side):
+    """Occupied grid cells (= hits of the sparse first layer) of every recurrent step, counted on the host from the
+    positions the step ran on: encoder step s pools observed[s + 1], decoder step k pools the model's own prediction of
+    that frame (n_predict mode, lstm/lstm.py:240-250).  Same fp32 cell arithmetic and last-writer / cell-0 clobber rules
+    as the kernels (gridbased_pooling.py:276-293); returns one count per step, summed over all egos."""
+    obs, prd, sp = observed.cpu().numpy(), pred.cpu().numpy(), split.cpu().numpy()
+    T_obs = obs.shape[0]
+    frames = [obs[s + 1] for s in range(T_obs - 1)] + [prd[T_obs - 2 + k] for k in range(prd.shape[0] - (T_obs - 1))]
+    cs, half = np.float32(cell_side), np.float32(n / 2)
+    counts = []
+    for pos in frames:
+        pos = np.where(np.isnan(pos).any(axis=1, keepdims=True), np.float32(-500.0), pos).astype(np.float32)
+        total = 0
+        for lo, hi in zip(sp[:-1], sp[1:]):
+            p = pos[lo:hi]
+            o = (p[None, :, :] - p[:, None, :]) / cs + half                     # [ego, neighbour, 2]
+            inr = ((o >= 0) & (o < n)).all(axis=2)
+            np.fill_diagonal(inr, False)
+            cell = np.where(inr, o[..., 0].astype(np.int64) * n + o[..., 1].astype(np.int64), -1)
+            for e in range(hi - lo):
+                js = np.nonzero(inr[e])[0]
+                occupied = set(cell[e, js].tolist())
+                oor = np.nonzero(~inr[e])[0]
+                oor = oor[oor != e]
+                if 0 in occupied and oor.size and oor.max() > js[cell[e, js] == 0].max():
+                    occupied.discard(0)                                          # clobbered by a later out-of-range neighbour
+                total += len(occupied)
+        counts.append(total)
+    return counts
 
 
 def cpu_baseline_classical(st, pos, vel, goals, speed, obs, z, starts, agents, scenes_sample, scenes_total):
@@ -227,7 +268,7 @@ def pmc_traffic(kernel_regex, extra_args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', default='social', choices=sorted(CONFIGS))
     ap.add_argument('--variant', type=int, default=0, help='kernel variant selector (DESIGN.md)')
@@ -236,6 +277,7 @@ def main():
     ap.add_argument('--dense', action='store_true', help='dense MFMA first embedding layer instead of the sparse one')
     ap.add_argument('--no-roofline', action='store_true', help='skip the HIP-event roofline leg (used by the PMC child run)')
     ap.add_argument('--no-traffic', action='store_true', help='skip roofline.traffic (two short rocprofv3 PMC child runs at N=1)')
+    ap.add_argument('--no-train', action='store_true', help='skip the "training" leg of the default run')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -318,6 +360,44 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- training leg: the optimisation step of the same model on the same shard, all-reduce included at N > 1 ----
+    training = None
+    if not args.train and not is_sgan and not args.no_train and not args.no_roofline:
+        from trajnetplusplusbaselines_amd import parallel
+        from trajnetplusplusbaselines_amd.lstm import PredictionLoss
+        from trajnetplusplusbaselines_amd.lstm.train_step import train_batch
+        tmodel = build_model(cfg, device)                     # same seed on every rank: replicas start identical
+        tmodel.kernel_variant = args.variant
+        optimizer = torch.optim.Adam(tmodel.parameters(), lr=1e-3, weight_decay=1e-4)   # lstm/trainer.py:497
+        buckets = parallel.GradBuckets(tmodel.parameters()) if distributed else None
+        criterion = PredictionLoss()
+        scene_dev = xy.to(device)
+        t_steps, t_warm = max(5, min(args.steps, 30)), 3
+
+        def tstep():
+            return train_batch(tmodel, optimizer, criterion, scene_dev, goals, split, 9, 12, batch_size=cfg['scenes'] * world,
+                               n_global_scenes=cfg['scenes'] * world, pad_to=cfg['agents'], buckets=buckets)
+        for _ in range(t_warm):
+            tstep()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(t_steps):
+            loss_last = tstep()
+        barrier()
+        t_el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if distributed:
+            dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        t_el = float(t_el.item())
+        grad_bytes = sum(p.numel() * 4 for p in tmodel.parameters() if p.grad is not None)
+        training = dict(value=cfg['scenes'] * world * 21 * t_steps / t_el, unit='scene-steps/s', steps=t_steps, warmup=t_warm,
+                        ms_per_step=t_el / t_steps * 1e3, loss_last=loss_last,
+                        workload='Trainer.train_batch of the same model on the same shard: teacher-forced forward, NLL loss, '
+                                 'backward, Adam%s' % (' + SUM all-reduce of %.1f MB of fp32 gradients over RCCL (%d flat buckets, '
+                                                       'asynchronous)' % (grad_bytes / 1e6, len(buckets.buckets)) if distributed else ''),
+                        allreduce_bytes=grad_bytes if distributed else 0)
+        del tmodel, optimizer, buckets
+
+    with torch.set_grad_enabled(args.train):
         # ---- roofline leg: same region again with HIP events around every launch of the dominant kernel ----
         L = _lib.lib()
         roof = None
@@ -335,11 +415,14 @@ def main():
             N0 = model.pool.embedding_layers()[0].weight.shape[0]
             dense_flops = 2.0 * M * N0 * K0                # dense Linear(C*n*n -> N0) on the grid
             sparse = bool(model.sparse_embedding and cfg['type_'] == 'social')
+            hits = None
             if sparse:
                 # gather formulation: at most A-1 occupied cells per ego, C values each (SURVEY 8d "sparse lower
                 # bound for the first embedding layer"); the kernel runs on the fp32 VALU, whose peak equals the
                 # fp32 MFMA peak on CDNA4 (157.3 TFLOP/s)
                 flops = 2.0 * M * (cfg['agents'] - 1) * model.pool.pooling_dim * N0
+                _, pred_once = step()
+                hits = occupied_cells_per_step(observed, pred_once, split, cfg['n'], 0.6)
                 kname = ('pool_embed_cellsplit_kernel (winner tile from the positions + pool.embedding.0 on it: '
                          '%d egos x <=%d occupied cells x %d values -> %d)' % (M, cfg['agents'] - 1,
                                                                               model.pool.pooling_dim, N0))
@@ -358,6 +441,14 @@ def main():
                             launches=n.value, avg_launch_us=avg_s * 1e6, flops_per_launch=flops,
                             dense_equivalent_tflops=dense_flops / avg_s / 1e12,
                             share_of_step=ms.value * 1e-3 / elapsed)
+                if hits is not None:
+                    # the (A-1)-cell bound is an upper bound of the work; this is the work that was actually there
+                    mean_hits = float(np.mean(hits))
+                    hit_flops = 2.0 * mean_hits * model.pool.pooling_dim * N0
+                    roof.update(hits_per_launch=mean_hits, hits_per_ego=mean_hits / M,
+                                hits_per_ego_first_last_step=[hits[0] / M, hits[-1] / M],
+                                achieved_on_hits=hit_flops / avg_s / 1e12,
+                                frac_on_hits=hit_flops / avg_s / 1e12 / FP32_MFMA_PEAK_TFLOPS)
                 if not args.no_traffic and world == 1 and not under_profiler():
                     child = ['--config', args.config] + (['--dense'] if args.dense else []) + \
                         (['--variant', str(args.variant)] if args.variant else [])
@@ -403,6 +494,7 @@ def main():
                        'first_embedding_layer': 'dense mfma' if args.dense else 'sparse gather (social) / dense mfma'},
             'recurrent_scene_steps_per_s': scenes_total * ((3 * 19 + 2 * 20) if is_sgan else 19) * args.steps / elapsed,
             'roofline': roof,
+            'training': training,
         }
         if world == 1 and not args.no_cpu_baseline and not is_sgan:
             out['cpu_baseline'] = cpu_baseline(cfg, xy, split)

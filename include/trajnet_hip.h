@@ -86,7 +86,7 @@ TNP_API int tnp_pool_pair_cells(const float *obs2, const int32_t *row_base, cons
  * Dense layer on the matrix cores: torch.nn.Linear (+ReLU) as used by the grid embedding
  * MLPs (lstm/gridbased_pooling.py:308-335).   C[M,N] = act(A[M,K] @ W[N,K]^T + bias)
  * fp32-in / fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products.
- *   variant: 0 = default tile selection; see DESIGN.md for the list
+ *   variant: 0 = automatic tile selection; 12 / 24 pin one of the two fast kernels
  * ----------------------------------------------------------------------------------------- */
 TNP_API int tnp_linear_forward(const float *A, int lda, const float *W, int ldw, const float *bias, float *C,
                        int ldc, int M, int N, int K, int relu, int variant, void *stream);
@@ -179,7 +179,7 @@ typedef struct tnp_lstm_model {
     const float *Wp0_cell_major; /* optional [n*n][C][dims[1]] copy of Wp[0] (W'[c][ch][o] =
                                     Wp[0][o][ch*n*n + c]); enables the sparse first layer
                                     for social pooling with constant == 0; NULL = dense   */
-    int32_t variant;      /* bits 0-15 kernel-variant selector (0 = default); bit 16: force the dense first
+    int32_t variant;      /* bits 0-7 / 8-15: tile selection of the dense embedding GEMM / the gates GEMM (0 = automatic); bit 16: force the dense first
                              embedding layer; bit 17: LSTM(pool_to_input=False) -- the interaction vector (P == H) is
                              added to the hidden operand of the LSTMCell instead of concatenated to its input */
     /* TNP_POOL_ATTNMLP only (fields as for HIDDENMLP, `constant` = fill_value): the linear maps around the single-head
@@ -517,14 +517,6 @@ TNP_API int tnp_orca_rollout(const float *pos0, const float *vel0, const double 
                      float radius, float *out, int *nbr_dbg, void *stream);
 TNP_API int tnp_kalman_predict(const double *obs, int n_tracks, int T, int n_iter, int n_steps, int n_samples,
                        const double *z, double transition_var, double observation_var, double *out, void *stream);
-
-/* -------------------------------------------------------------------------------------------
- * Calibration probe (measurement only): launches `blocks` workgroups of `waves_per_wg` waves,
- * each issuing iters*8*n_acc v_mfma_f32_32x32x2_f32 (4096 FLOP each) with no memory traffic.
- * scratch: >= 4 bytes of device memory (never written in practice).
- * ----------------------------------------------------------------------------------------- */
-TNP_API int tnp_mfma_ablate(int mode, int iters, int blocks, const float *src, float *scratch, void *stream);
-TNP_API int tnp_mfma_probe(int waves_per_wg, int n_acc, int iters, int blocks, float *scratch, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,25 @@
+"""bench.py's host-side hit counter (roofline.frac_on_hits) against the oracle's occupancy grids."""
+import numpy as np
+import torch
+
+import bench
+from oracle import oracle
+from trajnetplusplusbaselines_amd import synth
+
+
+def test_occupied_cells_counter_matches_oracle_grids():
+    xy, split = synth.ragged_crowd(7, 2, 14, seed=5)
+    xy[:, :, :] = xy * 0.6                                  # denser: duplicates, clobbers, out-of-range neighbours
+    n, cs = 8, 0.6
+    obs = xy[:9]
+    pred = xy[2:21]                                         # stand-in for the 19 predicted frames (frames 2..20)
+    got = bench.occupied_cells_per_step(obs, pred, split, n, cs)
+    sp = split.numpy()
+    frames = [obs[s + 1].numpy() for s in range(8)] + [pred[7 + k].numpy() for k in range(11)]
+    assert len(got) == 19
+    for cnt, pos in zip(got, frames):
+        want = 0
+        for lo, hi in zip(sp[:-1], sp[1:]):                 # one scene at a time: no padded slots, like the counter
+            g = oracle.grid('occupancy', pos[None, lo:hi].astype(np.float32), pos[None, lo:hi].astype(np.float32), n=n, cell_side=cs)
+            want += int((np.asarray(g) != 0).sum())
+        assert cnt == want

@@ -15,7 +15,8 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize('variant', list(range(0, 16)) + list(range(20, 29)) + [30, 31, 33, 100, 101])
+@pytest.mark.parametrize('variant', [0, 12, 24])   # automatic selection and the two fast kernels it picks from; shapes
+# the fast kernels cannot take (K not a multiple of the K step / of 4) fall through to the masked general kernel
 @pytest.mark.parametrize('M,N,K', SHAPES)
 def test_linear_matches_oracle(M, N, K, variant):
     rng = np.random.RandomState(M + 7 * N + 13 * K)

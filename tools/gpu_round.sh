@@ -7,7 +7,6 @@ export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" | tee -a gpurun_out/summary.log
 timeout 900 python -m pytest tests -q -m gpu --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/summary.log
 tail -5 gpurun_out/pytest_gpu.log
-timeout 600 python tools/gpu_check.py ${GPU_CHECK_ARGS:-} > gpurun_out/gpu_check.log 2>&1; echo "gpu_check rc=$?" | tee -a gpurun_out/summary.log
 timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.log 2>&1; echo "bench rc=$?" | tee -a gpurun_out/summary.log
 tail -2 gpurun_out/bench.log
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/rocprof.log" 2>&1); echo "rocprof rc=$?" | tee -a gpurun_out/summary.log

@@ -163,7 +163,6 @@ def lib():
                                      ctypes.c_double, ctypes.c_double, _fp, _fp]
     L.tnp_pool_pair_cells.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_float, _fp, _fp]
-    L.tnp_mfma_probe.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]
     if L.tnp_abi_version() != ABI_VERSION:
         raise RuntimeError('libtrajnet_hip.so ABI version mismatch')
     _LIB = L
@@ -288,21 +287,3 @@ def linear_forward(x, weight, bias, relu=False, variant=0, out=None):
     check(lib().tnp_linear_forward(ptr(x), x.stride(0), ptr(weight), weight.stride(0), ptr(bias_t), ptr(out),
                                    out.stride(0), M, N, K, int(relu), int(variant), stream_ptr()), 'tnp_linear_forward')
     return out
-
-
-def mfma_probe_tflops(waves_per_wg=4, n_acc=2, iters=2000, blocks=None):
-    """Sustained fp32 MFMA rate of this GPU (TFLOP/s) from a memory-free v_mfma_f32_32x32x2_f32 stream."""
-    if blocks is None:
-        blocks = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    scratch = torch.zeros(4, dtype=torch.float32, device='cuda')
-    L = lib()
-    check(L.tnp_mfma_probe(waves_per_wg, n_acc, 10, blocks, ptr(scratch), stream_ptr()), 'tnp_mfma_probe')
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    check(L.tnp_mfma_probe(waves_per_wg, n_acc, iters, blocks, ptr(scratch), stream_ptr()), 'tnp_mfma_probe')
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1)
-    flops = 4096.0 * 8 * n_acc * iters * waves_per_wg * blocks
-    return flops / (ms * 1e-3) / 1e12

@@ -744,42 +744,13 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
     GemmArgs g = g_in;
     check_vec(g);
     const long big_tiles = (long)((g.M + 127) / 128) * ((g.N + 63) / 64);
-    if (variant == 0) variant = (big_tiles >= 192) ? 12 : 24;  // measured best on MI355X (tools/gpu_check.py)
+    // tile selection measured on MI355X (profiles/round1_b_variant_sweep.jsonl): 64x64 tiles when they fill the chip, else
+    // the pipelined 32x64 split-K 2 kernel; `variant` pins one of the two (12 / 24), anything else is an error
+    if (variant == 0) variant = (big_tiles >= 192) ? 12 : 24;
     switch (variant) {
-        //                  WM WN WK AN BK
-        case 1: TNP_TRY_FAST(4, 2, 1, 1, 32, EPI_BIAS); break;   // 128x64, 8 waves
-        case 2: TNP_TRY_FAST(2, 4, 1, 1, 64, EPI_BIAS); break;   // 64x128, 8 waves, BK 64
-        case 3: TNP_TRY_FAST(4, 2, 1, 1, 64, EPI_BIAS); break;   // 128x64, 8 waves, BK 64
-        case 4: TNP_TRY_FAST(2, 4, 1, 1, 32, EPI_BIAS); break;   // 64x128, 8 waves
-        case 5: TNP_TRY_FAST(1, 2, 2, 1, 32, EPI_BIAS); break;   // 32x64, split-K 2
-        case 6: TNP_TRY_FAST(1, 2, 2, 1, 64, EPI_BIAS); break;   // 32x64, split-K 2, BK 64
-        case 7: TNP_TRY_FAST(1, 1, 4, 1, 32, EPI_BIAS); break;   // 32x32, split-K 4 (512 workgroups at M=2048,N=256)
-        case 8: TNP_TRY_FAST(1, 1, 4, 1, 64, EPI_BIAS); break;   // 32x32, split-K 4, BK 64
-        case 9: TNP_TRY_FAST(2, 2, 2, 1, 32, EPI_BIAS); break;   // 64x64, split-K 2, 8 waves
-        case 10: TNP_TRY_FAST(4, 1, 1, 2, 32, EPI_BIAS); break;  // 128x64, 4 waves x 2 blocks
-        case 11: TNP_TRY_FAST(2, 2, 1, 1, 64, EPI_BIAS); break;  // 64x64, 4 waves, BK 64 (2 workgroups / CU)
         case 12: TNP_TRY_FAST(2, 2, 1, 1, 32, EPI_BIAS); break;  // 64x64, 4 waves
-        case 13: TNP_TRY_FAST(2, 1, 1, 2, 64, EPI_BIAS); break;  // 64x64, 2 waves x 2 blocks, BK 64
-        case 14: TNP_TRY_FAST(4, 1, 1, 2, 64, EPI_BIAS); break;  // 128x64, 4 waves x 2 blocks, BK 64
-        case 15: TNP_TRY_FAST(2, 2, 1, 2, 32, EPI_BIAS); break;  // 64x128, 4 waves x 2 blocks
-        case 16: TNP_TRY_FAST(1, 1, 4, 1, 16, EPI_BIAS); break;  // 32x32, split-K 4, BK 16 (3 workgroups / CU)
-        case 17: TNP_TRY_FAST(1, 1, 4, 1, 32, EPI_BIAS); break;  // 32x32, split-K 4 (2 workgroups / CU)
-        case 29: TNP_TRY_PIPE(1, 1, 4, 1, 16, EPI_BIAS); break;  // pipelined: 32x32, split-K 4, BK 16 (2 workgroups / CU)
-        case 20: TNP_TRY_PIPE(2, 4, 1, 1, 32, EPI_BIAS); break;  // pipelined: 64x128, 8 waves
-        case 21: TNP_TRY_PIPE(4, 2, 1, 1, 32, EPI_BIAS); break;  // pipelined: 128x64, 8 waves
-        case 22: TNP_TRY_PIPE(2, 2, 1, 1, 32, EPI_BIAS); break;  // pipelined: 64x64, 4 waves
-        case 23: TNP_TRY_PIPE(2, 4, 1, 1, 64, EPI_BIAS); break;  // pipelined: 64x128, BK 64
         case 24: TNP_TRY_PIPE(1, 2, 2, 1, 32, EPI_BIAS); break;  // pipelined: 32x64, split-K 2
-        case 25: TNP_TRY_PIPE(1, 1, 4, 1, 32, EPI_BIAS); break;  // pipelined: 32x32, split-K 4
-        case 26: TNP_TRY_PIPE(2, 2, 1, 2, 32, EPI_BIAS); break;  // pipelined: 64x128, 4 waves x 2 blocks
-        case 27: TNP_TRY_PIPE(4, 1, 1, 2, 32, EPI_BIAS); break;  // pipelined: 128x64, 4 waves x 2 blocks
-        case 28: TNP_TRY_PIPE(1, 2, 2, 1, 16, EPI_BIAS); break;  // pipelined: 32x64, split-K 2, BK 16
-        case 30: g.prio = 1; TNP_TRY_PIPE(2, 4, 1, 1, 32, EPI_BIAS); break;  // variant 20 + static wave priority
-        case 31: g.prio = 1; TNP_TRY_PIPE(4, 2, 1, 1, 32, EPI_BIAS); break;
-        case 33: g.prio = 1; TNP_TRY_PIPE(2, 4, 1, 1, 64, EPI_BIAS); break;
-        case 100: return launch_general<4, 2, 1, 1, 32, EPI_BIAS>(g, s);  // round-1a kernels, kept for A/B
-        case 101: return launch_general<1, 2, 2, 1, 32, EPI_BIAS>(g, s);
-        default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d", variant);
+        default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d (0 = automatic, 12, 24)", variant);
     }
     // shape not eligible for the fast path: masked general kernel
     if (big_tiles >= 192) return launch_general<4, 2, 1, 1, 32, EPI_BIAS>(g, s);
@@ -790,20 +761,11 @@ int launch_lstm_gates(const GemmArgs &g_in, int variant, hipStream_t s) {
     GemmArgs g = g_in;
     check_vec(g);
     if (g.H % 32 != 0) TNP_FAIL(-1, "LSTM hidden_dim must be a multiple of 32 (got %d)", g.H);
-    if (variant == 0) variant = (g.M >= 4096) ? 5 : 20;  // measured best on MI355X (tools/gpu_check.py)
+    if (variant == 0) variant = (g.M >= 4096) ? 5 : 20;  // measured best on MI355X (profiles/round1_b_variant_sweep.jsonl)
     switch (variant) {
-        case 1: TNP_TRY_FAST(2, 1, 2, 4, 32, EPI_LSTM); break;  // 64 tracks x 32 units, split-K 2
-        case 2: TNP_TRY_FAST(1, 1, 4, 4, 16, EPI_LSTM); break;  // 32 tracks x 32 units, split-K 4
-        case 3: TNP_TRY_FAST(2, 1, 2, 4, 16, EPI_LSTM); break;  // 64 tracks, BK 16
-        case 4: TNP_TRY_FAST(1, 1, 2, 4, 32, EPI_LSTM); break;  // 32 tracks, split-K 2, 2 waves
-        case 5: TNP_TRY_FAST(4, 1, 2, 4, 16, EPI_LSTM); break;  // 128 tracks x 32 units, 8 waves
+        case 5: TNP_TRY_FAST(4, 1, 2, 4, 16, EPI_LSTM); break;   // 128 tracks x 32 units, 8 waves
         case 20: TNP_TRY_PIPE(1, 1, 4, 4, 16, EPI_LSTM); break;  // pipelined: 32 tracks x 32 units, split-K 4
-        case 21: TNP_TRY_PIPE(2, 1, 2, 4, 16, EPI_LSTM); break;  // pipelined: 64 tracks, split-K 2
-        case 22: TNP_TRY_PIPE(4, 1, 2, 4, 16, EPI_LSTM); break;  // pipelined: 128 tracks, 8 waves
-        case 23: TNP_TRY_PIPE(1, 1, 2, 4, 16, EPI_LSTM); break;  // pipelined: 32 tracks, split-K 2, 2 waves
-        case 100: return launch_general<2, 1, 2, 4, 32, EPI_LSTM>(g, s);
-        case 101: return launch_general<1, 1, 4, 4, 16, EPI_LSTM>(g, s);
-        default: TNP_FAIL(-1, "lstm gates: unknown variant %d", variant);
+        default: TNP_FAIL(-1, "lstm gates: unknown variant %d (0 = automatic, 5, 20)", variant);
     }
     if (g.M >= 4096) return launch_general<2, 1, 2, 4, 32, EPI_LSTM>(g, s);
     return launch_general<1, 1, 4, 4, 16, EPI_LSTM>(g, s);
@@ -811,107 +773,3 @@ int launch_lstm_gates(const GemmArgs &g_in, int variant, hipStream_t s) {
 
 }  // namespace tnp
 
-// ---------------------------------------------------------------------------------------------------------
-// Calibration probe: a pure v_mfma_f32_32x32x2_f32 stream (no memory traffic) on every SIMD of the chip.
-// bench.py / tools use it to report what the matrix pipe sustains on THIS box (clock, power state) next to
-// the datasheet peak, so that roofline fractions can be read against both.
-// ---------------------------------------------------------------------------------------------------------
-namespace tnp {
-typedef float pf32x16 __attribute__((ext_vector_type(16)));
-template <int NACC>
-__global__ void __launch_bounds__(512) mfma_probe_kernel(float *out, int iters) {
-    pf32x16 acc[NACC];
-#pragma unroll
-    for (int a = 0; a < NACC; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
-    float x = (float)(threadIdx.x & 7) * 0.25f, y = (float)(threadIdx.x & 3) * 0.5f;
-    for (int i = 0; i < iters; ++i) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[a], 0, 0, 0);
-    }
-    float s = 0.0f;
-#pragma unroll
-    for (int a = 0; a < NACC; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += acc[a][r];
-    if (s == 12345.678f) out[0] = s;  // keep the chain alive
-}
-}  // namespace tnp
-
-extern "C" TNP_API int tnp_mfma_probe(int waves_per_wg, int n_acc, int iters, int blocks, float *scratch, void *stream) {
-    hipStream_t s = (hipStream_t)stream;
-    if (waves_per_wg < 1 || waves_per_wg > 8) TNP_FAIL(-1, "waves_per_wg must be 1..8");
-    dim3 grid(blocks), block(64 * waves_per_wg);
-    if (n_acc == 1) hipLaunchKernelGGL(tnp::mfma_probe_kernel<1>, grid, block, 0, s, scratch, iters);
-    else if (n_acc == 2) hipLaunchKernelGGL(tnp::mfma_probe_kernel<2>, grid, block, 0, s, scratch, iters);
-    else if (n_acc == 4) hipLaunchKernelGGL(tnp::mfma_probe_kernel<4>, grid, block, 0, s, scratch, iters);
-    else TNP_FAIL(-1, "n_acc must be 1, 2 or 4");
-    TNP_HIP(hipGetLastError());
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Ablation probe: the same MFMA stream with the GEMM's side traffic added one ingredient at a time
-// (bit 0: fragments via ds_read_b128, bit 1: a barrier every 16 MFMAs, bit 2: global loads + ds_write per 16).
-// ---------------------------------------------------------------------------------------------------------
-namespace tnp {
-typedef float af32x4 __attribute__((ext_vector_type(4)));
-template <int MODE>
-__global__ void __launch_bounds__(512) mfma_ablate_kernel(const float *src, float *out, int iters) {
-    extern __shared__ __attribute__((aligned(16))) float asm_[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < 16384; i += blockDim.x) asm_[i] = (iters < 0) ? src[(blockIdx.x * 16384 + i) & 0xFFFFF] : (float)(i & 15) * 0.125f;
-    if (iters < 0) iters = -iters;
-    __syncthreads();
-    pf32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    af32x4 a4 = {0.5f, 0.25f, 0.125f, 1.0f}, b4 = {1.0f, 0.5f, 0.25f, 0.125f};
-    const float *lbase = asm_ + ((tid >> 6) * 1024) + (lane & 31) * 36 + (lane >> 5) * 4;
-    const float *gp = src + (size_t)blockIdx.x * 8192 + tid * 4;
-    af32x4 st[3];
-    for (int i = 0; i < iters; ++i) {
-        if (MODE & 4) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) st[c] = *reinterpret_cast<const af32x4 *>(gp + ((i * 3 + c) & 3) * 2048);
-        }
-#pragma unroll
-        for (int k8 = 0; k8 < 4; ++k8) {
-            if (MODE & 1) {
-                a4 = *reinterpret_cast<const af32x4 *>(lbase + k8 * 8);
-                b4 = *reinterpret_cast<const af32x4 *>(lbase + 4608 + k8 * 8);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], b4[q], acc, 0, 0, 0);
-        }
-        if (MODE & 4) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                *reinterpret_cast<af32x4 *>(asm_ + 8192 + ((i & 1) * 4096) + (tid * 4 + c * 2048) % 4096) = st[c];
-        }
-        if (MODE & 2) __syncthreads();
-    }
-    float s = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s += acc[r];
-    if (s == 12345.678f) out[0] = s;
-}
-}  // namespace tnp
-
-extern "C" TNP_API int tnp_mfma_ablate(int mode, int iters, int blocks, const float *src, float *scratch, void *stream) {
-    hipStream_t s = (hipStream_t)stream;
-    dim3 grid(blocks), block(512);
-    const size_t smem = 16384 * sizeof(float);
-    static bool set = false;
-#define TNP_ABL(M) case M: { if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(tnp::mfma_ablate_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); } \
-        hipLaunchKernelGGL(tnp::mfma_ablate_kernel<M>, grid, block, smem, s, src, scratch, iters); break; }
-    switch (mode) {
-        TNP_ABL(0) TNP_ABL(1) TNP_ABL(2) TNP_ABL(3) TNP_ABL(4) TNP_ABL(5) TNP_ABL(6) TNP_ABL(7)
-        default: TNP_FAIL(-1, "mode 0..7");
-    }
-    TNP_HIP(hipGetLastError());
-    return 0;
-}

@@ -506,9 +506,9 @@ static int launch_dgrid_cells(const float *dy, int ldy, const float *Wc, const i
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
-    static int ysplit = 0;   // workgroups per cell (each stages the cell's weight block once and takes every ysplit-th ego group)
+    // workgroups per cell (each stages the cell's weight block once and takes every ysplit-th ego group):
     // 2 measured best at config 2 (1: 43.6, 2: 31.9, 3: 38.8, 4: 35.8 us per launch)
-    if (!ysplit) { const char *e = getenv("TNP_DGRID_Y"); ysplit = e ? atoi(e) : 2; if (ysplit < 1) ysplit = 1; }
+    const int ysplit = 2;
     hipLaunchKernelGGL(dgrid_cells_kernel<NB>, dim3(ncell, ysplit), dim3(256), lds, s, dy, ldy, Wc, list, count, R, nseg, seg, M, C,
                        ncell, N1, dcell);
     TNP_HIP(hipGetLastError());

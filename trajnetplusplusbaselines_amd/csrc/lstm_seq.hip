@@ -297,10 +297,8 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
         w.row_base = (int32_t *)take((size_t)M * sizeof(int32_t));
         w.row_end = (int32_t *)take((size_t)M * sizeof(int32_t));
         w.row_padded = (int32_t *)take((size_t)M * sizeof(int32_t));
-        // default kernel variant only (bits 0-15 of `variant` select measurement variants that read the winner table)
-        w.fuse_grid = (md->variant & 0xFFFF) == 0 && sparse_fuses_grid(md->n * md->n, 32767) &&
-                      (size_t)M * md->C * sizeof(float) < ((size_t)1 << 32) && getenv("TNP_SPARSE_VARIANT") == nullptr &&
-                      getenv("TNP_NO_GRID_FUSION") == nullptr;
+        // winner tile built inside the sparse kernel (no grid kernel, no table) whenever the tile fits in LDS
+        w.fuse_grid = sparse_fuses_grid(md->n * md->n, 32767) && (size_t)M * md->C * sizeof(float) < ((size_t)1 << 32);
         const size_t pb = sparse_partial_bytes(M, md->dims[1], md->n * md->n);
         if (pb) w.partial = (float *)take(pb);
     }

@@ -24,7 +24,6 @@
 // Grids above 440 cells (winner tile does not fit beside the accumulators) fall back to pool_embed_sparse_kernel:
 // 128 egos x 256 columns x a RANGE of cells per workgroup, partial tiles summed by sparse_reduce_kernel.
 #include "tnp_internal.h"
-#include <stdlib.h>
 
 namespace tnp {
 
@@ -59,10 +58,9 @@ struct SparseArgs {
 // (egos of group q) x (columns of set cs): every (ego, column) address has exactly one writer wave, so the LDS
 // float adds are race free and their order is program order (deterministic), while SP_EQ waves per SIMD hide the
 // scalar-load and LDS latencies of each other.
-// ABL (measurement only, tools/sparse_sweep.sh): 1 = no neighbour-row loads, 2 = no accumulator read-modify-write,
-// 4 = no weight loads, 8 = no hits at all.  ABL != 0 computes garbage; it isolates where the time goes.
-template <int C, int EQ, bool ATOMIC, int PF = 2, int ABL = 0>
+template <int C, int EQ>
 __global__ void __launch_bounds__(256 * EQ) pool_embed_sparse_kernel(const SparseArgs a) {
+    constexpr int PF = 2;
     extern __shared__ __attribute__((aligned(16))) float ssm[];
     float *acc = ssm;                                                  // [SP_TE][SP_OB]
     int16_t *wl = reinterpret_cast<int16_t *>(ssm + SP_TE * SP_OB);    // [cps][SP_TE + 2]
@@ -114,9 +112,8 @@ __global__ void __launch_bounds__(256 * EQ) pool_embed_sparse_kernel(const Spars
     auto load_w = [&](float (&w)[C], int cc) {
         const float *wb = a.Wp + (size_t)(c0 + cc) * C * a.N1;
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) w[ch] = (ABL & 4) ? (float)(cc + ch) : (wb + (size_t)ch * a.N1)[ocu];
+        for (int ch = 0; ch < C; ++ch) w[ch] = (wb + (size_t)ch * a.N1)[ocu];
     };
-    float abl_sum = 0.0f;
     auto process = [&](float (&w)[C], int cc) {
         // pin the wait for THIS cell's weights here (straight-line code, so the compiler emits vmcnt(#younger
         // loads) and the prefetched sets stay in flight); inside the hit loop it would fall back to vmcnt(0)
@@ -128,7 +125,6 @@ __global__ void __launch_bounds__(256 * EQ) pool_embed_sparse_kernel(const Spars
         const int wv = (lego < EPG) ? (int)wl[cc * WLS + eq * EPG + lego] : -1;
         const int rb = rbv[hh];
         unsigned long long mask = __ballot(wv >= 0);
-        if (ABL & 8) mask = 0ull;
         while (mask) {
             int eg[SP_U];
             const float *ep[SP_U];
@@ -144,26 +140,7 @@ __global__ void __launch_bounds__(256 * EQ) pool_embed_sparse_kernel(const Spars
                 eg[u] = eq * EPG + hh * 64 + b;
                 ep[u] = a.enc + (size_t)j * a.ldv;
             }
-            if (ABL & 3) {
-                // ablations: neighbour values from the row index instead of memory and / or a private sum
-                // instead of the LDS tile
-#pragma unroll
-                for (int u = 0; u < SP_U; ++u) {
-                    float v = (ABL & 2) ? 0.0f : accl[eg[u] * SP_OB];
-#pragma unroll
-                    for (int ch = 0; ch < C; ++ch)
-                        v = fmaf(w[ch], (ABL & 1) ? (float)((int)(ep[u] - a.enc) + ch) : ep[u][ch], v);
-                    if (ABL & 2) { abl_sum += v; } else if (ok[u]) accl[eg[u] * SP_OB] = v;
-                }
-            } else if (ATOMIC) {
-#pragma unroll
-                for (int u = 0; u < SP_U; ++u) {
-                    float c = 0.0f;
-#pragma unroll
-                    for (int ch = 0; ch < C; ++ch) c = fmaf(w[ch], ep[u][ch], c);
-                    if (ok[u]) __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)(accl + eg[u] * SP_OB), c, 0, 0, false);
-                }
-            } else {
+            {
                 float av[SP_U];
 #pragma unroll
                 for (int u = 0; u < SP_U; ++u) av[u] = accl[eg[u] * SP_OB];
@@ -194,7 +171,6 @@ __global__ void __launch_bounds__(256 * EQ) pool_embed_sparse_kernel(const Spars
             }
         }
     }
-    if (ABL & 2) accl[eq * EPG * SP_OB] = abl_sum;
     __syncthreads();   // all adds of the tile have landed before it is read back
 
     // epilogue: wave (q, cs) writes its egos' rows of its columns
@@ -296,12 +272,12 @@ __device__ __forceinline__ void sload_row(typename SRow<C>::type &v, const float
     else asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(base), "s"(byte_off));
 }
 
-// ABL: measurement only (4 = no weight loads, 8 = no hits).
-// TE egos x 8192/TE columns per workgroup.  TE = 64 (experiment, TNP_SPARSE_VARIANT 6/7): half the weight stream, 8 waves,
-// winner tile stored as int8 (needs n_max <= 127).
-template <int C, int PF, int U, bool SASM, int ABL = 0, int TE = TL_TE, typename WT = int16_t, bool FG = false>
-__global__ void __launch_bounds__(64 * TL_NQ * (8192 / TE / 64)) pool_embed_cellsplit_kernel(const SparseArgs a) {
-    constexpr int OB = 8192 / TE, NCS = OB / 64;
+// SASM: neighbour rows addressed with a 32-bit byte offset and loaded by inline-asm scalar loads (C <= 16); FG: the winner
+// tile is built from the positions inside the kernel instead of read from the table.
+template <int C, bool SASM, bool FG>
+__global__ void __launch_bounds__(64 * TL_NQ * (TL_OB / 64)) pool_embed_cellsplit_kernel(const SparseArgs a) {
+    constexpr int TE = TL_TE, OB = TL_OB, NCS = OB / 64, U = 2;
+    typedef int16_t WT;
     constexpr int NQ = TL_NQ, WLS = TE + (sizeof(WT) == 1 ? 4 : 2), NTH = 64 * NQ * NCS;
     extern __shared__ __attribute__((aligned(16))) float csm[];
     float *acc = csm;                                                        // [NQ][TE][OB]
@@ -371,7 +347,7 @@ __global__ void __launch_bounds__(64 * TL_NQ * (8192 / TE / 64)) pool_embed_cell
     auto load_w = [&](float (&w)[C], int c) {
         const float *wb = a.Wp + (size_t)c * C * a.N1;
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) w[ch] = (ABL & 4) ? (float)(c + ch) : (wb + (size_t)ch * a.N1)[ocu];
+        for (int ch = 0; ch < C; ++ch) w[ch] = (wb + (size_t)ch * a.N1)[ocu];
     };
     auto process = [&](float (&w)[C], int c) {
         const int wv = lane < TE ? (int)wl[c * WLS + lane] : -1;
@@ -400,20 +376,8 @@ __global__ void __launch_bounds__(64 * TL_NQ * (8192 / TE / 64)) pool_embed_cell
                 }
                 accl[b * OB] = p.x + p.y;
             };
-            if constexpr (U >= 4) {
-                while (__builtin_popcountll(mask) >= 4) {           // four hits in flight (64-ego tiles: ~5 hits per cell)
-                    int b[4];
-                    typename SRow<C>::type e[4];
-                    float av[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { b[u] = pop_bit(mask); one(b[u], e[u], av[u]); }
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e[0]), "+s"(e[1]), "+s"(e[2]), "+s"(e[3]));
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) fin(b[u], e[u], av[u]);
-                }
-            }
-            if constexpr (U >= 2) {
-                while (mask & (mask - 1ull)) {                      // at least two hits left
+            {
+                while (mask & (mask - 1ull)) {                      // at least two hits left: both in flight before the wait
                     const int b0 = pop_bit(mask);
                     const int b1 = pop_bit(mask);
                     typename SRow<C>::type e0, e1;
@@ -482,9 +446,8 @@ __global__ void __launch_bounds__(64 * TL_NQ * (8192 / TE / 64)) pool_embed_cell
         if (occ[1]) { const int k = __ffsll((long long)occ[1]) - 1; occ[1] &= occ[1] - 1ull; return q + NQ * (64 + k); }
         return -1;
     };
-    static_assert(PF == 2, "double-buffered weights");
     float wA[C], wB[C];
-    int ca = (ABL & 8) ? -1 : pop();
+    int ca = pop();
     if (ca >= 0) load_w(wA, ca);
     while (ca >= 0) {
         const int cb = pop();
@@ -544,54 +507,31 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
                              float *out, int ldo, float *partial, hipStream_t s, const SparseGridFuse *fg) {
     if (M <= 0) return 0;
     if (!sparse_supported(C, N1, ncell)) TNP_FAIL(-1, "sparse pooling embedding: unsupported C=%d N1=%d", C, N1);
-    // TNP_SPARSE_VARIANT (measurement, tools/sparse_sweep.sh): 0 default; 1 = one hit in flight; 2 = compiler-
-    // scheduled scalar loads; 8 / 9 = ablations (no hits / no weight loads: WRONG results, timing only)
-    static int sp_variant = -1;
-    if (sp_variant < 0) { const char *e = getenv("TNP_SPARSE_VARIANT"); sp_variant = e ? atoi(e) : 0; }
     SparseArgs a;
     a.winners = winners; a.enc = enc; a.ldv = ldv; a.row_base = row_base; a.Wp = Wp; a.bias = bias;
     a.M = M; a.ncell = ncell; a.C = C; a.N1 = N1; a.relu = relu; a.ldo = ldo;
     a.obs2 = nullptr; a.row_end = nullptr; a.row_padded = nullptr; a.G = 0; a.cell = 1.0f; a.half_x = a.half_y = 0.0f; a.winners_out = nullptr;
-    if (ncell <= TL_MAXCELL_LDS && (sp_variant == 6 || sp_variant == 7) && C == 16) {
-        // experiment: 64-ego tiles (assumes n_max <= 127: int8 winner tile)
-        a.out = out;
-        a.S = 1; a.cps = ncell; a.ego_tiles = (M + 63) / 64; a.out_blocks = (N1 + 127) / 128;
-        const size_t smem64 = (size_t)TL_NQ * 8192 * 4 + (((size_t)ncell * 68 + 15) & ~(size_t)15);
-        const int blocks64 = a.ego_tiles * a.out_blocks;
-#define CS_LAUNCH64(UU) { static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
-        pool_embed_cellsplit_kernel<16, 2, UU, true, 0, 64, int8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        hipLaunchKernelGGL((pool_embed_cellsplit_kernel<16, 2, UU, true, 0, 64, int8_t>), dim3(blocks64), dim3(512), smem64, s, a); }
-        if (sp_variant == 6) CS_LAUNCH64(4) else CS_LAUNCH64(2)
-        TNP_HIP(hipGetLastError());
-        return 0;
-    }
     if (ncell <= TL_MAXCELL_LDS) {
         a.out = out;
         a.S = 1; a.cps = ncell; a.ego_tiles = (M + TL_TE - 1) / TL_TE; a.out_blocks = (N1 + TL_OB - 1) / TL_OB;
         const size_t csmem = (size_t)TL_NQ * TL_TE * TL_OB * 4 + (((size_t)ncell * (TL_TE + 2) * 2 + 15) & ~(size_t)15);
         const int cblocks = a.ego_tiles * a.out_blocks;
         // the lean path addresses neighbour rows with a 32-bit byte offset
-        const bool lean = (size_t)M * ldv * sizeof(float) < ((size_t)1 << 32) && sp_variant != 2;
-        if (fg && lean && sp_variant == 0) {   // winner tile computed in the kernel: no grid kernel, no winner table
+        const bool lean = (size_t)M * ldv * sizeof(float) < ((size_t)1 << 32);
+        if (fg && !lean) TNP_FAIL(-1, "sparse pooling embedding: fused grid build needs 32-bit row offsets");
+        if (fg) {   // winner tile computed in the kernel: no grid kernel, no winner table
             a.obs2 = fg->obs2; a.row_end = fg->row_end; a.row_padded = fg->row_padded; a.G = fg->G;
             a.cell = fg->cell; a.half_x = fg->half_x; a.half_y = fg->half_y; a.winners_out = fg->winners_out;
-#define CS_LAUNCH_FG(CC) { static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
-        pool_embed_cellsplit_kernel<CC, 2, 2, true, 0, TL_TE, int16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        hipLaunchKernelGGL((pool_embed_cellsplit_kernel<CC, 2, 2, true, 0, TL_TE, int16_t, true>), dim3(cblocks), dim3(1024), csmem, s, a); }
-            if (C == 4) CS_LAUNCH_FG(4) else if (C == 8) CS_LAUNCH_FG(8) else if (C == 16) CS_LAUNCH_FG(16) else CS_LAUNCH_FG(32)
-            TNP_HIP(hipGetLastError());
-            return 0;
         }
-        if (fg) TNP_FAIL(-1, "sparse pooling embedding: fused grid build needs the default kernel variant");
-#define CS_LAUNCH(CC, UU, SA, ABLM) { static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
-        pool_embed_cellsplit_kernel<CC, 2, UU, SA, ABLM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        hipLaunchKernelGGL((pool_embed_cellsplit_kernel<CC, 2, UU, SA, ABLM>), dim3(cblocks), dim3(1024), csmem, s, a); }
-#define CS_SWITCH(CC) { if (!lean) CS_LAUNCH(CC, 2, false, 0) else switch (sp_variant) { case 1: CS_LAUNCH(CC, 1, true, 0) break; \
-        case 8: CS_LAUNCH(CC, 2, true, 8) break; case 9: CS_LAUNCH(CC, 2, true, 4) break; default: CS_LAUNCH(CC, 2, true, 0) break; } }
+#define CS_LAUNCH(CC, SA, FGB) { static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
+        pool_embed_cellsplit_kernel<CC, SA, FGB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((pool_embed_cellsplit_kernel<CC, SA, FGB>), dim3(cblocks), dim3(1024), csmem, s, a); }
+#define CS_SWITCH(CC) { if (fg) CS_LAUNCH(CC, true, true) else if (lean) CS_LAUNCH(CC, true, false) else CS_LAUNCH(CC, false, false) }
         if (C == 4) CS_SWITCH(4) else if (C == 8) CS_SWITCH(8) else if (C == 16) CS_SWITCH(16) else CS_SWITCH(32)
         TNP_HIP(hipGetLastError());
         return 0;
     }
+    if (fg) TNP_FAIL(-1, "sparse pooling embedding: fused grid build needs a grid of at most %d cells", TL_MAXCELL_LDS);
     // ---- fallback for grids too large for the LDS winner tile: cell ranges across workgroups + reduce ----
     sparse_plan(M, N1, ncell, a.S, a.cps, a.ego_tiles, a.out_blocks);
     if (a.cps > 120) TNP_FAIL(-1, "sparse pooling embedding: %d cells per split exceed the LDS winner tile", a.cps);
@@ -601,8 +541,8 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
     const size_t smem = (size_t)SP_TE * SP_OB * 4 + (((size_t)a.cps * (SP_TE + 2) * 2 + 15) & ~(size_t)15);
     const int blocks = a.ego_tiles * a.out_blocks * a.S;
 #define SP_LAUNCH(CC) { static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
-        pool_embed_sparse_kernel<CC, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        hipLaunchKernelGGL((pool_embed_sparse_kernel<CC, 4, false>), dim3(blocks), dim3(1024), smem, s, a); }
+        pool_embed_sparse_kernel<CC, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((pool_embed_sparse_kernel<CC, 4>), dim3(blocks), dim3(1024), smem, s, a); }
     if (C == 4) SP_LAUNCH(4) else if (C == 8) SP_LAUNCH(8) else if (C == 16) SP_LAUNCH(16) else SP_LAUNCH(32)
     TNP_HIP(hipGetLastError());
     if (a.S > 1) {
