@@ -47,6 +47,7 @@ CONFIGS = {
 CONFIGS['classical'] = dict(classical=True, scenes=4096, agents=128,
                             name='classical.socialforce + ORCA + Kalman batched rollouts (BASELINE config 5)')
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+FP64_VALU_PEAK_TFLOPS = 157.3 / 2   # fp64 vector FMA issues at half the fp32 vector rate (= the 78.6 TFLOP/s of AMD's datasheet)
 
 
 def build_model(cfg, device):
@@ -148,7 +149,10 @@ def cpu_baseline_classical(st, pos, vel, goals, speed, obs, z, starts, agents, s
 def bench_classical(args, cfg, device):
     """BASELINE config 5: social force, ORCA and Kalman rollouts of 4096 scenes x 128 agents (9 obs + 12 pred), inputs
     resident in HBM, one "step" = all three predictors over the whole batch (one workgroup per scene, state in LDS).
-    Latency / LDS-bound scalar work per scene: no HBM or MFMA roofline applies (roofline: null)."""
+    `roofline` prices the dominant predictor (social force, float64) against the fp64 vector peak: SURVEY 8(d) counts ~107
+    floating-point operations per ordered pair per simulation step (three evaluations of the elliptical potential with
+    2 sqrt + 1 exp each, the finite-difference gradient, the field-of-view test) -- counting sqrt / exp / divide as one
+    operation each, which flatters nothing: they cost several issue slots on the hardware."""
     S, A = cfg['scenes'], cfg['agents']
     rng = np.random.RandomState(11)
     M = S * A
@@ -204,6 +208,15 @@ def bench_classical(args, cfg, device):
                       'ms_per_predictor': per,
                       'scene_steps_per_s_per_predictor': {k: S * 21 / (v * 1e-3) for k, v in per.items()}},
            'roofline': None, 'cpu_baseline': None}
+    sf_ops = float(S) * A * (A - 1) * (12 * 8) * 107.0
+    sf_s = per['socialforce'] * 1e-3
+    out['roofline'] = {'bound': 'valu-f64', 'achieved': sf_ops / sf_s / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                       'frac': sf_ops / sf_s / 1e12 / FP64_VALU_PEAK_TFLOPS, 'traffic': None,
+                       'kernel': 'sf_rollout_kernel (one workgroup per scene, state in LDS, 96 Euler steps fused)',
+                       'ops_per_launch': sf_ops, 'launch_ms': per['socialforce'],
+                       'note': 'operations = scenes x A(A-1) ordered pairs x 96 steps x ~107 (3 potential evaluations with 2 sqrt + 1 exp '
+                               'each, gradient, field-of-view test; sqrt / exp / divide counted as ONE operation); HBM traffic is '
+                               'the 6 input and 24 output doubles per agent (63 MB per batch) -- irrelevant next to the arithmetic'}
     if not args.no_cpu_baseline:
         sub_n = 64
         cpu = cpu_baseline_classical(st, pos, vel, goals, speed, obs, z, starts, A, sub_n, S)

@@ -9,7 +9,8 @@
  * compiled here by gcc for the host and by hipcc for gfx950: these functions therefore check the GPU EXECUTION
  * (batching over scenes, LDS staging, lane-parallel neighbour search, synchronous updates, sampling cadence), not the
  * formulae; tests/test_classical.py adds formula-independent invariants (constant-velocity limit, mirror symmetry,
- * ORCA collision-freeness, Kalman on noise-free lines).
+ * ORCA collision-freeness, Kalman on noise-free lines) and compares this core with oracle/classical_numpy.py, a second,
+ * independent numpy restatement of the same published algorithms that does not include the header.
  */
 #include <stdint.h>
 #include <stdlib.h>

@@ -188,3 +188,37 @@ def test_gpu_config5_scale_properties():
     idx = (perm[:, None] * 128 + np.arange(128)[None, :]).reshape(-1)
     c = orca.rollout_batch(pos[idx], vel[idx], speed[idx], goals[idx], sizes)
     assert np.array_equal(c, a[:, idx])
+
+
+# ---- independent numpy restatement (oracle/classical_numpy.py: does not include csrc/classical_core.h) vs the C restatement ----
+def test_independent_social_force_restatements_agree():
+    from oracle import classical_numpy as cn
+    pos, vel, goals, speed, sizes = crowd(5, 9, 21)
+    st = np.concatenate([pos, vel, goals], axis=1)
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    np.testing.assert_allclose(cn.sf_rollout(st, starts), oracle.sf_rollout(st, starts), rtol=0, atol=1e-9)
+
+
+def test_independent_kalman_restatements_agree():
+    from oracle import classical_numpy as cn
+    rng = np.random.RandomState(31)
+    n = 12
+    t = np.arange(9)[None, :, None]
+    obs = rng.randn(n, 1, 2) + rng.randn(n, 1, 2) * 0.4 * t + rng.randn(n, 9, 2) * 0.03
+    z = rng.standard_normal((n, 5, 13, 6))
+    np.testing.assert_allclose(cn.kalman_predict(obs, z), oracle.kalman_predict(obs, z), rtol=0, atol=1e-7)
+
+
+def test_independent_orca_restatements_agree():
+    """float32 on both sides; the two restatements order a few operations differently, so positions agree to a few ulp
+    of accumulated rounding rather than bit for bit -- neighbour sets of the first step are identical"""
+    from oracle import classical_numpy as cn
+    pos, vel, goals, speed, sizes = crowd(4, 7, 41)
+    pos = pos * 0.45                                           # dense: collisions, leg / cut-off / fallback branches
+    goals = pos + vel * 4.8
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    got, nb = cn.orca_rollout(pos, vel, goals, speed, 1.3 * speed, starts, want_neighbors=True)
+    want, wnb = oracle.orca_rollout(pos, vel, goals, speed, 1.3 * speed, starts, want_neighbors=True)
+    assert np.array_equal(nb, wnb)
+    assert np.isfinite(got).all() and got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-4

@@ -360,3 +360,44 @@ def test_train_batch_with_collision_loss_matches_the_reference_trainer(kind):
                 worst = max(worst, float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-3)))
             assert worst < 5e-5, worst
     np.testing.assert_allclose(losses, z[pre + 'losses'], rtol=1e-4)
+
+
+def test_scene_batcher_on_the_device_matches_the_trainers_host_assembly():
+    """data.SceneBatcher (scenes tensorised once, a batch = a column gather, per-scene rotation on the
+    device) against the reference trainer's per-scene host arithmetic: drop_distant (lstm/lstm.py:16-22), center_scene
+    (lstm/utils.py:32-51), random_rotation (lstm/utils.py:10-17, one angle per scene from Python's `random`), and the
+    batch assembly of lstm/trainer.py:120-131 -- then one optimisation step straight from the batcher's device tensors."""
+    import random
+    from trajnetplusplusbaselines_amd import data, synth
+    from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling, PredictionLoss, drop_distant
+    from trajnetplusplusbaselines_amd.lstm.train_step import train_batch
+    xy, split = synth.ragged_crowd(9, 2, 11, seed=23)
+    xy = xy.numpy().astype(np.float64) * 1.6                      # spread out: drop_distant removes some neighbours
+    scenes = [xy[:, split[s]:split[s + 1]] for s in range(9)]
+    for normalize in (False, True):
+        batcher = data.SceneBatcher(scenes, device='cuda', obs_length=9, normalize_scene=normalize)
+        ids = [4, 0, 7, 2]
+        random.seed(99)
+        got_xy, got_goals, got_split = batcher.batch(ids, augment=True)
+        random.seed(99)
+        want, want_goals = [], []
+        for i in ids:                                              # what lstm/trainer.py:96-133 does per scene, on the host
+            sc, _ = drop_distant(scenes[i])
+            g = np.zeros((sc.shape[1], 2))
+            if normalize:
+                sc, _, _, g = data.center_scene(sc, 9, goals=g)
+            sc, g = data.random_rotation(sc, g)
+            want.append(sc)
+            want_goals.append(g)
+        want_xy, want_split = data.batch_scenes(want)
+        assert got_xy.is_cuda and got_split.tolist() == want_split.tolist()
+        helpers.assert_close_nan(got_xy.cpu().numpy(), want_xy, 2e-5, 'batched scenes')
+        helpers.assert_close_nan(got_goals.cpu().numpy(), np.concatenate(want_goals, axis=0), 2e-5, 'batched goals')
+    assert (np.diff(want_split) < np.array([scenes[i].shape[1] for i in ids])).any()    # drop_distant did remove tracks
+    pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=8, out_dim=64, embedding_arch='two_layer',
+                            layer_dims=[128], latent_dim=8)
+    torch.manual_seed(3)
+    model = LSTM(pool=pool).cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    losses = [train_batch(model, opt, PredictionLoss(), got_xy, got_goals, got_split, 9, 12) for _ in range(3)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
