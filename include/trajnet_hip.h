@@ -229,6 +229,18 @@ typedef struct tnp_lstm_extras {
     int32_t noise_group_tracks;   /* 0: one vector; g > 0: tracks [i*g, (i+1)*g) carry vector i -- k generator samples
                                      batched as k replicas of the scenes (sgan/sgan.py:78-100 runs them one by one) */
     float *h_final;               /* optional out [M,H] */
+    /* Loss fused into the sequence (PredictionLoss / L2Loss on the primaries, lstm/loss.py:52-135; what
+     * Trainer.val_batch evaluates on rel_outputs[-pred_length:], lstm/trainer.py:296-309): while the kernel that finishes a
+     * step still holds the step's normal (mu, sigma, rho) in registers, it evaluates the per-element loss of every PRIMARY
+     * row against loss_targets and stores it -- the [T, M, 5] normals are not read back.
+     *   loss_targets [loss_steps, M, 2]  targets of the LAST loss_steps outputs (NULL = no fused loss)
+     *   loss_values  [loss_steps, M]     out: entry [t, scene_start[s]] = loss of scene s at step t (other rows untouched);
+     *                                    tnp_primary_loss_reduce turns it into the mean / per-scene means
+     *   loss_mode 0 = PredictionLoss (loss_background_rate), 1 = L2 (sum of the two squared errors) */
+    const float *loss_targets;
+    float *loss_values;
+    int32_t loss_steps, loss_mode;
+    float loss_background_rate;
 } tnp_lstm_extras;
 TNP_API int tnp_lstm_forward_ex(const tnp_lstm_model *model, const float *observed, int T_obs, int M,
                         const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,
@@ -470,6 +482,10 @@ TNP_API int tnp_directional_scatter_backward(const float *dgrid, int ldg, const 
 TNP_API int tnp_primary_loss_forward(int mode, const float *inputs, const float *targets, const int32_t *scene_start,
                              int B, int T, int M, float background_rate, int keep_batch_dim, float scale,
                              float *values_ws, float *out, void *stream);
+/* reduction of the fused loss (tnp_lstm_extras.loss_values, [T, ld] row-indexed) exactly as tnp_primary_loss_forward
+ * reduces its values: out [1] or [B]; values_ws T*B floats */
+TNP_API int tnp_primary_loss_reduce(const float *row_values, int ld, const int32_t *scene_start, int B, int T,
+                            int keep_batch_dim, float scale, float *values_ws, float *out, void *stream);
 TNP_API int tnp_primary_loss_backward(int mode, const float *inputs, const float *targets, const int32_t *scene_start,
                               int B, int T, int M, float background_rate, int keep_batch_dim, float scale,
                               const float *grad_out, float *d_inputs, void *stream);

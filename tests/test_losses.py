@@ -186,3 +186,34 @@ def test_gpu_collision_gradient_matches_reference_autograd(k):
         assert np.array_equal(got != 0, np.abs(want) > 0) or np.abs(got - want).max() < 1e-6
         some |= bool(np.abs(want).max() > 0)
     assert some or k == 2                                       # every case but the single-track one collides
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['social', 'vanilla'])
+def test_gpu_loss_fused_into_the_sequence_equals_the_stand_alone_loss(kind):
+    """LSTM.forward_with_loss (the kernel that finishes a step evaluates the primaries' loss from registers) == the criterion
+    applied to the returned normals, bit for bit, for PredictionLoss / L2Loss, both reductions, teacher-forced and free
+    running; train_step.val_batch == Trainer.val_batch's two numbers computed the long way."""
+    from trajnetplusplusbaselines_amd import synth
+    from trajnetplusplusbaselines_amd.lstm import PredictionLoss, L2Loss
+    from trajnetplusplusbaselines_amd.lstm.train_step import val_batch
+    sd, cfg, d = helpers.load_lstm_case(kind)
+    model = helpers.build_amd_model(sd, cfg)
+    xy, split = synth.ragged_crowd(7, 2, 9, seed=77)
+    M = xy.shape[1]
+    goals = torch.zeros(M, 2)
+    targets = (xy[9:21] - xy[8:20]).cuda()
+    with torch.no_grad():
+        for crit in (PredictionLoss(), PredictionLoss(keep_batch_dim=True, background_rate=0.1), L2Loss(), L2Loss(keep_batch_dim=True)):
+            for kw in (dict(n_predict=12), dict(prediction_truth=xy[9:20].clone())):
+                rel, pred, loss = model.forward_with_loss(xy[:9], goals, split, targets, crit, **kw)
+                rel2, pred2 = model(xy[:9], goals, split, **kw)
+                assert torch.equal(torch.nan_to_num(rel), torch.nan_to_num(rel2)) and torch.equal(torch.nan_to_num(pred), torch.nan_to_num(pred2))
+                want = crit(rel2[-12:], targets, split)
+                assert torch.equal(loss, want), (float(loss.sum()), float(want.sum()))
+        crit = PredictionLoss()
+        got = val_batch(model, crit, xy, goals, split, 9, 12, batch_size=8)
+        rel_t, _ = model(xy[:9], goals, split, xy[9:20].clone())
+        rel_f, _ = model(xy[:9], goals, split, n_predict=12)
+        want = (float(crit(rel_t[-12:], targets, split)) * 8, float(crit(rel_f[-12:], targets, split)) * 8)
+        assert got == want

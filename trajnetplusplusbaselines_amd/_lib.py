@@ -43,7 +43,8 @@ class LstmModel(ctypes.Structure):
 class LstmExtras(ctypes.Structure):
     """mirror of ``struct tnp_lstm_extras``"""
     _fields_ = [('W_ctx', _fp), ('b_ctx', _fp), ('noise', _fp), ('noise_dim', ctypes.c_int32), ('noise_group_tracks', ctypes.c_int32),
-                ('h_final', _fp)]
+                ('h_final', _fp), ('loss_targets', _fp), ('loss_values', _fp), ('loss_steps', ctypes.c_int32),
+                ('loss_mode', ctypes.c_int32), ('loss_background_rate', ctypes.c_float)]
 
 
 _LIB = None
@@ -150,6 +151,7 @@ def lib():
                                             ctypes.c_float, ctypes.c_int, ctypes.c_float, _fp, _fp, _fp]
     L.tnp_primary_loss_forward.argtypes = [ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_float, ctypes.c_int, ctypes.c_float, _fp, _fp, _fp]
+    L.tnp_primary_loss_reduce.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, _fp, _fp, _fp]
     L.tnp_collision_loss_forward.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_float, ctypes.c_float, _fp, _fp, _fp]
     L.tnp_collision_loss_backward.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -5,18 +5,6 @@
 
 namespace tnp {
 
-__device__ __forceinline__ float gaussian_2d_dev(float mu1, float mu2, float s1, float s2, float rho, float x1, float x2) {
-    // lstm/loss.py:23-50, same operation order
-    const float norm1 = x1 - mu1, norm2 = x2 - mu2;
-    const float s1s2 = s1 * s2;
-    const float q1 = norm1 / s1, q2 = norm2 / s2;
-    const float z = q1 * q1 + q2 * q2 - 2.0f * rho * norm1 * norm2 / s1s2;
-    const float omr = 1.0f - rho * rho;
-    const float num = expf(-z / (2.0f * omr));
-    const float den = 6.283185307179586f * s1s2 * sqrtf(omr);
-    return num / den;
-}
-
 // values[t*B + s] = per-element loss of primary s at step t;  mode 0 = PredictionLoss, 1 = L2 (sum of the 2 squared errors)
 __global__ void loss_values_kernel(int mode, const float *inputs, const float *targets, const int32_t *scene_start,
                                    int B, int T, int M, float bg, float *values) {
@@ -26,16 +14,7 @@ __global__ void loss_values_kernel(int mode, const float *inputs, const float *t
     const int m = scene_start[s];
     const float *in = inputs + ((size_t)t * M + m) * 5;
     const float *tg = targets + ((size_t)t * M + m) * 2;
-    float v;
-    if (mode == 0) {
-        const float g_bg = gaussian_2d_dev(in[0], in[1], 3.0f, 3.0f, 0.0f, tg[0], tg[1]);   // :73-76
-        const float g = gaussian_2d_dev(in[0], in[1], in[2], in[3], in[4], tg[0], tg[1]);
-        v = -logf(0.01f + bg * g_bg + (0.99f - bg) * g);                                       // :78-82
-    } else {
-        const float d0 = in[0] - tg[0], d1 = in[1] - tg[1];
-        v = d0 * d0 + d1 * d1;
-    }
-    values[idx] = v;
+    values[idx] = primary_loss_value(mode, in[0], in[1], in[2], in[3], in[4], tg[0], tg[1], bg);
 }
 
 // d(out)/d(inputs) of tnp_primary_loss_forward times the upstream gradient: one lane per (step, scene) writes the five
@@ -186,6 +165,30 @@ extern "C" TNP_API int tnp_primary_loss_forward(int mode, const float *inputs, c
     TNP_HIP(hipGetLastError());
     hipLaunchKernelGGL(tnp::loss_reduce_kernel, dim3(keep_batch_dim ? B : 1), dim3(256), 0, s, values_ws, B, T,
                        keep_batch_dim, scale, out);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+// values laid out per ROW ([T][ld], the primaries' entries written by the sequence driver's fused loss): gather the
+// primaries' columns into [T][B], then the same fixed-order reduction
+namespace tnp {
+__global__ void loss_gather_kernel(const float *rows, int ld, const int32_t *scene_start, int B, int T, float *values) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * B) return;
+    const int t = idx / B, s = idx - t * B;
+    values[idx] = rows[(size_t)t * ld + scene_start[s]];
+}
+}  // namespace tnp
+
+extern "C" TNP_API int tnp_primary_loss_reduce(const float *row_values, int ld, const int32_t *scene_start, int B, int T,
+                                               int keep_batch_dim, float scale, float *values_ws, float *out, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (B <= 0 || T <= 0) return 0;
+    const int n = T * B;
+    hipLaunchKernelGGL(tnp::loss_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, row_values, ld, scene_start, B, T, values_ws);
+    TNP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(tnp::loss_reduce_kernel, dim3(keep_batch_dim ? B : 1), dim3(256), 0, s, values_ws, B, T, keep_batch_dim,
+                       scale, out);
     TNP_HIP(hipGetLastError());
     return 0;
 }

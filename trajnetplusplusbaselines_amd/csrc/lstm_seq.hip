@@ -69,6 +69,11 @@ struct PrepArgs {
     const float *We, *be, *Wg, *bg;
     const float *Wh, *bh;        // social encoding [C,H]
     float *enc;                  // [M,C]
+    // fused loss of the step being finished (primaries only)
+    const float *loss_tgt;       // [M,2] or NULL
+    float *loss_out;             // [M]
+    int loss_mode; float loss_bg;
+    const uint8_t *prim_prev;    // [M] primary flags (read when loss_tgt is set)
 };
 
 #define PREP_TRACKS 8
@@ -94,9 +99,13 @@ __global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
 
     // phase-2 operands of lane 0 are fetched now so their latency hides behind phase 1
     float pf_o2x = NAN, pf_o2y = NAN, pf_e1x = NAN, pf_e1y = NAN, pf_e2x = NAN, pf_e2y = NAN, pf_p1x = NAN, pf_p1y = NAN;
-    int pf_maskprev = 0, pf_prim = 0;
+    int pf_maskprev = 0, pf_prim = 0, pf_lossprim = 0;
+    float pf_tx = 0.0f, pf_ty = 0.0f;
     if (l32 == 0 && valid) {
-        if (a.have_prev) { pf_o2x = a.obs2_prev[2 * m]; pf_o2y = a.obs2_prev[2 * m + 1]; pf_maskprev = a.mask_prev[m]; }
+        if (a.have_prev) {
+            pf_o2x = a.obs2_prev[2 * m]; pf_o2y = a.obs2_prev[2 * m + 1]; pf_maskprev = a.mask_prev[m];
+            if (a.loss_tgt) { pf_lossprim = a.prim_prev[m]; pf_tx = a.loss_tgt[2 * m]; pf_ty = a.loss_tgt[2 * m + 1]; }
+        }
         if (a.have_next) {
             pf_prim = a.primary[m];
             if (a.ext1) { pf_e1x = a.ext1[2 * m]; pf_e1y = a.ext1[2 * m + 1]; }
@@ -151,6 +160,7 @@ __global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
             }
             float *no = a.normal_out + (size_t)m * 5;
             no[0] = n0; no[1] = n1; no[2] = n2; no[3] = n3; no[4] = n4;
+            if (pf_lossprim) a.loss_out[m] = primary_loss_value(a.loss_mode, n0, n1, n2, n3, n4, pf_tx, pf_ty, a.loss_bg);
             px = pf_o2x + n0;      // positions.append(obs2 + normal[:, :2]), lstm.py:232,255
             py = pf_o2y + n1;
             a.pos_out[2 * m] = px; a.pos_out[2 * m + 1] = py;
@@ -578,6 +588,9 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
     if (T_dec < 0) TNP_FAIL(-1, "negative decoder length");
     if (M <= 0 || B <= 0) return 0;
     if (md->goal_flag && !goals) TNP_FAIL(-1, "goal_flag set but goals == NULL");
+    if (ex && ex->loss_targets && (!ex->loss_values || ex->loss_steps < 1 || ex->loss_steps > (T_obs - 1) + T_dec ||
+                                   (ex->loss_mode != 0 && ex->loss_mode != 1)))
+        TNP_FAIL(-1, "tnp_lstm_forward_ex: bad fused-loss request (loss_steps %d, mode %d)", ex->loss_steps, ex->loss_mode);
     const bool noisy = ex && ex->noise_dim > 0;
     if (noisy && (ex->noise_dim >= md->H || !ex->W_ctx || !ex->b_ctx || !ex->noise || ex->noise_group_tracks < 0))
         TNP_FAIL(-1, "tnp_lstm_forward_ex: bad noise interface (noise_dim %d)", ex->noise_dim);
@@ -639,6 +652,11 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
             p.mask_prev = w.mask;       // read before this launch overwrites it: each thread owns one track
             p.obs2_prev = obs2_prev;
             p.normal_out = rel_pred + (size_t)nnorm * M * 5;
+            if (ex && ex->loss_targets && nnorm >= n_steps - ex->loss_steps) {   // loss of this output, fused
+                const int t = nnorm - (n_steps - ex->loss_steps);
+                p.loss_tgt = ex->loss_targets + (size_t)t * M * 2; p.loss_out = ex->loss_values + (size_t)t * M;
+                p.loss_mode = ex->loss_mode; p.loss_bg = ex->loss_background_rate; p.prim_prev = primary_flag;
+            }
             p.pos_out = pred + (size_t)npos * F;
             ++nnorm; ++npos;            // the entry being written is positions[-1] for the next step
         }

@@ -88,6 +88,30 @@ int launch_pool_attn_pair(const float *obs1, const float *obs2, const float *hen
 int launch_pool_traj(const float *obs1, const float *obs2, int M, const float *W, const float *bias, int P, float *out,
                      int ldo, double *scratch4, hipStream_t s, float *inputs = nullptr);
 
+// ---- per-primary loss value (lstm/loss.py:23-91 / :107-135), shared by loss.hip and the sequence driver's fused form ----
+__device__ __forceinline__ float gaussian_2d_dev(float mu1, float mu2, float s1, float s2, float rho, float x1, float x2) {
+    // lstm/loss.py:23-50, same operation order
+    const float norm1 = x1 - mu1, norm2 = x2 - mu2;
+    const float s1s2 = s1 * s2;
+    const float q1 = norm1 / s1, q2 = norm2 / s2;
+    const float z = q1 * q1 + q2 * q2 - 2.0f * rho * norm1 * norm2 / s1s2;
+    const float omr = 1.0f - rho * rho;
+    const float num = expf(-z / (2.0f * omr));
+    const float den = 6.283185307179586f * s1s2 * sqrtf(omr);
+    return num / den;
+}
+// mode 0 = PredictionLoss (NLL with flat background), 1 = L2 (sum of the two squared errors)
+__device__ __forceinline__ float primary_loss_value(int mode, float n0, float n1, float n2, float n3, float n4, float tx, float ty,
+                                                    float bg) {
+    if (mode == 0) {
+        const float g_bg = gaussian_2d_dev(n0, n1, 3.0f, 3.0f, 0.0f, tx, ty);   // :73-76
+        const float g = gaussian_2d_dev(n0, n1, n2, n3, n4, tx, ty);
+        return -logf(0.01f + bg * g_bg + (0.99f - bg) * g);                     // :78-82
+    }
+    const float d0 = n0 - tx, d1 = n1 - ty;
+    return d0 * d0 + d1 * d1;
+}
+
 // ---- profiling hook -------------------------------------------------------------------------
 enum { PROF_GEMM1 = 0, PROF_ALL_GEMM = 1 };
 void prof_before(int cls, hipStream_t s);

@@ -248,9 +248,42 @@ class LSTM(torch.nn.Module):
         rel_pred, pred, _ = self._run_sequence(observed, goals, batch_split, prediction_truth, T_dec, pad_to=pad_to)
         return rel_pred, pred
 
+    def forward_with_loss(self, observed, goals, batch_split, targets, criterion, prediction_truth=None, n_predict=None,
+                          pad_to=None):
+        """``forward`` + ``criterion(rel_pred[-T:], targets, batch_split)`` in one pass (no gradients): the kernel that
+        finishes a step evaluates the primaries' loss while the step's normal is still in registers (SURVEY.md 8f rank 3:
+        what Trainer.val_batch computes, lstm/trainer.py:296-309).  ``criterion`` is a PredictionLoss or L2Loss (their
+        auxiliary collision term needs predicted positions and is not part of the validation loss in the reference
+        either).  Returns (rel_pred, pred, loss) with loss exactly what the criterion returns."""
+        from .loss import PredictionLoss, L2Loss
+        assert ((prediction_truth is None) + (n_predict is None)) == 1
+        if isinstance(criterion, PredictionLoss):
+            mode, bg, scale = 0, criterion.background_rate, float(criterion.loss_multiplier)
+        elif isinstance(criterion, L2Loss):
+            mode, bg, scale = 1, 0.0, 0.5 * criterion.loss_multiplier
+        else:
+            raise TypeError('forward_with_loss takes a PredictionLoss or an L2Loss')
+        if prediction_truth is not None and isinstance(prediction_truth, (list, tuple)):
+            prediction_truth = torch.stack(list(prediction_truth), dim=0)
+        T_dec = prediction_truth.size(0) if prediction_truth is not None else n_predict - 1
+        rel_pred, pred, rows = self._run_sequence(observed, goals, batch_split, prediction_truth, T_dec, pad_to=pad_to,
+                                                  fused_loss=(targets, mode, bg))
+        dev = rel_pred.device
+        idx = _lib.SceneIndex.get(batch_split, dev)
+        keep = bool(criterion.keep_batch_dim)
+        T = rows.size(0)
+        out = torch.empty(idx.B if keep else 1, dtype=torch.float32, device=dev)
+        ws = torch.empty(T * idx.B, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().tnp_primary_loss_reduce(_lib.ptr(rows), rows.size(1), _lib.ptr(idx.starts), idx.B, T, int(keep),
+                                                      scale, _lib.ptr(ws), _lib.ptr(out), _lib.stream_ptr()),
+                   'tnp_primary_loss_reduce')
+        return rel_pred, pred, (out if keep else out[0])
+
     def _run_sequence(self, observed, goals, batch_split, truth, T_dec, w_ctx=None, b_ctx=None, noise=None,
-                      want_h_final=False, pad_to=None):
-        """tnp_lstm_forward(_ex): T_obs-1 encoder steps + T_dec decoder steps; optional S-GAN hooks."""
+                      want_h_final=False, pad_to=None, fused_loss=None):
+        """tnp_lstm_forward(_ex): T_obs-1 encoder steps + T_dec decoder steps; optional S-GAN hooks.
+        ``fused_loss`` = (targets [T_loss, M, 2], mode, background_rate): the per-primary loss values of the last T_loss
+        outputs are evaluated inside the sequence (returned in place of h_final as [T_loss, M] rows)."""
         m, keep, dev = self._descriptor()
         observed = _lib.f32c(observed, dev)
         T_obs, M = observed.size(0), observed.size(1)
@@ -278,10 +311,21 @@ class LSTM(torch.nn.Module):
         if want_h_final:
             h_final = torch.empty(M, self.hidden_dim, dtype=torch.float32, device=dev)
             ex.h_final = _lib.ptr(h_final)
+        loss_rows = None
+        if fused_loss is not None:
+            tgt, mode, bg = fused_loss
+            tgt = _lib.f32c(tgt, dev)
+            if tgt.dim() != 3 or tgt.size(1) != M or tgt.size(2) != 2:
+                raise ValueError('fused loss targets must be [T_loss, M, 2]')
+            loss_rows = torch.empty(tgt.size(0), M, dtype=torch.float32, device=dev)
+            ex.loss_targets, ex.loss_values = _lib.ptr(tgt), _lib.ptr(loss_rows)
+            ex.loss_steps, ex.loss_mode, ex.loss_background_rate = int(tgt.size(0)), int(mode), float(bg)
         _lib.check(_lib.lib().tnp_lstm_forward_ex(
             ctypes.byref(m), _lib.ptr(observed), T_obs, M, _lib.ptr(goals_t), _lib.ptr(idx.starts),
             _lib.ptr(idx.primary), idx.B, idx.n_max, _lib.ptr(idx.slots), _lib.ptr(truth), T_dec, _lib.ptr(rel_pred), _lib.ptr(pred),
             _lib.ptr(ws), need, ctypes.byref(ex), _lib.stream_ptr()), 'tnp_lstm_forward')
+        if fused_loss is not None:
+            return rel_pred, pred, loss_rows
         return rel_pred, pred, h_final
 
 

@@ -72,3 +72,27 @@ def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batc
         parallel.allreduce_gradients(list(model.parameters()), group=group)
     optimizer.step()
     return float(loss_value)
+
+
+def val_batch(model, criterion, batch_scene, batch_scene_goal, batch_split, obs_length=9, pred_length=12, batch_size=None,
+              pad_to=None, start_length=0):
+    """Trainer.val_batch (lstm/trainer.py:271-311): the validation loss with the neighbours' ground truth provided
+    (teacher forced) and without it (``n_predict``, the evaluation scenario), each ``criterion(rel_outputs[-pred_length:],
+    targets, batch_split) * batch_size`` -- evaluated inside the two forward passes (``LSTM.forward_with_loss``).
+    Returns (loss, loss_test) as floats."""
+    dev = next(model.parameters()).device
+    split = torch.as_tensor(batch_split, dtype=torch.int64)
+    batch_size = batch_size or (split.numel() - 1)
+    batch_scene = batch_scene.to(dev)
+    observed = batch_scene[start_length:obs_length]
+    prediction_truth = batch_scene[obs_length:obs_length + pred_length - 1].clone()
+    targets = batch_scene[obs_length:obs_length + pred_length] - batch_scene[obs_length - 1:obs_length + pred_length - 1]
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        _, _, loss = model.forward_with_loss(observed, batch_scene_goal, split, targets, criterion,
+                                             prediction_truth=prediction_truth, pad_to=pad_to)
+        _, _, loss_test = model.forward_with_loss(observed.clone(), batch_scene_goal, split, targets, criterion,
+                                                  n_predict=pred_length, pad_to=pad_to)
+    model.train(was_training)
+    return float(loss) * batch_size, float(loss_test) * batch_size
