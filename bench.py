@@ -344,7 +344,7 @@ def main():
 
         def step():
             return train_batch(model, optimizer, criterion, scene_dev, goals, split, 9, 12, batch_size=cfg['scenes'] * world,
-                               n_global_scenes=cfg['scenes'] * world)
+                               n_global_scenes=cfg['scenes'] * world, pad_to=cfg['agents'], overlap=True)
     elif is_sgan:
         truth = xy[9:21].to(device)
 
@@ -382,14 +382,18 @@ def main():
         tmodel = build_model(cfg, device)                     # same seed on every rank: replicas start identical
         tmodel.kernel_variant = args.variant
         optimizer = torch.optim.Adam(tmodel.parameters(), lr=1e-3, weight_decay=1e-4)   # lstm/trainer.py:497
-        buckets = parallel.GradBuckets(tmodel.parameters()) if distributed else None
+        # gradient all-reduce: 'overlap' (default) = from inside the backward pass, each gradient as soon as it is enqueued
+        # (parallel.GradReducer); 'buckets' = flat persistent buckets launched asynchronously after the backward pass
+        ar_mode = os.environ.get('TNP_BENCH_ALLREDUCE', 'overlap')
+        buckets = parallel.GradBuckets(tmodel.parameters()) if (distributed and ar_mode == 'buckets') else None
         criterion = PredictionLoss()
         scene_dev = xy.to(device)
         t_steps, t_warm = max(5, min(args.steps, 30)), 3
 
         def tstep():
             return train_batch(tmodel, optimizer, criterion, scene_dev, goals, split, 9, 12, batch_size=cfg['scenes'] * world,
-                               n_global_scenes=cfg['scenes'] * world, pad_to=cfg['agents'], buckets=buckets)
+                               n_global_scenes=cfg['scenes'] * world, pad_to=cfg['agents'], buckets=buckets,
+                               overlap=(ar_mode == 'overlap'))
         for _ in range(t_warm):
             tstep()
         barrier()
@@ -405,8 +409,9 @@ def main():
         training = dict(value=cfg['scenes'] * world * 21 * t_steps / t_el, unit='scene-steps/s', steps=t_steps, warmup=t_warm,
                         ms_per_step=t_el / t_steps * 1e3, loss_last=loss_last,
                         workload='Trainer.train_batch of the same model on the same shard: teacher-forced forward, NLL loss, '
-                                 'backward, Adam%s' % (' + SUM all-reduce of %.1f MB of fp32 gradients over RCCL (%d flat buckets, '
-                                                       'asynchronous)' % (grad_bytes / 1e6, len(buckets.buckets)) if distributed else ''),
+                                 'backward, Adam%s' % (' + SUM all-reduce of %.1f MB of fp32 gradients over RCCL (%s)' % (
+                                     grad_bytes / 1e6, 'launched from inside the backward pass as each gradient is enqueued, largest first'
+                                     if ar_mode == 'overlap' else 'flat buckets after the backward pass') if distributed else ''),
                         allreduce_bytes=grad_bytes if distributed else 0)
         del tmodel, optimizer, buckets
 

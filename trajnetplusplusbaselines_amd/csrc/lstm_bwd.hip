@@ -401,24 +401,32 @@ __global__ void __launch_bounds__(256) hits_transpose_kernel(const T *__restrict
 // weight gradient, one step for the ego lists): list[c][y*seg + k] = (ego row, entry), count[c*nseg + y]
 __global__ void __launch_bounds__(256) hits_compact_kernel(const int32_t *__restrict__ hit_t, int R, int seg,
                                                            int2 *__restrict__ list, int32_t *__restrict__ count) {
+    // Two passes without a barrier inside the loops (the first version synchronised the workgroup twice per 256 rows: 152
+    // round trips for the whole-sweep list): each wave owns a contiguous quarter of the segment, counts its hits, the four
+    // counts are exchanged once, and the second pass writes the wave's hits behind those of the waves before it.
     __shared__ int wcnt[4];
     const int c = blockIdx.x, y = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t *src = hit_t + (size_t)c * R + (size_t)y * seg;
     int2 *dst = list + (size_t)c * R + (size_t)y * seg;
-    int total = 0;
-    for (int base = 0; base < seg; base += 256) {
-        const int k = base + tid;
-        const int e = (k < seg) ? src[k] : -1;
-        const unsigned long long m = __ballot(e >= 0);
-        if (lane == 0) wcnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = total;
-        for (int q = 0; q < wave; ++q) off += wcnt[q];
-        if (e >= 0) dst[off + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(y * seg + k, e);
-        total += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        __syncthreads();
+    const int per = ((seg + 255) / 256) * 64;                 // rows per wave, a multiple of 64
+    const int k0 = wave * per, k1 = min(seg, k0 + per);
+    int mine = 0;
+    for (int base = k0; base < k1; base += 64) {
+        const int k = base + lane;
+        mine += __popcll(__ballot(k < k1 && src[k] >= 0));
     }
-    if (tid == 0) count[c * gridDim.y + y] = total;
+    if (lane == 0) wcnt[wave] = mine;
+    __syncthreads();
+    int off = 0;
+    for (int q = 0; q < wave; ++q) off += wcnt[q];
+    for (int base = k0; base < k1; base += 64) {
+        const int k = base + lane;
+        const int e = (k < k1) ? src[k] : -1;
+        const unsigned long long m = __ballot(e >= 0);
+        if (e >= 0) dst[off + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(y * seg + k, e);
+        off += __popcll(m);
+    }
+    if (tid == 0) count[c * gridDim.y + y] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
 }
 
 // dW'[c][ch][n] = sum over the hits (r, e) of cell c of  dy1[r, n] * enc[e, ch]   (all steps of the sweep at once)

@@ -61,10 +61,11 @@ class LSTM(torch.nn.Module):
         #: run the first grid-embedding layer on the sparse winner table when the configuration allows it
         self.sparse_embedding = True
         self._ws = None
+        self._grad_reduce_fn = None   # data-parallel training: parallel.GradReducer, see lstm/train_step.py
         self._cell_major = None  # (key, tensor): cell-major copy of pool.embedding[0].weight
 
     # device-side caches (workspace, re-laid-out weight copies): rebuilt lazily, never pickled / deep-copied
-    _CACHES = ('_ws', '_cell_major', '_dummy_head')
+    _CACHES = ('_ws', '_cell_major', '_dummy_head', '_grad_reduce_fn')
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -242,8 +243,8 @@ class LSTM(torch.nn.Module):
                 raise NotImplementedError('training (backward) through %s is not available on the MI355X path yet; '
                                           'use model.eval() / torch.no_grad() for inference' % type(self.pool).__name__)
             from .training import run_sequence_with_grad
-            rel_pred, pred, _ = run_sequence_with_grad(self, observed, goals, batch_split, prediction_truth, T_dec,
-                                                       {'pad_to': pad_to} if pad_to is not None else None)
+            opts = {'pad_to': pad_to, 'reduce_fn': getattr(self, '_grad_reduce_fn', None)}
+            rel_pred, pred, _ = run_sequence_with_grad(self, observed, goals, batch_split, prediction_truth, T_dec, opts)
             return rel_pred, pred
         rel_pred, pred, _ = self._run_sequence(observed, goals, batch_split, prediction_truth, T_dec, pad_to=pad_to)
         return rel_pred, pred

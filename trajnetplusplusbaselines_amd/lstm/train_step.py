@@ -9,7 +9,7 @@ from .. import parallel
 
 def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batch_split, obs_length=9, pred_length=12,
                 batch_size=None, group=None, n_global_scenes=None, pad_to=None, start_length=0, obs_dropout=False,
-                buckets=None):
+                buckets=None, overlap=False):
     """batch_scene [obs+pred, M, 2] (NaN = absent), batch_scene_goal [M, 2], batch_split [B+1].
 
     Single process: loss = criterion(rel_outputs[-pred_length:], targets, batch_split, primary_prediction) * batch_size,
@@ -24,7 +24,8 @@ def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batc
     persistent buffers, asynchronous launch) when given, else one flattened bucket -- and every rank applies the same
     optimizer step.  A rank whose shard is empty (fewer scenes than ranks) back-propagates a zero-weighted one-track
     dummy scene: it contributes zero gradients for exactly the parameters the other ranks have gradients for, so the
-    collectives line up.  Returns the loss value of this rank."""
+    collectives line up.  ``overlap=True`` (our ``LSTM`` only) all-reduces every gradient from inside the backward pass
+    as soon as it is enqueued (parallel.GradReducer) instead of after it.  Returns the loss value of this rank."""
     model.train()
     dev = next(model.parameters()).device
     distributed = group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())
@@ -48,6 +49,9 @@ def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batc
     observed = batch_scene[start_length:obs_length].clone()
     prediction_truth = batch_scene[obs_length:obs_length + pred_length - 1].clone()
     targets = batch_scene[obs_length:obs_length + pred_length] - batch_scene[obs_length - 1:obs_length + pred_length - 1]
+    in_backward = distributed and overlap and hasattr(model, '_grad_reduce_fn')
+    if in_backward:
+        model._grad_reduce_fn = parallel.GradReducer(group)
     rel_outputs, outputs = model(observed, batch_scene_goal, split, prediction_truth, pad_to=pad_to)
     if getattr(criterion, 'col_wt', 0):
         prim = split[:-1].to(dev)
@@ -65,7 +69,9 @@ def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batc
         loss = loss_mean * batch_size
     loss.backward()
     loss_value = loss.detach()
-    if buckets is not None:
+    if in_backward:
+        model._grad_reduce_fn = None                  # gradients were summed over the ranks inside the backward pass
+    elif buckets is not None:
         buckets.launch_all()
         buckets.wait()
     elif distributed:

@@ -180,6 +180,7 @@ class SequenceFn(torch.autograd.Function):
                                'the MI355X path has no CPU fallback' % dev)
         opts = opts or {}
         noise = opts.get('noise')
+        ctx.reduce_fn = opts.get('reduce_fn')
         ctx.input_grad = bool(opts.get('input_grad')) and observed.requires_grad
         if ctx.input_grad and T_dec != 0:
             raise NotImplementedError('gradients with respect to the observed positions: encoder-only runs')
@@ -474,6 +475,20 @@ class SequenceFn(torch.autograd.Function):
                 d_obs[1:S + 1] += torch.where(torch.isfinite(d_o2) & (nf > 0), d_o2, torch.zeros_like(d_o2))
 
         # ---- deferred weight gradients: one GEMM per parameter over the stacked steps ----
+        # Data-parallel training hands in `reduce_fn` (parallel.GradReducer): every gradient tensor is all-reduced over
+        # RCCL as soon as its kernel is enqueued -- asynchronously, on RCCL's stream, largest message first -- so the
+        # collectives overlap the remaining weight-gradient GEMMs; the compute stream waits for them before the gradients
+        # are handed to autograd.
+        reduce_fn = ctx.reduce_fn
+        pending = []
+
+        pending_tensors = []
+
+        def publish(t):
+            if reduce_fn is not None:
+                pending_tensors.append(t)
+                pending.append(reduce_fn(t))
+
         wg_ws = [None]
 
         def wgrad(name, dy, x, bias_name):
@@ -490,28 +505,12 @@ class SequenceFn(torch.autograd.Function):
             grads[name] = dw
             if bias_name is not None:
                 grads[bias_name] = db
+            if not name.startswith('_'):       # '_t' / '_b': intermediates of the attention un-folding, combined further on the
+                publish(dw)                    # compute stream -- their final forms are published at the end
+                if bias_name is not None:
+                    publish(db)
 
-        h_out_all, h_prev_all = h_all[1:], h_all[:-1]
-        if ctx.noise_at is not None:     # the last encoder step's output is the hidden state BEFORE the noise was added
-            h_out_all = h_out_all.clone()
-            h_out_all[ctx.noise_at[0] - 1] = ctx.noise_at[1]
-        if has_h2n:
-            wgrad('hidden2normal.linear.weight', dlin_all, h_out_all, 'hidden2normal.linear.bias')
-        n_enc = sum(1 for d in decs if not d)
-        # hidden operand of the LSTMCell: h, or h + interaction vector for LSTM(pool_to_input=False)
-        hid_all = h_prev_all
-        if ctx.st_saves is not None and ctx.st_saves.get('pvec') is not None:
-            hid_all = torch.nan_to_num(h_prev_all + ctx.st_saves['pvec'])
-        for pre, lo, hi in (('encoder', 0, n_enc), ('decoder', n_enc, S)):
-            if hi > lo:
-                wgrad(pre + '.weight_ih', dG_all[lo:hi], X_all[lo:hi], pre + '.bias_ih')
-                wgrad(pre + '.weight_hh', dG_all[lo:hi], hid_all[lo:hi], None)
-                grads[pre + '.bias_hh'] = grads[pre + '.bias_ih'].clone()
-        vel_all = torch.nan_to_num(o2_all - o1_all) * 4.0
-        wgrad('input_embedding.input_embeddings.0.weight', de_all, vel_all, 'input_embedding.input_embeddings.0.bias')
-        if GD:
-            wgrad('goal_embedding.input_embeddings.0.weight', dgoal_all, gdir_all, 'goal_embedding.input_embeddings.0.bias')
-        for li, name in enumerate(lay_names):
+        def layer_wgrad(li, name):
             if li == 0 and sparse_bwd:
                 # dW'[cell][ch][:] from the per-cell hit lists of the whole sweep, then back to the parameter's layout
                 N1 = dy_all[0].shape[2]
@@ -523,16 +522,44 @@ class SequenceFn(torch.autograd.Function):
                 dwc = torch.empty(ncell, C, N1, device=dev)
                 _lib.check(L.tnp_sparse_wgrad(_lib.ptr(dy_all[0]), N1, _lib.ptr(enc_all), C, _lib.ptr(hits), _lib.ptr(count),
                                               R, C, ncell, N1, _lib.ptr(dwc), sp()), 'sparse_wgrad')
-                grads[name + '.weight'] = dwc.permute(2, 1, 0).reshape(N1, C * ncell)
+                grads[name + '.weight'] = dwc.permute(2, 1, 0).reshape(N1, C * ncell)   # back to the parameter's layout (a copy)
+                publish(grads[name + '.weight'])
                 grads[name + '.bias'] = dy_all[0].reshape(-1, N1).sum(0)
-                continue
+                publish(grads[name + '.bias'])
+                return
             wgrad(name + '.weight', dy_all[li], grid_all if li == 0 else act_all[li - 1], name + '.bias')
+        if lay_names:
+            layer_wgrad(0, lay_names[0])     # first: the largest gradient (16.8 MB at config 2) gets the longest overlap
+        h_out_all, h_prev_all = h_all[1:], h_all[:-1]
+        if ctx.noise_at is not None:     # the last encoder step's output is the hidden state BEFORE the noise was added
+            h_out_all = h_out_all.clone()
+            h_out_all[ctx.noise_at[0] - 1] = ctx.noise_at[1]
+        if has_h2n:
+            wgrad('hidden2normal.linear.weight', dlin_all, h_out_all, 'hidden2normal.linear.bias')
+        n_enc = sum(1 for d in decs if not d)
+        # hidden operand of the LSTMCell: h, or h + interaction vector for LSTM(pool_to_input=False)
+        hid_all = h_prev_all
+        if ctx.st_saves is not None and ctx.st_saves.get('pvec') is not None:
+            hid_all = torch.nan_to_num(h_prev_all + ctx.st_saves['pvec'])
+        hh_clones = []
+        for pre, lo, hi in (('encoder', 0, n_enc), ('decoder', n_enc, S)):
+            if hi > lo:
+                wgrad(pre + '.weight_ih', dG_all[lo:hi], X_all[lo:hi], pre + '.bias_ih')
+                wgrad(pre + '.weight_hh', dG_all[lo:hi], hid_all[lo:hi], None)
+                hh_clones.append((pre + '.bias_hh', pre + '.bias_ih'))
+        vel_all = torch.nan_to_num(o2_all - o1_all) * 4.0
+        wgrad('input_embedding.input_embeddings.0.weight', de_all, vel_all, 'input_embedding.input_embeddings.0.bias')
+        if GD:
+            wgrad('goal_embedding.input_embeddings.0.weight', dgoal_all, gdir_all, 'goal_embedding.input_embeddings.0.bias')
+        for li, name in enumerate(lay_names):
+            if li > 0:
+                layer_wgrad(li, name)
         if st_pool:
             ph_all = st_saves['ph']
             wgrad('pool.hidden2pool.weight', dy_all[0], ph_all[1:], 'pool.hidden2pool.bias')
             wgrad('pool.pool_lstm.weight_ih', st_bufs['dG'], act_all[0], 'pool.pool_lstm.bias_ih')
             wgrad('pool.pool_lstm.weight_hh', st_bufs['dG'], ph_all[:-1], None)
-            grads['pool.pool_lstm.bias_hh'] = grads['pool.pool_lstm.bias_ih'].clone()
+            hh_clones.append(('pool.pool_lstm.bias_hh', 'pool.pool_lstm.bias_ih'))
             if st_saves['traj_in'] is None:     # NearestNeighborLSTM: rows = (step, track, neighbour slot)
                 d = pool.out_dim // pool.n
                 wgrad('pool.embedding.0.weight', st_bufs['dfeat'].reshape(-1, d), ctx.attrs_all.reshape(-1, 4), 'pool.embedding.0.bias')
@@ -561,6 +588,23 @@ class SequenceFn(torch.autograd.Function):
         if social:
             wgrad('pool.hidden_dim_encoding.weight', denc_all, h_prev_all, 'pool.hidden_dim_encoding.bias')
 
+        if reduce_fn is not None:      # gradients formed outside wgrad() / layer_wgrad() (torch expressions) are reduced here
+            done = set(id(t) for t in pending_tensors)
+            for n in ctx.param_names:
+                g = grads.get(n)
+                if g is None:
+                    continue
+                base = g._base if g._base is not None else g      # slices / re-layouts of a buffer: reduce the buffer once
+                if id(base) not in done:
+                    if not base.is_contiguous():
+                        base = base.contiguous()
+                        grads[n] = base
+                    done.add(id(base))
+                    publish(base)
+            for w in pending:
+                w.wait()                  # the compute stream waits for RCCL's stream; no host synchronisation
+        for dst_name, src_name in hh_clones:
+            grads[dst_name] = grads[src_name].clone()
         # parameters the forward never touches get no gradient (None, as autograd does for the reference), so that
         # optimizers skip them: a zero gradient would still let Adam + weight decay move them
         out = [None, d_obs, None, None, None, None, None]
