@@ -54,6 +54,11 @@ def _worker(rank, world, port, ret):
         p1.grad = torch.full((5, 3), float(rank + 1))
         p2.grad = torch.full((7,), 10.0 * (rank + 1))
         n_msgs = parallel.allreduce_gradients([p1, p2, p3], bucket_bytes=16)
+        reducer = parallel.GradReducer()                      # the in-backward form: asynchronous, one handle per gradient
+        t1, t2 = torch.full((6,), float(rank + 1)), torch.full((3, 2), 10.0 * (rank + 1))
+        handles = [reducer(t1), reducer(t2)]
+        for h in handles:
+            h.wait()
         if rank == 0:
             ret['full'] = full.numpy()
             ret['ranges'] = rng
@@ -62,6 +67,7 @@ def _worker(rank, world, port, ret):
             ret['g2'] = p2.grad.numpy().copy()
             ret['n_msgs'] = n_msgs
             ret['p3_none'] = p3.grad is None
+            ret['reducer'] = (t1.tolist(), t2.reshape(-1).tolist(), reducer.messages, reducer.bytes)
     finally:
         dist.destroy_process_group()
 
@@ -87,6 +93,7 @@ def test_two_rank_scene_sharding_matches_single_process():
     assert ret['tmax'] == 2.0
     assert np.all(ret['g1'] == 3.0) and np.all(ret['g2'] == 30.0)
     assert ret['n_msgs'] == 2 and ret['p3_none']
+    assert ret['reducer'] == ([3.0] * 6, [30.0] * 6, 2, 48)
 
 
 @pytest.mark.parametrize('balance', ['scenes', 'tracks', 'pairs'])

@@ -410,21 +410,29 @@ __global__ void __launch_bounds__(256) hits_compact_kernel(const int32_t *__rest
     int2 *dst = list + (size_t)c * R + (size_t)y * seg;
     const int per = ((seg + 255) / 256) * 64;                 // rows per wave, a multiple of 64
     const int k0 = wave * per, k1 = min(seg, k0 + per);
-    int mine = 0;
-    for (int base = k0; base < k1; base += 64) {
-        const int k = base + lane;
-        mine += __popcll(__ballot(k < k1 && src[k] >= 0));
+    constexpr int UN = 8;                                     // rows are fetched UN x 64 at a time: the loads of a batch are
+    int mine = 0;                                             // independent, so one memory round trip serves 512 rows
+    for (int base = k0; base < k1; base += 64 * UN) {
+        int e[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { const int k = base + 64 * u + lane; e[u] = (k < k1) ? src[k] : -1; }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) mine += __popcll(__ballot(e[u] >= 0));
     }
     if (lane == 0) wcnt[wave] = mine;
     __syncthreads();
     int off = 0;
     for (int q = 0; q < wave; ++q) off += wcnt[q];
-    for (int base = k0; base < k1; base += 64) {
-        const int k = base + lane;
-        const int e = (k < k1) ? src[k] : -1;
-        const unsigned long long m = __ballot(e >= 0);
-        if (e >= 0) dst[off + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(y * seg + k, e);
-        off += __popcll(m);
+    for (int base = k0; base < k1; base += 64 * UN) {
+        int e[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { const int k = base + 64 * u + lane; e[u] = (k < k1) ? src[k] : -1; }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const unsigned long long m = __ballot(e[u] >= 0);
+            if (e[u] >= 0) dst[off + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(y * seg + base + 64 * u + lane, e[u]);
+            off += __popcll(m);
+        }
     }
     if (tid == 0) count[c * gridDim.y + y] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
 }
