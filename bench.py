@@ -441,7 +441,7 @@ def main():
                 flops = 2.0 * M * (cfg['agents'] - 1) * model.pool.pooling_dim * N0
                 _, pred_once = step()
                 hits = occupied_cells_per_step(observed, pred_once, split, cfg['n'], 0.6)
-                kname = ('pool_embed_cellsplit_kernel (winner tile from the positions + pool.embedding.0 on it: '
+                kname = ('pool_embed_regacc_kernel (winner tile from the positions + pool.embedding.0 on it: '
                          '%d egos x <=%d occupied cells x %d values -> %d)' % (M, cfg['agents'] - 1,
                                                                               model.pool.pooling_dim, N0))
             else:
@@ -470,7 +470,7 @@ def main():
                 if not args.no_traffic and world == 1 and not under_profiler():
                     child = ['--config', args.config] + (['--dense'] if args.dense else []) + \
                         (['--variant', str(args.variant)] if args.variant else [])
-                    t = pmc_traffic('pool_embed_cellsplit|pool_embed_sparse_kernel' if sparse else 'gemm_nt_', child)
+                    t = pmc_traffic('pool_embed_regacc|pool_embed_cellsplit|pool_embed_sparse_kernel' if sparse else 'gemm_nt_', child)
                     if t is not None:
                         roof['traffic'] = t['bytes']
                         roof['traffic_detail'] = t

@@ -1,0 +1,132 @@
+// Timing harness for the sparse first layer (csrc/pool_embed_sparse.hip): runs the product kernel and its timing
+// ablations (template parameter ABL) on a synthetic config-2 crowd, stand-alone (no torch).  Build + run:
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -Itrajnetplusplusbaselines_amd/csrc \
+//       tools/experiments/sparse_ablate.hip -o tools/experiments/sparse_ablate && tools/experiments/sparse_ablate
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <random>
+#include "pool_embed_sparse.hip"
+
+namespace tnp { void set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); } }
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <typename T> T *dev(const std::vector<T> &h) {
+    T *d; CK(hipMalloc(&d, h.size() * sizeof(T))); CK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); return d;
+}
+
+typedef void (*kern_t)(const tnp::SparseArgs);
+
+static float time_kernel(kern_t k, const tnp::SparseArgs &a, int blocks, size_t smem, int reps, int threads = 1024) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), smem, 0, a);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), smem, 0, a);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipGetLastError());
+    return ms * 1000.0f / reps;
+}
+
+int main(int argc, char **argv) {
+    const int scenes = 64, agents = 32, M = scenes * agents, G = 16, ncell = G * G, C = 16, N1 = 1024;
+    const float tstep = argc > 1 ? atof(argv[1]) : 10.0f;
+    const int only = argc > 2 ? atoi(argv[2]) : 0;                                  // 3: only the register-accumulator kernels
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    std::mt19937 rng(7);
+    std::uniform_real_distribution<float> U(-4.0f, 4.0f); std::normal_distribution<float> Nrm(0.0f, 1.0f);
+    std::vector<float> obs(M * 2), enc((size_t)M * C), W((size_t)ncell * C * N1), bias(N1);
+    for (int i = 0; i < M; ++i) for (int d = 0; d < 2; ++d) obs[2 * i + d] = U(rng) + 0.3f * Nrm(rng) * tstep;
+    for (auto &v : enc) v = Nrm(rng);
+    for (auto &v : W) v = 0.02f * Nrm(rng);
+    for (auto &v : bias) v = 0.1f * Nrm(rng);
+    std::vector<int32_t> rb(M), re(M), rp(M);
+    for (int i = 0; i < M; ++i) { rb[i] = i / agents * agents; re[i] = rb[i] + agents; rp[i] = agents; }
+    tnp::SparseArgs a{};
+    a.winners = nullptr; a.enc = dev(enc); a.ldv = C; a.row_base = dev(rb); a.Wp = dev(W); a.bias = dev(bias);
+    a.M = M; a.ncell = ncell; a.C = C; a.N1 = N1; a.S = 1; a.cps = ncell; a.ego_tiles = M / tnp::TL_TE; a.out_blocks = N1 / tnp::TL_OB;
+    float *out; CK(hipMalloc(&out, (size_t)M * N1 * 4)); a.out = out; a.ldo = N1; a.relu = 1;
+    a.obs2 = dev(obs); a.row_end = dev(re); a.row_padded = dev(rp); a.G = G; a.cell = 0.6f; a.half_x = a.half_y = G / 2.0f;
+    a.winners_out = nullptr;
+    const size_t smem = (size_t)tnp::TL_NQ * tnp::TL_TE * tnp::TL_OB * 4 + (((size_t)ncell * (tnp::TL_TE + 2) * 2 + 15) & ~(size_t)15) + ncell * 4;
+    const int blocks = a.ego_tiles * a.out_blocks;
+    // hits on the host (for the per-hit figures)
+    long hits = 0;
+    for (int i = 0; i < M; ++i) {
+        std::vector<char> occ(ncell, 0);
+        for (int j = rb[i]; j < re[i]; ++j) {
+            if (j == i) continue;
+            const float ox = (obs[2 * j] - obs[2 * i]) / 0.6f + 8.0f, oy = (obs[2 * j + 1] - obs[2 * i + 1]) / 0.6f + 8.0f;
+            if (ox >= 0 && ox < G && oy >= 0 && oy < G) occ[(int)ox * G + (int)oy] = 1;
+        }
+        for (char o : occ) hits += o;
+    }
+    printf("M %d hits/ego %.2f blocks %d smem %zu\n", M, (double)hits / M, blocks, smem);
+    // host reference of every 37th ego (last writer in ascending j wins a cell; out-of-range neighbours clobber cell 0)
+    auto check = [&](const std::vector<float> &y, const char *name) {
+        double md = 0;
+        for (int i = 0; i < M; i += 37) {
+            std::vector<int> win(ncell, -1);
+            for (int j = rb[i]; j < re[i]; ++j) {
+                if (j == i) continue;
+                const float ox = (obs[2 * j] - obs[2 * i]) / 0.6f + 8.0f, oy = (obs[2 * j + 1] - obs[2 * i + 1]) / 0.6f + 8.0f;
+                const bool inr = !(ox < 0) && !(ox >= G) && !(oy < 0) && !(oy >= G);
+                win[inr ? (int)ox * G + (int)oy : 0] = inr ? j : -1;
+            }
+            for (int o = 0; o < N1; o += 5) {
+                double acc = bias[o];
+                for (int c = 0; c < ncell; ++c) if (win[c] >= 0)
+                    for (int ch = 0; ch < C; ++ch) acc += (double)W[((size_t)c * C + ch) * N1 + o] * enc[(size_t)win[c] * C + ch];
+                md = fmax(md, fabs(fmax(acc, 0.0) - y[(size_t)i * N1 + o]));
+            }
+        }
+        printf("   %s: max |y - host reference| %.3g\n", name, md);
+    };
+    struct V { const char *name; kern_t k; };
+#define KV(abl) (kern_t)tnp::pool_embed_cellsplit_kernel<16, true, true, abl>
+    const V vs[] = {{"product", KV(0)}, {"no weight loads (1)", KV(1)}, {"no hits (2)", KV(2)}, {"no weights, no hits (3)", KV(3)},
+                    {"no row loads (4)", KV(4)}, {"no acc rmw (8)", KV(8)}, {"no row loads, no rmw (12)", KV(12)},
+                    {"no weights, no row loads, no rmw (13)", KV(13)}, {"no cell loop (16)", KV(16)}};
+    std::vector<float> ref((size_t)M * N1), got((size_t)M * N1);
+    for (const V &v : vs) {
+        if (only == 3 && v.k != vs[0].k) continue;
+        const float us = time_kernel(v.k, a, blocks, smem, 50);
+        printf("%-42s %8.2f us\n", v.name, us);
+        if (v.k == vs[0].k) { CK(hipMemcpy(ref.data(), out, ref.size() * 4, hipMemcpyDeviceToHost)); check(ref, "product"); }
+    }
+    {   // 64 egos x 128 columns, 4 cell groups x 2 column sets = 8 waves, int8 winner tile
+        tnp::SparseArgs b = a; b.ego_tiles = M / 64; b.out_blocks = N1 / 128;
+        const size_t smem2 = (size_t)4 * 64 * 128 * 4 + (((size_t)ncell * (64 + 4) + 15) & ~(size_t)15) + ncell * 4;
+#define KW(abl) (kern_t)tnp::pool_embed_cellsplit_kernel<16, true, true, abl, 64, 128, 4, int8_t>
+        const V ws[] = {{"64x128 8 waves", KW(0)}, {"64x128 no weight loads", KW(1)}, {"64x128 no hits", KW(2)}, {"64x128 no cell loop", KW(16)}};
+        for (const V &v : ws) {
+            if (only == 3) continue;
+            const float us = time_kernel(v.k, b, b.ego_tiles * b.out_blocks, smem2, 50, 512);
+            printf("%-42s %8.2f us\n", v.name, us);
+            if (v.k == ws[0].k) {
+                CK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
+                double md = 0; for (size_t i = 0; i < got.size(); ++i) md = fmax(md, fabs((double)got[i] - ref[i]));
+                printf("   max |diff| vs product %.3g\n", md);
+            }
+        }
+    }
+    {   // register accumulators: 64 egos x 128 columns, 8 cell groups x 2 column sets = 16 waves
+        tnp::SparseArgs b = a; b.ego_tiles = M / 64; b.out_blocks = N1 / 128;
+        const size_t smem3 = tnp::ra_smem_bytes(ncell);
+#define KR(abl) (kern_t)tnp::pool_embed_regacc_kernel<16, true, abl>
+        const V ws[] = {{"regacc", KR(0)}, {"regacc no weight loads", KR(1)}, {"regacc no hits", KR(2)}, {"regacc no cell loop", KR(16)},
+                        {"regacc no loop, no pairs", KR(48)}, {"regacc no loop, no pairs, no conversion", KR(112)}, {"regacc no loop, no epilogue", KR(144)},
+                        {"regacc nothing (240)", KR(240)}};
+        for (const V &v : ws) {
+            const float us = time_kernel(v.k, b, b.ego_tiles * b.out_blocks, smem3, 50, 1024);
+            printf("%-42s %8.2f us\n", v.name, us);
+            if (v.k == ws[0].k) { CK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost)); check(got, "regacc"); }
+        }
+    }
+    return 0;
+}

@@ -274,11 +274,12 @@ __device__ __forceinline__ void sload_row(typename SRow<C>::type &v, const float
 
 // SASM: neighbour rows addressed with a 32-bit byte offset and loaded by inline-asm scalar loads (C <= 16); FG: the winner
 // tile is built from the positions inside the kernel instead of read from the table.
-template <int C, bool SASM, bool FG>
-__global__ void __launch_bounds__(64 * TL_NQ * (TL_OB / 64)) pool_embed_cellsplit_kernel(const SparseArgs a) {
-    constexpr int TE = TL_TE, OB = TL_OB, NCS = OB / 64, U = 2;
-    typedef int16_t WT;
-    constexpr int NQ = TL_NQ, WLS = TE + (sizeof(WT) == 1 ? 4 : 2), NTH = 64 * NQ * NCS;
+// ABL (tools/experiments/sparse_ablate.hip only; the library instantiates 0): timing ablations -- 1 no weight loads,
+// 2 no hits, 4 no neighbour-row loads, 8 no accumulator read-modify-write, 16 no cell loop at all.
+template <int C, bool SASM, bool FG, int ABL = 0, int TE = TL_TE, int OB = TL_OB, int NQ = TL_NQ, typename WT = int16_t>
+__global__ void __launch_bounds__(64 * NQ * (OB / 64)) pool_embed_cellsplit_kernel(const SparseArgs a) {
+    constexpr int NCS = OB / 64, U = 2;
+    constexpr int WLS = TE + (sizeof(WT) == 1 ? 4 : 2), NTH = 64 * NQ * NCS;
     extern __shared__ __attribute__((aligned(16))) float csm[];
     float *acc = csm;                                                        // [NQ][TE][OB]
     WT *wl = reinterpret_cast<WT *>(csm + NQ * TE * OB);    // [ncell][WLS]
@@ -291,77 +292,147 @@ __global__ void __launch_bounds__(64 * TL_NQ * (TL_OB / 64)) pool_embed_cellspli
     const unsigned ocu = (unsigned)(o < a.N1 ? o : a.N1 - 1);
 
     float *accl = acc + (size_t)q * TE * OB + cs * 64 + lane;
+    constexpr int NW = NTH / 64;
+    int *socc = reinterpret_cast<int *>(wl + (((size_t)a.ncell * WLS * sizeof(WT) + 15) & ~(size_t)15) / sizeof(WT));   // [ncell] cell has a hit in the tile
+    int *wkey = reinterpret_cast<int *>(acc);                                     // FG: [TE][ncell] keys (not yet the accumulators)
+    int *sg = wkey + TE * a.ncell;                                                // FG: lo / ns / ki / pad [TE] each, then x / y
+    float *sp = reinterpret_cast<float *>(sg + 4 * TE);
+    for (int c = tid; c < a.ncell; c += NTH) socc[c] = 0;
     if constexpr (FG) {
         // Winner tile straight from the positions (what grid_build_kernel computes, pool_grid.hip: the reference's exact
         // fp32 cell arithmetic, LDS integer max on key = 2*j + in_range = "last writer in ascending j wins", cell-0
         // clobber by out-of-range / absent / padded neighbours).  One wave per ego, lanes over the neighbours of its
-        // scene; the int32 keys live in the (not yet zeroed) accumulator space.  The four column-set workgroups of a tile
-        // repeat this (32 x 31 pairs): cheaper than a kernel launch and the winner table's HBM round trip.
-        int *wkey = reinterpret_cast<int *>(acc);                                 // [TE][ncell]
-        for (int idx = tid; idx < TE * a.ncell; idx += NTH) wkey[idx] = -1;
+        // scene; the int32 keys live in the (not yet zeroed) accumulator space.  The column-block workgroups of a tile
+        // repeat this (TE x <= n_max pairs): cheaper than a kernel launch and the winner table's HBM round trip.
+        // The egos' scene geometry is staged first (one thread per ego), so that the per-ego loop has one global load
+        // per neighbour chunk and those of EU egos are in flight together.
+        {
+            const int4 m1 = {-1, -1, -1, -1};
+            for (int idx = tid; idx < TE * a.ncell / 4; idx += NTH) reinterpret_cast<int4 *>(wkey)[idx] = m1;
+        }
+        if (tid < TE) {
+            const int row = row0 + tid;
+            int lo = 0, ns = 0, pad = 0;
+            float2 pi = {-500.0f, -500.0f};
+            if (row < a.M) {
+                lo = a.row_base[row]; ns = a.row_end[row] - lo; pad = a.row_padded[row];
+                pi = reinterpret_cast<const float2 *>(a.obs2)[row];
+                if (pi.x != pi.x || pi.y != pi.y) { pi.x = -500.0f; pi.y = -500.0f; }
+            }
+            sg[tid] = lo; sg[TE + tid] = ns; sg[2 * TE + tid] = row - lo; sg[3 * TE + tid] = pad;
+            sp[tid] = pi.x; sp[TE + tid] = pi.y;
+        }
         __syncthreads();
         const float fG = (float)a.G;
-        for (int e = wave; e < TE; e += NTH / 64) {
-            const int row = row0 + e;
-            if (row >= a.M) continue;
-            const int lo = a.row_base[row], ns = a.row_end[row] - lo, ki = row - lo;
-            float2 pi = reinterpret_cast<const float2 *>(a.obs2)[row];
-            if (pi.x != pi.x || pi.y != pi.y) { pi.x = -500.0f; pi.y = -500.0f; }
-            int *wk = wkey + e * a.ncell;
-            for (int j = lane; j < ns; j += 64) {
-                if (j == ki) continue;
-                float2 pj = reinterpret_cast<const float2 *>(a.obs2)[lo + j];
-                if (pj.x != pj.x || pj.y != pj.y) { pj.x = -500.0f; pj.y = -500.0f; }
-                const float ox = __fadd_rn(__fdiv_rn(__fsub_rn(pj.x, pi.x), a.cell), a.half_x);
-                const float oy = __fadd_rn(__fdiv_rn(__fsub_rn(pj.y, pi.y), a.cell), a.half_y);
-                const bool inr = !(ox < 0.0f) && !(ox >= fG) && !(oy < 0.0f) && !(oy >= fG);
-                const int cellid = inr ? ((int)ox * a.G + (int)oy) : 0;
-                atomicMax(&wk[cellid], 2 * j + (inr ? 1 : 0));
-            }
-            const int pad = a.row_padded[row];
-            if (ns < pad && lane == 0) atomicMax(&wk[0], 2 * (pad - 1));
-        }
-        __syncthreads();
-        for (int idx = tid; idx < TE * a.ncell; idx += NTH) {
-            const int e = idx / a.ncell, c = idx - e * a.ncell;
-            const int row = row0 + e;
-            const int k = wkey[idx];
-            const WT v = (row < a.M && k >= 0 && (k & 1)) ? (WT)(k >> 1) : (WT)-1;
-            wl[c * WLS + e] = v;
-            if (a.winners_out && ob == 0 && row < a.M) a.winners_out[(size_t)row * a.ncell + c] = (int16_t)v;
-        }
-        __syncthreads();
-    }
+        constexpr int EU = (TE / NW) >= 8 ? 8 : ((TE / NW) >= 4 ? 4 : ((TE / NW) >= 2 ? 2 : 1));
+        auto pair = [&](int e, int j, float2 pj) {
+            if (j == sg[2 * TE + e]) return;
+            if (pj.x != pj.x || pj.y != pj.y) { pj.x = -500.0f; pj.y = -500.0f; }
+            const float ox = __fadd_rn(__fdiv_rn(__fsub_rn(pj.x, sp[e]), a.cell), a.half_x);
+            const float oy = __fadd_rn(__fdiv_rn(__fsub_rn(pj.y, sp[TE + e]), a.cell), a.half_y);
+            const bool inr = !(ox < 0.0f) && !(ox >= fG) && !(oy < 0.0f) && !(oy >= fG);
+            const int cellid = inr ? ((int)ox * a.G + (int)oy) : 0;
+            atomicMax(&wkey[e * a.ncell + cellid], 2 * j + (inr ? 1 : 0));
+        };
+        for (int e0 = wave * EU; e0 < TE; e0 += NW * EU) {
+            float2 pj[EU];
 #pragma unroll
-    for (int e = 0; e < TE; ++e) accl[e * OB] = 0.0f;
-    if constexpr (!FG) {
-        for (int idx = tid; idx < TE * a.ncell; idx += NTH) {
-            const int e = idx / a.ncell, c = idx - e * a.ncell;
-            const int row = row0 + e;
-            wl[c * WLS + e] = row < a.M ? (WT)a.winners[(size_t)row * a.ncell + c] : (WT)-1;
+            for (int u = 0; u < EU; ++u)
+                if (lane < sg[TE + e0 + u]) pj[u] = reinterpret_cast<const float2 *>(a.obs2)[sg[e0 + u] + lane];
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                const int e = e0 + u, lo = sg[e], ns = sg[TE + e], pad = sg[3 * TE + e];
+                if (lane < ns) pair(e, lane, pj[u]);
+                for (int j = lane + 64; j < ns; j += 64) pair(e, j, reinterpret_cast<const float2 *>(a.obs2)[lo + j]);
+                if (ns < pad && lane == 0) atomicMax(&wkey[e * a.ncell], 2 * (pad - 1));
+            }
+        }
+        __syncthreads();
+    }
+    if constexpr (!FG) __syncthreads();                                          // socc zeroed
+    // winner tile, transposed ([cell][ego]: a cell's hits are one ballot), and the cells that have a hit at all
+    for (int e = wave; e < TE; e += NW) {
+        const int row = row0 + e;
+        for (int c0 = 0; c0 < a.ncell; c0 += 256) {                       // four independent 64-cell chunks in flight
+            int kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * 64 + lane;
+                kk[u] = -1;
+                if (c < a.ncell && row < a.M) {
+                    if constexpr (FG) { const int k = wkey[e * a.ncell + c]; kk[u] = (k >= 0 && (k & 1)) ? (k >> 1) : -1; }
+                    else kk[u] = a.winners[(size_t)row * a.ncell + c];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * 64 + lane;
+                if (c >= a.ncell) continue;
+                if constexpr (FG) if (a.winners_out && ob == 0 && row < a.M) a.winners_out[(size_t)row * a.ncell + c] = (int16_t)kk[u];
+                wl[c * WLS + e] = (WT)kk[u];
+                if (kk[u] >= 0) socc[c] = 1;
+            }
         }
     }
-    const int rb = a.row_base[min(row0 + (lane & (TE - 1)), a.M - 1)];
+    int rb;
+    if constexpr (FG) rb = sg[lane & (TE - 1)];
+    else rb = a.row_base[min(row0 + (lane & (TE - 1)), a.M - 1)];
     __syncthreads();
+#pragma unroll
+    for (int e = 0; e < TE; ++e) accl[e * OB] = 0.0f;      // own column of own copy: no barrier needed before the cell loop
+    asm volatile("" : "+v"(rb));    // landed here: a compiler-placed vmcnt(0) inside the cell loop would drain the weight prefetch
 
+    // Weight loads of the lean path are inline asm (saddr form: scalar base of the (cell, channel) row + this lane's
+    // 32-bit byte offset) with MANUAL vmcnt waits: the compiler's own placement serialised the two weight sets (64-bit
+    // VALU address chains in registers of the set still in flight => vmcnt(0) before every issue).  Every load_w issues
+    // exactly C loads, so "this set has landed, the younger set may still be in flight" is s_waitcnt vmcnt(C).
+    constexpr bool ASMW = SASM && C <= 16;
+    const unsigned vo = ocu * 4u;
     auto load_w = [&](float (&w)[C], int c) {
         const float *wb = a.Wp + (size_t)c * C * a.N1;
+        if constexpr (ABL & 1) {
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) w[ch] = (wb + (size_t)ch * a.N1)[ocu];
+            for (int ch = 0; ch < C; ++ch) w[ch] = 1.0f + ch;
+        } else if constexpr (ASMW) {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch)
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(w[ch]) : "v"(vo), "s"(wb + (size_t)ch * a.N1) : "memory");
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) w[ch] = (wb + (size_t)ch * a.N1)[ocu];
+        }
+    };
+    auto wait_w = [&](float (&w)[C]) {
+        if constexpr (ABL & 1) {
+        } else if constexpr (ASMW) {
+            static_assert(C == 4 || C == 8 || C == 16, "vmcnt immediate");
+            if constexpr (C == 16)
+                asm volatile("s_waitcnt vmcnt(16)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]),
+                             "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
+            else if constexpr (C == 8)
+                asm volatile("s_waitcnt vmcnt(8)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
+            else
+                asm volatile("s_waitcnt vmcnt(4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) asm("" : "+v"(w[ch]));
+        }
     };
     auto process = [&](float (&w)[C], int c) {
         const int wv = lane < TE ? (int)wl[c * WLS + lane] : -1;
         unsigned long long mask = __ballot(wv >= 0);
-        if (mask == 0ull) return;
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) asm("" : "+v"(w[ch]));
+        // wait for THIS cell's weights only: the loads of the next cell (issued unconditionally by the caller, so that
+        // their number is known) stay in flight behind them -- vmcnt counts in order
+        wait_w(w);
+        if constexpr (ABL & 2) { if (mask == 1234567ull) accl[0] = w[0] + w[C - 1]; return; }
         if constexpr (SASM && C <= 16) {
             // lean path: the byte offset of every lane's neighbour row is one VALU op per cell; a hit then costs
             // ff1 + bit clear + one readlane + one SMEM load (SGPR offset) + LDS read-modify-write + C FMAs
             const unsigned off = __umul24((unsigned)(rb + wv), (unsigned)(a.ldv * 4));   // rows, row bytes < 2^24: full-rate multiply
             auto one = [&](int b, typename SRow<C>::type &ev, float &av) {
-                sload_row<C>(ev, a.enc, (unsigned)__builtin_amdgcn_readlane((int)off, b));
-                av = accl[b * OB];
+                if constexpr (ABL & 4) asm volatile("" : "=s"(ev) : "s"(__builtin_amdgcn_readlane((int)off, b)));
+                else sload_row<C>(ev, a.enc, (unsigned)__builtin_amdgcn_readlane((int)off, b));
+                if constexpr (ABL & 8) av = 0.0f; else av = accl[b * OB];
             };
             // even / odd channels accumulate in the two halves of one packed register: C/2 v_pk_fma_f32 with the
             // weight pair (w[2k], w[2k+1]) and the SGPR pair (e[2k], e[2k+1]) instead of C v_fmac_f32
@@ -374,7 +445,7 @@ __global__ void __launch_bounds__(64 * TL_NQ * (TL_OB / 64)) pool_embed_cellspli
                     const f2 ek = {ev[2 * k], ev[2 * k + 1]};
                     p = __builtin_elementwise_fma(wk, ek, p);
                 }
-                accl[b * OB] = p.x + p.y;
+                if constexpr (ABL & 8) { if (p.x + p.y == 1.2345e33f) accl[b * OB] = p.x; } else accl[b * OB] = p.x + p.y;
             };
             {
                 while (mask & (mask - 1ull)) {                      // at least two hits left: both in flight before the wait
@@ -427,36 +498,39 @@ __global__ void __launch_bounds__(64 * TL_NQ * (TL_OB / 64)) pool_embed_cellspli
                 if (ok[u]) accl[eg[u] * OB] = av[u];
         }
     };
-    // Occupancy of this wave group's cells (cell q + NQ*k <-> bit k; lane k and lane k + 64 scan the 32 egos of
-    // their cell): only cells with at least one hit in the tile are visited, and only their weights are loaded.
+    // Occupancy of this wave group's cells (cell q + NQ*k <-> bit k): only cells with at least one hit in the tile are
+    // visited, and only their weights are loaded.
     const int nk = (a.ncell - q + NQ - 1) / NQ;                      // <= 128 (ncell <= 440 + NQ)
     unsigned long long occ[2];
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
         const int k = hh * 64 + lane;
-        bool any = false;
-        if (k < nk) {
-            const WT *col = wl + (q + NQ * k) * WLS;
-            for (int e = 0; e < TE; ++e) any |= col[e] >= 0;
-        }
-        occ[hh] = __ballot(any);
+        occ[hh] = __ballot(k < nk && socc[q + NQ * (k < nk ? k : 0)] != 0);
     }
     auto pop = [&]() -> int {                                         // next occupied cell of the group, or -1
         if (occ[0]) { const int k = __ffsll((long long)occ[0]) - 1; occ[0] &= occ[0] - 1ull; return q + NQ * k; }
         if (occ[1]) { const int k = __ffsll((long long)occ[1]) - 1; occ[1] &= occ[1] - 1ull; return q + NQ * (64 + k); }
         return -1;
     };
+    // Two weight sets: the next occupied cell's C weights are in flight while the current cell's hits are processed.
+    // Every load_w is unconditional (past the last occupied cell it re-reads the last one): only then does the compiler
+    // know how many loads are younger than the set it waits for and emit vmcnt(C) instead of vmcnt(0).
     float wA[C], wB[C];
     int ca = pop();
-    if (ca >= 0) load_w(wA, ca);
-    while (ca >= 0) {
-        const int cb = pop();
-        if (cb >= 0) load_w(wB, cb);
-        process(wA, ca);
-        if (cb < 0) break;
-        ca = pop();
-        if (ca >= 0) load_w(wA, ca);
-        process(wB, cb);
+    if constexpr (ABL & 16) ca = -1;
+    if (ca >= 0) {
+        load_w(wA, ca);
+        while (true) {
+            const int cb = pop();
+            load_w(wB, cb >= 0 ? cb : ca);
+            process(wA, ca);
+            if (cb < 0) break;
+            ca = pop();
+            load_w(wA, ca >= 0 ? ca : cb);
+            process(wB, cb);
+            if (ca < 0) break;
+        }
+        if constexpr (ASMW && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 
@@ -478,6 +552,256 @@ __global__ void __launch_bounds__(64 * TL_NQ * (TL_OB / 64)) pool_embed_cellspli
         *reinterpret_cast<float4 *>(a.out + (size_t)row * a.ldo + oo) = v;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Register-accumulator kernel (default for C <= 16 and grids up to 417 cells): 64 egos x 128 columns per workgroup,
+// 16 waves = 8 cell groups x 2 column sets.  Same hit discovery as the cell-split kernel (winner tile in LDS, one ballot
+// per cell with lane <-> ego, scalar loads of the neighbour rows), but
+//   * a wave's accumulators -- 64 egos x its lane's column -- live in VGPRs (two 32-element vectors): the ego of a hit
+//     is wave-uniform, so acc[ego] is a register access through s_set_gpr_idx; no LDS read-modify-write per hit and no
+//     accumulator copies in LDS, which is what capped the cell-split kernel's tile at 32 egos;
+//   * a weight register set W'[c][.][o] serves the hits of 64 egos instead of 32: the L2 -> CU weight stream (1 GB per
+//     launch at BASELINE config 2, ~45 us at the ~25 TB/s the L1 fill path sustains) is halved;
+//   * weight loads are inline asm with manual vmcnt (see load_w) so that the next cell's set really is in flight;
+//   * the 8 cell groups' partial sums are combined once at the end through LDS, 32 egos per round, in fixed order
+//     (group 0 + 1 + ... + 7, then bias and activation): deterministic, independent of the ego's position in the tile.
+// Measured (tools/experiments/sparse_ablate.hip, config-2 crowd): 41 us against 50 us for the cell-split kernel.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int RA_TE = 64, RA_OB = 128, RA_NQ = 8, RA_NCS = RA_OB / 64, RA_RED = 32;
+typedef float ra_f32x32 __attribute__((ext_vector_type(32)));
+
+static size_t ra_smem_bytes(int ncell) {
+    const size_t keys = (size_t)RA_TE * ncell * 4 + 6 * RA_TE * 4, red = (size_t)RA_NQ * RA_RED * RA_OB * 4;
+    const size_t wl = (((size_t)ncell * (RA_TE + 2) * 2 + 15) & ~(size_t)15) + (size_t)ncell * 4;
+    const size_t pro = ((keys + 15) & ~(size_t)15) + wl;
+    return pro > red ? pro : red;
+}
+
+template <int C, bool FG, int ABL = 0>
+__global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(const SparseArgs a) {
+    constexpr int TE = RA_TE, OB = RA_OB, NQ = RA_NQ, NCS = RA_NCS, WLS = TE + 2, NTH = 64 * NQ * NCS, NW = NTH / 64;
+    extern __shared__ __attribute__((aligned(16))) float rsm[];
+    int *wkey = reinterpret_cast<int *>(rsm);                                       // [TE][ncell] keys, then the geometry
+    int *sg = wkey + TE * a.ncell;
+    float *sp = reinterpret_cast<float *>(sg + 4 * TE);
+    int16_t *wl = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(rsm) + ((((size_t)TE * a.ncell * 4 + 6 * TE * 4) + 15) & ~(size_t)15));
+    int *socc = reinterpret_cast<int *>(reinterpret_cast<char *>(wl) + (((size_t)a.ncell * WLS * 2 + 15) & ~(size_t)15));
+    float *red = rsm;                                                               // epilogue: [NQ][RA_RED][OB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cs = wave % NCS, q = wave / NCS;
+    const int ob = blockIdx.x % a.out_blocks, tile = blockIdx.x / a.out_blocks;     // blocks b, b+8, .. share an XCD
+    const int row0 = tile * TE;
+    const int o = ob * OB + cs * 64 + lane;
+    const unsigned ocu = (unsigned)(o < a.N1 ? o : a.N1 - 1);
+
+    for (int c = tid; c < a.ncell; c += NTH) socc[c] = 0;
+    if constexpr (FG) {
+        {
+            const int4 m1 = {-1, -1, -1, -1};
+            for (int idx = tid; idx < TE * a.ncell / 4; idx += NTH) reinterpret_cast<int4 *>(wkey)[idx] = m1;
+        }
+        if (tid < TE) {
+            const int row = row0 + tid;
+            int lo = 0, ns = 0, pad = 0;
+            float2 pi = {-500.0f, -500.0f};
+            if (row < a.M) {
+                lo = a.row_base[row]; ns = a.row_end[row] - lo; pad = a.row_padded[row];
+                pi = reinterpret_cast<const float2 *>(a.obs2)[row];
+                if (pi.x != pi.x || pi.y != pi.y) { pi.x = -500.0f; pi.y = -500.0f; }
+            }
+            sg[tid] = lo; sg[TE + tid] = ns; sg[2 * TE + tid] = row - lo; sg[3 * TE + tid] = pad;
+            sp[tid] = pi.x; sp[TE + tid] = pi.y;
+        }
+        __syncthreads();
+        const float fG = (float)a.G;
+        constexpr int EU = TE / NW;
+        auto pair = [&](int e, int j, float2 pj) {
+            if (j == sg[2 * TE + e]) return;
+            if (pj.x != pj.x || pj.y != pj.y) { pj.x = -500.0f; pj.y = -500.0f; }
+            const float ox = __fadd_rn(__fdiv_rn(__fsub_rn(pj.x, sp[e]), a.cell), a.half_x);
+            const float oy = __fadd_rn(__fdiv_rn(__fsub_rn(pj.y, sp[TE + e]), a.cell), a.half_y);
+            const bool inr = !(ox < 0.0f) && !(ox >= fG) && !(oy < 0.0f) && !(oy >= fG);
+            const int cellid = inr ? ((int)ox * a.G + (int)oy) : 0;
+            atomicMax(&wkey[e * a.ncell + cellid], 2 * j + (inr ? 1 : 0));
+        };
+        if constexpr (!(ABL & 32)) {
+            const int e0 = wave * EU;
+            float2 pj[EU];
+#pragma unroll
+            for (int u = 0; u < EU; ++u)
+                if (lane < sg[TE + e0 + u]) pj[u] = reinterpret_cast<const float2 *>(a.obs2)[sg[e0 + u] + lane];
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                const int e = e0 + u, lo = sg[e], ns = sg[TE + e], pad = sg[3 * TE + e];
+                if (lane < ns) pair(e, lane, pj[u]);
+                for (int j = lane + 64; j < ns; j += 64) pair(e, j, reinterpret_cast<const float2 *>(a.obs2)[lo + j]);
+                if (ns < pad && lane == 0) atomicMax(&wkey[e * a.ncell], 2 * (pad - 1));
+            }
+        }
+        __syncthreads();
+    } else {
+        __syncthreads();
+    }
+    if constexpr (!(ABL & 64))
+    for (int e = wave; e < TE; e += NW) {
+        const int row = row0 + e;
+        for (int c0 = 0; c0 < a.ncell; c0 += 256) {
+            int kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * 64 + lane;
+                kk[u] = -1;
+                if (c < a.ncell && row < a.M) {
+                    if constexpr (FG) { const int k = wkey[e * a.ncell + c]; kk[u] = (k >= 0 && (k & 1)) ? (k >> 1) : -1; }
+                    else kk[u] = a.winners[(size_t)row * a.ncell + c];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * 64 + lane;
+                if (c >= a.ncell) continue;
+                if constexpr (FG) if (a.winners_out && ob == 0 && row < a.M) a.winners_out[(size_t)row * a.ncell + c] = (int16_t)kk[u];
+                wl[c * WLS + e] = (int16_t)kk[u];
+                if (kk[u] >= 0) socc[c] = 1;
+            }
+        }
+    }
+    int rb;
+    if constexpr (FG) rb = sg[lane];
+    else rb = a.row_base[min(row0 + lane, a.M - 1)];
+    __syncthreads();
+    asm volatile("" : "+v"(rb));
+
+    ra_f32x32 accA, accB;                                                           // egos 0..31 / 32..63 of the tile, this lane's column
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { accA[i] = 0.0f; accB[i] = 0.0f; }
+
+    const unsigned vo = ocu * 4u;
+    auto load_w = [&](float (&w)[C], int c) {
+        const float *wb = a.Wp + (size_t)c * C * a.N1;
+        if constexpr (ABL & 1) {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) w[ch] = 1.0f + ch;
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch)
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(w[ch]) : "v"(vo), "s"(wb + (size_t)ch * a.N1) : "memory");
+        }
+    };
+    auto wait_w = [&](float (&w)[C]) {
+        static_assert(C == 4 || C == 8 || C == 16, "vmcnt immediate");
+        if constexpr (ABL & 1) {
+        } else if constexpr (C == 16)
+            asm volatile("s_waitcnt vmcnt(16)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]),
+                         "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
+        else if constexpr (C == 8)
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
+        else
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+    };
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    auto fin = [&](const float (&w)[C], const typename SRow<C>::type &ev, float av) -> float {
+        f2 p = {av, 0.0f};
+#pragma unroll
+        for (int k = 0; k < C / 2; ++k) {
+            const f2 wk = {w[2 * k], w[2 * k + 1]};
+            const f2 ek = {ev[2 * k], ev[2 * k + 1]};
+            p = __builtin_elementwise_fma(wk, ek, p);
+        }
+        return p.x + p.y;
+    };
+    auto half = [&](const float (&w)[C], ra_f32x32 &acc, unsigned m, unsigned off, int lane0) {
+        while (m & (m - 1u)) {
+            const int b0 = __builtin_ctz(m); m &= m - 1u;
+            const int b1 = __builtin_ctz(m); m &= m - 1u;
+            typename SRow<C>::type e0, e1;
+            sload_row<C>(e0, a.enc, (unsigned)__builtin_amdgcn_readlane((int)off, lane0 + b0));
+            sload_row<C>(e1, a.enc, (unsigned)__builtin_amdgcn_readlane((int)off, lane0 + b1));
+            const float a0 = acc[b0], a1 = acc[b1];
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e0), "+s"(e1));
+            acc[b0] = fin(w, e0, a0);
+            acc[b1] = fin(w, e1, a1);
+        }
+        if (m) {
+            const int b0 = __builtin_ctz(m);
+            typename SRow<C>::type e0;
+            sload_row<C>(e0, a.enc, (unsigned)__builtin_amdgcn_readlane((int)off, lane0 + b0));
+            const float a0 = acc[b0];
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e0));
+            acc[b0] = fin(w, e0, a0);
+        }
+    };
+    auto process = [&](float (&w)[C], int c) {
+        const int wv = (int)wl[c * WLS + lane];                                     // lane <-> ego of the tile
+        const unsigned long long mask = __ballot(wv >= 0);
+        wait_w(w);
+        if constexpr (ABL & 2) { if (mask == 1234567ull) accA[0] += w[0] + w[C - 1]; return; }
+        const unsigned off = __umul24((unsigned)(rb + wv), (unsigned)(a.ldv * 4));
+        half(w, accA, (unsigned)mask, off, 0);
+        half(w, accB, (unsigned)(mask >> 32), off, 32);
+    };
+    // cells of this wave's group with a hit in the tile; group q takes cell NQ k + ((q - k) mod NQ) of every block k of NQ cells
+    const int nk = (a.ncell + NQ - 1) / NQ;                                          // <= 64: ncell <= 512
+    auto cell_of = [&](int k) { return NQ * k + ((q - k) & (NQ - 1)); };
+    unsigned long long occ;
+    {
+        const int c = cell_of(lane);
+        occ = __ballot(lane < nk && c < a.ncell && socc[c < a.ncell ? c : 0] != 0);
+    }
+    auto pop = [&]() -> int { if (!occ) return -1; const int k = pop_bit(occ); return cell_of(k); };
+    // Two weight sets: the next occupied cell's weights are in flight while the current cell's hits are processed; every
+    // load_w is unconditional (past the last occupied cell it re-reads the last one) so that vmcnt(C) is exact.
+    float wA[C], wB[C];
+    int ca = pop();
+    if constexpr (ABL & 16) ca = -1;
+    if (ca >= 0) {
+        load_w(wA, ca);
+        while (true) {
+            const int cb = pop();
+            load_w(wB, cb >= 0 ? cb : ca);
+            process(wA, ca);
+            if (cb < 0) break;
+            ca = pop();
+            load_w(wA, ca >= 0 ? ca : cb);
+            process(wB, cb);
+            if (ca < 0) break;
+        }
+        if constexpr (!(ABL & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    // ---- the 8 cell groups' partial sums, 32 egos per round: every wave leaves its partials in LDS, then wave w sums the
+    //      copies of egos w and w + 16 of the round in fixed order (group 0 + 1 + ... + 7), bias + activation, coalesced rows
+    const int col2 = 2 * lane;                                                      // this lane's column pair in the epilogue
+    float2 bias2 = {0.0f, 0.0f};
+    if (a.bias && ob * OB + col2 + 1 < a.N1) bias2 = *reinterpret_cast<const float2 *>(a.bias + ob * OB + col2);
+    if constexpr (ABL & 128) { if (accA[3] + accB[5] == 1.234e30f) a.out[tid] = 0.0f; return; }
+#pragma unroll
+    for (int r = 0; r < TE / RA_RED; ++r) {
+        __syncthreads();                                                            // prologue data / previous round no longer read
+#pragma unroll
+        for (int e = 0; e < RA_RED; ++e)
+            red[(q * RA_RED + e) * OB + cs * 64 + lane] = r == 0 ? accA[e] : accB[e];
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < RA_RED / NW; ++h) {
+            const int e = wave + NW * h;
+            float2 v = *reinterpret_cast<const float2 *>(red + (size_t)e * OB + col2);
+#pragma unroll
+            for (int qq = 1; qq < NQ; ++qq) {
+                const float2 t = *reinterpret_cast<const float2 *>(red + ((size_t)qq * RA_RED + e) * OB + col2);
+                v.x += t.x; v.y += t.y;
+            }
+            v.x += bias2.x; v.y += bias2.y;
+            if (a.relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); }
+            const int row = row0 + RA_RED * r + e;
+            if (row < a.M && ob * OB + col2 + 1 < a.N1) *reinterpret_cast<float2 *>(a.out + (size_t)row * a.ldo + ob * OB + col2) = v;
+        }
+    }
+}
+
+
+bool regacc_supported(int C, int ncell) { return (C == 4 || C == 8 || C == 16) && ncell <= 64 * RA_NQ && ra_smem_bytes(ncell) <= (size_t)160 * 1024; }
 
 bool sparse_supported(int C, int N1, int ncell) {
     return (C == 4 || C == 8 || C == 16 || C == 32) && N1 >= 4 && (N1 % 4 == 0) && ncell >= 1;
@@ -511,10 +835,28 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
     a.winners = winners; a.enc = enc; a.ldv = ldv; a.row_base = row_base; a.Wp = Wp; a.bias = bias;
     a.M = M; a.ncell = ncell; a.C = C; a.N1 = N1; a.relu = relu; a.ldo = ldo;
     a.obs2 = nullptr; a.row_end = nullptr; a.row_padded = nullptr; a.G = 0; a.cell = 1.0f; a.half_x = a.half_y = 0.0f; a.winners_out = nullptr;
+    const bool lean_rows = (size_t)M * ldv * sizeof(float) < ((size_t)1 << 32);   // 32-bit byte offsets of the neighbour rows
+    if (lean_rows && regacc_supported(C, ncell)) {                                // register accumulators, 64-ego tiles
+        a.out = out;
+        a.S = 1; a.cps = ncell; a.ego_tiles = (M + RA_TE - 1) / RA_TE; a.out_blocks = (N1 + RA_OB - 1) / RA_OB;
+        if (fg) {
+            a.obs2 = fg->obs2; a.row_end = fg->row_end; a.row_padded = fg->row_padded; a.G = fg->G;
+            a.cell = fg->cell; a.half_x = fg->half_x; a.half_y = fg->half_y; a.winners_out = fg->winners_out;
+        }
+        const size_t rsmem = ra_smem_bytes(ncell);
+        const int rblocks = a.ego_tiles * a.out_blocks;
+#define RA_LAUNCH(CC, FGB) { static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
+        pool_embed_regacc_kernel<CC, FGB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((pool_embed_regacc_kernel<CC, FGB>), dim3(rblocks), dim3(64 * RA_NQ * RA_NCS), rsmem, s, a); }
+#define RA_SWITCH(CC) { if (fg) RA_LAUNCH(CC, true) else RA_LAUNCH(CC, false) }
+        if (C == 4) RA_SWITCH(4) else if (C == 8) RA_SWITCH(8) else RA_SWITCH(16)
+        TNP_HIP(hipGetLastError());
+        return 0;
+    }
     if (ncell <= TL_MAXCELL_LDS) {
         a.out = out;
         a.S = 1; a.cps = ncell; a.ego_tiles = (M + TL_TE - 1) / TL_TE; a.out_blocks = (N1 + TL_OB - 1) / TL_OB;
-        const size_t csmem = (size_t)TL_NQ * TL_TE * TL_OB * 4 + (((size_t)ncell * (TL_TE + 2) * 2 + 15) & ~(size_t)15);
+        const size_t csmem = (size_t)TL_NQ * TL_TE * TL_OB * 4 + (((size_t)ncell * (TL_TE + 2) * 2 + 15) & ~(size_t)15) + (size_t)ncell * 4;
         const int cblocks = a.ego_tiles * a.out_blocks;
         // the lean path addresses neighbour rows with a 32-bit byte offset
         const bool lean = (size_t)M * ldv * sizeof(float) < ((size_t)1 << 32);
