@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNP_ABI_VERSION 4
+#define TNP_ABI_VERSION 5
 #define TNP_API __attribute__((visibility("default")))
 
 /* pooling types: GridBasedPooling(type_=...)  lstm/gridbased_pooling.py:16-19,55-66 */
@@ -193,6 +193,11 @@ typedef struct tnp_lstm_model {
      * Wx/bx[1] = pool_lstm.weight_hh/bias_hh [4Hp,Hp], Wx/bx[2] = hidden2pool [P,Hp] */
     const float *Wx[3];
     const float *bx[3];
+    const float *Wp0_quad_major; /* optional second copy of Wp[0] next to Wp0_cell_major, laid out for the register-
+                                    accumulator sparse kernel: [n*n][dims[1]/64][C/4][64][4],
+                                    W''[c][o/64][ch/4][o%64][ch%4] = Wp[0][o][ch*n*n + c]  (needs dims[1] % 64 == 0 and
+                                    C % 4 == 0; a wave's C x 64 weights of a cell are one contiguous 4 C x 64-byte block).
+                                    NULL = that kernel reads Wp0_cell_major (slower: two scalar address ops per channel) */
 } tnp_lstm_model;
 
 /* bytes of scratch HBM tnp_lstm_forward / tnp_lstm_step need for M tracks in B scenes */

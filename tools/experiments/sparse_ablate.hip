@@ -4,9 +4,11 @@
 //       tools/experiments/sparse_ablate.hip -o tools/experiments/sparse_ablate && tools/experiments/sparse_ablate
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <cmath>
 #include <vector>
+#include <algorithm>
 #include <random>
 #include "pool_embed_sparse.hip"
 
@@ -70,7 +72,7 @@ int main(int argc, char **argv) {
     // host reference of every 37th ego (last writer in ascending j wins a cell; out-of-range neighbours clobber cell 0)
     auto check = [&](const std::vector<float> &y, const char *name) {
         double md = 0;
-        for (int i = 0; i < M; i += 37) {
+        for (int i = 0; i < M; i += (getenv("FULLCHECK") ? 1 : 37)) {
             std::vector<int> win(ncell, -1);
             for (int j = rb[i]; j < re[i]; ++j) {
                 if (j == i) continue;
@@ -78,7 +80,7 @@ int main(int argc, char **argv) {
                 const bool inr = !(ox < 0) && !(ox >= G) && !(oy < 0) && !(oy >= G);
                 win[inr ? (int)ox * G + (int)oy : 0] = inr ? j : -1;
             }
-            for (int o = 0; o < N1; o += 5) {
+            for (int o = 0; o < N1; o += (getenv("FULLCHECK") ? 1 : 5)) {
                 double acc = bias[o];
                 for (int c = 0; c < ncell; ++c) if (win[c] >= 0)
                     for (int ch = 0; ch < C; ++ch) acc += (double)W[((size_t)c * C + ch) * N1 + o] * enc[(size_t)win[c] * C + ch];
@@ -118,15 +120,86 @@ int main(int argc, char **argv) {
     {   // register accumulators: 64 egos x 128 columns, 8 cell groups x 2 column sets = 16 waves
         tnp::SparseArgs b = a; b.ego_tiles = M / 64; b.out_blocks = N1 / 128;
         const size_t smem3 = tnp::ra_smem_bytes(ncell);
-#define KR(abl) (kern_t)tnp::pool_embed_regacc_kernel<16, true, abl>
+#define KR(abl) (kern_t)tnp::pool_embed_regacc_kernel<16, true, false, abl>
+#define KQ(abl) (kern_t)tnp::pool_embed_regacc_kernel<16, true, true, abl>
         const V ws[] = {{"regacc", KR(0)}, {"regacc no weight loads", KR(1)}, {"regacc no hits", KR(2)}, {"regacc no cell loop", KR(16)},
-                        {"regacc no loop, no pairs", KR(48)}, {"regacc no loop, no pairs, no conversion", KR(112)}, {"regacc no loop, no epilogue", KR(144)},
-                        {"regacc nothing (240)", KR(240)}};
+                        {"regacc no loop, no votes", KR(48)}, {"regacc no loop, no epilogue", KR(144)}, {"regacc nothing (176)", KR(176)}};
         for (const V &v : ws) {
             const float us = time_kernel(v.k, b, b.ego_tiles * b.out_blocks, smem3, 50, 1024);
             printf("%-42s %8.2f us\n", v.name, us);
             if (v.k == ws[0].k) { CK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost)); check(got, "regacc"); }
         }
+    }
+    tnp::SparseArgs a2 = a; a2.ego_tiles = M / 64; a2.out_blocks = N1 / 128;
+    {   // quad-major weights [cell][N1/64][C/4][64][4] (what the sequence driver hands over)
+        std::vector<float> W4(W.size());
+        for (int c = 0; c < ncell; ++c) for (int ch = 0; ch < C; ++ch) for (int o = 0; o < N1; ++o)
+            W4[((((size_t)c * (N1 / 64) + o / 64) * (C / 4) + ch / 4) * 64 + o % 64) * 4 + ch % 4] = W[((size_t)c * C + ch) * N1 + o];
+        tnp::SparseArgs b = a2; b.Wp = dev(W4);
+        const int nb = b.ego_tiles * b.out_blocks;
+        const V ws[] = {{"regacc quad-major", KQ(0)}, {"regacc quad-major no weight loads", KQ(1)}, {"regacc quad-major no hits", KQ(2)},
+                        {"regacc quad-major no cell loop", KQ(16)}};
+        for (const V &v : ws) {
+            printf("%-42s %8.2f us\n", v.name, time_kernel(v.k, b, nb, tnp::ra_smem_bytes(ncell), 50, 1024));
+            if (v.k == ws[0].k) { CK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost)); check(got, "regacc quad-major"); }
+        }
+        {   // determinism: repeated launches must agree bit for bit, with and without the winner table being written
+            const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 20;
+            int16_t *wout; CK(hipMalloc(&wout, (size_t)M * ncell * 2));
+            std::vector<float> first(got.size()), again(got.size());
+            struct T { const char *name; kern_t k; tnp::SparseArgs args; bool wo; };
+            T ts[] = {{"quad-major", KQ(0), b, false}, {"quad-major + winners_out", KQ(0), b, true}, {"cell-major + winners_out", KR(0), a2, true}};
+            int ti = -1;
+            for (T &t : ts) {
+                ++ti;
+                if (getenv("ONLY") && atoi(getenv("ONLY")) != ti) continue;
+                int bad = 0;
+                t.args.winners_out = t.wo ? wout : nullptr;
+                const bool cs = t.k == KV(0);
+                for (int rep = 0; rep < reps; ++rep) {
+                    CK(hipMemsetAsync(out, 0xff, got.size() * 4));
+                    if (cs) hipLaunchKernelGGL(t.k, dim3(blocks), dim3(1024), smem, 0, t.args);
+                    else hipLaunchKernelGGL(t.k, dim3(nb), dim3(1024), tnp::ra_smem_bytes(ncell), 0, t.args);
+                    CK(hipMemcpy(rep ? again.data() : first.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
+                    if (rep && memcmp(first.data(), again.data(), got.size() * 4)) {
+                        size_t n = 0, f = 0; std::vector<char> rows(M, 0);
+                        for (size_t i = 0; i < got.size(); ++i) if (memcmp(&first[i], &again[i], 4)) { if (!n) f = i; ++n; rows[i / N1] = 1; }
+                        int nr = 0; for (char r : rows) nr += r;
+                        if (bad < 4) printf("   rep %d: %zu elements in %d rows differ, first at row %zu col %zu (%g vs %g)\n", rep, n, nr, f / N1, f % N1, first[f], again[f]);
+                        ++bad;
+                    }
+                }
+                printf("   %-36s %d of %d repeats differ from the first\n", t.name, bad, reps - 1);
+            }
+        }
+        long long *dbg; CK(hipMalloc(&dbg, (size_t)nb * 16 * 8 * 8)); CK(hipMemset(dbg, 0, (size_t)nb * 16 * 8 * 8));
+        b.winners = reinterpret_cast<const int16_t *>(dbg);
+        time_kernel(KQ(256), b, nb, tnp::ra_smem_bytes(ncell), 3, 1024);
+        std::vector<long long> h((size_t)nb * 16 * 8); CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double tot = 0, ml = 0; for (int w = 0; w < nb; ++w) { long long lo = 1ll << 62, hi = 0, m = 0; for (int v = 0; v < 16; ++v) { lo = std::min(lo, h[((size_t)w * 16 + v) * 8]); hi = std::max(hi, h[((size_t)w * 16 + v) * 8 + 5]); m = std::max(m, h[((size_t)w * 16 + v) * 8 + 4] - h[((size_t)w * 16 + v) * 8 + 3]); } tot += hi - lo; ml += m; }
+        printf("quad-major weights: workgroup residency %.0f clocks, main loop (slowest wave) %.0f\n", tot / nb, ml / nb);
+    }
+    {   // per-wave phase stamps of the register-accumulator kernel
+        tnp::SparseArgs b = a; b.ego_tiles = M / 64; b.out_blocks = N1 / 128;
+        const int nb = b.ego_tiles * b.out_blocks;
+        long long *dbg; CK(hipMalloc(&dbg, (size_t)nb * 16 * 8 * 8)); CK(hipMemset(dbg, 0, (size_t)nb * 16 * 8 * 8));
+        b.winners = reinterpret_cast<const int16_t *>(dbg);
+        time_kernel(KR(256), b, nb, tnp::ra_smem_bytes(ncell), 3, 1024);
+        std::vector<long long> h((size_t)nb * 16 * 8); CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        const char *names[] = {"stage geometry + key init", "pairs", "conversion", "main loop", "epilogue"};
+        for (int ph = 0; ph < 5; ++ph) {
+            std::vector<double> med, mx, mn;
+            for (int w = 0; w < nb; ++w) {
+                std::vector<long long> d;
+                for (int v = 0; v < 16; ++v) d.push_back(h[((size_t)w * 16 + v) * 8 + ph + 1] - h[((size_t)w * 16 + v) * 8 + ph]);
+                std::sort(d.begin(), d.end());
+                med.push_back(d[8]); mx.push_back(d[15]); mn.push_back(d[0]);
+            }
+            auto mean = [](const std::vector<double> &x) { double t = 0; for (double v : x) t += v; return t / x.size(); };
+            printf("phase %-28s clocks per wave: min %8.0f median %8.0f max %8.0f (mean over workgroups)\n", names[ph], mean(mn), mean(med), mean(mx));
+        }
+        double tot = 0; for (int w = 0; w < nb; ++w) { long long lo = 1ll << 62, hi = 0; for (int v = 0; v < 16; ++v) { lo = std::min(lo, h[((size_t)w * 16 + v) * 8]); hi = std::max(hi, h[((size_t)w * 16 + v) * 8 + 5]); } tot += hi - lo; }
+        printf("workgroup residency %.0f clocks (100 MHz shader clock units: x24 for 2.4 GHz cycles?)\n", tot / nb);
     }
     return 0;
 }

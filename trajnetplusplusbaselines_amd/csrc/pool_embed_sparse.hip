@@ -563,29 +563,36 @@ __global__ void __launch_bounds__(64 * NQ * (OB / 64)) pool_embed_cellsplit_kern
 //   * a weight register set W'[c][.][o] serves the hits of 64 egos instead of 32: the L2 -> CU weight stream (1 GB per
 //     launch at BASELINE config 2, ~45 us at the ~25 TB/s the L1 fill path sustains) is halved;
 //   * weight loads are inline asm with manual vmcnt (see load_w) so that the next cell's set really is in flight;
+//   * the winner keys are built transposed ([cell][ego]) and read by the cell loop as they are: no conversion pass;
 //   * the 8 cell groups' partial sums are combined once at the end through LDS, 32 egos per round, in fixed order
 //     (group 0 + 1 + ... + 7, then bias and activation): deterministic, independent of the ego's position in the tile.
-// Measured (tools/experiments/sparse_ablate.hip, config-2 crowd): 41 us against 50 us for the cell-split kernel.
+// Measured (tools/experiments/sparse_ablate.hip, config-2 crowd, 11.7 hits per ego): 32.5 us with quad-major weights (39 us
+// with the cell-major copy) against 50 us for the cell-split kernel.  ABL: timing ablations for that harness (1 no weight
+// loads, 2 no hits, 16 no cell loop, 32 no votes, 128 no epilogue, 256 shader-clock stamps); the library instantiates 0.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int RA_TE = 64, RA_OB = 128, RA_NQ = 8, RA_NCS = RA_OB / 64, RA_RED = 32;
 typedef float ra_f32x32 __attribute__((ext_vector_type(32)));
 
+constexpr int RA_KS = RA_TE + 1;   // row stride of the transposed key table (odd: conflict-free both ways)
 static size_t ra_smem_bytes(int ncell) {
-    const size_t keys = (size_t)RA_TE * ncell * 4 + 6 * RA_TE * 4, red = (size_t)RA_NQ * RA_RED * RA_OB * 4;
-    const size_t wl = (((size_t)ncell * (RA_TE + 2) * 2 + 15) & ~(size_t)15) + (size_t)ncell * 4;
-    const size_t pro = ((keys + 15) & ~(size_t)15) + wl;
-    return pro > red ? pro : red;
+    const size_t keys = (((size_t)ncell * RA_KS * 4 + 15) & ~(size_t)15) + (size_t)ncell * 4 + 6 * RA_TE * 4;
+    const size_t red = (size_t)RA_NQ * RA_RED * RA_OB * 4;
+    return keys > red ? keys : red;
 }
 
-template <int C, bool FG, int ABL = 0>
+// QW: weights in the quad-major layout W''[c][o / 64][ch / 4][o % 64][ch % 4] (one scalar base per cell and column block,
+// one 16-byte load per lane and channel quad); else the cell-major W'[c][ch][o].
+template <int C, bool FG, bool QW, int ABL = 0>
 __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(const SparseArgs a) {
-    constexpr int TE = RA_TE, OB = RA_OB, NQ = RA_NQ, NCS = RA_NCS, WLS = TE + 2, NTH = 64 * NQ * NCS, NW = NTH / 64;
+    constexpr int TE = RA_TE, OB = RA_OB, NQ = RA_NQ, NCS = RA_NCS, NTH = 64 * NQ * NCS, NW = NTH / 64;
     extern __shared__ __attribute__((aligned(16))) float rsm[];
-    int *wkey = reinterpret_cast<int *>(rsm);                                       // [TE][ncell] keys, then the geometry
-    int *sg = wkey + TE * a.ncell;
+    // keys [ncell][KS]: key of (cell, ego) = 2 * neighbour + in_range, -1 = empty -- written by LDS integer max ("last writer
+    // in ascending j wins"), read by the cell loop as one row per cell (lane <-> ego)
+    constexpr int KS = RA_KS;
+    int *keyT = reinterpret_cast<int *>(rsm);
+    int *socc = keyT + (((size_t)a.ncell * KS + 3) & ~(size_t)3);                   // [ncell] cell may have a hit in the tile
+    int *sg = socc + a.ncell;                                                       // lo / ns / ki / pad [TE] each, then x / y
     float *sp = reinterpret_cast<float *>(sg + 4 * TE);
-    int16_t *wl = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(rsm) + ((((size_t)TE * a.ncell * 4 + 6 * TE * 4) + 15) & ~(size_t)15));
-    int *socc = reinterpret_cast<int *>(reinterpret_cast<char *>(wl) + (((size_t)a.ncell * WLS * 2 + 15) & ~(size_t)15));
     float *red = rsm;                                                               // epilogue: [NQ][RA_RED][OB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -594,13 +601,23 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
     const int row0 = tile * TE;
     const int o = ob * OB + cs * 64 + lane;
     const unsigned ocu = (unsigned)(o < a.N1 ? o : a.N1 - 1);
+    // ABL & 256 (harness only): shader-clock stamps per wave and phase into the buffer passed in place of `winners`
+    long long *dbg = nullptr;
+    if constexpr (ABL & 256) dbg = reinterpret_cast<long long *>(const_cast<int16_t *>(a.winners));
+#define RA_T(k) do { if constexpr (ABL & 256) { if (lane == 0) dbg[(blockIdx.x * 16 + wave) * 8 + (k)] = (long long)__builtin_readcyclecounter(); } } while (0)
+    RA_T(0);
 
     for (int c = tid; c < a.ncell; c += NTH) socc[c] = 0;
+    {
+        const int4 m1 = {-1, -1, -1, -1};
+        const int nk4 = (a.ncell * KS + 3) / 4;
+        for (int idx = tid; idx < nk4; idx += NTH) reinterpret_cast<int4 *>(keyT)[idx] = m1;
+    }
     if constexpr (FG) {
-        {
-            const int4 m1 = {-1, -1, -1, -1};
-            for (int idx = tid; idx < TE * a.ncell / 4; idx += NTH) reinterpret_cast<int4 *>(wkey)[idx] = m1;
-        }
+        // Winner keys straight from the positions (what grid_build_kernel computes, pool_grid.hip: the reference's exact fp32
+        // cell arithmetic, integer max on key = 2*j + in_range, cell-0 clobber by out-of-range / absent / padded
+        // neighbours).  The egos' scene geometry is staged first (one thread per ego); a wave then has the LDS reads and
+        // the neighbour positions of its TE / 16 egos in flight together: two global round trips for the whole tile.
         if (tid < TE) {
             const int row = row0 + tid;
             int lo = 0, ns = 0, pad = 0;
@@ -614,85 +631,117 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
             sp[tid] = pi.x; sp[TE + tid] = pi.y;
         }
         __syncthreads();
+        RA_T(1);
         const float fG = (float)a.G;
         constexpr int EU = TE / NW;
-        auto pair = [&](int e, int j, float2 pj) {
-            if (j == sg[2 * TE + e]) return;
+        // branch-free votes: every lane computes its (ego, neighbour) pair, invalid ones are masked at the atomic only.  A
+        // cell other than 0 that receives an in-range vote ends up with an in-range winner; cell 0 may still be clobbered
+        // (then the cell loop finds no hit there: harmless).
+        auto vote = [&](int e, int j, bool valid, float2 pj, float px, float py) {
             if (pj.x != pj.x || pj.y != pj.y) { pj.x = -500.0f; pj.y = -500.0f; }
-            const float ox = __fadd_rn(__fdiv_rn(__fsub_rn(pj.x, sp[e]), a.cell), a.half_x);
-            const float oy = __fadd_rn(__fdiv_rn(__fsub_rn(pj.y, sp[TE + e]), a.cell), a.half_y);
+            const float ox = __fadd_rn(__fdiv_rn(__fsub_rn(pj.x, px), a.cell), a.half_x);
+            const float oy = __fadd_rn(__fdiv_rn(__fsub_rn(pj.y, py), a.cell), a.half_y);
             const bool inr = !(ox < 0.0f) && !(ox >= fG) && !(oy < 0.0f) && !(oy >= fG);
             const int cellid = inr ? ((int)ox * a.G + (int)oy) : 0;
-            atomicMax(&wkey[e * a.ncell + cellid], 2 * j + (inr ? 1 : 0));
+            if (valid) {
+                atomicMax(&keyT[cellid * KS + e], 2 * j + (inr ? 1 : 0));
+                if (inr) socc[cellid] = 1;
+            }
         };
         if constexpr (!(ABL & 32)) {
             const int e0 = wave * EU;
+            int lo[EU], ns[EU], ki[EU], pad[EU];
+            float px[EU], py[EU];
             float2 pj[EU];
 #pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                const int e = e0 + u;
+                lo[u] = sg[e]; ns[u] = sg[TE + e]; ki[u] = sg[2 * TE + e]; pad[u] = sg[3 * TE + e];
+                px[u] = sp[e]; py[u] = sp[TE + e];
+            }
+#pragma unroll
             for (int u = 0; u < EU; ++u)
-                if (lane < sg[TE + e0 + u]) pj[u] = reinterpret_cast<const float2 *>(a.obs2)[sg[e0 + u] + lane];
+                pj[u] = reinterpret_cast<const float2 *>(a.obs2)[lo[u] + (lane < ns[u] ? lane : 0)];   // ns == 0: row 0, unused
+#pragma unroll
+            for (int u = 0; u < EU; ++u) vote(e0 + u, lane, lane < ns[u] && lane != ki[u], pj[u], px[u], py[u]);
 #pragma unroll
             for (int u = 0; u < EU; ++u) {
-                const int e = e0 + u, lo = sg[e], ns = sg[TE + e], pad = sg[3 * TE + e];
-                if (lane < ns) pair(e, lane, pj[u]);
-                for (int j = lane + 64; j < ns; j += 64) pair(e, j, reinterpret_cast<const float2 *>(a.obs2)[lo + j]);
-                if (ns < pad && lane == 0) atomicMax(&wkey[e * a.ncell], 2 * (pad - 1));
+                for (int j = lane + 64; j < ns[u]; j += 64)                          // scenes of more than 64 tracks
+                    vote(e0 + u, j, j != ki[u], reinterpret_cast<const float2 *>(a.obs2)[lo[u] + j], px[u], py[u]);
+                if (ns[u] < pad[u] && lane == 0) atomicMax(&keyT[e0 + u], 2 * (pad[u] - 1));
             }
         }
         __syncthreads();
-    } else {
-        __syncthreads();
-    }
-    if constexpr (!(ABL & 64))
-    for (int e = wave; e < TE; e += NW) {
-        const int row = row0 + e;
-        for (int c0 = 0; c0 < a.ncell; c0 += 256) {
-            int kk[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = c0 + u * 64 + lane;
-                kk[u] = -1;
-                if (c < a.ncell && row < a.M) {
-                    if constexpr (FG) { const int k = wkey[e * a.ncell + c]; kk[u] = (k >= 0 && (k & 1)) ? (k >> 1) : -1; }
-                    else kk[u] = a.winners[(size_t)row * a.ncell + c];
+        RA_T(2);
+        if (a.winners_out && ob == 0) {                                             // training: the winner table for the backward
+            for (int e = wave; e < TE; e += NW) {
+                const int row = row0 + e;
+                if (row >= a.M) continue;
+                for (int c = lane; c < a.ncell; c += 64) {
+                    const int kq = keyT[c * KS + e];
+                    a.winners_out[(size_t)row * a.ncell + c] = (kq >= 0 && (kq & 1)) ? (int16_t)(kq >> 1) : (int16_t)-1;
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = c0 + u * 64 + lane;
-                if (c >= a.ncell) continue;
-                if constexpr (FG) if (a.winners_out && ob == 0 && row < a.M) a.winners_out[(size_t)row * a.ncell + c] = (int16_t)kk[u];
-                wl[c * WLS + e] = (int16_t)kk[u];
-                if (kk[u] >= 0) socc[c] = 1;
+        }
+    } else {
+        __syncthreads();
+        for (int e = wave; e < TE; e += NW) {                                       // keys from the given winner table
+            const int row = row0 + e;
+            if (row >= a.M) continue;
+            for (int c = lane; c < a.ncell; c += 64) {
+                const int w = a.winners[(size_t)row * a.ncell + c];
+                if (w >= 0) { keyT[c * KS + e] = 2 * w + 1; socc[c] = 1; }
             }
         }
+        __syncthreads();
     }
     int rb;
     if constexpr (FG) rb = sg[lane];
     else rb = a.row_base[min(row0 + lane, a.M - 1)];
-    __syncthreads();
     asm volatile("" : "+v"(rb));
+    RA_T(3);
 
     ra_f32x32 accA, accB;                                                           // egos 0..31 / 32..63 of the tile, this lane's column
 #pragma unroll
     for (int i = 0; i < 32; ++i) { accA[i] = 0.0f; accB[i] = 0.0f; }
 
     const unsigned vo = ocu * 4u;
-    auto load_w = [&](float (&w)[C], int c) {
-        const float *wb = a.Wp + (size_t)c * C * a.N1;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr bool QUAD = QW;
+    struct WS { float f[QUAD ? 1 : C]; f4 q[QUAD ? C / 4 : 1]; };
+    auto wch = [](const WS &w, int ch) -> float { if constexpr (QUAD) return w.q[ch >> 2][ch & 3]; else return w.f[ch]; };
+    auto load_w = [&](WS &ws, int c) {
+        float (&w)[QUAD ? 1 : C] = ws.f;
         if constexpr (ABL & 1) {
 #pragma unroll
-            for (int ch = 0; ch < C; ++ch) w[ch] = 1.0f + ch;
+            for (int ch = 0; ch < (QUAD ? 1 : C); ++ch) w[ch] = 1.0f + ch;
+        } else if constexpr (QUAD) {
+            // one scalar base per cell (the column block's C x 64 weights are contiguous), channel quad = immediate offset:
+            // 3 scalar instructions per cell instead of 2 per channel -- the scalar pipe is what bounds this loop
+            const float *wb = a.Wp + ((size_t)c * (a.N1 >> 6) + (size_t)(ob * NCS + cs)) * (C * 64);
+            const unsigned vl = lane * 16u;
+#pragma unroll
+            for (int kq = 0; kq < C / 4; ++kq)
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(ws.q[kq]) : "v"(vl), "s"(wb), "i"(kq * 1024) : "memory");
         } else {
+            const float *wb = a.Wp + (size_t)c * C * a.N1;
 #pragma unroll
             for (int ch = 0; ch < C; ++ch)
                 asm volatile("global_load_dword %0, %1, %2" : "=v"(w[ch]) : "v"(vo), "s"(wb + (size_t)ch * a.N1) : "memory");
         }
     };
-    auto wait_w = [&](float (&w)[C]) {
+    auto wait_w = [&](WS &ws) {
+        float (&w)[QUAD ? 1 : C] = ws.f;
         static_assert(C == 4 || C == 8 || C == 16, "vmcnt immediate");
         if constexpr (ABL & 1) {
-        } else if constexpr (C == 16)
+        } else if constexpr (QUAD && C == 16) {
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(ws.q[0]), "+v"(ws.q[QUAD ? 1 : 0]), "+v"(ws.q[QUAD ? 2 : 0]), "+v"(ws.q[QUAD ? 3 : 0]));
+        } else if constexpr (QUAD && C == 8) {
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(ws.q[0]), "+v"(ws.q[QUAD ? 1 : 0]));
+        } else if constexpr (QUAD) {
+            asm volatile("s_waitcnt vmcnt(1)" : "+v"(ws.q[0]));
+        }
+        else if constexpr (C == 16)
             asm volatile("s_waitcnt vmcnt(16)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]),
                          "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
         else if constexpr (C == 8)
@@ -701,18 +750,26 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
             asm volatile("s_waitcnt vmcnt(4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
     };
     typedef float f2 __attribute__((ext_vector_type(2)));
-    auto fin = [&](const float (&w)[C], const typename SRow<C>::type &ev, float av) -> float {
+    // one hit: acc[ego] += sum_ch w[ch] * e[ch] (even / odd channels in the two halves of a packed register: C/2
+    // v_pk_fma_f32).  The ego is wave-uniform, so acc[ego] is a relative register access which the compiler lowers to
+    // s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off around the read and around the write.  Keep this exact shape (read,
+    // chain, write): with `acc[b] += t` the compiler moves the vectors to scratch memory (launch_pool_embed_sparse refuses
+    // a build whose kernel has a private segment).  A hand-written single  s_set_gpr_idx_on b, SRC1|DST ; v_add_f32 acc0,
+    // t, acc0 ; s_set_gpr_idx_off  on pinned registers is 2 % faster but corrupts ~1 launch in 150 on gfx950 (wrong sums in
+    // a few egos of one wave, or a wild scalar load), whatever wait states surround it -- tools/experiments/README.md.
+    auto fin = [&](const WS &w, const typename SRow<C>::type &ev, float av) -> float {
         f2 p = {av, 0.0f};
 #pragma unroll
         for (int k = 0; k < C / 2; ++k) {
-            const f2 wk = {w[2 * k], w[2 * k + 1]};
+            const f2 wk = {wch(w, 2 * k), wch(w, 2 * k + 1)};
             const f2 ek = {ev[2 * k], ev[2 * k + 1]};
             p = __builtin_elementwise_fma(wk, ek, p);
         }
         return p.x + p.y;
     };
-    auto half = [&](const float (&w)[C], ra_f32x32 &acc, unsigned m, unsigned off, int lane0) {
-        while (m & (m - 1u)) {
+    // the hits of one half of the tile (32 egos, bits of `m`) against the accumulator vector of that half
+    auto half = [&](const WS &w, ra_f32x32 &acc, unsigned m, unsigned off, int lane0) {
+        while (m & (m - 1u)) {                                                      // two hits: both rows in flight before the wait
             const int b0 = __builtin_ctz(m); m &= m - 1u;
             const int b1 = __builtin_ctz(m); m &= m - 1u;
             typename SRow<C>::type e0, e1;
@@ -732,11 +789,12 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
             acc[b0] = fin(w, e0, a0);
         }
     };
-    auto process = [&](float (&w)[C], int c) {
-        const int wv = (int)wl[c * WLS + lane];                                     // lane <-> ego of the tile
+    auto process = [&](WS &w, int c) {
+        const int kq = keyT[c * KS + lane];                                         // lane <-> ego of the tile
+        const int wv = (kq >= 0 && (kq & 1)) ? (kq >> 1) : -1;
         const unsigned long long mask = __ballot(wv >= 0);
         wait_w(w);
-        if constexpr (ABL & 2) { if (mask == 1234567ull) accA[0] += w[0] + w[C - 1]; return; }
+        if constexpr (ABL & 2) { if (mask == 1234567ull) accA[0] += wch(w, 0) + wch(w, C - 1); return; }
         const unsigned off = __umul24((unsigned)(rb + wv), (unsigned)(a.ldv * 4));
         half(w, accA, (unsigned)mask, off, 0);
         half(w, accB, (unsigned)(mask >> 32), off, 32);
@@ -752,7 +810,7 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
     auto pop = [&]() -> int { if (!occ) return -1; const int k = pop_bit(occ); return cell_of(k); };
     // Two weight sets: the next occupied cell's weights are in flight while the current cell's hits are processed; every
     // load_w is unconditional (past the last occupied cell it re-reads the last one) so that vmcnt(C) is exact.
-    float wA[C], wB[C];
+    WS wA, wB;
     int ca = pop();
     if constexpr (ABL & 16) ca = -1;
     if (ca >= 0) {
@@ -770,6 +828,7 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
         if constexpr (!(ABL & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
+    RA_T(4);
     // ---- the 8 cell groups' partial sums, 32 egos per round: every wave leaves its partials in LDS, then wave w sums the
     //      copies of egos w and w + 16 of the round in fixed order (group 0 + 1 + ... + 7), bias + activation, coalesced rows
     const int col2 = 2 * lane;                                                      // this lane's column pair in the epilogue
@@ -798,8 +857,9 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
             if (row < a.M && ob * OB + col2 + 1 < a.N1) *reinterpret_cast<float2 *>(a.out + (size_t)row * a.ldo + ob * OB + col2) = v;
         }
     }
+    RA_T(5);
+#undef RA_T
 }
-
 
 bool regacc_supported(int C, int ncell) { return (C == 4 || C == 8 || C == 16) && ncell <= 64 * RA_NQ && ra_smem_bytes(ncell) <= (size_t)160 * 1024; }
 
@@ -828,7 +888,7 @@ bool sparse_fuses_grid(int ncell, int n_max) { return ncell <= TL_MAXCELL_LDS &&
 
 int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, const int32_t *row_base,
                              const float *Wp, const float *bias, int M, int ncell, int C, int N1, int relu,
-                             float *out, int ldo, float *partial, hipStream_t s, const SparseGridFuse *fg) {
+                             float *out, int ldo, float *partial, hipStream_t s, const SparseGridFuse *fg, const float *Wq) {
     if (M <= 0) return 0;
     if (!sparse_supported(C, N1, ncell)) TNP_FAIL(-1, "sparse pooling embedding: unsupported C=%d N1=%d", C, N1);
     SparseArgs a;
@@ -845,10 +905,15 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
         }
         const size_t rsmem = ra_smem_bytes(ncell);
         const int rblocks = a.ego_tiles * a.out_blocks;
-#define RA_LAUNCH(CC, FGB) { static bool set = false; if (!set) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
-        pool_embed_regacc_kernel<CC, FGB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        hipLaunchKernelGGL((pool_embed_regacc_kernel<CC, FGB>), dim3(rblocks), dim3(64 * RA_NQ * RA_NCS), rsmem, s, a); }
-#define RA_SWITCH(CC) { if (fg) RA_LAUNCH(CC, true) else RA_LAUNCH(CC, false) }
+        const bool quad = Wq != nullptr && fg != nullptr && N1 % 64 == 0 && C % 4 == 0;
+        if (quad) a.Wp = Wq;
+#define RA_LAUNCH(CC, FGB, QB) { static bool set = false; if (!set) { hipFuncAttributes fa; \
+        TNP_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(pool_embed_regacc_kernel<CC, FGB, QB>))); \
+        if (fa.localSizeBytes != 0) TNP_FAIL(-3, "pool_embed_regacc_kernel: accumulators left the register file (%zu bytes of scratch)", (size_t)fa.localSizeBytes); \
+        TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
+        pool_embed_regacc_kernel<CC, FGB, QB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        hipLaunchKernelGGL((pool_embed_regacc_kernel<CC, FGB, QB>), dim3(rblocks), dim3(64 * RA_NQ * RA_NCS), rsmem, s, a); }
+#define RA_SWITCH(CC) { if (quad) RA_LAUNCH(CC, true, true) else if (fg) RA_LAUNCH(CC, true, false) else RA_LAUNCH(CC, false, false) }
         if (C == 4) RA_SWITCH(4) else if (C == 8) RA_SWITCH(8) else RA_SWITCH(16)
         TNP_HIP(hipGetLastError());
         return 0;

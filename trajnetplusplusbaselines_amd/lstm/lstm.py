@@ -63,9 +63,10 @@ class LSTM(torch.nn.Module):
         self._ws = None
         self._grad_reduce_fn = None   # data-parallel training: parallel.GradReducer, see lstm/train_step.py
         self._cell_major = None  # (key, tensor): cell-major copy of pool.embedding[0].weight
+        self._quad_major = None  # (key, tensor): its quad-major copy (register-accumulator sparse kernel)
 
     # device-side caches (workspace, re-laid-out weight copies): rebuilt lazily, never pickled / deep-copied
-    _CACHES = ('_ws', '_cell_major', '_dummy_head', '_grad_reduce_fn')
+    _CACHES = ('_ws', '_cell_major', '_quad_major', '_dummy_head', '_grad_reduce_fn')
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -166,6 +167,8 @@ class LSTM(torch.nn.Module):
                 if self.sparse_embedding and float(pool.constant) == 0.0 and pool.pooling_dim in (4, 8, 16, 32) \
                         and layers[0].weight.shape[0] % 4 == 0:
                     m.Wp0_cell_major = P(self._cell_major_weight(layers[0].weight, pool))
+                    if layers[0].weight.shape[0] % 64 == 0 and pool.pooling_dim % 4 == 0:
+                        m.Wp0_quad_major = P(self._quad_major_weight(layers[0].weight, pool))
         m.variant = int(self.kernel_variant)
         if pool is not None and not self.pool_to_input:
             m.variant |= 1 << 17   # interaction vector added to the hidden state (lstm/lstm.py:150-151)
@@ -180,6 +183,16 @@ class LSTM(torch.nn.Module):
             w = weight.detach().float().view(n1, pool.pooling_dim, pool.n * pool.n).permute(2, 1, 0).contiguous()
             self._cell_major = (key, w)
         return self._cell_major[1]
+
+    def _quad_major_weight(self, weight, pool):
+        """W''[c][o/64][ch/4][o%64][ch%4] = W[o][ch*n*n + c]: the layout the register-accumulator sparse kernel streams
+        (a wave's C x 64 weights of a cell are one contiguous block: one scalar base per cell, 16-byte loads per lane)."""
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device))
+        if getattr(self, '_quad_major', None) is None or self._quad_major[0] != key:
+            n1, C = weight.shape[0], pool.pooling_dim
+            w = weight.detach().float().view(n1 // 64, 64, C // 4, 4, pool.n * pool.n).permute(4, 0, 2, 1, 3).contiguous()
+            self._quad_major = (key, w)
+        return self._quad_major[1]
 
     def _workspace(self, m, M, B, dev):
         need = _lib.lib().tnp_lstm_workspace_bytes(ctypes.byref(m), M, B)
