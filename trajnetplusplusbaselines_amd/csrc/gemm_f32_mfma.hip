@@ -96,13 +96,42 @@ __device__ __forceinline__ void lstm_cell_store(const GemmArgs &g, int row, int 
     }
 }
 
+// same, with c_in / mask of the (row, unit) fetched by the caller before its main loop
+__device__ __forceinline__ void lstm_cell_store_pf(const GemmArgs &g, int row, int unit, float pi, float pf, float pg,
+                                                   float po, float c_prev, int present) {
+    if (row >= g.M) return;
+    const size_t o = (size_t)row * g.H + unit;
+    if (present) {
+        const float ig = sigmoidf_acc(pi);
+        const float fg = sigmoidf_acc(pf);
+        const float gg = tanhf(pg);
+        const float og = sigmoidf_acc(po);
+        const float cn = fg * c_prev + ig * gg;
+        g.c_out[o] = cn;
+        g.h_out[o] = og * tanhf(cn);
+        if (g.gates_out) {
+            float *go = g.gates_out + (size_t)row * 4 * g.H + unit;
+            go[0] = ig; go[g.H] = fg; go[2 * g.H] = gg; go[3 * g.H] = og;
+        }
+    } else {
+        g.c_out[o] = c_prev;
+        g.h_out[o] = g.h_in[o];
+    }
+}
+
 // Split-K reduction fused with the LSTM epilogue, spread over ALL WK k-group waves: wave kg owns accumulator
 // registers [kg*16/WK, (kg+1)*16/WK) of the 32x32 block (x 4 gates), receives the other waves' partials for those
 // through LDS, and runs the transcendental epilogue for its rows only.  Partials are added in k-group order, so the
 // result is bit-identical to the single-wave reduction it replaces.  LDS: (WK-1)*WMN*4*16*64 floats.
+struct LstmPrefetch {           // epilogue operands of one wave, fetched before the main loop (gemm_nt_pipe)
+    float bias[4];              // bias_ih + bias_hh of the lane's unit, per gate
+    float c[16];                // c_in of the wave's (row, unit) entries, r = kg * RN + rr
+    int present[16];
+};
+
 template <int WK, int WMN>
 __device__ __forceinline__ void lstm_reduce_epilogue(const GemmArgs &g, f32x16 (&acc)[4], float *red, int kg, int wq,
-                                                     int lane, int rbase, int tn) {
+                                                     int lane, int rbase, int tn, const LstmPrefetch *pf = nullptr) {
     constexpr int RN = 16 / WK;
 #pragma unroll
     for (int o = 0; o < WK; ++o) {
@@ -120,7 +149,7 @@ __device__ __forceinline__ void lstm_reduce_epilogue(const GemmArgs &g, f32x16 (
     if (unit >= H) return;
     float bias[4];
 #pragma unroll
-    for (int an = 0; an < 4; ++an) bias[an] = g.bias1[an * H + unit] + g.bias2[an * H + unit];
+    for (int an = 0; an < 4; ++an) bias[an] = pf ? pf->bias[an] : g.bias1[an * H + unit] + g.bias2[an * H + unit];
 #pragma unroll
     for (int o = 0; o < WK; ++o) {
         if (o != kg) continue;
@@ -139,22 +168,24 @@ __device__ __forceinline__ void lstm_reduce_epilogue(const GemmArgs &g, f32x16 (
                 pre[an] = s + bias[an];
             }
             const int r = o * RN + rr;
-            lstm_cell_store(g, rbase + (r & 3) + 8 * (r >> 2), unit, pre[0], pre[1], pre[2], pre[3]);
+            if (pf) lstm_cell_store_pf(g, rbase + (r & 3) + 8 * (r >> 2), unit, pre[0], pre[1], pre[2], pre[3], pf->c[rr], pf->present[rr]);
+            else lstm_cell_store(g, rbase + (r & 3) + 8 * (r >> 2), unit, pre[0], pre[1], pre[2], pre[3]);
         }
     }
 }
 
 template <int AN, int EPI>
 __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[AN], int rbase, int n0, int wn, int tn,
-                                         int lane) {
+                                         int lane, const float *pbias = nullptr) {
     // ---- epilogue: accumulator (lane, reg r) <-> row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31 ----
     if (EPI == EPI_BIAS) {
 #pragma unroll
         for (int an = 0; an < AN; ++an) {
             const int col = n0 + (wn * AN + an) * 32 + (lane & 31);
             if (col >= g.N) continue;
-            float b = g.bias1 ? g.bias1[col] : 0.0f;
-            if (g.bias2) b += g.bias2[col];
+            float b;
+            if (pbias) b = pbias[an];
+            else { b = g.bias1 ? g.bias1[col] : 0.0f; if (g.bias2) b += g.bias2[col]; }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
@@ -502,9 +533,20 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_fast(const GemmArgs
 //     second half: MFMAs of tile t   | global loads of tile t+2 -> registers | first fragments of tile t+1
 // so there is no barrier at the step boundary, fragments are always one k8 step ahead of the MFMAs that use
 // them, and a wave that waits at the barrier still has its last MFMA in the pipe while its SIMD partner issues.
+// SCHED = 1 (what launch_pipe instantiates): the global loads of tile t+2 move into the first half as well, and
+// sched_group_barrier interleaves one MFMA with at most one LDS write / LDS read / global load, so the memory
+// instructions issue in the shadow of the matrix pipe instead of in a clump in front of it.  The epilogue's operands
+// (bias; previous cell state and presence mask of the LSTM epilogue) are fetched before the main loop: all workgroups
+// run in lockstep, so a load issued after it exposes its whole latency.  What is left (gemm_probe ablations, second
+// embedding layer 14.6 us): matrix pipe 7.6 us, launch / kernarg / first tile ~2.7 us, LDS writes of the staging
+// registers ~2 us (direct-to-LDS loads with a swizzled layout would remove them), global loads 1.4 us, barrier 0.9 us.
 // ---------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int WK, int AN, int BK, int EPI, bool DUAL>
+// Template switches beyond the tile shape are for tools/experiments/gemm_probe.hip: DBG shader-clock stamps per wave (buffer
+// passed as g.gates_out, g.C for the LSTM epilogue), ACC2 two accumulator chains per tile, GABL timing ablations.
+template <int WM, int WN, int WK, int AN, int BK, int EPI, bool DUAL, int DBG = 0, bool ACC2 = false, int SCHED = 0, int GABL = 0>
 __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_pipe(const GemmArgs g) {
+#define GP_T(k) do { if constexpr (DBG) { if ((threadIdx.x & 63) == 0) reinterpret_cast<long long *>(EPI == EPI_LSTM ? (float *)g.C : g.gates_out)[(blockIdx.x * (WM * WN * WK) + (threadIdx.x >> 6)) * 8 + (k)] = (long long)__builtin_readcyclecounter(); } } while (0)
+    GP_T(0);
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * WN * AN;
     constexpr int NT = 64 * WM * WN * WK;
@@ -586,10 +628,11 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_pipe(const GemmArgs
     };
 
     f32x16 acc[AN];
+    f32x16 accb[ACC2 ? AN : 1];     // ACC2 (probe): odd k-pairs accumulate separately -- two independent MFMA chains per tile
 #pragma unroll
     for (int an = 0; an < AN; ++an)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[an][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) { acc[an][r] = 0.0f; if (ACC2) accb[an][r] = 0.0f; }
 
     const int a_off = kg * GROUP_FLOATS + (wm * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
     const int b_off = kg * GROUP_FLOATS + BM * LDS_STRIDE + (wn * AN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
@@ -607,9 +650,34 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_pipe(const GemmArgs
 
     // prologue: tile 0 in LDS buffer 0, tile 1 in registers, first fragments of tile 0 in flight
     load_stage(0);
+    // epilogue operands (bias, previous cell state, presence mask) are fetched now: every workgroup runs in lockstep, so a
+    // load issued after the main loop would expose its full latency on the whole chip
+    LstmPrefetch lpf;
+    float ebias[AN];
+    if constexpr (EPI == EPI_LSTM && WK > 1) {
+        constexpr int RN = 16 / WK;
+        const int unit = tn * 32 + (lane & 31), uc = unit < g.H ? unit : g.H - 1;
+#pragma unroll
+        for (int an = 0; an < 4; ++an) lpf.bias[an] = g.bias1[an * g.H + uc] + g.bias2[an * g.H + uc];
+#pragma unroll
+        for (int rr = 0; rr < RN; ++rr) {
+            const int r = kg * RN + rr;
+            const int row = min(m0 + wm * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2), g.M - 1);
+            lpf.c[rr] = g.c_in[(size_t)row * g.H + uc];
+            lpf.present[rr] = g.mask[row];
+        }
+    } else if constexpr (EPI == EPI_BIAS) {
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+            const int col = min(n0 + (wn * AN + an) * 32 + (lane & 31), g.N - 1);
+            ebias[an] = (g.bias1 ? g.bias1[col] : 0.0f) + (g.bias2 ? g.bias2[col] : 0.0f);
+        }
+    }
+    GP_T(1);
     store_stage(0);
     if (KT > 1) load_stage(1);
     __syncthreads();
+    GP_T(2);
     f32x4 a4[2];
     f32x4 b4[2][AN];
     read_frags(0, 0, a4[0], b4[0]);
@@ -621,16 +689,40 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_pipe(const GemmArgs
 #pragma unroll
         for (int k8 = 0; k8 < NK8; ++k8) {
             // fragments one k8 step ahead (the first ones of the next tile once its buffer is published)
+            if constexpr (!(GABL & 8)) {
             if (k8 + 1 < NK8) read_frags(buf_cur, k8 + 1, a4[(k8 + 1) & 1], b4[(k8 + 1) & 1]);
             else if (has_next) read_frags(buf_nxt, 0, a4[(k8 + 1) & 1], b4[(k8 + 1) & 1]);
-            if (k8 == WRITE_AT && has_next) store_stage(buf_nxt);
-            __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (!(GABL & 2)) if (k8 == WRITE_AT && has_next) store_stage(buf_nxt);
+            if constexpr (SCHED) {
+                // the global loads of tile t+2 are issued in the same k8 step as the LDS writes of tile t+1 (the stage
+                // registers are free as soon as those writes have issued) and everything is interleaved with the MFMAs
+                if constexpr (!(GABL & 1)) if (k8 == WRITE_AT && kt + 2 < KT) load_stage(kt + 2);
+            } else {
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int an = 0; an < AN; ++an)
-                    acc[an] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[k8 & 1][q], b4[k8 & 1][an][q], acc[an], 0, 0, 0);
-            if (k8 == WRITE_AT) {
+                for (int an = 0; an < AN; ++an) {
+                    if (ACC2 && (q & 1)) accb[an] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[k8 & 1][q], b4[k8 & 1][an][q], accb[an], 0, 0, 0);
+                    else acc[an] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[k8 & 1][q], b4[k8 & 1][an][q], acc[an], 0, 0, 0);
+                }
+            if constexpr (SCHED) {
+                // one MFMA, then at most one LDS write, one LDS read and one global load, repeated
+#pragma unroll
+                for (int i = 0; i < 4 * AN; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, (CH + 4 * AN - 1) / (4 * AN), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, (1 + AN + 4 * AN - 1) / (4 * AN), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, (CH + 4 * AN - 1) / (4 * AN), 0);
+                }
+                if (k8 == WRITE_AT && !(GABL & 4)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (k8 == WRITE_AT) {
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
                 if (kt + 2 < KT) load_stage(kt + 2);
@@ -639,10 +731,18 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_pipe(const GemmArgs
         }
         buf_cur = buf_nxt;
     }
+    if constexpr (ACC2) {
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[an][r] += accb[an][r];
+    }
+    GP_T(3);
 
     if constexpr (WK > 1 && EPI == EPI_LSTM) {
         __syncthreads();  // everybody is done with the tile ring before it is reused for the reduction
-        lstm_reduce_epilogue<WK, WMN>(g, acc, smem, kg, wq, lane, m0 + wm * 32 + 4 * (lane >> 5), tn);
+        lstm_reduce_epilogue<WK, WMN>(g, acc, smem, kg, wq, lane, m0 + wm * 32 + 4 * (lane >> 5), tn, &lpf);
+        GP_T(5);
         return;
     } else if (WK > 1) {
         __syncthreads();  // everybody is done with the tile ring before it is reused for the reduction
@@ -664,8 +764,11 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_pipe(const GemmArgs
                         acc[an][r] += red[(((gk - 1) * WMN + wq) * AN * 16 + an * 16 + r) * 64 + lane];
         }
     }
+    GP_T(4);
     if (kg != 0) return;
-    epilogue<AN, EPI>(g, acc, m0 + wm * 32 + 4 * (lane >> 5), n0, wn, tn, lane);
+    epilogue<AN, EPI>(g, acc, m0 + wm * 32 + 4 * (lane >> 5), n0, wn, tn, lane, EPI == EPI_BIAS ? ebias : nullptr);
+    GP_T(5);
+#undef GP_T
 }
 
 template <typename KernT>
@@ -729,10 +832,13 @@ static int launch_pipe(GemmArgs g, hipStream_t s) {
     constexpr size_t smem = (size_t)3 * WK * (BM + BN) * (BK + 4) * sizeof(float);
     static_assert(smem <= 163840, "LDS ring does not fit");
     static bool attr_1 = false, attr_2 = false;
-    if (g.K2 > 0) return launch_kernel(gemm_nt_pipe<WM, WN, WK, AN, BK, EPI, true>, g, BM, BN, NT, smem,
+    // interleaved schedule (SCHED = 1) + static priority for the second half of the waves: 16.1 -> 14.6 us on the second
+    // embedding layer, 18.2 -> 17.8 us on the gates (tools/experiments/gemm_probe.hip); results are bit-identical
+    g.prio = 1;
+    if (g.K2 > 0) return launch_kernel(gemm_nt_pipe<WM, WN, WK, AN, BK, EPI, true, 0, false, 1>, g, BM, BN, NT, smem,
                                        EPI == EPI_LSTM, s, attr_2);
-    return launch_kernel(gemm_nt_pipe<WM, WN, WK, AN, BK, EPI, false>, g, BM, BN, NT, smem, EPI == EPI_LSTM, s,
-                         attr_1);
+    return launch_kernel(gemm_nt_pipe<WM, WN, WK, AN, BK, EPI, false, 0, false, 1>, g, BM, BN, NT, smem,
+                         EPI == EPI_LSTM, s, attr_1);
 }
 
 #define TNP_TRY_FAST(WM, WN, WK, AN, BK, EPI) \
