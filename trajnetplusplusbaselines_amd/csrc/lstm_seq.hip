@@ -88,8 +88,8 @@ __global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
     const int H = a.H;
     const int nout = (a.have_prev ? 5 : 0) + (a.have_next ? a.C : 0);  // rows of the stacked weight
     float *hs = psm;                        // [8][H]
-    float *ws = hs + PREP_TRACKS * H;       // [nout][H+1]
-    float *outs = ws + nout * (H + 1);      // [8][nout]
+    float *ws = hs + PREP_TRACKS * H;       // [nout][H+4]: rows 16-byte aligned, lanes (= outputs) 4 banks apart
+    float *outs = ws + nout * (H + 4);      // [8][nout]
     float *ob = outs + PREP_TRACKS * (nout > 0 ? nout : 1);  // [8][8]: obs1.xy obs2.xy mask goal.xy
     const int tid = threadIdx.x;
     const int t_local = tid >> 5, l32 = tid & 31;
@@ -113,33 +113,81 @@ __global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
             if (a.pos1) { pf_p1x = a.pos1[2 * m]; pf_p1y = a.pos1[2 * m + 1]; }
         }
     }
-    if (nout > 0) {
-        for (int q = tid; q < PREP_TRACKS * H; q += 256) {
-            const int t = q / H, k = q - t * H;
-            hs[q] = (m0 + t < a.M) ? a.h[(size_t)(m0 + t) * H + k] : 0.0f;
+    float pf_b0 = 0.0f;                                        // bias of this lane's first output row (phase 1)
+    if (l32 < nout) pf_b0 = (a.have_prev && l32 < 5) ? a.bn[l32] : a.bh[l32 - (a.have_prev ? 5 : 0)];
+    // InputEmbedding / goal embedding weights of this lane's outputs (phase 3) are fetched now as well
+    constexpr int EPF = 2;                                     // outputs per lane held in registers (E, goal_dim <= 64)
+    float pf_we[EPF][3], pf_wg[EPF][3];
+    const bool epf = a.have_next && a.E <= 32 * EPF && (!a.goal_flag || a.goal_dim <= 32 * EPF);
+    if (epf) {
+#pragma unroll
+        for (int i = 0; i < EPF; ++i) {
+            const int o = l32 + 32 * i;
+            pf_we[i][0] = pf_we[i][1] = pf_we[i][2] = 0.0f;
+            pf_wg[i][0] = pf_wg[i][1] = pf_wg[i][2] = 0.0f;
+            if (o < a.E - 2) { pf_we[i][0] = a.We[2 * o]; pf_we[i][1] = a.We[2 * o + 1]; pf_we[i][2] = a.be[o]; }
+            if (a.goal_flag && o < a.goal_dim - 2) { pf_wg[i][0] = a.Wg[2 * o]; pf_wg[i][1] = a.Wg[2 * o + 1]; pf_wg[i][2] = a.bg[o]; }
         }
-        for (int q = tid; q < nout * H; q += 256) {
-            const int o = q / H, k = q - o * H;
-            float w;
-            if (a.have_prev && o < 5) w = a.Wn[o * H + k];
-            else w = a.Wh[(o - (a.have_prev ? 5 : 0)) * H + k];
-            ws[o * (H + 1) + k] = w;
+    }
+    if (nout > 0) {
+        // all global loads of the staging first, then the LDS stores: a load -> store loop with a runtime trip count exposes
+        // one global round trip per iteration (this was 10 of the kernel's 20 k cycles)
+        const int H4 = H >> 2;                                 // H % 4 == 0
+        constexpr int HB = 2, WB = 6;                          // float4 per thread per batch
+        for (int q0 = 0; q0 < PREP_TRACKS * H4; q0 += 256 * HB) {
+            float4 v[HB];
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                const int q = q0 + tid + 256 * i;
+                const int t = q / H4, k4 = q - t * H4;
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q < PREP_TRACKS * H4 && m0 + t < a.M) v[i] = reinterpret_cast<const float4 *>(a.h + (size_t)(m0 + t) * H)[k4];
+            }
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                const int q = q0 + tid + 256 * i;
+                if (q < PREP_TRACKS * H4) reinterpret_cast<float4 *>(hs)[q] = v[i];
+            }
+        }
+        for (int q0 = 0; q0 < nout * H4; q0 += 256 * WB) {
+            float4 v[WB];
+#pragma unroll
+            for (int i = 0; i < WB; ++i) {
+                const int q = q0 + tid + 256 * i;
+                const int o = q / H4, k4 = q - o * H4;
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q < nout * H4) {
+                    const float *row = (a.have_prev && o < 5) ? a.Wn + (size_t)o * H : a.Wh + (size_t)(o - (a.have_prev ? 5 : 0)) * H;
+                    v[i] = reinterpret_cast<const float4 *>(row)[k4];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < WB; ++i) {
+                const int q = q0 + tid + 256 * i;
+                const int o = q / H4, k4 = q - o * H4;
+                if (q < nout * H4) {
+                    *reinterpret_cast<float4 *>(ws + o * (H + 4) + 4 * k4) = v[i];
+                }
+            }
         }
     }
     __syncthreads();
     for (int o = l32; o < nout; o += 32) {
         const float *hr = hs + t_local * H;
-        const float *wr = ws + o * (H + 1);
+        const float *wr = ws + o * (H + 4);
         float acc;
-        if (a.have_prev && o < 5) acc = a.bn[o];
+        if (o == l32) acc = pf_b0;
+        else if (a.have_prev && o < 5) acc = a.bn[o];
         else acc = a.bh[o - (a.have_prev ? 5 : 0)];
         // four interleaved partial sums (H % 4 == 0): breaks the 128-long dependent FMA chain
         float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll 4
         for (int k = 0; k < H; k += 4) {
-            acc = fmaf(hr[k], wr[k], acc);
-            s1 = fmaf(hr[k + 1], wr[k + 1], s1);
-            s2 = fmaf(hr[k + 2], wr[k + 2], s2);
-            s3 = fmaf(hr[k + 3], wr[k + 3], s3);
+            const float4 hv = *reinterpret_cast<const float4 *>(hr + k), wv = *reinterpret_cast<const float4 *>(wr + k);
+            acc = fmaf(hv.x, wv.x, acc);
+            s1 = fmaf(hv.y, wv.y, s1);
+            s2 = fmaf(hv.z, wv.z, s2);
+            s3 = fmaf(hv.w, wv.w, s3);
         }
         outs[t_local * nout + o] = (acc + s1) + (s2 + s3);
     }
@@ -198,6 +246,30 @@ __global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
         const float *b = ob + t_local * 8;
         const float vx = (b[2] - b[0]) * 4.0f, vy = (b[3] - b[1]) * 4.0f;  // lstm.py:127
         float *xr = a.X + (size_t)m * a.I;
+        if (epf) {
+#pragma unroll
+            for (int i = 0; i < EPF; ++i) {
+                const int o = l32 + 32 * i;
+                if (o < a.E) {
+                    float v = 0.0f;
+                    if (o < a.E - 2) {
+                        v = fmaf(vy, pf_we[i][1], fmaf(vx, pf_we[i][0], pf_we[i][2]));
+                        v = v > 0.0f ? v : 0.0f;
+                    }
+                    xr[o] = v;
+                }
+                if (a.goal_flag && o < a.goal_dim) {
+                    const float gx = b[4] * 4.0f, gy = b[5] * 4.0f;
+                    float v = 0.0f;
+                    if (o < a.goal_dim - 2) {
+                        v = fmaf(gy, pf_wg[i][1], fmaf(gx, pf_wg[i][0], pf_wg[i][2]));
+                        v = v > 0.0f ? v : 0.0f;
+                    }
+                    xr[a.E + o] = v;
+                }
+            }
+            return;
+        }
         for (int o = l32; o < a.E; o += 32) {
             float v = 0.0f;
             if (o < a.E - 2) {
@@ -222,7 +294,7 @@ __global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
 
 static int launch_prepare(const PrepArgs &a, hipStream_t s) {
     const int nout = (a.have_prev ? 5 : 0) + (a.have_next ? a.C : 0);
-    size_t smem = ((size_t)PREP_TRACKS * a.H + (size_t)nout * (a.H + 1) + (size_t)PREP_TRACKS * (nout > 0 ? nout : 1) +
+    size_t smem = ((size_t)PREP_TRACKS * a.H + (size_t)nout * (a.H + 4) + (size_t)PREP_TRACKS * (nout > 0 ? nout : 1) +
                    PREP_TRACKS * 8) * sizeof(float);
     if (smem > 60000) TNP_FAIL(-1, "track_prepare: hidden_dim %d too large for the LDS staging", a.H);
     const int blocks = (a.M + PREP_TRACKS - 1) / PREP_TRACKS;
