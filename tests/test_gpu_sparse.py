@@ -84,11 +84,14 @@ def test_sparse_ragged_scenes():
         np.testing.assert_allclose(got[starts[s]:starts[s + 1]], want, atol=3e-5)
 
 
-def test_forward_sparse_equals_dense_path():
-    """Whole Social-LSTM forward: the sparse first layer and the dense MFMA first layer agree to fp32 rounding."""
+@pytest.mark.parametrize('n1,latent', [(1024, 16), (192, 8), (64, 4), (100, 16)])
+def test_forward_sparse_equals_dense_path(n1, latent):
+    """Whole Social-LSTM forward: the sparse first layer and the dense MFMA first layer agree to fp32 rounding.  The
+    sequence driver hands the register-accumulator kernel the quad-major weight copy when N1 % 64 == 0 (192: the last
+    column block is half empty; C = 8 / 4: shorter weight sets), else the cell-major one (100)."""
     torch.manual_seed(3)
     pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=16, out_dim=256,
-                            embedding_arch='two_layer', layer_dims=[1024], latent_dim=16)
+                            embedding_arch='two_layer', layer_dims=[n1], latent_dim=latent)
     model = LSTM(pool=pool).eval().cuda()
     xy, split = synth.ragged_crowd(24, 3, 40, seed=4)
     goals = torch.zeros(xy.shape[1], 2)

@@ -718,7 +718,8 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
         } else if constexpr (QUAD) {
             // one scalar base per cell (the column block's C x 64 weights are contiguous), channel quad = immediate offset:
             // 3 scalar instructions per cell instead of 2 per channel -- the scalar pipe is what bounds this loop
-            const float *wb = a.Wp + ((size_t)c * (a.N1 >> 6) + (size_t)(ob * NCS + cs)) * (C * 64);
+            const int cb = min(ob * NCS + cs, (a.N1 >> 6) - 1);        // a column set past N1 (N1 % 128 == 64) re-reads the last block
+            const float *wb = a.Wp + ((size_t)c * (a.N1 >> 6) + (size_t)cb) * (C * 64);
             const unsigned vl = lane * 16u;
 #pragma unroll
             for (int kq = 0; kq < C / 4; ++kq)
