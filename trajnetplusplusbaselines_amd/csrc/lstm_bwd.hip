@@ -74,13 +74,38 @@ __global__ void __launch_bounds__(64) h2n_cell_backward_kernel(const float *__re
                                                           float *__restrict__ dc_prev, float *__restrict__ dh_pass) {
     const int m = blockIdx.x, lane = threadIdx.x;
     if (m >= M) return;
+    // Every operand is fetched before anything is used (one global round trip for the whole kernel instead of one per
+    // phase: presence test -> Hidden2Normal dot products -> loss gradients -> cell derivatives); lanes own elements
+    // k = lane, lane + 64 (H <= 128 runs entirely from these registers, larger H falls back to loops for the rest).
+    constexpr int KP = 2;
     const float a = obs1[2 * m], b = obs2[2 * m];
+    float pbn[5], pdn[5], ppx = 0.0f, ppy = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { pbn[q] = bn[q]; pdn[q] = d_normal ? d_normal[(size_t)m * 5 + q] : 0.0f; }
+    if (d_pos) { ppx = d_pos[2 * m]; ppy = d_pos[2 * m + 1]; }
+    float ph[KP], pw[KP][5], pdh[KP], pdc[KP], pg[KP][4], pcp[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        const int k = lane + 64 * i, kc = k < H ? k : H - 1;
+        const size_t q = (size_t)m * H + kc;
+        ph[i] = h_out[q]; pdh[i] = dh_in[q]; pdc[i] = dc[q]; pcp[i] = c_prev[q];
+#pragma unroll
+        for (int w = 0; w < 5; ++w) pw[i][w] = Wn[w * H + kc];
+        const float *gs = gates + (size_t)m * 4 * H + kc;
+        pg[i][0] = gs[0]; pg[i][1] = gs[H]; pg[i][2] = gs[2 * H]; pg[i][3] = gs[3 * H];
+    }
     const bool present = (a == a) && (b == b);                       // lstm/lstm.py:118
     float dl[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (present) {
         // Linear output of Hidden2Normal (needed for the sigmoid derivatives): 5 dot products over H
         float lin[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        for (int k = lane; k < H; k += 64) {
+#pragma unroll
+        for (int i = 0; i < KP; ++i)
+            if (lane + 64 * i < H) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) lin[q] = fmaf(ph[i], pw[i][q], lin[q]);
+            }
+        for (int k = lane + 64 * KP; k < H; k += 64) {
             const float hv = h_out[(size_t)m * H + k];
 #pragma unroll
             for (int q = 0; q < 5; ++q) lin[q] = fmaf(hv, Wn[q * H + k], lin[q]);
@@ -89,19 +114,18 @@ __global__ void __launch_bounds__(64) h2n_cell_backward_kernel(const float *__re
         for (int q = 0; q < 5; ++q) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) lin[q] += __shfl_xor(lin[q], off, 64);
-            lin[q] += bn[q];
+            lin[q] += pbn[q];
         }
         float dn[5];
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            float v = d_normal ? d_normal[(size_t)m * 5 + q] : 0.0f;
+            float v = pdn[q];
             if (v != v) v = 0.0f;                                    // NaN rows of absent tracks carry no gradient
             dn[q] = v;
         }
         if (d_pos) {                                                // positions = obs2 + normal[:, :2]
-            float px = d_pos[2 * m], py = d_pos[2 * m + 1];
-            dn[0] += (px == px) ? px : 0.0f;
-            dn[1] += (py == py) ? py : 0.0f;
+            dn[0] += (ppx == ppx) ? ppx : 0.0f;
+            dn[1] += (ppy == ppy) ? ppy : 0.0f;
         }
         const float s2 = sigm(lin[2]), s3 = sigm(lin[3]), s4 = sigm(lin[4]);
         dl[0] = dn[0]; dl[1] = dn[1];
@@ -110,17 +134,10 @@ __global__ void __launch_bounds__(64) h2n_cell_backward_kernel(const float *__re
         dl[4] = dn[4] * 0.7f * s4 * (1.0f - s4);
     }
     if (lane < 5) dlin[(size_t)m * 5 + lane] = dl[lane];
-    for (int k = lane; k < H; k += 64) {
-        float acc = dh_in[(size_t)m * H + k];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) acc = fmaf(dl[q], Wn[q * H + k], acc);
+    auto cell = [&](int k, float acc, float dcv, float gi, float gf, float gg, float go, float cp) {
         const size_t q = (size_t)m * H + k;
         float *g = dG + (size_t)m * 4 * H + k;
-        const float dcv = dc[q];
         if (present) {
-            const float *gs = gates + (size_t)m * 4 * H + k;
-            const float gi = gs[0], gf = gs[H], gg = gs[2 * H], go = gs[3 * H];
-            const float cp = c_prev[q];
             const float cn = gf * cp + gi * gg;
             const float tc = tanhf(cn);
             const float d_o = acc * tc;
@@ -136,6 +153,22 @@ __global__ void __launch_bounds__(64) h2n_cell_backward_kernel(const float *__re
             dc_prev[q] = dcv;
             dh_pass[q] = acc;
         }
+    };
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        const int k = lane + 64 * i;
+        if (k >= H) continue;
+        float acc = pdh[i];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc = fmaf(dl[q], pw[i][q], acc);
+        cell(k, acc, pdc[i], pg[i][0], pg[i][1], pg[i][2], pg[i][3], pcp[i]);
+    }
+    for (int k = lane + 64 * KP; k < H; k += 64) {
+        float acc = dh_in[(size_t)m * H + k];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc = fmaf(dl[q], Wn[q * H + k], acc);
+        const float *gs = gates + (size_t)m * 4 * H + k;
+        cell(k, acc, dc[(size_t)m * H + k], gs[0], gs[H], gs[2 * H], gs[3 * H], c_prev[(size_t)m * H + k]);
     }
 }
 
@@ -549,11 +582,42 @@ __global__ void __launch_bounds__(256) state_grad_combine_kernel(const float *__
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= (long)M * H) return;
     const int m = (int)(q / H), k = (int)(q - (long)m * H);
-    float v = dxh[(size_t)m * ld + k] + pass[q];
-    if (extra) v += extra[q];
-    if (denc) {
+    // all operands in flight before the first use (the C-term loop otherwise pays a round trip per iteration)
+    const float v0 = dxh[(size_t)m * ld + k], v1 = pass[q], v2 = extra ? extra[q] : 0.0f;
+    float v = v0 + v1;
+    if (extra) v += v2;
+    if (denc && (C & 3) == 0) {
+        // 16-byte loads: a lane's whT row is C contiguous floats, scalar loads of it are 64 accesses 4 C bytes apart per
+        // instruction (this kernel was bound by exactly that)
         float acc = 0.0f;
-        for (int c = 0; c < C; ++c) acc = fmaf(denc[(size_t)m * C + c], whT[(size_t)k * C + c], acc);
+        const float4 *d4 = reinterpret_cast<const float4 *>(denc + (size_t)m * C), *w4 = reinterpret_cast<const float4 *>(whT + (size_t)k * C);
+        constexpr int QB = 4;
+        for (int c0 = 0; c0 < C / 4; c0 += QB) {
+            float4 dv[QB], wv[QB];
+#pragma unroll
+            for (int i = 0; i < QB; ++i) { const int c = c0 + i < C / 4 ? c0 + i : C / 4 - 1; dv[i] = d4[c]; wv[i] = w4[c]; }
+#pragma unroll
+            for (int i = 0; i < QB; ++i)
+                if (c0 + i < C / 4) {
+                    acc = fmaf(dv[i].x, wv[i].x, acc); acc = fmaf(dv[i].y, wv[i].y, acc);
+                    acc = fmaf(dv[i].z, wv[i].z, acc); acc = fmaf(dv[i].w, wv[i].w, acc);
+                }
+        }
+        v += acc;
+    } else if (denc) {
+        float acc = 0.0f;
+        constexpr int CB = 16;
+        for (int c0 = 0; c0 < C; c0 += CB) {
+            float dv[CB], wv[CB];
+#pragma unroll
+            for (int i = 0; i < CB; ++i) {
+                const int c = c0 + i < C ? c0 + i : C - 1;
+                dv[i] = denc[(size_t)m * C + c]; wv[i] = whT[(size_t)k * C + c];
+            }
+#pragma unroll
+            for (int i = 0; i < CB; ++i)
+                if (c0 + i < C) acc = fmaf(dv[i], wv[i], acc);
+        }
         v += acc;
     }
     out[q] = v;
