@@ -186,12 +186,21 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[AN], i
             float b;
             if (pbias) b = pbias[an];
             else { b = g.bias1 ? g.bias1[col] : 0.0f; if (g.bias2) b += g.bias2[col]; }
+            float mk[16];
+            if (g.mask_act) {                                   // all sixteen mask operands in flight before the first use
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1);
+                    mk[r] = g.mask_act[(size_t)row * g.ld_mask + col];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row < g.M) {
                     float v = acc[an][r] + b;
                     if (g.relu) v = v > 0.0f ? v : 0.0f;
+                    if (g.mask_act) v = mk[r] > 0.0f ? v : 0.0f;
                     g.C[(size_t)row * g.ldc + col] = v;
                 }
             }

@@ -901,10 +901,12 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
             // (last layer: its ReLU output is the pooled part of X, masked above)
             for (int l = nl - 1; l >= 1; --l) {
                 const int n_out = md->dims[l + 1], n_in = md->dims[l];
-                TNP_RC(tnp_linear_forward(a->dy_all[l] + r * n_out, n_out, a->layT[l], n_out, nullptr, w.d_in, n_in, M, n_in, n_out,
-                                          0, 0, stream));
-                TNP_RC(tnp_relu_mask(w.d_in, n_in, sv->act_all[l - 1] + r * n_in, n_in, M, n_in, a->dy_all[l - 1] + r * n_in, n_in,
-                                     stream));
+                // d(act_{l-1}) = (dy_l . W_l) masked by act_{l-1} > 0: the ReLU backward rides on the GEMM's epilogue
+                tnp::GemmArgs g = {};
+                g.A1 = a->dy_all[l] + r * n_out; g.lda1 = n_out; g.K1 = n_out; g.B1 = a->layT[l]; g.ldb1 = n_out;
+                g.M = M; g.N = n_in; g.C = a->dy_all[l - 1] + r * n_in; g.ldc = n_in;
+                g.mask_act = sv->act_all[l - 1] + r * n_in; g.ld_mask = n_in;
+                TNP_RC(tnp::launch_linear(g, 0, s));
             }
             const int N1 = md->dims[1];
             const float *dy0 = a->dy_all[0] + r * N1;

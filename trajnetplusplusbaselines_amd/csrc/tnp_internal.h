@@ -35,6 +35,9 @@ struct GemmArgs {
     // EPI_LSTM: N == 4*H, tile columns = 4 gates x 32 hidden units
     int H; const float *h_in; float *h_out; const float *c_in; float *c_out; const uint8_t *mask;
     float *gates_out;     // optional [M, 4H]: post-activation i, f, g, o of the present rows (training saves)
+    // EPI_BIAS, optional: C[row, col] = mask_act[row, col] > 0 ? value : 0 -- the ReLU backward of the layer below fused into
+    // the data-gradient GEMM (what a separate relu_mask launch did)
+    const float *mask_act; int ld_mask;
 };
 
 // generic dense layer (variant selects the tile configuration)
