@@ -84,14 +84,30 @@ __global__ void __launch_bounds__(256) wgrad_tn_kernel(const float *__restrict__
     }
 }
 
-// out[e] = sum over the splits of part[s][e], ascending s
+// out[e] = sum over the splits of part[s][e], ascending s.  One launch covers the weight tile and (blocks past it) the bias
+// column; eight partials are in flight before the first add (the adds stay in split order: bit-identical to a serial loop).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ part, int SK, long n, int cols, float *__restrict__ out,
-                                                           int ldo) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
-    float acc = part[e];
-    for (int s = 1; s < SK; ++s) acc += part[(size_t)s * n + e];
-    out[(e / cols) * ldo + (e % cols)] = acc;
+                                                           int ldo, const float *__restrict__ bpart, long nb, float *__restrict__ bout) {
+    const long nblk = (n + 255) / 256;
+    long e = (long)blockIdx.x * 256 + threadIdx.x;
+    long cnt = n;
+    const float *src = part;
+    bool bias = false;
+    if ((long)blockIdx.x >= nblk) { e -= nblk * 256; cnt = nb; src = bpart; bias = true; }
+    if (e >= cnt) return;
+    float acc = src[e];
+    constexpr int U = 8;
+    int s = 1;
+    for (; s + U <= SK; s += U) {
+        float v[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) v[i] = src[(size_t)(s + i) * cnt + e];
+#pragma unroll
+        for (int i = 0; i < U; ++i) acc += v[i];
+    }
+    for (; s < SK; ++s) acc += src[(size_t)s * cnt + e];
+    if (bias) bout[e] = acc;
+    else out[(e / cols) * ldo + (e % cols)] = acc;
 }
 
 static void wgrad_plan(int Mo, int No, int K, int &regions, int &SK, int &kchunk) {
@@ -129,12 +145,9 @@ extern "C" TNP_API int tnp_wgrad(const float *dy, int ld_dy, const float *x, int
                        dbias ? bpart : nullptr);
     TNP_HIP(hipGetLastError());
     const long n = (long)Mo * No;
-    hipLaunchKernelGGL(tnp::wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, SK, n, No, dw, ld_dw);
+    const unsigned rblocks = (unsigned)((n + 255) / 256) + (dbias ? (unsigned)((Mo + 255) / 256) : 0u);
+    hipLaunchKernelGGL(tnp::wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, s, part, SK, n, No, dw, ld_dw,
+                       dbias ? bpart : nullptr, (long)Mo, dbias);
     TNP_HIP(hipGetLastError());
-    if (dbias) {
-        hipLaunchKernelGGL(tnp::wgrad_reduce_kernel, dim3((unsigned)((Mo + 255) / 256)), dim3(256), 0, s, bpart, SK, (long)Mo, Mo, dbias,
-                           Mo);
-        TNP_HIP(hipGetLastError());
-    }
     return 0;
 }

@@ -495,9 +495,13 @@ __global__ void __launch_bounds__(256) sparse_wgrad_kernel(const float *__restri
     const int n = chunk * 64 + lane;
     const int cnt = count[c];
     const int2 *L = list + (size_t)c * R;
-    float acc[C];
+    // even / odd channels in the two halves of a packed register: C/2 v_pk_fma_f32 per hit; every channel still accumulates
+    // its hits in list order
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    static_assert(C % 2 == 0, "channel pairs");
+    f2 acc[C / 2];
 #pragma unroll
-    for (int ch = 0; ch < C; ++ch) acc[ch] = 0.0f;
+    for (int ch = 0; ch < C / 2; ++ch) acc[ch] = f2{0.0f, 0.0f};
     int k = wave * 4;
     for (; k + 4 <= cnt; k += 16) {
         const int2 h0 = L[k], h1 = L[k + 1], h2 = L[k + 2], h3 = L[k + 3];
@@ -505,26 +509,32 @@ __global__ void __launch_bounds__(256) sparse_wgrad_kernel(const float *__restri
         const float d2 = dy[(size_t)h2.x * ldy + n], d3 = dy[(size_t)h3.x * ldy + n];
         const float *e0 = enc + (size_t)h0.y * lde, *e1 = enc + (size_t)h1.y * lde;
         const float *e2 = enc + (size_t)h2.y * lde, *e3 = enc + (size_t)h3.y * lde;
+        const f2 dd0 = {d0, d0}, dd1 = {d1, d1}, dd2 = {d2, d2}, dd3 = {d3, d3};
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch)
-            acc[ch] = fmaf(d3, e3[ch], fmaf(d2, e2[ch], fmaf(d1, e1[ch], fmaf(d0, e0[ch], acc[ch]))));
+        for (int ch = 0; ch < C / 2; ++ch) {
+            f2 t = __builtin_elementwise_fma(dd0, f2{e0[2 * ch], e0[2 * ch + 1]}, acc[ch]);
+            t = __builtin_elementwise_fma(dd1, f2{e1[2 * ch], e1[2 * ch + 1]}, t);
+            t = __builtin_elementwise_fma(dd2, f2{e2[2 * ch], e2[2 * ch + 1]}, t);
+            acc[ch] = __builtin_elementwise_fma(dd3, f2{e3[2 * ch], e3[2 * ch + 1]}, t);
+        }
     }
     for (int kk = k; kk < cnt && kk < k + 4; ++kk) {   // ragged last batch (if it falls to this wave)
         const int2 h = L[kk];
         const float d = dy[(size_t)h.x * ldy + n];
         const float *e = enc + (size_t)h.y * lde;
+        const f2 dd = {d, d};
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) acc[ch] = fmaf(d, e[ch], acc[ch]);
+        for (int ch = 0; ch < C / 2; ++ch) acc[ch] = __builtin_elementwise_fma(dd, f2{e[2 * ch], e[2 * ch + 1]}, acc[ch]);
     }
     if (wave > 0) {
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) red[wave - 1][ch][lane] = acc[ch];
+        for (int ch = 0; ch < C; ++ch) red[wave - 1][ch][lane] = acc[ch / 2][ch & 1];
     }
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
         for (int ch = 0; ch < C; ++ch)
-            dWc[((size_t)c * C + ch) * N1 + n] = (acc[ch] + red[0][ch][lane]) + (red[1][ch][lane] + red[2][ch][lane]);
+            dWc[((size_t)c * C + ch) * N1 + n] = (acc[ch / 2][ch & 1] + red[0][ch][lane]) + (red[1][ch][lane] + red[2][ch][lane]);
     }
 }
 
@@ -564,9 +574,95 @@ static int launch_dgrid_cells(const float *dy, int ldy, const float *Wc, const i
     return 0;
 }
 
+// Matrix-core form for C <= 16: dW'[c][ch][n] = sum over the cell's hits of enc[hit][ch] * dy[hit][n] is a [16 x hits] x
+// [hits x 64] product per (cell, 64-column chunk).  v_mfma_f32_16x16x4_f32 takes four hits per instruction: lane (g = l >> 4,
+// i = l & 15) holds A[ch i][hit g] = enc[hit g][i] and B[hit g][col] from one 16-byte load of dy (columns 4 i .. 4 i + 3 of
+// the chunk feed four MFMAs).  Everything comes through the vector memory path in 64-byte (enc) / 256-byte (dy) pieces; the
+// VALU form above needs the encoding row of every hit in SGPRs, and those 4.7 M scalar loads of 2.5 MB of randomly addressed
+// rows (scalar-cache misses) are what held it at 313 us against a 68 us arithmetic floor.  Hits are taken in list order,
+// four per MFMA, batches b = wave, wave + 4, ... per wave, the four waves' tiles added in fixed order: deterministic.
+template <int C>
+__global__ void __launch_bounds__(256) sparse_wgrad_mfma_kernel(const float *__restrict__ dy, int ldy,
+                                                                const float *__restrict__ enc, int lde,
+                                                                const int2 *__restrict__ list, const int32_t *__restrict__ count,
+                                                                int R, int N1, int ncell, float *__restrict__ dWc) {
+    static_assert(C <= 16, "one 16-channel A tile");
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ float red[3][16][64];
+    int c, chunk;
+    {
+        const int nchunk = N1 >> 6, bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+        if ((nchunk & 7) == 0) { chunk = xcd + 8 * (slot / ncell); c = slot - (slot / ncell) * ncell; }
+        else { chunk = bid / ncell; c = bid - chunk * ncell; }
+    }
+    const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cnt = count[c];
+    const int2 *L = list + (size_t)c * R;
+    const float *dyc = dy + chunk * 64 + 4 * i;
+    f4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int nb = (cnt + 3) >> 2;                                  // batches of four hits
+    auto entry = [&](int b) -> int2 {                               // this lane's hit of batch b ((-1, -1) past the end)
+        const int k = 4 * b + g;
+        int2 e = {-1, -1};
+        if (b < nb && k < cnt) e = L[k];
+        return e;
+    };
+    auto fetch = [&](int2 e, float &av, f4 &bv) {
+        av = 0.0f; bv = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (e.x >= 0) {
+            if (i < C) av = enc[(size_t)e.y * lde + i];
+            bv = *reinterpret_cast<const f4 *>(dyc + (size_t)e.x * ldy);
+        }
+    };
+    // two batches in flight: list entries of batch t + 2 and operands of batch t + 1 while batch t runs on the matrix pipe
+    int b = wave;
+    int2 e0 = entry(b), e1 = entry(b + 4);
+    float a0; f4 b0;
+    fetch(e0, a0, b0);
+    for (; b < nb; b += 4) {
+        const int2 e2 = entry(b + 8);
+        float a1; f4 b1;
+        fetch(e1, a1, b1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[q], acc[q], 0, 0, 0);
+        a0 = a1; b0 = b1; e1 = e2;
+    }
+    // acc[q][r]: channel 4 g + r, column 4 i + q of the chunk
+    if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave - 1][4 * g + r][4 * i + q] = acc[q][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = 4 * g + r;
+            if (ch >= C) continue;
+            f4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                o[q] = (acc[q][r] + red[0][ch][4 * i + q]) + (red[1][ch][4 * i + q] + red[2][ch][4 * i + q]);
+            *reinterpret_cast<f4 *>(dWc + ((size_t)c * C + ch) * N1 + chunk * 64 + 4 * i) = o;
+        }
+    }
+}
+
 template <int C>
 static int launch_sparse_wgrad(const float *dy, int ldy, const float *enc, int lde, const int2 *list, const int32_t *count, int R,
                                int ncell, int N1, float *dWc, hipStream_t s) {
+    if constexpr (C <= 16) {
+        if (ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(dWc) & 15) == 0) {
+            hipLaunchKernelGGL(sparse_wgrad_mfma_kernel<C>, dim3(ncell * (N1 / 64)), dim3(256), 0, s, dy, ldy, enc, lde, list, count, R, N1,
+                               ncell, dWc);
+            TNP_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(sparse_wgrad_kernel<C>, dim3(ncell * (N1 / 64)), dim3(256), 0, s, dy, ldy, enc, lde, list, count, R, N1, ncell, dWc);
     TNP_HIP(hipGetLastError());
     return 0;
