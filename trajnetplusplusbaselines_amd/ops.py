@@ -1,0 +1,191 @@
+"""``torch.library`` registration of the C-ABI entry points ("each registered as a torch.library op taking /
+returning torch.Tensor on the current HIP stream, no host sync, errors surfaced as exceptions").
+
+The ops live in the ``trajnet`` namespace (``torch.ops.trajnet.linear`` ...).  Each has a fake (meta) implementation, so
+``torch.compile`` / ``FakeTensorMode`` can trace through them, and ``trajnet::linear`` carries its autograd formula; the
+recurrent sequence keeps its ``torch.autograd.Function`` (lstm/training.py) because its saved state is a set of per-step
+buffers owned by the module, not tensors an op schema can describe.  The implementations are the same ctypes calls the
+module classes make -- the ops add dispatcher visibility, not another code path -- and there is no CPU kernel: a host
+tensor raises, as everywhere in this package.
+
+    pool_grid_winners(obs1, obs2, scene_start, n_max, n, cell_side)                     -> int16 [M, n*n]
+    pool_grid(type, obs1, obs2, values?, scene_start, n_max, n, cell_side, constant)    -> fp32 [M, C*n*n]
+    linear(x, weight, bias?, relu)                                                      -> fp32 [M, N]        (+ autograd)
+    pool_embed_sparse(winners, values, scene_start, weight, bias?, relu)                -> fp32 [M, N1]
+    constant_velocity(last, prev, n_predict)                                            -> fp64 [n_predict, N, 2]
+    sf_rollout(state, scene_start, n_max, n_predict, v0, sigma, tau)                    -> fp64 [n_predict, M, 2]
+"""
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_POOL = {'occupancy': _lib.POOL_OCCUPANCY, 'directional': _lib.POOL_DIRECTIONAL, 'social': _lib.POOL_SOCIAL}
+
+
+def _dev(t, what):
+    _lib.require_device(t, what)
+    return t.device
+
+
+def _starts(scene_start, dev):
+    return scene_start.to(device=dev, dtype=torch.int32).contiguous()
+
+
+@torch.library.custom_op('trajnet::pool_grid_winners', mutates_args=())
+def pool_grid_winners(obs1: torch.Tensor, obs2: torch.Tensor, scene_start: torch.Tensor, n_max: int, n: int,
+                      cell_side: float) -> torch.Tensor:
+    """Winner table of the occupancy map (reference lstm/gridbased_pooling.py:227-305): for every track and cell the
+    scene-local index of the neighbour whose value the grid holds (last writer wins), -1 = empty."""
+    dev = _dev(obs2, 'obs2')
+    o1, o2 = _lib.f32c(obs1, dev).reshape(-1, 2), _lib.f32c(obs2, dev).reshape(-1, 2)
+    st = _starts(scene_start, dev)
+    M = o2.shape[0]
+    win = torch.empty(M, n * n, dtype=torch.int16, device=dev)
+    _lib.check(_lib.lib().tnp_pool_grid_forward(_lib.POOL_OCCUPANCY, _lib.ptr(o1), _lib.ptr(o2), None, 0, _lib.ptr(st),
+                                                st.numel() - 1, int(n_max), None, int(n), 1, float(cell_side), n / 2, n / 2,
+                                                0.0, None, 0, _lib.ptr(win), _lib.stream_ptr()), 'tnp_pool_grid_forward')
+    return win
+
+
+@pool_grid_winners.register_fake
+def _(obs1, obs2, scene_start, n_max, n, cell_side):
+    return obs2.new_empty((obs2.reshape(-1, 2).shape[0], n * n), dtype=torch.int16)
+
+
+@torch.library.custom_op('trajnet::pool_grid', mutates_args=())
+def pool_grid(type_: str, obs1: torch.Tensor, obs2: torch.Tensor, values: Optional[torch.Tensor],
+              scene_start: torch.Tensor, n_max: int, n: int, cell_side: float, constant: float) -> torch.Tensor:
+    """Dense grid of GridBasedPooling.occupancies / directional / social (lstm/gridbased_pooling.py:112-170):
+    [M, C*n*n] with C = 1 / 2 / values.shape[1]."""
+    dev = _dev(obs2, 'obs2')
+    o1, o2 = _lib.f32c(obs1, dev).reshape(-1, 2), _lib.f32c(obs2, dev).reshape(-1, 2)
+    st = _starts(scene_start, dev)
+    M = o2.shape[0]
+    vals = _lib.f32c(values, dev).reshape(M, -1) if values is not None else None
+    C = {'occupancy': 1, 'directional': 2}.get(type_, vals.shape[1] if vals is not None else 0)
+    if type_ not in _POOL or C <= 0:
+        raise ValueError('pool_grid: type %r (social needs `values`)' % (type_,))
+    grid = torch.empty(M, C * n * n, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().tnp_pool_grid_forward(_POOL[type_], _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(vals),
+                                                vals.stride(0) if vals is not None else 0, _lib.ptr(st), st.numel() - 1,
+                                                int(n_max), None, int(n), C, float(cell_side), n / 2, n / 2, float(constant),
+                                                _lib.ptr(grid), C * n * n, None, _lib.stream_ptr()), 'tnp_pool_grid_forward')
+    return grid
+
+
+@pool_grid.register_fake
+def _(type_, obs1, obs2, values, scene_start, n_max, n, cell_side, constant):
+    M = obs2.reshape(-1, 2).shape[0]
+    C = {'occupancy': 1, 'directional': 2}.get(type_, values.reshape(M, -1).shape[1] if values is not None else 1)
+    return obs2.new_empty((M, C * n * n), dtype=torch.float32)
+
+
+@torch.library.custom_op('trajnet::linear', mutates_args=())
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], relu: bool) -> torch.Tensor:
+    """act(x @ weight.T + bias) on the fp32 matrix cores (tnp_linear_forward): the embedding MLPs of
+    lstm/gridbased_pooling.py:308-335."""
+    _dev(x, 'x')
+    return _lib.linear_forward(x, weight, bias, relu=relu)
+
+
+@linear.register_fake
+def _(x, weight, bias, relu):
+    return x.new_empty((x.shape[0], weight.shape[0]), dtype=torch.float32)
+
+
+def _linear_setup(ctx, inputs, output):
+    x, weight, bias, relu = inputs
+    ctx.relu, ctx.has_bias = relu, bias is not None
+    ctx.save_for_backward(x, weight, output)
+
+
+def _linear_backward(ctx, grad):
+    x, weight, out = ctx.saved_tensors
+    g = grad.contiguous()
+    if ctx.relu:
+        g = torch.where(out > 0, g, torch.zeros_like(g))
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+        dx = _lib.linear_forward(g, weight.t().contiguous(), None)            # data gradient: the same GEMM kernel
+    if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        L = _lib.lib()
+        K, Mo, No = g.shape[0], g.shape[1], x.shape[1]
+        nbytes = L.tnp_wgrad_workspace_bytes(Mo, No, K)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
+        dw = torch.empty(Mo, No, device=g.device)
+        db = torch.empty(Mo, device=g.device) if ctx.has_bias else None
+        xc = _lib.f32c(x)
+        _lib.check(L.tnp_wgrad(_lib.ptr(g), g.stride(0), _lib.ptr(xc), xc.stride(0), K, Mo, No, _lib.ptr(dw), No, _lib.ptr(db),
+                               _lib.ptr(ws), nbytes, _lib.stream_ptr()), 'tnp_wgrad')
+    return dx, dw, db, None
+
+
+linear.register_autograd(_linear_backward, setup_context=_linear_setup)
+
+
+@torch.library.custom_op('trajnet::pool_embed_sparse', mutates_args=())
+def pool_embed_sparse(winners: torch.Tensor, values: torch.Tensor, scene_start: torch.Tensor, weight: torch.Tensor,
+                      bias: Optional[torch.Tensor], relu: bool) -> torch.Tensor:
+    """First Linear of the grid embedding applied to the social grid without materialising it (tnp_pool_embed_sparse_forward):
+    ``weight`` is the module's parameter [N1, C*n*n]; the cell-major copy the kernel streams is made here."""
+    dev = _dev(values, 'values')
+    M, C = values.shape
+    ncell, N1 = winners.shape[1], weight.shape[0]
+    L = _lib.lib()
+    st = _starts(scene_start, dev)
+    row_base = torch.empty(M, dtype=torch.int32, device=dev)
+    _lib.check(L.tnp_row_base(_lib.ptr(st), st.numel() - 1, _lib.ptr(row_base), _lib.stream_ptr()), 'tnp_row_base')
+    wcm = _lib.f32c(weight, dev).view(N1, C, ncell).permute(2, 1, 0).contiguous()
+    vals, bt = _lib.f32c(values, dev), (_lib.f32c(bias, dev) if bias is not None else None)
+    win = winners.to(device=dev, dtype=torch.int16).contiguous()
+    need = L.tnp_pool_embed_sparse_workspace_bytes(M, N1, ncell)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    out = torch.empty(M, N1, dtype=torch.float32, device=dev)
+    _lib.check(L.tnp_pool_embed_sparse_forward(_lib.ptr(win), _lib.ptr(vals), vals.stride(0), _lib.ptr(row_base), _lib.ptr(wcm),
+                                               _lib.ptr(bt), M, ncell, C, N1, int(relu), _lib.ptr(out), N1, _lib.ptr(ws), need,
+                                               _lib.stream_ptr()), 'tnp_pool_embed_sparse_forward')
+    return out
+
+
+@pool_embed_sparse.register_fake
+def _(winners, values, scene_start, weight, bias, relu):
+    return values.new_empty((values.shape[0], weight.shape[0]), dtype=torch.float32)
+
+
+@torch.library.custom_op('trajnet::constant_velocity', mutates_args=())
+def constant_velocity(last: torch.Tensor, prev: torch.Tensor, n_predict: int) -> torch.Tensor:
+    """classical/constant_velocity.py:4-20 on fp64 positions [N, 2] -> [n_predict, N, 2]."""
+    dev = _dev(last, 'last')
+    a, b = last.to(torch.float64).contiguous(), prev.to(device=dev, dtype=torch.float64).contiguous()
+    N = a.shape[0]
+    out = torch.empty(n_predict, N, 2, dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().tnp_constant_velocity(_lib.ptr(a), _lib.ptr(b), N, int(n_predict), _lib.ptr(out), _lib.stream_ptr()),
+               'tnp_constant_velocity')
+    return out
+
+
+@constant_velocity.register_fake
+def _(last, prev, n_predict):
+    return last.new_empty((n_predict, last.shape[0], 2), dtype=torch.float64)
+
+
+@torch.library.custom_op('trajnet::sf_rollout', mutates_args=())
+def sf_rollout(state: torch.Tensor, scene_start: torch.Tensor, n_max: int, n_predict: int, v0: float, sigma: float,
+               tau: float) -> torch.Tensor:
+    """Social-force rollout of many scenes (classical/socialforce.py:84-95): state [M, 6] fp64 (x, y, vx, vy, goal),
+    one output row every 8 simulator steps of 1/20 s."""
+    dev = _dev(state, 'state')
+    s0 = state.to(torch.float64).contiguous()
+    st = _starts(scene_start, dev)
+    M = s0.shape[0]
+    out = torch.empty(n_predict, M, 2, dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().tnp_sf_rollout(_lib.ptr(s0), _lib.ptr(st), st.numel() - 1, M, int(n_max), int(n_predict) * 8, 8, float(v0),
+                                         float(sigma), float(tau), 1.0 / 20, _lib.ptr(out), _lib.stream_ptr()), 'tnp_sf_rollout')
+    return out
+
+
+@sf_rollout.register_fake
+def _(state, scene_start, n_max, n_predict, v0, sigma, tau):
+    return state.new_empty((n_predict, state.shape[0], 2), dtype=torch.float64)
