@@ -300,12 +300,22 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch multi-GPU runs with python -m torch.distributed.run --nproc-per-node %d' % args.gpus)
     distributed = world > 1
+    # Test hooks for boxes with fewer GPUs than ranks (the N > 1 code path -- sharding, barrier, max over ranks, the
+    # gradient all-reduce from inside the backward pass -- can then be exercised on ONE GPU): TNP_BENCH_SHARE_GPU=1 maps
+    # rank r to device r % device_count, TNP_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
+    # Numbers measured that way mean nothing; the driver's runs use neither.
+    if os.environ.get('TNP_BENCH_SHARE_GPU') == '1':
+        local_rank %= max(torch.cuda.device_count(), 1)
+    backend = os.environ.get('TNP_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = CONFIGS[args.config]
     if cfg.get('classical'):
