@@ -385,45 +385,50 @@ def main():
 
     # ---- training leg: the optimisation step of the same model on the same shard, all-reduce included at N > 1 ----
     training = None
+    training_failed = False
     if not args.train and not is_sgan and not args.no_train and not args.no_roofline:
-        from trajnetplusplusbaselines_amd import parallel
-        from trajnetplusplusbaselines_amd.lstm import PredictionLoss
-        from trajnetplusplusbaselines_amd.lstm.train_step import train_batch
-        tmodel = build_model(cfg, device)                     # same seed on every rank: replicas start identical
-        tmodel.kernel_variant = args.variant
-        optimizer = torch.optim.Adam(tmodel.parameters(), lr=1e-3, weight_decay=1e-4)   # lstm/trainer.py:497
-        # gradient all-reduce: 'overlap' (default) = from inside the backward pass, each gradient as soon as it is enqueued
-        # (parallel.GradReducer); 'buckets' = flat persistent buckets launched asynchronously after the backward pass
-        ar_mode = os.environ.get('TNP_BENCH_ALLREDUCE', 'overlap')
-        buckets = parallel.GradBuckets(tmodel.parameters()) if (distributed and ar_mode == 'buckets') else None
-        criterion = PredictionLoss()
-        scene_dev = xy.to(device)
-        t_steps, t_warm = max(5, min(args.steps, 30)), 3
+        try:
+            from trajnetplusplusbaselines_amd import parallel
+            from trajnetplusplusbaselines_amd.lstm import PredictionLoss
+            from trajnetplusplusbaselines_amd.lstm.train_step import train_batch
+            tmodel = build_model(cfg, device)                     # same seed on every rank: replicas start identical
+            tmodel.kernel_variant = args.variant
+            optimizer = torch.optim.Adam(tmodel.parameters(), lr=1e-3, weight_decay=1e-4)   # lstm/trainer.py:497
+            # gradient all-reduce: 'overlap' (default) = from inside the backward pass, each gradient as soon as it is enqueued
+            # (parallel.GradReducer); 'buckets' = flat persistent buckets launched asynchronously after the backward pass
+            ar_mode = os.environ.get('TNP_BENCH_ALLREDUCE', 'overlap')
+            buckets = parallel.GradBuckets(tmodel.parameters()) if (distributed and ar_mode == 'buckets') else None
+            criterion = PredictionLoss()
+            scene_dev = xy.to(device)
+            t_steps, t_warm = max(5, min(args.steps, 30)), 3
 
-        def tstep():
-            return train_batch(tmodel, optimizer, criterion, scene_dev, goals, split, 9, 12, batch_size=cfg['scenes'] * world,
-                               n_global_scenes=cfg['scenes'] * world, pad_to=cfg['agents'], buckets=buckets,
-                               overlap=(ar_mode == 'overlap'))
-        for _ in range(t_warm):
-            tstep()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(t_steps):
-            loss_last = tstep()
-        barrier()
-        t_el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-        if distributed:
-            dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
-        t_el = float(t_el.item())
-        grad_bytes = sum(p.numel() * 4 for p in tmodel.parameters() if p.grad is not None)
-        training = dict(value=cfg['scenes'] * world * 21 * t_steps / t_el, unit='scene-steps/s', steps=t_steps, warmup=t_warm,
-                        ms_per_step=t_el / t_steps * 1e3, loss_last=loss_last,
-                        workload='Trainer.train_batch of the same model on the same shard: teacher-forced forward, NLL loss, '
-                                 'backward, Adam%s' % (' + SUM all-reduce of %.1f MB of fp32 gradients over RCCL (%s)' % (
-                                     grad_bytes / 1e6, 'launched from inside the backward pass as each gradient is enqueued, largest first'
-                                     if ar_mode == 'overlap' else 'flat buckets after the backward pass') if distributed else ''),
-                        allreduce_bytes=grad_bytes if distributed else 0)
-        del tmodel, optimizer, buckets
+            def tstep():
+                return train_batch(tmodel, optimizer, criterion, scene_dev, goals, split, 9, 12, batch_size=cfg['scenes'] * world,
+                                   n_global_scenes=cfg['scenes'] * world, pad_to=cfg['agents'], buckets=buckets,
+                                   overlap=(ar_mode == 'overlap'))
+            for _ in range(t_warm):
+                tstep()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(t_steps):
+                loss_last = tstep()
+            barrier()
+            t_el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            if distributed:
+                dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+            t_el = float(t_el.item())
+            grad_bytes = sum(p.numel() * 4 for p in tmodel.parameters() if p.grad is not None)
+            training = dict(value=cfg['scenes'] * world * 21 * t_steps / t_el, unit='scene-steps/s', steps=t_steps, warmup=t_warm,
+                            ms_per_step=t_el / t_steps * 1e3, loss_last=loss_last,
+                            workload='Trainer.train_batch of the same model on the same shard: teacher-forced forward, NLL loss, '
+                                     'backward, Adam%s' % (' + SUM all-reduce of %.1f MB of fp32 gradients over RCCL (%s)' % (
+                                         grad_bytes / 1e6, 'launched from inside the backward pass as each gradient is enqueued, largest first'
+                                         if ar_mode == 'overlap' else 'flat buckets after the backward pass') if distributed else ''),
+                            allreduce_bytes=grad_bytes if distributed else 0)
+            del tmodel, optimizer, buckets
+        except Exception as exc:   # the inference line above is already measured: report the failure instead of losing the run
+            training = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:300]))
+            training_failed = True
 
     with torch.set_grad_enabled(args.train):
         # ---- roofline leg: same region again with HIP events around every launch of the dominant kernel ----
@@ -530,6 +535,9 @@ def main():
             out['cpu_baseline'] = None
         print(json.dumps(out))
     if distributed:
+        if training_failed:   # a failed collective leaves the group unusable: do not wait on it
+            sys.stdout.flush()
+            os._exit(0)
         dist.barrier()   # rank 0 ran the roofline / cpu_baseline legs; leave together
         dist.destroy_process_group()
 
