@@ -43,7 +43,7 @@ def run_sparse(obs1, obs2, enc, starts, n_max, n, cell_side, W, b, relu=True):
 
 
 @pytest.mark.parametrize('scenes,agents,n,C,N1', [(3, 7, 8, 8, 64), (64, 32, 16, 16, 1024), (5, 40, 16, 16, 260),
-                                                   (20, 13, 12, 4, 128), (2, 130, 16, 32, 256),
+                                                   (20, 13, 12, 4, 128), (2, 130, 16, 32, 256), (3, 130, 16, 16, 192),
                                                    (4, 20, 24, 8, 128)])  # 576 cells: cell-range fallback kernel
 def test_sparse_embedding_matches_dense_oracle(scenes, agents, n, C, N1):
     rng = np.random.RandomState(scenes * 31 + agents)
@@ -102,3 +102,21 @@ def test_forward_sparse_equals_dense_path(n1, latent):
     assert torch.equal(torch.isnan(pred_s), torch.isnan(pred_d))
     assert (torch.nan_to_num(pred_s) - torch.nan_to_num(pred_d)).abs().max().item() < 2e-5
     assert (torch.nan_to_num(rel_s) - torch.nan_to_num(rel_d)).abs().max().item() < 2e-5
+
+
+def test_forward_with_scenes_larger_than_a_wave():
+    """Scenes of up to 90 tracks: the fused winner build of the register-accumulator kernel votes in 64-neighbour chunks, a
+    tile of 64 egos lies inside one scene, and the sparse path must still agree with the dense one."""
+    torch.manual_seed(5)
+    pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=16, out_dim=256,
+                            embedding_arch='two_layer', layer_dims=[256], latent_dim=16)
+    model = LSTM(pool=pool).eval().cuda()
+    xy, split = synth.ragged_crowd(5, 60, 90, seed=11)
+    goals = torch.zeros(xy.shape[1], 2)
+    with torch.no_grad():
+        model.sparse_embedding = True
+        rel_s, pred_s = model(xy[:9], goals, split, n_predict=12)
+        model.sparse_embedding = False
+        rel_d, pred_d = model(xy[:9], goals, split, n_predict=12)
+    assert torch.equal(torch.isnan(pred_s), torch.isnan(pred_d))
+    assert (torch.nan_to_num(pred_s) - torch.nan_to_num(pred_d)).abs().max().item() < 3e-5
