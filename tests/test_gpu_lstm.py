@@ -264,3 +264,20 @@ def test_config4_full_size_sgan_forward_properties():
         lo, hi = r * 32 * 32, (r + 1) * 32 * 32
         _, p = run(xy[:9, lo:hi], torch.arange(0, 32 * 32 + 1, 32), 7)
         assert (p - pred_a[:, lo:hi]).abs().max().item() < 1e-4          # same noise, scenes independent (tile choice may differ)
+
+
+def test_gates_kernel_variants_agree():
+    """The LSTM-gates GEMM has three tilings (tnp_lstm_model.variant bits 8-15: 5 = 128-track tiles, 20 = split-K 4 per
+    workgroup, 21 = one gate block per wave; 0 picks 21 here): same forward within fp32 summation order."""
+    model = _config2_model(seed=4).cuda().eval()
+    xy, split = synth.ragged_crowd(12, 5, 30, seed=21)
+    goals = torch.zeros(xy.shape[1], 2)
+    outs = {}
+    with torch.no_grad():
+        for v in (0, 5, 20, 21):
+            model.kernel_variant = v << 8
+            outs[v] = model(xy[:9], goals, split, n_predict=12)[1]
+    model.kernel_variant = 0
+    assert torch.equal(torch.nan_to_num(outs[0]), torch.nan_to_num(outs[21]))
+    for v in (5, 20):
+        assert (torch.nan_to_num(outs[v]) - torch.nan_to_num(outs[21])).abs().max().item() < 2e-5

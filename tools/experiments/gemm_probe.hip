@@ -158,7 +158,17 @@ int main() {
             CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             printf("gates 2048x512x448     interleaved schedule          %7.2f us\n", time_us([&] { hipLaunchKernelGGL(k2, dim3(d.tiles_m * d.tiles_n), dim3(256), smem, 0, d); }));
         }
-        // reference check of h_out against the host
+        {   // gate split: four waves own one gate block each over the whole K
+            GemmArgs d = g; d.tiles_m = M / 32; d.tiles_n = H / 32; d.prio = 1;
+            auto t = [&](const char *name, auto k2, size_t smem) {
+                CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                CK(hipMemset(ho, 0, (size_t)M * H * 4));
+                printf("gates 2048x512x448     %-28s %7.2f us\n", name, time_us([&] { hipLaunchKernelGGL(k2, dim3(d.tiles_m * d.tiles_n), dim3(256), smem, 0, d); }));
+            };
+            t("gate split BK 32", gemm_nt_pipe<1, 4, 1, 1, 32, EPI_LSTM, true, 0, false, 1>, (size_t)3 * 160 * 36 * 4);
+            t("gate split BK 32, 2 chains", gemm_nt_pipe<1, 4, 1, 1, 32, EPI_LSTM, true, 0, true, 1>, (size_t)3 * 160 * 36 * 4);
+        }
+        // reference check of h_out against the host (of the LAST variant run above)
         std::vector<float> hh((size_t)M * H); CK(hipMemcpy(hh.data(), ho, hh.size() * 4, hipMemcpyDeviceToHost));
         double md = 0;
         for (int m = 0; m < M; m += 61) for (int u = 0; u < H; u += 7) {

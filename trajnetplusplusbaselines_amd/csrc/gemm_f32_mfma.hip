@@ -571,7 +571,10 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_pipe(const GemmArgs
     constexpr int NK8 = BK / 8;
     static_assert(NK8 >= 2 && NK8 % 2 == 0, "BK must be a multiple of 16");
     constexpr int WRITE_AT = NK8 / 2 - 1;
-    static_assert(EPI != EPI_LSTM || (WN == 1 && AN == 4), "LSTM epilogue: 4 gate blocks per wave");
+    // LSTM epilogue: either a wave owns all four gate blocks of its 32 units (WN == 1, AN == 4; K split over the waves), or
+    // "gate split": four waves own one gate block each over the whole K (WN == 4, AN == 1, WK == 1) and swap tiles through LDS
+    constexpr bool GSPLIT = EPI == EPI_LSTM && WM == 1 && WN == 4 && AN == 1 && WK == 1;
+    static_assert(EPI != EPI_LSTM || (WN == 1 && AN == 4) || GSPLIT, "LSTM epilogue: 4 gate blocks per wave or gate split");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][WK][GROUP_FLOATS]
 
@@ -663,14 +666,14 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_pipe(const GemmArgs
     // load issued after the main loop would expose its full latency on the whole chip
     LstmPrefetch lpf;
     float ebias[AN];
-    if constexpr (EPI == EPI_LSTM && WK > 1) {
-        constexpr int RN = 16 / WK;
+    if constexpr ((EPI == EPI_LSTM && WK > 1) || GSPLIT) {
+        constexpr int RN = GSPLIT ? 4 : 16 / WK;
         const int unit = tn * 32 + (lane & 31), uc = unit < g.H ? unit : g.H - 1;
 #pragma unroll
         for (int an = 0; an < 4; ++an) lpf.bias[an] = g.bias1[an * g.H + uc] + g.bias2[an * g.H + uc];
 #pragma unroll
         for (int rr = 0; rr < RN; ++rr) {
-            const int r = kg * RN + rr;
+            const int r = (GSPLIT ? wn : kg) * RN + rr;
             const int row = min(m0 + wm * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2), g.M - 1);
             lpf.c[rr] = g.c_in[(size_t)row * g.H + uc];
             lpf.present[rr] = g.mask[row];
@@ -748,7 +751,29 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_pipe(const GemmArgs
     }
     GP_T(3);
 
-    if constexpr (WK > 1 && EPI == EPI_LSTM) {
+    if constexpr (GSPLIT) {
+        // wave `wn` holds the pre-activations of gate `wn` for the tile's 32 tracks x 32 units; the tiles are swapped through
+        // LDS and wave w runs the cell update of accumulator registers 4 w .. 4 w + 3 (8 tracks x 32 units)
+        __syncthreads();  // everybody is done with the tile ring before it is reused
+        float *red = smem;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wn * 16 + r) * 64 + lane] = acc[0][r];
+        __syncthreads();
+        const int unit = tn * 32 + (lane & 31);
+        if (unit < g.H) {
+            const int rbase = m0 + 4 * (lane >> 5);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = wn * 4 + rr;
+                float pre[4];
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) pre[gt] = red[(gt * 16 + r) * 64 + lane] + lpf.bias[gt];
+                lstm_cell_store_pf(g, rbase + (r & 3) + 8 * (r >> 2), unit, pre[0], pre[1], pre[2], pre[3], lpf.c[rr], lpf.present[rr]);
+            }
+        }
+        GP_T(5);
+        return;
+    } else if constexpr (WK > 1 && EPI == EPI_LSTM) {
         __syncthreads();  // everybody is done with the tile ring before it is reused for the reduction
         lstm_reduce_epilogue<WK, WMN>(g, acc, smem, kg, wq, lane, m0 + wm * 32 + 4 * (lane >> 5), tn, &lpf);
         GP_T(5);
@@ -876,11 +901,15 @@ int launch_lstm_gates(const GemmArgs &g_in, int variant, hipStream_t s) {
     GemmArgs g = g_in;
     check_vec(g);
     if (g.H % 32 != 0) TNP_FAIL(-1, "LSTM hidden_dim must be a multiple of 32 (got %d)", g.H);
-    if (variant == 0) variant = (g.M >= 4096) ? 5 : 20;  // measured best on MI355X (profiles/round1_b_variant_sweep.jsonl)
+    // measured on MI355X (profiles/round1_b_variant_sweep.jsonl, tools/experiments/gemm_probe.hip): big batches the 128-track
+    // kernel, else "gate split" (four waves own one gate block each over the whole K and swap tiles through LDS: no split-K
+    // reduction, half the staged chunks per thread; 17.9 -> 16.1 us at config 2) when K1, K2 are multiples of 32
+    if (variant == 0) variant = (g.M >= 4096) ? 5 : (fast_ok(g, 1, 32) ? 21 : 20);
     switch (variant) {
         case 5: TNP_TRY_FAST(4, 1, 2, 4, 16, EPI_LSTM); break;   // 128 tracks x 32 units, 8 waves
         case 20: TNP_TRY_PIPE(1, 1, 4, 4, 16, EPI_LSTM); break;  // pipelined: 32 tracks x 32 units, split-K 4
-        default: TNP_FAIL(-1, "lstm gates: unknown variant %d (0 = automatic, 5, 20)", variant);
+        case 21: TNP_TRY_PIPE(1, 4, 1, 1, 32, EPI_LSTM); TNP_TRY_PIPE(1, 1, 4, 4, 16, EPI_LSTM); break;   // gate split
+        default: TNP_FAIL(-1, "lstm gates: unknown variant %d (0 = automatic, 5, 20, 21)", variant);
     }
     if (g.M >= 4096) return launch_general<2, 1, 2, 4, 32, EPI_LSTM>(g, s);
     return launch_general<1, 1, 4, 4, 16, EPI_LSTM>(g, s);
