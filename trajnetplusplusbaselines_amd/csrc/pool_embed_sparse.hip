@@ -659,6 +659,28 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
                 lo[u] = sg[e]; ns[u] = sg[TE + e]; ki[u] = sg[2 * TE + e]; pad[u] = sg[3 * TE + e];
                 px[u] = sp[e]; py[u] = sp[TE + e];
             }
+            bool small = true;                                       // wave-uniform: all of the wave's scenes have <= 32 tracks
+#pragma unroll
+            for (int u = 0; u < EU; ++u) small = small && ns[u] <= 32;
+            if (EU % 2 == 0 && __builtin_amdgcn_readfirstlane((int)small)) {
+                // two egos per pass: lanes 0-31 vote for ego e0 + 2 p, lanes 32-63 for ego e0 + 2 p + 1 (half the vector work
+                // of the one-ego-per-pass form below for scenes that fill half a wave; the votes themselves are the same)
+                const int hi = lane >> 5, j = lane & 31;
+                float2 pq[EU / 2];
+#pragma unroll
+                for (int p = 0; p < EU / 2; ++p) {
+                    const int lo_ = hi ? lo[2 * p + 1] : lo[2 * p], ns_ = hi ? ns[2 * p + 1] : ns[2 * p];
+                    pq[p] = reinterpret_cast<const float2 *>(a.obs2)[lo_ + (j < ns_ ? j : 0)];
+                }
+#pragma unroll
+                for (int p = 0; p < EU / 2; ++p) {
+                    const int ns_ = hi ? ns[2 * p + 1] : ns[2 * p], ki_ = hi ? ki[2 * p + 1] : ki[2 * p];
+                    vote(e0 + 2 * p + hi, j, j < ns_ && j != ki_, pq[p], hi ? px[2 * p + 1] : px[2 * p], hi ? py[2 * p + 1] : py[2 * p]);
+                }
+#pragma unroll
+                for (int u = 0; u < EU; ++u)
+                    if (ns[u] < pad[u] && lane == 0) atomicMax(&keyT[e0 + u], 2 * (pad[u] - 1));
+            } else {
 #pragma unroll
             for (int u = 0; u < EU; ++u)
                 pj[u] = reinterpret_cast<const float2 *>(a.obs2)[lo[u] + (lane < ns[u] ? lane : 0)];   // ns == 0: row 0, unused
@@ -669,6 +691,7 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
                 for (int j = lane + 64; j < ns[u]; j += 64)                          // scenes of more than 64 tracks
                     vote(e0 + u, j, j != ki[u], reinterpret_cast<const float2 *>(a.obs2)[lo[u] + j], px[u], py[u]);
                 if (ns[u] < pad[u] && lane == 0) atomicMax(&keyT[e0 + u], 2 * (pad[u] - 1));
+            }
             }
         }
         __syncthreads();
