@@ -179,7 +179,7 @@ typedef struct tnp_lstm_model {
     const float *Wp0_cell_major; /* optional [n*n][C][dims[1]] copy of Wp[0] (W'[c][ch][o] =
                                     Wp[0][o][ch*n*n + c]); enables the sparse first layer
                                     for social pooling with constant == 0; NULL = dense   */
-    int32_t variant;      /* bits 0-7 / 8-15: tile selection of the dense embedding GEMM / the gates GEMM (0 = automatic); bit 16: force the dense first
+    int32_t variant;      /* bits 0-7 / 8-15: tile selection of the dense embedding GEMM (12, 24) / the gates GEMM (5, 20, 21) -- 0 = automatic; bit 16: force the dense first
                              embedding layer; bit 17: LSTM(pool_to_input=False) -- the interaction vector (P == H) is
                              added to the hidden operand of the LSTMCell instead of concatenated to its input */
     /* TNP_POOL_ATTNMLP only (fields as for HIDDENMLP, `constant` = fill_value): the linear maps around the single-head
