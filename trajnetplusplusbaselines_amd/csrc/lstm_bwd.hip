@@ -574,6 +574,131 @@ static int launch_dgrid_cells(const float *dy, int ldy, const float *Wc, const i
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// K-slice-per-XCD form of the same product (C <= 16, N1 % 128 == 0): dgrid_cells_kernel gathers every dy row for each of
+// the ~12 cells its ego occupies, from workgroups on all eight XCDs, right after another kernel produced dy on yet other
+// XCDs -- it moves ~136 MB per launch at 4.9 TB/s and that, not the matrix pipe, is its 31 us (tools/experiments/README.md).
+// Here workgroup (cell c, slice x) takes columns [x N1/8, (x+1) N1/8) of the contraction only, and x = blockIdx.x & 7 puts
+// all workgroups of a slice on ONE XCD: that XCD's L2 then holds an eighth of the step's dy (1 MB at config 2) and an eighth
+// of the weights (2 MB), both re-read from it.  The eight partial results go to eight copies of `dcell`; the scatter that
+// consumes them (social_scatter_backward_cells8_kernel) adds the copies in slice order, so nothing is atomic and the order
+// is fixed.  A wave owns whole 16-ego groups (g = wave, wave + 4, ...): no barrier and no cross-wave reduction in the loop.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dgrid_cells_xcd_kernel(const float *__restrict__ dy, int ldy, const float *__restrict__ Wc,
+                                                              const int2 *__restrict__ list, const int32_t *__restrict__ count,
+                                                              int R, int nseg, int seg, int M, int C, int ncell, int N1,
+                                                              float *__restrict__ dcell8) {
+    extern __shared__ __attribute__((aligned(16))) float4 xcd_lds[];          // [T][64] weights of the slice, B-operand order
+    const int x = blockIdx.x & 7, c = blockIdx.x >> 3;
+    const int cnt = count[c * nseg + seg];
+    if (cnt <= 0) return;
+    const int ngroups = (cnt + 15) >> 4;
+    const int2 *L = list + (size_t)c * R + (size_t)seg * M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane & 15, kq = lane >> 4;
+    const int ncol = N1 >> 3, T = ncol >> 4, k0 = x * ncol;
+    for (int q = tid; q < T * 64; q += 256) {                                   // T <= 8 for N1 <= 1024: one or two loads per thread
+        const int t = q >> 6, l = q & 63, ch = l & 15, kk = l >> 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ch < C) v = *reinterpret_cast<const float4 *>(Wc + ((size_t)c * C + ch) * N1 + k0 + 16 * t + 4 * kk);
+        xcd_lds[q] = v;
+    }
+    __syncthreads();
+    const int row_off = seg * M;
+    float *out = dcell8 + (size_t)x * M * ncell * C;
+    // software pipeline over the wave's groups: list entries two groups ahead, dy operands one group ahead (a group is
+    // otherwise a chain of two global round trips in front of 32 MFMAs, and the busiest cells have five groups per wave)
+    auto rows_of = [&](int g, int &rl, int (&ro)[4]) {
+        const int idx = g * 16 + row;
+        rl = L[(g < ngroups && idx < cnt) ? idx : 0].x - row_off;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const int id2 = g * 16 + 4 * kq + v; ro[v] = L[(g < ngroups && id2 < cnt) ? id2 : 0].x - row_off; }
+    };
+    auto load_a = [&](float4 (&a)[8], int rl, int t0) {
+        const float *src = dy + (size_t)rl * ldy + k0 + 4 * kq;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (t0 + u < T) a[u] = *reinterpret_cast<const float4 *>(src + 16 * (t0 + u));
+    };
+    int g = wave;
+    if (g >= ngroups) return;
+    int rl0, ro0[4], rl1, ro1[4];
+    rows_of(g, rl0, ro0);
+    rows_of(g + 4, rl1, ro1);
+    float4 a0[8], a1[8];
+    load_a(a0, rl0, 0);
+    for (; g < ngroups; g += 4) {
+        int rl2, ro2[4];
+        rows_of(g + 8, rl2, ro2);
+        if (g + 4 < ngroups) load_a(a1, rl1, 0);
+        floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int t0 = 0; t0 < T; t0 += 8) {
+            if (t0 > 0) load_a(a0, rl0, t0);                          // N1 > 1024: further K batches of this group, not prefetched
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (t0 + u < T) {
+                    const float4 b = xcd_lds[(t0 + u) * 64 + lane];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].x, b.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].y, b.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].z, b.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].w, b.w, acc, 0, 0, 0);
+                }
+        }
+        // lane (row = channel, kq) holds D[ego 4 kq + v][channel row]
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (g * 16 + 4 * kq + v < cnt && row < C) out[((size_t)ro0[v] * ncell + c) * C + row] = acc[v];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a0[u] = a1[u];
+        rl0 = rl1; rl1 = rl2;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { ro0[v] = ro1[v]; ro1[v] = ro2[v]; }
+    }
+}
+
+// social_scatter_backward_cells_kernel over the eight slice copies: the copies of an (ego, cell) entry are added in slice order
+__global__ void __launch_bounds__(256) social_scatter_backward_cells8_kernel(const float *__restrict__ dcell8,
+                                                                             const int32_t *__restrict__ cells,
+                                                                             const int32_t *__restrict__ row_base,
+                                                                             const int32_t *__restrict__ row_count, int M,
+                                                                             int n_max, int C, int ncell,
+                                                                             float *__restrict__ denc) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, sub = lane >> 4;
+    if (j >= M) return;
+    const int lo = row_base[j], ns = row_count[j], jj = j - lo;
+    const size_t slice = (size_t)M * ncell * C;
+    for (int ch = lane & 15; ch < ((C + 15) & ~15); ch += 16) {
+        float acc = 0.0f;
+#pragma unroll 2
+        for (int i = lo + sub; i < lo + ns; i += 4) {
+            const int c = cells[(size_t)i * n_max + jj];
+            if (c >= 0 && ch < C) {
+                const float *p = dcell8 + ((size_t)i * ncell + c) * C + ch;
+                float v[8];
+#pragma unroll
+                for (int xx = 0; xx < 8; ++xx) v[xx] = p[xx * slice];
+                float sum = v[0];
+#pragma unroll
+                for (int xx = 1; xx < 8; ++xx) sum += v[xx];
+                acc += sum;
+            }
+        }
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        if (sub == 0 && ch < C) denc[(size_t)j * C + ch] = acc;
+    }
+}
+
+static bool dgrid_xcd_ok(int C, int N1) { return C <= 16 && N1 % 128 == 0; }
+
+static int launch_dgrid_cells_xcd(const float *dy, int ldy, const float *Wc, const int2 *list, const int32_t *count, int R, int nseg,
+                                  int seg, int M, int C, int ncell, int N1, float *dcell8, hipStream_t s) {
+    const size_t lds = (size_t)(N1 / 8 / 16) * 64 * sizeof(float4);
+    hipLaunchKernelGGL(dgrid_cells_xcd_kernel, dim3(ncell * 8), dim3(256), lds, s, dy, ldy, Wc, list, count, R, nseg, seg, M, C, ncell, N1,
+                       dcell8);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
 // Matrix-core form for C <= 16: dW'[c][ch][n] = sum over the cell's hits of enc[hit][ch] * dy[hit][n] is a [16 x hits] x
 // [hits x 64] product per (cell, 64-column chunk).  v_mfma_f32_16x16x4_f32 takes four hits per instruction: lane (g = l >> 4,
 // i = l & 15) holds A[ch i][hit g] = enc[hit g][i] and B[hit g][col] from one 16-byte load of dy (columns 4 i .. 4 i + 3 of
@@ -777,7 +902,9 @@ static void plan_sweep(const tnp_bwd_sweep *a, void *base, SweepScratch &w) {
     const bool dense0 = grid && ((social && !a->social_sparse) || a->directional_in);
     w.dgrid = (float *)take(dense0 ? M * (size_t)md->dims[0] * 4 : 0);
     w.cells = (int32_t *)take(dense0 ? M * (size_t)a->n_max * 4 : 0);
-    w.dcell = (float *)take((social && a->social_sparse) ? M * (size_t)md->dims[0] * 4 : 0);
+    // eight slice copies for the K-slice-per-XCD data gradient of the first layer
+    const size_t dcell_copies = (social && a->social_sparse && dgrid_xcd_ok(md->C, md->dims[1])) ? 8 : 1;
+    w.dcell = (float *)take((social && a->social_sparse) ? dcell_copies * M * (size_t)md->dims[0] * 4 : 0);
     w.bytes = off;
 }
 
@@ -1016,10 +1143,18 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
             if (social) {
                 float *denc = a->denc_all + r * C;
                 if (a->social_sparse) {   // only the cells that hold a neighbour carry a gradient
+                    if (tnp::dgrid_xcd_ok(C, N1) && (reinterpret_cast<uintptr_t>(dy0) & 15) == 0) {
+                        TNP_RC(tnp::launch_dgrid_cells_xcd(dy0, N1, a->w_cell_major, reinterpret_cast<const int2 *>(a->ego_list), a->ego_count,
+                                                           S * M, S, st, M, C, ncell, N1, w.dcell, s));
+                        hipLaunchKernelGGL(tnp::social_scatter_backward_cells8_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s,
+                                           w.dcell, a->cells_all + r * a->n_max, a->row_base, a->row_count, M, a->n_max, C, ncell, denc);
+                        TNP_HIP(hipGetLastError());
+                    } else {
                     TNP_RC(tnp_social_dgrid_cells(dy0, N1, a->w_cell_major, a->ego_list, a->ego_count, S * M, st, M, C, ncell, N1,
                                                   w.dcell, stream));
                     TNP_RC(tnp_social_scatter_backward_cells(w.dcell, a->cells_all + r * a->n_max, a->row_base, a->row_count, M,
                                                              a->n_max, C, ncell, denc, stream));
+                    }
                 } else {
                     TNP_RC(tnp_pool_pair_cells(o2, a->row_base, a->row_count, M, a->n_max, md->n, md->cell, md->half_x,
                                                md->half_y, w.cells, stream));
