@@ -668,19 +668,27 @@ __global__ void __launch_bounds__(256) social_scatter_backward_cells8_kernel(con
     const size_t slice = (size_t)M * ncell * C;
     for (int ch = lane & 15; ch < ((C + 15) & ~15); ch += 16) {
         float acc = 0.0f;
-#pragma unroll 2
-        for (int i = lo + sub; i < lo + ns; i += 4) {
-            const int c = cells[(size_t)i * n_max + jj];
-            if (c >= 0 && ch < C) {
-                const float *p = dcell8 + ((size_t)i * ncell + c) * C + ch;
-                float v[8];
+        // four egos per batch: their cell indices first, then the 32 slice entries, then the adds (ego order, slice order)
+        for (int i0 = lo + sub; i0 < lo + ns; i0 += 16) {
+            int cc[4];
 #pragma unroll
-                for (int xx = 0; xx < 8; ++xx) v[xx] = p[xx * slice];
-                float sum = v[0];
+            for (int u = 0; u < 4; ++u) { const int i = i0 + 4 * u; cc[u] = i < lo + ns ? cells[(size_t)i * n_max + jj] : -1; }
+            float v[4][8];
 #pragma unroll
-                for (int xx = 1; xx < 8; ++xx) sum += v[xx];
-                acc += sum;
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = cc[u] >= 0 && ch < C;
+                const float *p = dcell8 + ((size_t)(ok ? i0 + 4 * u : lo) * ncell + (ok ? cc[u] : 0)) * C + (ch < C ? ch : 0);
+#pragma unroll
+                for (int xx = 0; xx < 8; ++xx) v[u][xx] = ok ? p[xx * slice] : 0.0f;
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (cc[u] >= 0 && ch < C) {
+                    float sum = v[u][0];
+#pragma unroll
+                    for (int xx = 1; xx < 8; ++xx) sum += v[u][xx];
+                    acc += sum;
+                }
         }
         acc += __shfl_xor(acc, 16);
         acc += __shfl_xor(acc, 32);
