@@ -724,6 +724,10 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
     asm volatile("" : "+v"(rb));
     RA_T(3);
 
+    const int col2 = 2 * lane;                                                      // this lane's column pair in the epilogue
+    float2 bias2 = {0.0f, 0.0f};                                                    // fetched here: after the cell loop its latency would be exposed
+    if (a.bias && ob * OB + col2 + 1 < a.N1) bias2 = *reinterpret_cast<const float2 *>(a.bias + ob * OB + col2);
+    asm volatile("" : "+v"(bias2));                                                 // landed before the loop (see rb above)
     ra_f32x32 accA, accB;                                                           // egos 0..31 / 32..63 of the tile, this lane's column
 #pragma unroll
     for (int i = 0; i < 32; ++i) { accA[i] = 0.0f; accB[i] = 0.0f; }
@@ -855,9 +859,6 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
     RA_T(4);
     // ---- the 8 cell groups' partial sums, 32 egos per round: every wave leaves its partials in LDS, then wave w sums the
     //      copies of egos w and w + 16 of the round in fixed order (group 0 + 1 + ... + 7), bias + activation, coalesced rows
-    const int col2 = 2 * lane;                                                      // this lane's column pair in the epilogue
-    float2 bias2 = {0.0f, 0.0f};
-    if (a.bias && ob * OB + col2 + 1 < a.N1) bias2 = *reinterpret_cast<const float2 *>(a.bias + ob * OB + col2);
     if constexpr (ABL & 128) { if (accA[3] + accB[5] == 1.234e30f) a.out[tid] = 0.0f; return; }
 #pragma unroll
     for (int r = 0; r < TE / RA_RED; ++r) {
