@@ -7,22 +7,25 @@
 // but the non-zeros are unstructured inside any 32-wide block, so the matrix cores cannot skip them.  The fp32
 // VECTOR rate of CDNA4 equals its fp32 MFMA rate (157.3 TFLOP/s), so the sparse sum runs on the VALU.
 //
-// Default kernel (pool_embed_cellsplit_kernel), one workgroup = 32 egos x 256 output columns, 16 waves:
-//   * wave (q, cs): cells c with c % 4 == q, columns cs*64 + lane.  The C weights of the current cell
-//     W'[c][ch][o] (cell-major copy of the weight, o contiguous -> 256-byte coalesced wave loads) sit in VGPRs,
-//     prefetched one cell ahead, and are reused by every ego of the tile that has cell c occupied;
-//   * the int16 winner table of the tile is staged transposed in LDS; a cell's hits are found with one ballot
-//     (lane <-> ego), and a hit costs: s_ff1 + bit clear, one v_readlane (32-bit byte offset of the neighbour's
-//     row, computed per cell for all lanes at once), one SMEM load of the C-float row (inline asm, so that two
-//     hits are in flight before the single s_waitcnt), one LDS read-modify-write of acc[q][ego][column] and
-//     C/2 v_pk_fma_f32 (even / odd channels in the two halves of a packed register);
-//   * every wave group q owns a private 32 x 256 accumulator copy (4 x 32 KiB of LDS): (ego, column) has one
-//     writer wave, adds happen in program order (deterministic), and the four copies are summed in the epilogue
-//     with bias + ReLU fused -- no partial sums in HBM, no reduce kernel, no atomics;
-//   * blocks b, b+8, ... share an XCD and the same output block, so the 4 MiB weight slice of an output block
-//     stays in that XCD's L2.
-// Grids above 440 cells (winner tile does not fit beside the accumulators) fall back to pool_embed_sparse_kernel:
-// 128 egos x 256 columns x a RANGE of cells per workgroup, partial tiles summed by sparse_reduce_kernel.
+// Three kernels, chosen by launch_pool_embed_sparse:
+//   * pool_embed_regacc_kernel (default: C <= 16, grids up to 512 cells) -- 64 egos x 128 columns per workgroup, 16 waves =
+//     8 cell groups x 2 column sets, a wave's accumulators in VGPRs indexed by the wave-uniform ego, weights streamed from
+//     a quad-major copy; described in front of the kernel;
+//   * pool_embed_cellsplit_kernel (C = 32, or encodings beyond 32-bit row offsets; up to 440 cells) -- round 1's default,
+//     one workgroup = 32 egos x 256 output columns, 16 waves:
+//       - wave (q, cs): cells c with c % 4 == q, columns cs*64 + lane.  The C weights of the current cell W'[c][ch][o]
+//         (cell-major copy of the weight, o contiguous -> 256-byte coalesced wave loads) sit in VGPRs, prefetched one
+//         occupied cell ahead, and are reused by every ego of the tile that has cell c occupied;
+//       - the int16 winner table of the tile is staged transposed in LDS; a cell's hits are found with one ballot (lane
+//         <-> ego), and a hit costs: s_ff1 + bit clear, one v_readlane (32-bit byte offset of the neighbour's row), one
+//         SMEM load of the C-float row (inline asm, two hits in flight before the single s_waitcnt), one LDS
+//         read-modify-write of acc[q][ego][column] and C/2 v_pk_fma_f32;
+//       - every wave group q owns a private 32 x 256 accumulator copy (4 x 32 KiB of LDS): one writer wave per entry,
+//         adds in program order (deterministic), the four copies summed in the epilogue with bias + ReLU fused;
+//   * pool_embed_sparse_kernel + sparse_reduce_kernel for larger grids: 128 egos x 256 columns x a RANGE of cells per
+//     workgroup, partial tiles summed in a second launch.
+// All three share the hit discovery (winner per (ego, cell), "last writer in ascending j wins", cell-0 clobber) and the
+// packed-FMA hit; blocks b, b+8, ... share an XCD and a column block, whose weight slice stays in that XCD's L2.
 #include "tnp_internal.h"
 
 namespace tnp {
