@@ -546,9 +546,9 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_fast(const GemmArgs
 // sched_group_barrier interleaves one MFMA with at most one LDS write / LDS read / global load, so the memory
 // instructions issue in the shadow of the matrix pipe instead of in a clump in front of it.  The epilogue's operands
 // (bias; previous cell state and presence mask of the LSTM epilogue) are fetched before the main loop: all workgroups
-// run in lockstep, so a load issued after it exposes its whole latency.  What is left (gemm_probe ablations, second
-// embedding layer 14.6 us): matrix pipe 7.6 us, launch / kernarg / first tile ~2.7 us, LDS writes of the staging
-// registers ~2 us (direct-to-LDS loads with a swizzled layout would remove them), global loads 1.4 us, barrier 0.9 us.
+// run in lockstep, so a load issued after it exposes its whole latency.  What is left (gemm_probe, second embedding layer
+// 14.6 us): matrix pipe 7.6 us, launch / kernarg / first tile ~2.7 us, the rest in waits on the tile loads and the
+// barrier; a direct-to-LDS variant (global_load_lds_dwordx4, swizzled unpadded ring) is exactly as fast, so not kept.
 // ---------------------------------------------------------------------------------------------------------
 // Template switches beyond the tile shape are for tools/experiments/gemm_probe.hip: DBG shader-clock stamps per wave (buffer
 // passed as g.gates_out, g.C for the LSTM epilogue), ACC2 two accumulator chains per tile, GABL timing ablations.
