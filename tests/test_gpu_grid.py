@@ -113,3 +113,28 @@ def test_ragged_scenes_padded_slot_clobber():
     got = grid.cpu().numpy()
     for s, ns in enumerate(sizes):
         assert np.array_equal(got[starts[s]:starts[s + 1]], want[s, :ns]), s
+
+
+def test_duplicate_cells_single_threaded_reference():
+    """tests/golden/dup_cells.npz through the HIP grid kernel: duplicate cells keep the last neighbour in ascending j,
+    as the single-threaded reference does (occupancy / directional bit-exact, social within fp32 rounding of the
+    hidden encoding; a wrong winner is off by O(1))."""
+    import os
+    z = np.load(os.path.join(helpers.GOLDEN, 'dup_cells.npz'))
+    o1, o2 = torch.tensor(z['obs1']).cuda(), torch.tensor(z['obs2']).cuda()
+    for type_ in ('occupancy', 'directional', 'social'):
+        pool = GridBasedPooling(type_=type_, hidden_dim=128, cell_side=0.6, n=12, out_dim=32, latent_dim=8).cuda()
+        if type_ == 'occupancy':
+            g = pool.occupancies(o1.clone(), o2.clone())
+        elif type_ == 'directional':
+            g = pool.directional(o1.clone(), o2.clone())
+        else:
+            with torch.no_grad():
+                pool.hidden_dim_encoding.weight.copy_(torch.tensor(z['Wh']))
+                pool.hidden_dim_encoding.bias.copy_(torch.tensor(z['bh']))
+            g = pool.social(torch.tensor(z['hidden']).cuda(), o1.clone(), o2.clone())
+        g = g.detach().cpu().numpy()
+        if type_ == 'social':
+            np.testing.assert_allclose(g, z['grid_social'], rtol=0, atol=2e-6)
+        else:
+            assert np.array_equal(g, z['grid_' + type_]), type_

@@ -241,3 +241,48 @@ def test_sgan_goals_generator_step_matches_reference():
         worst = max(worst, err)
         assert err < 2e-3, '%s: relative error %.2e (scale %.2e)' % (name, err, scale)
     print('goals g step: worst relative gradient error %.2e' % worst)
+
+
+def test_config4_full_size_matches_reference():
+    """BASELINE config 4 at its FULL size (S-GAN, directional n=12 generator + discriminator, k = 3, 128 scenes x 32
+    agents) against the REFERENCE's own outputs (tests/golden/sgan_full.npz, oracle/gen_golden_r3.py: reference
+    sgan/sgan.py:78-132 run single-threaded on synth.linear_crowd(128, 32, seed=44), weights = default init under seed 4 --
+    our modules construct their parameters in the reference's order, the per-tensor sums are checked): every stored
+    normal / position within 2e-5, discriminator scores within 2e-5, the primaries' ADE / FDE within 1e-4 m."""
+    from trajnetplusplusbaselines_amd import synth
+    from trajnetplusplusbaselines_amd.lstm import GridBasedPooling
+    from trajnetplusplusbaselines_amd.sgan import SGAN, LSTMGenerator, LSTMDiscriminator
+    z = np.load(os.path.join(helpers.GOLDEN, 'sgan_full.npz'))
+    torch.manual_seed(int(z['seed']))
+    mk = lambda: GridBasedPooling(type_='directional', hidden_dim=128, cell_side=0.6, n=12, out_dim=256)
+    model = SGAN(generator=LSTMGenerator(pool=mk(), noise_dim=16), discriminator=LSTMDiscriminator(pool=mk()), k=3,
+                 d_steps=1, g_steps=1).eval()
+    with torch.no_grad():
+        model.discriminator.real_classifier[4].bias.add_(float(z['bias_shift_last']))
+        model.discriminator.real_classifier[2].bias.add_(float(z['bias_shift_mid']))
+    for k, v in model.state_dict().items():
+        assert abs(v.double().sum().item() - float(z['wsum_' + k])) < 1e-9, 'seeded weight differs: ' + k
+    model = model.cuda()
+    xy, split = synth.linear_crowd(128, 32, seed=int(z['crowd_seed']))
+    goals = torch.zeros(xy.shape[1], 2)
+    prim, rows = split[:-1].numpy(), z['rows']
+    truth = xy[9:21, prim].numpy()
+    with torch.no_grad():
+        torch.manual_seed(5)
+        rel, pred, s_real, s_fake = model(xy[:9], goals, split, prediction_truth=xy[9:21].clone(), step_type='g',
+                                          pred_length=12)
+        np.testing.assert_allclose(s_real.cpu().numpy(), z['scores_real'], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(s_fake.cpu().numpy(), z['scores_fake'], rtol=0, atol=2e-5)
+        assert z['scores_fake'].std() > 1e-4              # the stored scores are not a constant
+        torch.manual_seed(6)
+        rel_n, pred_n, _, _ = model(xy[:9], goals, split, n_predict=12)
+    for tag, rr, pp in (('truth', rel, pred), ('npred', rel_n, pred_n)):
+        for i in range(3):
+            r, p = rr[i].cpu().numpy(), pp[i].cpu().numpy()
+            helpers.assert_close_nan(r[:, prim], z['%s_rel_prim%d' % (tag, i)], 2e-5, '%s rel prim %d' % (tag, i))
+            helpers.assert_close_nan(p[:, prim], z['%s_pred_prim%d' % (tag, i)], 2e-5, '%s pred prim %d' % (tag, i))
+            helpers.assert_close_nan(p[:, rows], z['%s_pred_rows%d' % (tag, i)], 2e-5, '%s pred rows %d' % (tag, i))
+            ade, fde = helpers.ade_fde(p[-12:, prim], truth)
+            ade_r, fde_r = helpers.ade_fde(z['%s_pred_prim%d' % (tag, i)][-12:], truth)
+            assert np.abs(ade - ade_r).max() < 1e-4 and np.abs(fde - fde_r).max() < 1e-4
+    assert not np.array_equal(z['npred_pred_prim0'], z['npred_pred_prim1'])      # the k samples differ

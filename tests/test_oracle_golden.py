@@ -167,3 +167,18 @@ def test_random_rotation_and_batcher_match_reference_arithmetic():
     for k, (i, th) in enumerate(zip((1, 3), thetas)):
         r = np.array([[math.cos(th), math.sin(th)], [-math.sin(th), math.cos(th)]])
         helpers.assert_close_nan(xy[:, sp[k]:sp[k + 1]].numpy(), (scenes[i] @ r).astype(np.float32), 2e-5, 'rotated scene')
+
+
+def test_duplicate_cells_single_threaded_reference():
+    """tests/golden/dup_cells.npz: a [9 x 13] batch with 289 duplicate (ego, cell) entries, grids computed by the
+    SINGLE-THREADED reference (the multi-threaded reference's index_put_ order differs on this very batch for social
+    grids, tests/test_oracle_vs_reference.py).  Last writer in ascending j wins: occupancy / directional bit-exact."""
+    import os
+    z = np.load(os.path.join(helpers.GOLDEN, 'dup_cells.npz'))
+    assert int(z['duplicate_pairs']) > 100
+    for type_ in ('occupancy', 'directional'):
+        g = oracle.grid(type_, z['obs1'], z['obs2'], n=12, cell_side=0.6)
+        assert np.array_equal(g, z['grid_' + type_]), type_
+    enc = helpers.social_enc(dict(hidden=z['hidden'], Wh=z['Wh'], bh=z['bh']))
+    g = oracle.grid('social', z['obs1'], z['obs2'], enc, n=12, cell_side=0.6)
+    np.testing.assert_allclose(g, z['grid_social'], rtol=0, atol=2e-6)    # a wrong winner would be off by O(1)

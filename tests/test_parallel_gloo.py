@@ -154,11 +154,27 @@ class _StandInModel(torch.nn.Module):
 
 
 class _StandInLoss(torch.nn.Module):
+    """A mean-type term (primaries' NLL, like PredictionLoss) plus a SUM-over-scenes collision penalty written with tensor
+    ops as the reference's CollisionLoss is (lstm/loss.py:138-162; the HIP kernel needs a GPU) -- exposed through
+    ``terms()`` like the product's losses so that the sharded step scales the two differently."""
     col_wt = 1.0      # train_batch then hands over primary_prediction (truth frames, primaries <- the model's positions)
+    col_distance = 2.5
+
+    def terms(self, inputs, targets, batch_split, positions=None):
+        nll = helpers.primary_loss_autograd(0, inputs, torch.nan_to_num(targets), batch_split, 0.2, False, 1.0)
+        mean_term = nll + 0.01 * positions[:, batch_split[:-1]].pow(2).mean()
+        col = positions.new_zeros(())
+        pos = torch.nan_to_num(positions, nan=-1000.0)
+        for lo, hi in zip(batch_split[:-1].tolist(), batch_split[1:].tolist()):
+            if hi - lo < 2:
+                continue
+            d = torch.norm(pos[:, lo:lo + 1] - pos[:, lo + 1:hi].detach(), dim=2)
+            col = col + self.col_wt * torch.relu(1.0 - d / self.col_distance).sum()
+        return mean_term, col
 
     def forward(self, inputs, targets, batch_split, positions=None):
-        nll = helpers.primary_loss_autograd(0, inputs, torch.nan_to_num(targets), batch_split, 0.2, False, 1.0)
-        return nll + 0.01 * positions[:, batch_split[:-1]].pow(2).mean()
+        mean_term, col = self.terms(inputs, targets, batch_split, positions)
+        return mean_term + col
 
 
 def _train_worker(rank, world, port, ret, n_scenes, use_buckets):
@@ -209,7 +225,13 @@ def test_train_batch_distributed_branch_equals_single_process(n_scenes, use_buck
     assert sum(ret[r]['n_local'] for r in range(world)) == n_scenes
     if n_scenes == 1:
         assert ret[1]['n_local'] == 0 and ret[1]['losses'] == [0.0, 0.0]
-    # the ranks' scaled losses add up to the single-process loss (mean over all primaries x batch_size)
+    # the collision-type term is live in this batch (otherwise the test would not see a mis-scaled SUM term)
+    rel, pos = _StandInModel()(xy[:9], None, split, xy[9:20])
+    crit = _StandInLoss()
+    primary_prediction = xy[-12:].clone()
+    primary_prediction[:, split[:-1]] = pos[-12:, split[:-1]]
+    assert n_scenes == 1 or float(crit.terms(rel[-12:], xy[9:21] - xy[8:20], split, primary_prediction)[1]) > 0.1
+    # the ranks' scaled losses add up to the single-process loss (mean over all primaries x batch_size + collision sum)
     assert np.allclose(np.sum([ret[r]['losses'] for r in range(world)], axis=0), single, rtol=1e-5)
     if use_buckets:
         assert ret[0]['n_buckets'] >= 2

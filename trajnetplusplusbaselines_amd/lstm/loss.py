@@ -109,15 +109,20 @@ class PredictionLoss(torch.nn.Module):
         self.col_wt = col_wt
         self.col_distance = col_distance
 
-    def forward(self, inputs, targets, batch_split, positions=None):
+    def terms(self, inputs, targets, batch_split, positions=None):
+        """(mean term, sum term or None): the primaries' NLL is a mean over frames x scenes (:85-91), the collision penalty
+        a sum over scenes added un-normalised (:90) -- scene-sharded training scales the two differently
+        (lstm/train_step.batch_loss)."""
         loss = _primary_loss(0, inputs, targets, batch_split, self.background_rate, self.keep_batch_dim,
                              self.loss_multiplier)
-        if self.keep_batch_dim:
-            return loss
-        if self.col_wt:
-            assert positions is not None, "Prediction positions required to calculate collision loss"
-            return loss + CollisionLoss(positions, batch_split, self.col_wt, self.col_distance) * self.loss_multiplier
-        return loss
+        if self.keep_batch_dim or not self.col_wt:
+            return loss, None
+        assert positions is not None, "Prediction positions required to calculate collision loss"
+        return loss, CollisionLoss(positions, batch_split, self.col_wt, self.col_distance) * self.loss_multiplier
+
+    def forward(self, inputs, targets, batch_split, positions=None):
+        loss, col = self.terms(inputs, targets, batch_split, positions)
+        return loss if col is None else loss + col
 
 
 class L2Loss(torch.nn.Module):
@@ -130,15 +135,18 @@ class L2Loss(torch.nn.Module):
         self.col_wt = col_wt
         self.col_distance = col_distance
 
-    def forward(self, inputs, targets, batch_split, positions=None):
+    def terms(self, inputs, targets, batch_split, positions=None):
+        """(mean term, sum term or None), see PredictionLoss.terms"""
         # MSE over (t, scene, 2 coordinates): the kernel sums the two squared errors, hence the 1/2
         loss = _primary_loss(1, inputs, targets, batch_split, 0.0, self.keep_batch_dim, 0.5 * self.loss_multiplier)
-        if self.keep_batch_dim:
-            return loss
-        if self.col_wt:
-            assert positions is not None, "Prediction positions required to calculate collision loss"
-            return loss + CollisionLoss(positions, batch_split, self.col_wt, self.col_distance) * self.loss_multiplier
-        return loss
+        if self.keep_batch_dim or not self.col_wt:
+            return loss, None
+        assert positions is not None, "Prediction positions required to calculate collision loss"
+        return loss, CollisionLoss(positions, batch_split, self.col_wt, self.col_distance) * self.loss_multiplier
+
+    def forward(self, inputs, targets, batch_split, positions=None):
+        loss, col = self.terms(inputs, targets, batch_split, positions)
+        return loss if col is None else loss + col
 
 
 # ---- S-GAN trainer losses (reference lstm/loss.py:165-208, sgan/trainer.py:371-400) ---------------------------

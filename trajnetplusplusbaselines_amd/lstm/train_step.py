@@ -34,6 +34,13 @@ def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batc
     batch_size = batch_size or n_local
     if obs_dropout:
         start_length = random.randint(0, obs_length - 2)
+        if distributed and torch.distributed.get_world_size(group) > 1:
+            # the reference draws ONE start_length per batch (lstm/trainer.py:246-247): the shards of a batch must be
+            # encoded from the same observation window, whatever the ranks' own `random` streams hold
+            box = [start_length]
+            src = torch.distributed.get_global_rank(group, 0) if group is not None else 0
+            torch.distributed.broadcast_object_list(box, src=src, group=group)
+            start_length = int(box[0])
     if buckets is not None:
         buckets.zero()
     else:
@@ -50,27 +57,25 @@ def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batc
     prediction_truth = batch_scene[obs_length:obs_length + pred_length - 1].clone()
     targets = batch_scene[obs_length:obs_length + pred_length] - batch_scene[obs_length - 1:obs_length + pred_length - 1]
     in_backward = distributed and overlap and hasattr(model, '_grad_reduce_fn')
+    if distributed and n_global_scenes is None and empty:
+        raise ValueError('an empty shard needs n_global_scenes')
+    if distributed:
+        n_global = n_global_scenes if n_global_scenes is not None else n_local * torch.distributed.get_world_size(group)
     if in_backward:
         model._grad_reduce_fn = parallel.GradReducer(group)
-    rel_outputs, outputs = model(observed, batch_scene_goal, split, prediction_truth, pad_to=pad_to)
-    if getattr(criterion, 'col_wt', 0):
-        prim = split[:-1].to(dev)
-        primary_prediction = batch_scene[-pred_length:].clone()
-        primary_prediction[:, prim] = outputs[-pred_length:, prim]
-        loss_mean = criterion(rel_outputs[-pred_length:], targets, split, primary_prediction)
-    else:
-        loss_mean = criterion(rel_outputs[-pred_length:], targets, split)
-    if distributed:
-        if n_global_scenes is None and empty:
-            raise ValueError('an empty shard needs n_global_scenes')
-        n_global = n_global_scenes if n_global_scenes is not None else n_local * torch.distributed.get_world_size(group)
-        loss = parallel.scale_loss_for_sharding(loss_mean, batch_size, n_local, n_global)   # n_local == 0: weight 0
-    else:
-        loss = loss_mean * batch_size
-    loss.backward()
+    try:
+        rel_outputs, outputs = model(observed, batch_scene_goal, split, prediction_truth, pad_to=pad_to)
+        loss = batch_loss(criterion, rel_outputs, outputs, batch_scene, targets, split, pred_length, batch_size,
+                          shard=(n_local, n_global) if distributed else None)
+        loss.backward()
+    finally:
+        if in_backward:
+            # also on an exception (NaN check, out of memory ...): a reducer left attached would all-reduce from inside
+            # the next, unrelated backward pass of this model
+            model._grad_reduce_fn = None              # gradients were summed over the ranks inside the backward pass
     loss_value = loss.detach()
     if in_backward:
-        model._grad_reduce_fn = None                  # gradients were summed over the ranks inside the backward pass
+        pass
     elif buckets is not None:
         buckets.launch_all()
         buckets.wait()
@@ -78,6 +83,34 @@ def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batc
         parallel.allreduce_gradients(list(model.parameters()), group=group)
     optimizer.step()
     return float(loss_value)
+
+
+def batch_loss(criterion, rel_outputs, outputs, batch_scene, targets, split, pred_length, batch_size, shard=None):
+    """The scalar `train_batch` back-propagates.  Single process (``shard`` None): ``criterion(...) * batch_size`` with
+    ``primary_prediction`` handed over when the criterion carries a collision weight (lstm/trainer.py:258-264).
+
+    ``shard = (n_local_scenes, n_global_scenes)``: this rank holds a shard of the batch and gradients are SUM-reduced.
+    The criterion has two kinds of terms: the primaries' NLL / L2 is a MEAN over (frames x scenes) (lstm/loss.py:85-91),
+    so a shard contributes ``mean_local * n_local / n_global``; the collision penalty is a SUM over the scenes
+    (lstm/loss.py:147-161, added un-normalised at :90), so a shard contributes its own sum as it is.  Criteria that
+    expose ``terms()`` (ours do) are scaled term by term; any other criterion is treated as a mean."""
+    dev = rel_outputs.device
+    positions = None
+    if getattr(criterion, 'col_wt', 0):
+        prim = split[:-1].to(dev)
+        positions = batch_scene[-pred_length:].clone()
+        positions[:, prim] = outputs[-pred_length:, prim]
+    args = (rel_outputs[-pred_length:], targets, split) + ((positions,) if positions is not None else ())
+    if shard is None:
+        return criterion(*args) * batch_size
+    n_local, n_global = shard
+    if hasattr(criterion, 'terms'):
+        mean_term, sum_term = criterion.terms(*args)
+        loss = parallel.scale_loss_for_sharding(mean_term, batch_size, n_local, n_global)     # n_local == 0: weight 0
+        if sum_term is not None:
+            loss = loss + sum_term * (batch_size if n_local > 0 else 0.0)
+        return loss
+    return parallel.scale_loss_for_sharding(criterion(*args), batch_size, n_local, n_global)
 
 
 def val_batch(model, criterion, batch_scene, batch_scene_goal, batch_split, obs_length=9, pred_length=12, batch_size=None,
