@@ -291,6 +291,11 @@ def main():
     ap.add_argument('--no-roofline', action='store_true', help='skip the HIP-event roofline leg (used by the PMC child run)')
     ap.add_argument('--no-traffic', action='store_true', help='skip roofline.traffic (two short rocprofv3 PMC child runs at N=1)')
     ap.add_argument('--no-train', action='store_true', help='skip the "training" leg of the default run')
+    ap.add_argument('--scenes', type=int, default=0, help='scenes per GPU instead of the configuration\'s (batch-size sweeps; the '
+                    'headline stays on the configuration\'s own size)')
+    ap.add_argument('--global-scenes', type=int, default=0, help='STRONG scaling: one fixed batch of this many scenes (BASELINE '
+                    'config 3: --config directional --global-scenes 256) sharded over the ranks with parallel.shard_batch')
+    ap.add_argument('--no-sustain', action='store_true', help='skip the sustained-throughput leg (>= 2 s of back-to-back forwards)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -327,8 +332,25 @@ def main():
     if not is_sgan:
         model.kernel_variant = args.variant
         model.sparse_embedding = not args.dense
-    # every rank gets its own shard of scenes (different seed): weak scaling, no data-path collective
-    xy, split = synth.linear_crowd(cfg['scenes'], cfg['agents'], seed=100 + rank)
+    if args.scenes > 0:
+        cfg = dict(cfg, scenes=args.scenes)
+    strong = args.global_scenes > 0
+    if strong:
+        # STRONG scaling (BASELINE config 3 is ONE batch of 256 scenes x 64 agents over 8 GPUs, assembled as one batch by
+        # lstm/trainer.py:96-133): every rank builds the same global batch and keeps its shard of scenes; the shard
+        # carries the batch-wide slot count and scene count (parallel.Shard), total work is fixed as N grows
+        from trajnetplusplusbaselines_amd import parallel
+        gxy, gsplit = synth.linear_crowd(args.global_scenes, cfg['agents'], seed=100)
+        shard = parallel.shard_batch(gxy, torch.zeros(gxy.shape[1], 2), gsplit, rank, world)
+        lo, hi = shard.track_range
+        xy, split = gxy[:, lo:hi].contiguous(), shard.batch_split
+        n_global, pad_to, scenes_local = shard.n_scenes_global, shard.pad_to, shard.n_scenes
+        cfg = dict(cfg, scenes=scenes_local)
+    else:
+        # every rank gets its own shard of scenes (different seed): weak scaling, no data-path collective
+        xy, split = synth.linear_crowd(cfg['scenes'], cfg['agents'], seed=100 + rank)
+        n_global, pad_to, scenes_local = cfg['scenes'] * world, cfg['agents'], cfg['scenes']
+    scenes_total = n_global
     M = xy.shape[1]
     observed = xy[:9].to(device)
     goals = torch.zeros(M, 2, device=device)
@@ -353,8 +375,8 @@ def main():
         scene_dev = xy.to(device)
 
         def step():
-            return train_batch(model, optimizer, criterion, scene_dev, goals, split, 9, 12, batch_size=cfg['scenes'] * world,
-                               n_global_scenes=cfg['scenes'] * world, pad_to=cfg['agents'], overlap=True)
+            return train_batch(model, optimizer, criterion, scene_dev, goals, split, 9, 12, batch_size=n_global,
+                               n_global_scenes=n_global, pad_to=pad_to, overlap=True)
     elif is_sgan:
         truth = xy[9:21].to(device)
 
@@ -362,7 +384,7 @@ def main():
             return model(observed, goals, split, prediction_truth=truth, step_type='g', pred_length=12)
     else:
         def step():
-            return model(observed, goals, split, n_predict=12)
+            return model(observed, goals, split, n_predict=12, pad_to=pad_to)
 
     def barrier():
         if distributed:
@@ -382,6 +404,25 @@ def main():
         if distributed:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- sustained leg: the same forward back to back for >= 2.5 s (the timed region above is a few tens of ms at the
+    #      driver's --steps 20: too short for a 5 s SMI sample to see the GPU busy, and a second, longer measurement of the
+    #      same quantity is a cross-check of `value`) ----
+    sustained = None
+    if not args.train and not args.no_sustain and not args.no_roofline:
+        n_sus = max(args.steps, int(2.5 / max(elapsed / args.steps, 1e-6)) + 1)     # `elapsed` is already the MAX over ranks
+        with torch.no_grad():
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(n_sus):
+                step()
+            barrier()
+            t_s = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if distributed:
+            dist.all_reduce(t_s, op=dist.ReduceOp.MAX)
+        t_s = float(t_s.item())
+        sustained = dict(value=scenes_total * 21 * n_sus / t_s, unit='scene-steps/s', forwards=n_sus, seconds=t_s,
+                         ms_per_step=t_s / n_sus * 1e3)
 
     # ---- training leg: the optimisation step of the same model on the same shard, all-reduce included at N > 1 ----
     training = None
@@ -403,8 +444,8 @@ def main():
             t_steps, t_warm = max(5, min(args.steps, 30)), 3
 
             def tstep():
-                return train_batch(tmodel, optimizer, criterion, scene_dev, goals, split, 9, 12, batch_size=cfg['scenes'] * world,
-                                   n_global_scenes=cfg['scenes'] * world, pad_to=cfg['agents'], buckets=buckets,
+                return train_batch(tmodel, optimizer, criterion, scene_dev, goals, split, 9, 12, batch_size=n_global,
+                                   n_global_scenes=n_global, pad_to=pad_to, buckets=buckets,
                                    overlap=(ar_mode == 'overlap'))
             for _ in range(t_warm):
                 tstep()
@@ -418,17 +459,35 @@ def main():
                 dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
             t_el = float(t_el.item())
             grad_bytes = sum(p.numel() * 4 for p in tmodel.parameters() if p.grad is not None)
-            training = dict(value=cfg['scenes'] * world * 21 * t_steps / t_el, unit='scene-steps/s', steps=t_steps, warmup=t_warm,
+            training = dict(value=scenes_total * 21 * t_steps / t_el, unit='scene-steps/s', steps=t_steps, warmup=t_warm,
                             ms_per_step=t_el / t_steps * 1e3, loss_last=loss_last,
                             workload='Trainer.train_batch of the same model on the same shard: teacher-forced forward, NLL loss, '
                                      'backward, Adam%s' % (' + SUM all-reduce of %.1f MB of fp32 gradients over RCCL (%s)' % (
                                          grad_bytes / 1e6, 'launched from inside the backward pass as each gradient is enqueued, largest first'
                                          if ar_mode == 'overlap' else 'flat buckets after the backward pass') if distributed else ''),
-                            allreduce_bytes=grad_bytes if distributed else 0)
+                            allreduce_bytes=grad_bytes if distributed else 0,
+                            scaling=dict(n=world, mode='strong' if strong else 'weak', global_scenes=scenes_total,
+                                         scenes_this_rank=scenes_local, ms_per_step=t_el / t_steps * 1e3,
+                                         allreduce_bytes=grad_bytes if distributed else 0,
+                                         overlap=(ar_mode if distributed else None)))
             del tmodel, optimizer, buckets
-        except Exception as exc:   # the inference line above is already measured: report the failure instead of losing the run
+        except Exception as exc:   # the inference line above is already measured: report the failure, then exit non-zero
             training = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:300]))
             training_failed = True
+    # a failed leg on ANY rank must be known to all of them before anybody enters another collective: agree through the
+    # rendezvous store (TCP, independent of RCCL), not through the process group a failed collective may have broken
+    any_failed = training_failed
+    if distributed:
+        try:
+            store = dist.distributed_c10d._get_default_store()
+            store.add('tnp_train_failed', int(training_failed))
+            store.add('tnp_train_done', 1)
+            t_wait = time.time()
+            while int(store.add('tnp_train_done', 0)) < world and time.time() - t_wait < 120:
+                time.sleep(0.05)
+            any_failed = int(store.add('tnp_train_failed', 0)) > 0 or int(store.add('tnp_train_done', 0)) < world
+        except Exception:
+            any_failed = training_failed
 
     with torch.set_grad_enabled(args.train):
         # ---- roofline leg: same region again with HIP events around every launch of the dominant kernel ----
@@ -494,6 +553,30 @@ def main():
                         roof['compulsory_bytes'] = float(N0 * K0 * 4 + M * N0 * 4 +
                                                          (M * 8 + M * model.pool.pooling_dim * 4 if sparse else M * K0 * 4))
 
+    # ---- whole-step roofline: how far the DESIGN (four launches per recurrent step) is from the chip, not only its
+    #      dominant kernel: algorithmic FLOPs of every kernel of a step over the measured step time ----
+    step_roof = None
+    if rank == 0 and not args.train and not is_sgan and model.pool is not None and hasattr(model.pool, 'embedding_layers'):
+        C = model.pool.pooling_dim
+        layers = model.pool.embedding_layers()
+        dims = [layers[0].weight.shape[1]] + [l.weight.shape[0] for l in layers]
+        sparse = bool(model.sparse_embedding and cfg['type_'] == 'social')
+        k = {}
+        k['first_embedding_layer'] = (2.0 * M * (cfg['agents'] - 1) * C * dims[1]) if sparse else 2.0 * M * dims[0] * dims[1]
+        k['other_embedding_layers'] = sum(2.0 * M * dims[i] * dims[i + 1] for i in range(1, len(dims) - 1))
+        k['lstm_gates'] = 2.0 * M * (model.encoder.weight_ih.shape[1] + model.hidden_dim) * 4 * model.hidden_dim
+        k['track_prepare'] = 2.0 * M * model.hidden_dim * (5 + (C if cfg['type_'] == 'social' else 0)) + 2.0 * M * 2 * 62
+        per_step = sum(k.values())
+        t_step = elapsed / args.steps / 19.0                             # every rank runs its own shard concurrently
+        step_roof = dict(flops_per_recurrent_step=per_step, gflop_by_kernel={n: v / 1e9 for n, v in k.items()},
+                         us_per_recurrent_step=t_step * 1e6, achieved=per_step / t_step / 1e12, peak=FP32_MFMA_PEAK_TFLOPS,
+                         unit='TFLOP/s', frac=per_step / t_step / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         note='sum of the algorithmic FLOPs of the launches of one recurrent step (first layer: %s) over the '
+                              'measured time of a step, per GPU' % ('gather bound 2*M*(A-1)*C*N1' if sparse else 'dense GEMM'))
+        if sparse and roof is not None and 'hits_per_launch' in roof:
+            on_hits = per_step - k['first_embedding_layer'] + 2.0 * roof['hits_per_launch'] * C * dims[1]
+            step_roof['frac_on_hits'] = on_hits / t_step / 1e12 / FP32_MFMA_PEAK_TFLOPS
+
     if args.train and is_sgan:
         workload_mode = 'S-GAN training: one discriminator step + one generator step (k=3, Adam)'
     elif args.train:
@@ -503,7 +586,6 @@ def main():
     else:
         workload_mode = 'inference forward (LSTM.forward, n_predict=12)'
     if rank == 0:
-        scenes_total = cfg['scenes'] * world
         value = scenes_total * 21 * args.steps / elapsed
         out = {
             'metric': 'scene-steps/sec (9 obs + 12 pred)',
@@ -514,19 +596,23 @@ def main():
             'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': '%s, %d scenes x %d agents x (9 obs + 12 pred) per GPU, %s' % (
-                           cfg['name'], cfg['scenes'], cfg['agents'], workload_mode),
-                       'scenes_per_gpu': cfg['scenes'], 'agents_per_scene': cfg['agents'],
+            'config': {'workload': ('%s, ONE batch of %d scenes x %d agents x (9 obs + 12 pred) sharded over %d GPU(s), %s' % (
+                                        cfg['name'], scenes_total, cfg['agents'], world, workload_mode) if strong else
+                                    '%s, %d scenes x %d agents x (9 obs + 12 pred) per GPU, %s' % (
+                                        cfg['name'], cfg['scenes'], cfg['agents'], workload_mode)),
+                       'scenes_per_gpu': cfg['scenes'], 'global_scenes': scenes_total, 'agents_per_scene': cfg['agents'],
                        'mode': 'training step (fwd + bwd + Adam%s)' % (' + gradient all-reduce' if world > 1 else '') if args.train else 'inference forward',
                        'recurrent_steps_per_forward': (3 * 19 + 2 * 20) if is_sgan else 19, 'parallelism': 'dp%d (scene sharding)' % world,
                        'kernel_variant': args.variant,
                        'first_embedding_layer': 'dense mfma' if args.dense else 'sparse gather (social) / dense mfma'},
             'recurrent_scene_steps_per_s': scenes_total * ((3 * 19 + 2 * 20) if is_sgan else 19) * args.steps / elapsed,
             'roofline': roof,
+            'step_roofline': step_roof,
+            'sustained': sustained,
             'training': training,
         }
         if world == 1 and not args.no_cpu_baseline and not is_sgan:
@@ -534,10 +620,13 @@ def main():
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))
+    if any_failed:
+        # a failed leg is a failed run: non-zero exit status on every rank (the JSON line above still carries what was
+        # measured and `training.error`); a failed collective leaves the group unusable, so nobody waits on it
+        sys.stdout.flush()
+        sys.stderr.write('bench.py: the training leg failed on at least one rank\n')
+        os._exit(3)
     if distributed:
-        if training_failed:   # a failed collective leaves the group unusable: do not wait on it
-            sys.stdout.flush()
-            os._exit(0)
         dist.barrier()   # rank 0 ran the roofline / cpu_baseline legs; leave together
         dist.destroy_process_group()
 

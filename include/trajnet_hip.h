@@ -500,15 +500,8 @@ TNP_API int tnp_collision_loss_backward(const float *predictions, int ld, const 
                                 int M, float col_wt, float col_distance, const float *grad_out, float *d_predictions,
                                 void *stream);
 
-/* -------------------------------------------------------------------------------------------
- * Kernel timing hook for bench.py's roofline leg: when enabled, every launch of the dominant
- * kernel class (`which`: 0 = first pooling-embedding GEMM, 1 = all GEMM launches) on `stream`
- * is bracketed by hipEvents; tnp_profile_read synchronises those events and returns the summed
- * milliseconds and the launch count since tnp_profile_begin.
- * ----------------------------------------------------------------------------------------- */
-TNP_API int tnp_profile_begin(int which);
-TNP_API int tnp_profile_read(double *total_ms, int *launches);
-TNP_API int tnp_profile_end(void);
+/* Measurement hooks (bench.py's roofline leg) are declared in trajnet_hip_profile.h: they are not part of the drop-in
+ * boundary. */
 
 /* -------------------------------------------------------------------------------------------
  * classical.constant_velocity.predict (classical/constant_velocity.py:4-20), batched:

@@ -1,0 +1,30 @@
+/*
+ * trajnet_hip_profile.h -- MEASUREMENT hooks of libtrajnet_hip.so.  Not part of the drop-in boundary (trajnet_hip.h):
+ * the reference has no counterpart, no caller of the reference's API needs them; bench.py's roofline leg is the only
+ * user.  Plain C99 like the main header.
+ */
+#ifndef TRAJNET_HIP_PROFILE_H
+#define TRAJNET_HIP_PROFILE_H
+
+#include "trajnet_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* -------------------------------------------------------------------------------------------
+ * Kernel timing hook: when enabled, every launch of the chosen kernel class (`which`: 0 = first
+ * pooling-embedding layer -- the sparse kernel or the dense GEMM --, 1 = all GEMM launches) is
+ * bracketed by hipEvents recorded on the stream the kernel is launched on; tnp_profile_read
+ * synchronises those events and returns the summed milliseconds and the launch count since
+ * tnp_profile_begin (at most 32768 launches are recorded, later ones are not timed).
+ * ----------------------------------------------------------------------------------------- */
+TNP_API int tnp_profile_begin(int which);
+TNP_API int tnp_profile_read(double *total_ms, int *launches);
+TNP_API int tnp_profile_end(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* TRAJNET_HIP_PROFILE_H */

@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 #include "trajnet_hip.h"
+#include "trajnet_hip_profile.h"
 
 int main(void) {
     tnp_lstm_model m;

@@ -10,6 +10,7 @@
 #include <vector>
 #include <algorithm>
 #include <random>
+#define TNP_EXPERIMENT_HOOKS 1   // compiles the timing ablations / clock stamps of the product kernels
 #include "pool_embed_sparse.hip"
 
 namespace tnp { void set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); } }
@@ -170,6 +171,65 @@ int main(int argc, char **argv) {
                     }
                 }
                 printf("   %-36s %d of %d repeats differ from the first\n", t.name, bad, reps - 1);
+            }
+        }
+        {   // wide register-accumulator kernels (round 3): 8 waves, 128 accumulators per lane
+            std::vector<float> refq(got);                                           // output of the quad-major 64 x 128 kernel
+            CK(hipMemset(out, 0, got.size() * 4));
+            time_kernel(KQ(0), b, nb, tnp::ra_smem_bytes(ncell), 1, 1024);
+            CK(hipMemcpy(refq.data(), out, refq.size() * 4, hipMemcpyDeviceToHost));
+#define KW1(abl) (kern_t)tnp::pool_embed_regwide_kernel<16, 128, 1, abl>
+#define KW2(abl) (kern_t)tnp::pool_embed_regwide_kernel<16, 64, 2, abl>
+            struct WV { const char *name; kern_t k; int TE, OB; };
+            const WV wv[] = {{"wide 128x64", KW1(0), 128, 64}, {"wide 128x64 no weight loads", KW1(1), 128, 64}, {"wide 128x64 no hits", KW1(2), 128, 64},
+                             {"wide 128x64 no w, no row loads (5)", KW1(5), 128, 64}, {"wide 128x64 no w, fixed acc index (9)", KW1(9), 128, 64},
+                             {"wide 128x64 no w, no FMAs (65)", KW1(65), 128, 64}, {"wide 128x64 no w, no rows, fixed idx (13)", KW1(13), 128, 64},
+                             {"wide 128x64 no w, no rows/idx/FMA (77)", KW1(77), 128, 64},
+                             {"wide 128x64 no cell loop", KW1(16), 128, 64}, {"wide 128x64 no loop, no votes", KW1(48), 128, 64},
+                             {"wide 128x64 no loop, no epilogue", KW1(144), 128, 64}, {"wide 128x64 nothing (176)", KW1(176), 128, 64},
+                             {"wide 64x128 2 columns / lane", KW2(0), 64, 128}, {"wide 64x128 no weight loads", KW2(1), 64, 128},
+                             {"wide 64x128 no hits", KW2(2), 64, 128},
+                             {"wide 64x128 no w, no row loads (5)", KW2(5), 64, 128}, {"wide 64x128 no w, fixed acc index (9)", KW2(9), 64, 128},
+                             {"wide 64x128 no w, no FMAs (65)", KW2(65), 64, 128}, {"wide 64x128 no w, no rows/idx/FMA (77)", KW2(77), 64, 128}, {"wide 64x128 no cell loop", KW2(16), 64, 128},
+                             {"wide 64x128 no loop, no votes", KW2(48), 64, 128}, {"wide 64x128 nothing (176)", KW2(176), 64, 128}};
+            for (const WV &v : wv) {
+                tnp::SparseArgs w = b; w.ego_tiles = M / v.TE; w.out_blocks = N1 / v.OB;
+                const size_t sm = tnp::rw_smem_bytes(ncell, v.TE, v.OB);
+                CK(hipMemset(out, 0, got.size() * 4));
+                printf("%-42s %8.2f us\n", v.name, time_kernel(v.k, w, w.ego_tiles * w.out_blocks, sm, 50, 512));
+                if (v.k == KW1(0) || v.k == KW2(0)) {
+                    CK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
+                    check(got, v.name);
+                    printf("   bit-identical to the 64 x 128 kernel: %s\n", memcmp(got.data(), refq.data(), got.size() * 4) ? "NO" : "yes");
+                    int bad = 0;
+                    std::vector<float> again(got.size());
+                    for (int rep = 0; rep < 20; ++rep) {
+                        CK(hipMemsetAsync(out, 0xff, got.size() * 4));
+                        hipLaunchKernelGGL(v.k, dim3(w.ego_tiles * w.out_blocks), dim3(512), sm, 0, w);
+                        CK(hipMemcpy(again.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
+                        bad += memcmp(again.data(), got.data(), got.size() * 4) != 0;
+                    }
+                    printf("   %d of 20 repeats differ\n", bad);
+                    // phase stamps
+                    long long *dbgw; CK(hipMalloc(&dbgw, (size_t)w.ego_tiles * w.out_blocks * 16 * 8 * 8));
+                    CK(hipMemset(dbgw, 0, (size_t)w.ego_tiles * w.out_blocks * 16 * 8 * 8));
+                    tnp::SparseArgs ws = w; ws.winners = reinterpret_cast<const int16_t *>(dbgw);
+                    kern_t ks = v.k == KW1(0) ? KW1(256) : KW2(256);
+                    time_kernel(ks, ws, w.ego_tiles * w.out_blocks, sm, 3, 512);
+                    const int nbw = w.ego_tiles * w.out_blocks;
+                    std::vector<long long> hh((size_t)nbw * 16 * 8); CK(hipMemcpy(hh.data(), dbgw, hh.size() * 8, hipMemcpyDeviceToHost));
+                    const char *names[] = {"init + geometry", "votes", "winners_out", "main loop", "epilogue"};
+                    for (int ph = 0; ph < 5; ++ph) {
+                        double mn = 0, mx = 0;
+                        for (int wg = 0; wg < nbw; ++wg) {
+                            long long lo = 1ll << 62, hi = 0;
+                            for (int x = 0; x < 8; ++x) { const long long d = hh[((size_t)wg * 16 + x) * 8 + ph + 1] - hh[((size_t)wg * 16 + x) * 8 + ph]; lo = std::min(lo, d); hi = std::max(hi, d); }
+                            mn += lo; mx += hi;
+                        }
+                        printf("   phase %-16s clocks per wave: min %8.0f max %8.0f (mean over workgroups; 100 MHz units x clock ratio)\n", names[ph], mn / nbw, mx / nbw);
+                    }
+                    CK(hipFree(dbgw));
+                }
             }
         }
         long long *dbg; CK(hipMalloc(&dbg, (size_t)nb * 16 * 8 * 8)); CK(hipMemset(dbg, 0, (size_t)nb * 16 * 8 * 8));

@@ -52,10 +52,14 @@ _LIB = None
 
 
 def exported_symbols_in_header():
-    """Names of every entry point include/trajnet_hip.h declares (used by the ABI test)."""
+    """Names of every entry point the headers under include/ declare (trajnet_hip.h = the drop-in boundary,
+    trajnet_hip_profile.h = the measurement hooks; used by the ABI test)."""
+    import glob
     import re
-    with open(HEADER_PATH) as f:
-        text = f.read()
+    text = ''
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(HEADER_PATH), '*.h'))):
+        with open(path) as f:
+            text += f.read()
     return sorted(set(re.findall(r'TNP_API\s+[\w\s\*]+?\b(tnp_\w+)\s*\(', text)))
 
 

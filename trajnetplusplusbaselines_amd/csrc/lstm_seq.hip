@@ -29,7 +29,7 @@ void set_error(const char *fmt, ...) {
 
 // ---- profiling hook (bench.py roofline leg) -------------------------------------------------
 static int g_prof_cls = -1;
-static const int PROF_MAX = 4096;
+static const int PROF_MAX = 32768;
 static hipEvent_t g_prof_ev[2 * PROF_MAX];
 static int g_prof_n = 0, g_prof_created = 0;
 void prof_before(int cls, hipStream_t s) {
@@ -550,7 +550,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
             fg.winners_out = w.save_winners ? w.winners : nullptr;
             rc = launch_pool_embed_sparse(w.winners, w.enc, md->C, w.row_base, md->Wp0_cell_major, md->bp[0], M,
                                           md->n * md->n, md->C, md->dims[1], 1, dst, ldo, w.partial, s,
-                                          fused_grid ? &fg : nullptr, md->Wp0_quad_major);
+                                          fused_grid ? &fg : nullptr, md->Wp0_quad_major, (md->variant >> 18) & 3);
             prof_after(PROF_GEMM1, s);
             if (rc) return rc;
             src = dst; lds = ldo; l0 = 1;

@@ -52,9 +52,9 @@ class LSTM(torch.nn.Module):
         # parameter containers only (weight_ih [4H, I], weight_hh [4H, H], gate order i,f,g,o); the cell itself
         # is the fused gates GEMM + pointwise epilogue of csrc/gemm_f32_mfma.hip
         self.encoder = torch.nn.LSTMCell(self.embedding_dim + goal_rep_dim + pooling_dim, self.hidden_dim)
-        self.decoder = torch.nn.LSTMCell(self.embedding_dim + goal_rep_dim + pooling_dim, self.hidden_dim)
-
-        self.hidden2normal = Hidden2Normal(self.hidden_dim)
+        if not self._ENCODER_ONLY:
+            self.decoder = torch.nn.LSTMCell(self.embedding_dim + goal_rep_dim + pooling_dim, self.hidden_dim)
+            self.hidden2normal = Hidden2Normal(self.hidden_dim)
 
         #: kernel-variant selector forwarded to the C ABI (0 = defaults), see DESIGN.md
         self.kernel_variant = 0
@@ -64,6 +64,10 @@ class LSTM(torch.nn.Module):
         self._grad_reduce_fn = None   # data-parallel training: parallel.GradReducer, see lstm/train_step.py
         self._cell_major = None  # (key, tensor): cell-major copy of pool.embedding[0].weight
         self._quad_major = None  # (key, tensor): its quad-major copy (register-accumulator sparse kernel)
+
+    #: subclasses that only run the encoder (the S-GAN discriminator) construct neither decoder nor Hidden2Normal, so that
+    #: they draw their parameters from the RNG in the reference's order (same seed => same weights)
+    _ENCODER_ONLY = False
 
     # device-side caches (workspace, re-laid-out weight copies): rebuilt lazily, never pickled / deep-copied
     _CACHES = ('_ws', '_cell_major', '_quad_major', '_dummy_head', '_grad_reduce_fn')

@@ -108,13 +108,14 @@ def _scene_local(pool):
 
 
 class LSTMDiscriminator(LSTM):
+    _ENCODER_ONLY = True
+
     def __init__(self, embedding_dim=64, hidden_dim=128, pool=None, pool_to_input=True, goal_dim=None, goal_flag=False):
-        """Arguments as in reference sgan/sgan.py:402-446.  Only `encoder` is used; the unused decoder / hidden2normal
-        parameters of the base class are removed so that the state_dict matches the reference."""
+        """Arguments as in reference sgan/sgan.py:402-446.  Only `encoder` is used: the base class constructs neither decoder
+        nor hidden2normal here, so the state_dict AND the order in which parameters are drawn from the RNG match the
+        reference (a seeded default init gives the reference's weights, tests/golden/sgan_full.npz)."""
         super(LSTMDiscriminator, self).__init__(embedding_dim=embedding_dim, hidden_dim=hidden_dim, pool=pool,
                                                 pool_to_input=pool_to_input, goal_dim=goal_dim, goal_flag=goal_flag)
-        del self.decoder
-        del self.hidden2normal
         self.real_classifier = make_mlp([self.hidden_dim, int(self.hidden_dim / 2), int(self.hidden_dim / 4), 1])
         self._dummy_head = None
 
