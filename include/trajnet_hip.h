@@ -500,6 +500,24 @@ TNP_API int tnp_collision_loss_backward(const float *predictions, int ld, const 
                                 int M, float col_wt, float col_distance, const float *grad_out, float *d_predictions,
                                 void *stream);
 
+/* -------------------------------------------------------------------------------------------
+ * Optimiser step of the reference's trainer (lstm/trainer.py:497, sgan/trainer.py:540-546:
+ * torch.optim.Adam(params, lr, weight_decay), amsgrad off): ONE launch over all parameter tensors
+ * instead of torch's nine per-operation multi-tensor launches; same single-tensor formulas,
+ * one rounding per torch operation.  Tensors whose gradient is None are simply not listed (torch
+ * skips them, weight decay included).  `tensors` is a HOST array of device pointers; `step` is the
+ * 1-based step count AFTER the increment, as in torch's state['step'].
+ * ----------------------------------------------------------------------------------------- */
+typedef struct tnp_adam_tensor {
+    float *param;          /* [n] updated in place */
+    const float *grad;     /* [n] */
+    float *exp_avg;        /* [n] first moment, updated in place */
+    float *exp_avg_sq;     /* [n] second moment, updated in place */
+    int64_t n;
+} tnp_adam_tensor;
+TNP_API int tnp_adam_step(const tnp_adam_tensor *tensors, int n_tensors, int step, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, void *stream);
+
 /* Measurement hooks (bench.py's roofline leg) are declared in trajnet_hip_profile.h: they are not part of the drop-in
  * boundary. */
 

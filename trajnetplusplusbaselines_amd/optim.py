@@ -1,0 +1,58 @@
+"""Adam as the reference's trainers construct it (``torch.optim.Adam(model.parameters(), lr=..., weight_decay=...)``,
+lstm/trainer.py:497, sgan/trainer.py:540-546) with the update executed by ONE native launch (csrc/optim.hip,
+``tnp_adam_step``) instead of torch's nine per-operation multi-tensor kernels.
+
+Same constructor arguments, ``state_dict`` layout (``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter) and semantics as
+``torch.optim.Adam`` with ``amsgrad=False, maximize=False``: parameters whose ``.grad`` is None are skipped, weight decay
+included; a checkpoint written by either optimiser loads into the other."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class AdamTensor(ctypes.Structure):
+    """mirror of ``struct tnp_adam_tensor`` (include/trajnet_hip.h)"""
+    _fields_ = [('param', ctypes.c_void_p), ('grad', ctypes.c_void_p), ('exp_avg', ctypes.c_void_p),
+                ('exp_avg_sq', ctypes.c_void_p), ('n', ctypes.c_int64)]
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError('invalid Adam hyper-parameters')
+        super(Adam, self).__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.lib()
+        for group in self.param_groups:
+            by_step = {}
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                _lib.require_device(p, 'parameter')
+                if p.dtype != torch.float32 or not p.is_contiguous() or p.grad.is_sparse:
+                    raise RuntimeError('tnp Adam: float32 contiguous dense parameters only')
+                state = self.state[p]
+                if len(state) == 0:
+                    state['step'] = torch.tensor(0.0, dtype=torch.float32)            # host tensor, like torch's default
+                    state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state['step'] += 1
+                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                by_step.setdefault((int(state['step']), p.device), []).append((p, grad, state['exp_avg'], state['exp_avg_sq']))
+            for (step, dev), items in by_step.items():
+                table = (AdamTensor * len(items))()
+                for i, (p, g, m, v) in enumerate(items):
+                    table[i] = AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
+                with torch.cuda.device(dev):
+                    _lib.check(L.tnp_adam_step(table, len(items), step, float(group['lr']), float(group['betas'][0]),
+                                               float(group['betas'][1]), float(group['eps']), float(group['weight_decay']),
+                                               _lib.stream_ptr()), 'tnp_adam_step')
+        return loss
