@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from trajnetplusplusbaselines_amd import _lib, synth  # noqa: E402
+from trajnetplusplusbaselines_amd import _lib, optim, synth  # noqa: E402
 from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling  # noqa: E402
 
 CONFIGS = {
@@ -48,6 +48,13 @@ CONFIGS['classical'] = dict(classical=True, scenes=4096, agents=128,
                             name='classical.socialforce + ORCA + Kalman batched rollouts (BASELINE config 5)')
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 FP64_VALU_PEAK_TFLOPS = 157.3 / 2   # fp64 vector FMA issues at half the fp32 vector rate (= the 78.6 TFLOP/s of AMD's datasheet)
+
+
+def make_adam(params):
+    """Adam(lr 1e-3, weight_decay 1e-4) as the reference's trainers construct it (lstm/trainer.py:497): the native
+    one-launch update (optim.Adam = tnp_adam_step) unless TNP_BENCH_TORCH_ADAM=1 asks for torch's foreach kernels."""
+    cls = torch.optim.Adam if os.environ.get('TNP_BENCH_TORCH_ADAM') == '1' else optim.Adam
+    return cls(params, lr=1e-3, weight_decay=1e-4)
 
 
 def build_model(cfg, device):
@@ -359,8 +366,8 @@ def main():
         # one discriminator step + one generator step (g_steps = d_steps = 1, sgan/trainer.py:119-135, 258-300)
         from trajnetplusplusbaselines_amd.lstm import PredictionLoss
         from trajnetplusplusbaselines_amd.sgan.train_step import train_batch as sgan_train_batch
-        g_opt = torch.optim.Adam(model.generator.parameters(), lr=1e-3, weight_decay=1e-4)
-        d_opt = torch.optim.Adam(model.discriminator.parameters(), lr=1e-3, weight_decay=1e-4)
+        g_opt = make_adam(model.generator.parameters())
+        d_opt = make_adam(model.discriminator.parameters())
         criterion = PredictionLoss(keep_batch_dim=True)
         scene_dev = xy.to(device)
 
@@ -370,7 +377,7 @@ def main():
     elif args.train:
         from trajnetplusplusbaselines_amd.lstm import PredictionLoss
         from trajnetplusplusbaselines_amd.lstm.train_step import train_batch
-        optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)   # lstm/trainer.py:497
+        optimizer = make_adam(model.parameters())   # lstm/trainer.py:497
         criterion = PredictionLoss()
         scene_dev = xy.to(device)
 
@@ -434,7 +441,7 @@ def main():
             from trajnetplusplusbaselines_amd.lstm.train_step import train_batch
             tmodel = build_model(cfg, device)                     # same seed on every rank: replicas start identical
             tmodel.kernel_variant = args.variant
-            optimizer = torch.optim.Adam(tmodel.parameters(), lr=1e-3, weight_decay=1e-4)   # lstm/trainer.py:497
+            optimizer = make_adam(tmodel.parameters())   # lstm/trainer.py:497
             # gradient all-reduce: 'overlap' (default) = from inside the backward pass, each gradient as soon as it is enqueued
             # (parallel.GradReducer); 'buckets' = flat persistent buckets launched asynchronously after the backward pass
             ar_mode = os.environ.get('TNP_BENCH_ALLREDUCE', 'overlap')
@@ -462,7 +469,7 @@ def main():
             training = dict(value=scenes_total * 21 * t_steps / t_el, unit='scene-steps/s', steps=t_steps, warmup=t_warm,
                             ms_per_step=t_el / t_steps * 1e3, loss_last=loss_last,
                             workload='Trainer.train_batch of the same model on the same shard: teacher-forced forward, NLL loss, '
-                                     'backward, Adam%s' % (' + SUM all-reduce of %.1f MB of fp32 gradients over RCCL (%s)' % (
+                                     'backward, Adam (' + type(optimizer).__module__ + ')%s' % (' + SUM all-reduce of %.1f MB of fp32 gradients over RCCL (%s)' % (
                                          grad_bytes / 1e6, 'launched from inside the backward pass as each gradient is enqueued, largest first'
                                          if ar_mode == 'overlap' else 'flat buckets after the backward pass') if distributed else ''),
                             allreduce_bytes=grad_bytes if distributed else 0,

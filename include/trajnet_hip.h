@@ -506,7 +506,8 @@ TNP_API int tnp_collision_loss_backward(const float *predictions, int ld, const 
  * instead of torch's nine per-operation multi-tensor launches; same single-tensor formulas,
  * one rounding per torch operation.  Tensors whose gradient is None are simply not listed (torch
  * skips them, weight decay included).  `tensors` is a HOST array of device pointers; `step` is the
- * 1-based step count AFTER the increment, as in torch's state['step'].
+ * 1-based step count AFTER the increment, as in torch's state['step'].  Hyper-parameters are doubles, as torch holds
+ * them (python floats): 1 - beta2 formed from a float32 beta2 would already differ from torch's by 1.3e-5 relative.
  * ----------------------------------------------------------------------------------------- */
 typedef struct tnp_adam_tensor {
     float *param;          /* [n] updated in place */
@@ -515,8 +516,8 @@ typedef struct tnp_adam_tensor {
     float *exp_avg_sq;     /* [n] second moment, updated in place */
     int64_t n;
 } tnp_adam_tensor;
-TNP_API int tnp_adam_step(const tnp_adam_tensor *tensors, int n_tensors, int step, float lr, float beta1, float beta2,
-                          float eps, float weight_decay, void *stream);
+TNP_API int tnp_adam_step(const tnp_adam_tensor *tensors, int n_tensors, int step, double lr, double beta1, double beta2,
+                          double eps, double weight_decay, void *stream);
 
 /* Measurement hooks (bench.py's roofline leg) are declared in trajnet_hip_profile.h: they are not part of the drop-in
  * boundary. */

@@ -28,8 +28,9 @@ ORC_API void orc_sf_rollout(const double *state0, const int32_t *scene_start, in
 #pragma omp parallel for schedule(dynamic, 1)
     for (int s = 0; s < B; ++s) {
         const int lo = scene_start[s], ns = scene_start[s + 1] - lo;
-        double *st = (double *)malloc(sizeof(double) * (size_t)ns * 10);
+        double *st = (double *)malloc(sizeof(double) * (size_t)ns * 10 + sizeof(sf_agent_terms) * (size_t)ns);
         double *nv = st + (size_t)ns * 7, *isp = nv + (size_t)ns * 2;
+        sf_agent_terms *terms = (sf_agent_terms *)(isp + ns);
         for (int a = 0; a < ns; ++a) {
             for (int k = 0; k < 6; ++k) st[a * 7 + k] = state0[(size_t)(lo + a) * 6 + k];
             st[a * 7 + 6] = tau;
@@ -37,7 +38,8 @@ ORC_API void orc_sf_rollout(const double *state0, const int32_t *scene_start, in
         }
         int n_out = 0;
         for (int step = 0; step < n_steps; ++step) {
-            for (int a = 0; a < ns; ++a) sf_agent_step(a, ns, st, isp[a], 1.3 * isp[a], &p, &nv[2 * a], &nv[2 * a + 1]);
+            for (int a = 0; a < ns; ++a) sf_terms(st + a * 7, &p, &terms[a]);
+            for (int a = 0; a < ns; ++a) sf_agent_step_terms(a, ns, st, terms, isp[a], 1.3 * isp[a], &p, &nv[2 * a], &nv[2 * a + 1]);
             for (int a = 0; a < ns; ++a) {
                 st[a * 7 + 0] += nv[2 * a] * delta_t; st[a * 7 + 1] += nv[2 * a + 1] * delta_t;
                 st[a * 7 + 2] = nv[2 * a]; st[a * 7 + 3] = nv[2 * a + 1];

@@ -297,3 +297,42 @@ def test_config4_full_size_matches_reference():
             assert np.abs(ade - ade_r).max() < 1e-4 and np.abs(fde - fde_r).max() < 1e-4
     assert not np.array_equal(z['npred_pred_prim0'], z['npred_pred_prim1'])      # the k samples differ
     print('sampled neighbour rows beyond 2e-5 (cell-edge flips) per (mode, sample):', flips)
+
+
+def test_sgan_generator_with_nongrid_pool_trains_like_the_reference():
+    """The reference's S-GAN accepts any interaction module (sgan/sgan.py:135-153).  Generator = NearestNeighborMLP (non-grid),
+    discriminator = directional grid: one generator step and one discriminator step against the reference's autograd
+    (tests/golden/sgan_train_nn.npz, oracle/gen_golden_r3.py) -- losses, scores, every parameter gradient."""
+    import random
+    from trajnetplusplusbaselines_amd.lstm import GridBasedPooling, NearestNeighborMLP, PredictionLoss
+    from trajnetplusplusbaselines_amd.sgan import SGAN, LSTMGenerator, LSTMDiscriminator
+    from trajnetplusplusbaselines_amd.sgan.train_step import loss_criterion
+    z = np.load(os.path.join(helpers.GOLDEN, 'sgan_train_nn.npz'))
+    model = SGAN(generator=LSTMGenerator(pool=NearestNeighborMLP(n=4, out_dim=32), noise_dim=16),
+                 discriminator=LSTMDiscriminator(pool=GridBasedPooling(type_='directional', hidden_dim=128, cell_side=0.6, n=12,
+                                                                       out_dim=64, embedding_arch='one_layer')),
+                 k=2, d_steps=1, g_steps=1)
+    model.load_state_dict({k[3:]: torch.tensor(z[k]) for k in z.files if k.startswith('sd_')})
+    model = model.cuda().train()
+    model.skip_generator_graph_on_d = False
+    xy, split = torch.tensor(z['xy']), torch.tensor(z['split'])
+    goals = torch.zeros(xy.shape[1], 2)
+    targets = (xy[9:21] - xy[8:20]).cuda()
+    for step_type, seed in (('g', 47), ('d', 48)):
+        model.zero_grad()
+        torch.manual_seed(seed)
+        random.seed(9)
+        rel, outs, s_real, s_fake = model(xy[:9].clone(), goals, split, xy[9:21].clone(), step_type=step_type, pred_length=12)
+        np.testing.assert_allclose(s_real.detach().cpu().numpy(), z[step_type + '_scores_real'], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(s_fake.detach().cpu().numpy(), z[step_type + '_scores_fake'], rtol=2e-4, atol=2e-5)
+        loss = loss_criterion(model, PredictionLoss(keep_batch_dim=True), rel, targets, split, s_fake, s_real, step_type)
+        np.testing.assert_allclose(float(loss.detach()), float(z[step_type + '_loss']), rtol=5e-5)
+        loss.backward()
+        for name, p in model.named_parameters():
+            want = z[step_type + '_grad_' + name]
+            if p.grad is None:
+                assert not np.any(want), (step_type, name)
+                continue
+            scale = max(1e-6, float(np.abs(want).max()))
+            err = float(np.abs(p.grad.cpu().numpy() - want).max()) / scale
+            assert err < 2e-3, '%s step, %s: relative error %.2e (scale %.2e)' % (step_type, name, err, scale)

@@ -98,8 +98,8 @@ def lib():
     L.tnp_lstm_backward_sweep.argtypes = [_fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_size_t, _fp]
     L.tnp_lstm_step.argtypes = [ctypes.POINTER(LstmModel), ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
                                 ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, ctypes.c_size_t, _fp]
-    L.tnp_adam_step.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                                ctypes.c_float, _fp]
+    L.tnp_adam_step.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                ctypes.c_double, _fp]
     L.tnp_profile_begin.argtypes = [ctypes.c_int]
     L.tnp_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     L.tnp_constant_velocity.argtypes = [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp]

@@ -20,23 +20,26 @@ __global__ void __launch_bounds__(256) sf_rollout_kernel(const double *state0, c
     double *st = sfs;                    // [ns][7]
     double *nv = st + (size_t)ns * 7;    // [ns][2]
     double *isp = nv + (size_t)ns * 2;   // [ns] initial speeds
+    sf_agent_terms *terms = reinterpret_cast<sf_agent_terms *>(isp + ns);   // [ns] per-agent terms of the current state
     for (int a = threadIdx.x; a < ns; a += blockDim.x) {
         const double *src = state0 + (size_t)(lo + a) * 6;
         for (int k = 0; k < 6; ++k) st[a * 7 + k] = src[k];
         st[a * 7 + 6] = tau;
         isp[a] = sqrt(src[2] * src[2] + src[3] * src[3]);
+        sf_terms(st + a * 7, &prm, &terms[a]);
     }
     __syncthreads();
     int n_out = 0;
     for (int step = 0; step < n_steps; ++step) {
         for (int a = threadIdx.x; a < ns; a += blockDim.x)
-            sf_agent_step(a, ns, st, isp[a], max_speed_mult * isp[a], &prm, &nv[2 * a], &nv[2 * a + 1]);
+            sf_agent_step_terms(a, ns, st, terms, isp[a], max_speed_mult * isp[a], &prm, &nv[2 * a], &nv[2 * a + 1]);
         __syncthreads();
         for (int a = threadIdx.x; a < ns; a += blockDim.x) {
             st[a * 7 + 0] += nv[2 * a] * prm.delta_t;
             st[a * 7 + 1] += nv[2 * a + 1] * prm.delta_t;
             st[a * 7 + 2] = nv[2 * a];
             st[a * 7 + 3] = nv[2 * a + 1];
+            sf_terms(st + a * 7, &prm, &terms[a]);   // direction / d e / d^2 of the NEW state, once per agent instead of per pair
             if (step % sample_every == 0) {   // reference keeps the states after steps 0, 8, 16, ... (socialforce.py:95)
                 out[((size_t)n_out * M + lo + a) * 2 + 0] = st[a * 7 + 0];
                 out[((size_t)n_out * M + lo + a) * 2 + 1] = st[a * 7 + 1];
@@ -124,7 +127,7 @@ extern "C" TNP_API int tnp_sf_rollout(const double *state0, const int32_t *scene
     p.delta_t = delta_t; p.v0 = v0; p.sigma = sigma;
     p.cosphi = cos(200.0 / 2.0 / 180.0 * M_PI);      // FieldOfView(twophi = 200 degrees)
     p.out_of_view = 0.5;
-    const size_t smem = (size_t)n_max * 10 * sizeof(double);
+    const size_t smem = (size_t)n_max * (10 + 6) * sizeof(double);
     if (smem > 160 * 1024) TNP_FAIL(-1, "tnp_sf_rollout: %d agents in one scene exceed the LDS-staged limit", n_max);
     static size_t attr = 0;
     if (smem > attr) {

@@ -32,25 +32,37 @@
  * ========================================================================================== */
 typedef struct { double delta_t, v0, sigma, cosphi, out_of_view; } sf_params;
 
-/* V(r_ab) for the pair (a, b): r = r_a - r_b (+ finite-difference offset), speed and desired direction of b */
-TNP_HD double sf_potential(double rx, double ry, double speed_b, double ebx, double eby, const sf_params *p) {
-    const double n1 = sqrt(rx * rx + ry * ry);
-    const double sx = rx - p->delta_t * speed_b * ebx, sy = ry - p->delta_t * speed_b * eby;
-    const double n2 = sqrt(sx * sx + sy * sy);
+/* Terms of agent b that every pair (a, b) of a simulation step needs and that depend on b's state only: desired direction
+ * e_b, d e_b and d^2 with d = delta_t * |v_b|.  The GPU kernel computes them once per agent and step (LDS table) instead
+ * of once per ordered pair; the products are formed exactly as the per-pair expressions were ((delta_t * speed_b) * e_b),
+ * so hoisting them changes no result bit. */
+typedef struct { double ex, ey, dex, dey, d2, pad; } sf_agent_terms;
+
+TNP_HD void sf_terms(const double *sb /* state row */, const sf_params *p, sf_agent_terms *t) {
+    const double speed_b = sqrt(sb[2] * sb[2] + sb[3] * sb[3]);
+    double gx = sb[4] - sb[0], gy = sb[5] - sb[1];
+    const double gn = sqrt(gx * gx + gy * gy);
+    t->ex = gx / gn; t->ey = gy / gn;
     const double d = p->delta_t * speed_b;
-    const double in_sqrt = (n1 + n2) * (n1 + n2) - d * d;
+    t->dex = d * t->ex; t->dey = d * t->ey; t->d2 = d * d; t->pad = 0.0;
+}
+
+/* V(r_ab) for the pair (a, b): r = r_a - r_b (+ finite-difference offset), b's terms from sf_terms */
+TNP_HD double sf_potential(double rx, double ry, const sf_agent_terms *tb, const sf_params *p) {
+    const double n1 = sqrt(rx * rx + ry * ry);
+    const double sx = rx - tb->dex, sy = ry - tb->dey;
+    const double n2 = sqrt(sx * sx + sy * sy);
+    const double in_sqrt = (n1 + n2) * (n1 + n2) - tb->d2;
     const double b = 0.5 * sqrt(in_sqrt);
     return p->v0 * exp(-b / p->sigma);
 }
 
-/* social force on agent a from the OLD state of all n agents of the scene; returns the new velocity (capped) */
-TNP_HD void sf_agent_step(int a, int n, const double *st /* [n][7] */, double initial_speed, double max_speed,
-                          const sf_params *p, double *vx_new, double *vy_new) {
+/* social force on agent a from the OLD state of all n agents of the scene (terms[b] = sf_terms of that state); returns the
+ * new velocity (capped) */
+TNP_HD void sf_agent_step_terms(int a, int n, const double *st /* [n][7] */, const sf_agent_terms *terms, double initial_speed,
+                                double max_speed, const sf_params *p, double *vx_new, double *vy_new) {
     const double *sa = st + 7 * a;
-    /* desired direction e_a */
-    double dx = sa[4] - sa[0], dy = sa[5] - sa[1];
-    double dn = sqrt(dx * dx + dy * dy);
-    const double eax = dx / dn, eay = dy / dn;
+    const double eax = terms[a].ex, eay = terms[a].ey;   /* desired direction e_a */
     const double tau = sa[6];
     double Fx = 1.0 / tau * (initial_speed * eax - sa[2]);
     double Fy = 1.0 / tau * (initial_speed * eay - sa[3]);
@@ -59,14 +71,11 @@ TNP_HD void sf_agent_step(int a, int n, const double *st /* [n][7] */, double in
     for (int b = 0; b < n; ++b) {
         if (b == a) continue;                          /* diagonal: zero force, zero weight */
         const double *sb = st + 7 * b;
+        const sf_agent_terms *tb = terms + b;
         const double rx = sa[0] - sb[0], ry = sa[1] - sb[1];
-        const double speed_b = sqrt(sb[2] * sb[2] + sb[3] * sb[3]);
-        double gx = sb[4] - sb[0], gy = sb[5] - sb[1];
-        const double gn = sqrt(gx * gx + gy * gy);
-        const double ebx = gx / gn, eby = gy / gn;
-        const double v = sf_potential(rx, ry, speed_b, ebx, eby, p);
-        const double dvdx = (sf_potential(rx + delta, ry, speed_b, ebx, eby, p) - v) / delta;
-        const double dvdy = (sf_potential(rx, ry + delta, speed_b, ebx, eby, p) - v) / delta;
+        const double v = sf_potential(rx, ry, tb, p);
+        const double dvdx = (sf_potential(rx + delta, ry, tb, p) - v) / delta;
+        const double dvdy = (sf_potential(rx, ry + delta, tb, p) - v) / delta;
         const double fx = -1.0 * dvdx, fy = -1.0 * dvdy;     /* f_ab = -grad V */
         /* field of view: e_a . (-f_ab) > |f_ab| cos(phi) */
         const double in_sight = (eax * (-fx) + eay * (-fy)) > sqrt(fx * fx + fy * fy) * p->cosphi;

@@ -432,16 +432,19 @@ __global__ void __launch_bounds__(256) hits_transpose_kernel(const T *__restrict
 
 // compact list of a cell's hits in ascending row order, per segment of `seg` rows (one segment = the whole sweep for the
 // weight gradient, one step for the ego lists): list[c][y*seg + k] = (ego row, entry), count[c*nseg + y]
-__global__ void __launch_bounds__(256) hits_compact_kernel(const int32_t *__restrict__ hit_t, int R, int seg,
-                                                           int2 *__restrict__ list, int32_t *__restrict__ count) {
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) hits_compact_kernel(const int32_t *__restrict__ hit_t, int R, int seg,
+                                                               int2 *__restrict__ list, int32_t *__restrict__ count) {
     // Two passes without a barrier inside the loops (the first version synchronised the workgroup twice per 256 rows: 152
-    // round trips for the whole-sweep list): each wave owns a contiguous quarter of the segment, counts its hits, the four
-    // counts are exchanged once, and the second pass writes the wave's hits behind those of the waves before it.
-    __shared__ int wcnt[4];
+    // round trips for the whole-sweep list): each of the NW waves owns a contiguous slice of the segment, counts its hits,
+    // the counts are exchanged once, and the second pass writes the wave's hits behind those of the waves before it.
+    // NW = 16 for the whole-sweep list (one segment of 19 * M rows per cell: 42 -> 14 us with four times the waves per
+    // cell), 4 for the per-step ego lists (19 short segments per cell).
+    __shared__ int wcnt[NW];
     const int c = blockIdx.x, y = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t *src = hit_t + (size_t)c * R + (size_t)y * seg;
     int2 *dst = list + (size_t)c * R + (size_t)y * seg;
-    const int per = ((seg + 255) / 256) * 64;                 // rows per wave, a multiple of 64
+    const int per = ((seg + 64 * NW - 1) / (64 * NW)) * 64;   // rows per wave, a multiple of 64
     const int k0 = wave * per, k1 = min(seg, k0 + per);
     constexpr int UN = 8;                                     // rows are fetched UN x 64 at a time: the loads of a batch are
     int mine = 0;                                             // independent, so one memory round trip serves 512 rows
@@ -454,8 +457,9 @@ __global__ void __launch_bounds__(256) hits_compact_kernel(const int32_t *__rest
     }
     if (lane == 0) wcnt[wave] = mine;
     __syncthreads();
-    int off = 0;
-    for (int q = 0; q < wave; ++q) off += wcnt[q];
+    int off = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) { const int w = wcnt[q]; if (q < wave) off += w; total += w; }
     for (int base = k0; base < k1; base += 64 * UN) {
         int e[UN];
 #pragma unroll
@@ -467,7 +471,7 @@ __global__ void __launch_bounds__(256) hits_compact_kernel(const int32_t *__rest
             off += __popcll(m);
         }
     }
-    if (tid == 0) count[c * gridDim.y + y] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (tid == 0) count[c * gridDim.y + y] = total;
 }
 
 // dW'[c][ch][n] = sum over the hits (r, e) of cell c of  dy1[r, n] * enc[e, ch]   (all steps of the sweep at once)
@@ -548,8 +552,12 @@ static int launch_hit_lists(bool occ, const void *table, const int32_t *row_base
         hipLaunchKernelGGL((hits_transpose_kernel<int16_t, false>), tg, dim3(256), 0, s, (const int16_t *)table, row_base, R, M,
                            ncell, hit_t);
     TNP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(hits_compact_kernel, dim3(ncell, R / seg), dim3(256), 0, s, hit_t, R, seg,
-                       reinterpret_cast<int2 *>(list), count);
+    if (seg > 8192)
+        hipLaunchKernelGGL(hits_compact_kernel<16>, dim3(ncell, R / seg), dim3(1024), 0, s, hit_t, R, seg,
+                           reinterpret_cast<int2 *>(list), count);
+    else
+        hipLaunchKernelGGL(hits_compact_kernel<4>, dim3(ncell, R / seg), dim3(256), 0, s, hit_t, R, seg,
+                           reinterpret_cast<int2 *>(list), count);
     TNP_HIP(hipGetLastError());
     return 0;
 }

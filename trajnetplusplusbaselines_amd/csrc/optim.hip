@@ -68,13 +68,13 @@ __global__ void __launch_bounds__(256) adam_step_kernel(const AdamTable t) {
 
 }  // namespace tnp
 
-extern "C" TNP_API int tnp_adam_step(const tnp_adam_tensor *tensors, int n_tensors, int step, float lr, float beta1,
-                                     float beta2, float eps, float weight_decay, void *stream) {
+extern "C" TNP_API int tnp_adam_step(const tnp_adam_tensor *tensors, int n_tensors, int step, double lr, double beta1,
+                                     double beta2, double eps, double weight_decay, void *stream) {
     using namespace tnp;
     if (n_tensors <= 0) return 0;
     if (tensors == nullptr || step < 1) TNP_FAIL(-1, "tnp_adam_step: tensors == NULL or step < 1");
     // host-side scalars exactly as torch.optim.Adam computes them (python floats = doubles, handed to the kernels as fp32)
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     int done = 0;
     while (done < n_tensors) {
         AdamTable t;
@@ -92,10 +92,10 @@ extern "C" TNP_API int tnp_adam_step(const tnp_adam_tensor *tensors, int n_tenso
             ++t.count;
         }
         if (t.count == 0) break;
-        t.wd = weight_decay; t.one_minus_b1 = (float)(1.0 - (double)beta1); t.b2 = beta2; t.one_minus_b2 = (float)(1.0 - (double)beta2);
-        t.step_size = (float)(-((double)lr / bc1));
+        t.wd = (float)weight_decay; t.one_minus_b1 = (float)(1.0 - beta1); t.b2 = (float)beta2; t.one_minus_b2 = (float)(1.0 - beta2);
+        t.step_size = (float)(-(lr / bc1));
         t.inv_bc2_sqrt_den = (float)sqrt(bc2);
-        t.eps = eps;
+        t.eps = (float)eps;
         hipLaunchKernelGGL(adam_step_kernel, dim3(t.first_block[t.count]), dim3(256), 0, (hipStream_t)stream, t);
         TNP_HIP(hipGetLastError());
     }

@@ -61,6 +61,8 @@ class LSTM(torch.nn.Module):
         #: run the first grid-embedding layer on the sparse winner table when the configuration allows it
         self.sparse_embedding = True
         self._ws = None
+        from .. import ops            # registers the torch.library ops; the handle is what trajnet::lstm_sequence looks the module up by
+        self._op_handle = ops.model_handle(self)
         self._grad_reduce_fn = None   # data-parallel training: parallel.GradReducer, see lstm/train_step.py
         self._cell_major = None  # (key, tensor): cell-major copy of pool.embedding[0].weight
         self._quad_major = None  # (key, tensor): its quad-major copy (register-accumulator sparse kernel)
@@ -78,6 +80,11 @@ class LSTM(torch.nn.Module):
             if k in state:
                 state[k] = None
         return state
+
+    def __setstate__(self, state):
+        super(LSTM, self).__setstate__(state)
+        from .. import ops            # an unpickled / deep-copied module is a new object: it gets its own op handle
+        self._op_handle = ops.model_handle(self)
 
     # ---- descriptor / workspace ---------------------------------------------------------------------
     def _decoder_cell(self):
@@ -263,6 +270,10 @@ class LSTM(torch.nn.Module):
             opts = {'pad_to': pad_to, 'reduce_fn': getattr(self, '_grad_reduce_fn', None)}
             rel_pred, pred, _ = run_sequence_with_grad(self, observed, goals, batch_split, prediction_truth, T_dec, opts)
             return rel_pred, pred
+        if torch.compiler.is_compiling() and (pad_to is None or isinstance(pad_to, int)):
+            # under torch.compile the whole sequence is ONE dispatcher op (ops.py: trajnet::lstm_sequence) -- no graph break
+            return torch.ops.trajnet.lstm_sequence(observed, goals, torch.as_tensor(batch_split), prediction_truth, T_dec,
+                                                   int(pad_to or 0), self._op_handle, list(self.parameters()))
         rel_pred, pred, _ = self._run_sequence(observed, goals, batch_split, prediction_truth, T_dec, pad_to=pad_to)
         return rel_pred, pred
 

@@ -2,9 +2,11 @@
 returning torch.Tensor on the current HIP stream, no host sync, errors surfaced as exceptions").
 
 The ops live in the ``trajnet`` namespace (``torch.ops.trajnet.linear`` ...).  Each has a fake (meta) implementation, so
-``torch.compile`` / ``FakeTensorMode`` can trace through them, and ``trajnet::linear`` carries its autograd formula; the
-recurrent sequence keeps its ``torch.autograd.Function`` (lstm/training.py) because its saved state is a set of per-step
-buffers owned by the module, not tensors an op schema can describe.  The implementations are the same ctypes calls the
+``torch.compile`` / ``FakeTensorMode`` can trace through them, and ``trajnet::linear`` carries its autograd formula.  The
+recurrent sequence itself is ``trajnet::lstm_sequence`` for inference (``LSTM.forward`` routes through it while
+``torch.compile`` traces, so an eval-mode model compiles without a graph break); the TRAINING sequence keeps its
+``torch.autograd.Function`` (lstm/training.py) because its saved state is a set of per-step buffers owned by the module,
+not tensors an op schema can describe -- ``torch.compile`` graph-breaks there.  The implementations are the same ctypes calls the
 module classes make -- the ops add dispatcher visibility, not another code path -- and there is no CPU kernel: a host
 tensor raises, as everywhere in this package.
 
@@ -14,8 +16,10 @@ tensor raises, as everywhere in this package.
     pool_embed_sparse(winners, values, scene_start, weight, bias?, relu)                -> fp32 [M, N1]
     constant_velocity(last, prev, n_predict)                                            -> fp64 [n_predict, N, 2]
     sf_rollout(state, scene_start, n_max, n_predict, v0, sigma, tau)                    -> fp64 [n_predict, M, 2]
+    lstm_sequence(observed, goals?, batch_split, truth?, t_dec, pad_to, model, params)  -> (fp32 [S, M, 5], fp32 [S', M, 2])
 """
-from typing import Optional
+import weakref
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -189,3 +193,39 @@ def sf_rollout(state: torch.Tensor, scene_start: torch.Tensor, n_max: int, n_pre
 @sf_rollout.register_fake
 def _(state, scene_start, n_max, n_predict, v0, sigma, tau):
     return state.new_empty((n_predict, state.shape[0], 2), dtype=torch.float64)
+
+
+# ---- the recurrent sequence (inference) ----------------------------------------------------------------------------------
+# An op schema carries tensors and scalars; the model's hyper-parameters (interaction module, grid size, ...) and cached
+# device buffers live in the module.  The op therefore takes an integer handle of the module (a weak registry: the handle
+# dies with the model) next to the module's parameters as a tensor list, which is what makes the data dependence visible.
+_MODELS = weakref.WeakValueDictionary()
+
+
+def model_handle(model) -> int:
+    h = id(model)
+    _MODELS[h] = model
+    return h
+
+
+@torch.library.custom_op('trajnet::lstm_sequence', mutates_args=())
+def lstm_sequence(observed: torch.Tensor, goals: Optional[torch.Tensor], batch_split: torch.Tensor,
+                  truth: Optional[torch.Tensor], t_dec: int, pad_to: int, model: int,
+                  params: List[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """LSTM.forward without gradients (reference lstm/lstm.py:170-264) as one dispatcher-visible call: ``truth`` =
+    prediction_truth (teacher forcing) or None with ``t_dec = n_predict - 1``; ``pad_to`` <= 0 = this batch's largest
+    scene; ``model`` = ops.model_handle(module); ``params`` = list(module.parameters()) (read, never written)."""
+    m = _MODELS.get(model)
+    if m is None:
+        raise RuntimeError('trajnet::lstm_sequence: unknown model handle (the module was garbage collected)')
+    rel, pred, _ = m._run_sequence(observed, goals, batch_split, truth, int(t_dec), pad_to=(int(pad_to) if pad_to > 0 else None))
+    return rel, pred
+
+
+@lstm_sequence.register_fake
+def _(observed, goals, batch_split, truth, t_dec, pad_to, model, params):
+    t_obs, M = observed.shape[0], observed.shape[1]
+    S = t_obs - 1 + t_dec
+    dev = params[0].device if len(params) else observed.device
+    return (torch.empty((S, M, 5), dtype=torch.float32, device=dev),
+            torch.empty((S + (1 if t_obs == 2 else 0), M, 2), dtype=torch.float32, device=dev))

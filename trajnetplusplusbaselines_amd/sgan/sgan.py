@@ -1,7 +1,9 @@
 """S-GAN on MI355X (reference sgan/sgan.py:46-630): the generator is the LSTM forecaster of lstm/lstm.py with a noise
 interface between encoder and decoder, the discriminator an encoder LSTM over observed + predicted frames followed
 by a small MLP on the primaries' hidden state.  Both run on the same HIP sequence driver (tnp_lstm_forward_ex);
-class names, constructor arguments, state_dict keys and return values mirror the reference.  Forward only."""
+class names, constructor arguments, state_dict keys and return values mirror the reference.  Forward and training: the
+generator trains through every interaction module lstm/training.py supports (grid and non-grid); a generator step whose
+DISCRIMINATOR pools with a non-grid module still raises (position gradients through those modules, training.py)."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -57,8 +59,6 @@ class LSTMGenerator(LSTM):
         else:
             truth, T_dec = None, n_predict - 1
         training = self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if training and (self.pool is not None and not hasattr(self.pool, 'embedding_layers')):
-            raise NotImplementedError('training through non-grid interaction modules is not available yet')
         if self.no_noise:
             if training:
                 from ..lstm.training import run_sequence_with_grad
