@@ -1,7 +1,7 @@
 // Timing harness for the sparse first layer (csrc/pool_embed_sparse.hip): runs the product kernel and its timing
 // ablations (template parameter ABL) on a synthetic config-2 crowd, stand-alone (no torch).  Build + run:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -Itrajnetplusplusbaselines_amd/csrc \
-//       tools/experiments/sparse_ablate.hip -o tools/experiments/sparse_ablate && tools/experiments/sparse_ablate
+//       -Itools/experiments tools/experiments/sparse_ablate.hip -o tools/experiments/sparse_ablate && tools/experiments/sparse_ablate
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -12,6 +12,7 @@
 #include <random>
 #define TNP_EXPERIMENT_HOOKS 1   // compiles the timing ablations / clock stamps of the product kernels
 #include "pool_embed_sparse.hip"
+#include "pool_embed_variants.hip"
 
 namespace tnp { void set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); } }
 
@@ -227,6 +228,67 @@ int main(int argc, char **argv) {
                             mn += lo; mx += hi;
                         }
                         printf("   phase %-16s clocks per wave: min %8.0f max %8.0f (mean over workgroups; 100 MHz units x clock ratio)\n", names[ph], mn / nbw, mx / nbw);
+                    }
+                    CK(hipFree(dbgw));
+                }
+            }
+        }
+        {   // shared-weight kernel (round 3): 128 egos x 64 columns, 16 waves, weights through an LDS ring (LDS-DMA)
+            std::vector<float> refq(got.size());
+            CK(hipMemset(out, 0, got.size() * 4));
+            time_kernel(KQ(0), b, nb, tnp::ra_smem_bytes(ncell), 1, 1024);
+            CK(hipMemcpy(refq.data(), out, refq.size() * 4, hipMemcpyDeviceToHost));
+#define KS(abl) (kern_t)tnp::pool_embed_regshare_kernel<16, abl>
+            struct SV { const char *name; kern_t k; };
+            const SV sv[] = {{"shared 128x64", KS(0)}, {"shared 128x64 no DMA / sync (1)", KS(1)}, {"shared 128x64 no hits (2)", KS(2)},
+                             {"shared 128x64 no DMA, no hits (3)", KS(3)}, {"shared 128x64 no DMA, no LDS weight reads (513)", KS(513)},
+                             {"shared 128x64 no DMA/LDS reads/hits (515)", KS(515)},
+                             {"shared 128x64 no cell loop (16)", KS(16)}, {"shared 128x64 no loop, no votes (48)", KS(48)},
+                             {"shared 128x64 no loop, no epilogue (144)", KS(144)}, {"shared 128x64 nothing (176)", KS(176)}};
+            tnp::SparseArgs w = b; w.ego_tiles = M / 128; w.out_blocks = N1 / 64;
+            const size_t sm = tnp::rs_smem_bytes(ncell, 16);
+            const int nbw = w.ego_tiles * w.out_blocks;
+            printf("shared-weight kernel: %d workgroups, %zu bytes of LDS\n", nbw, sm);
+            for (const SV &v : sv) {
+                CK(hipMemset(out, 0, got.size() * 4));
+                printf("%-42s %8.2f us\n", v.name, time_kernel(v.k, w, nbw, sm, 50, 1024));
+                if (v.k == KS(0)) {
+                    CK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
+                    check(got, v.name);
+                    size_t nd = 0; for (size_t i = 0; i < got.size(); ++i) nd += memcmp(&got[i], &refq[i], 4) != 0;
+                    printf("   bit-identical to the 64 x 128 kernel: %s (%zu elements differ)\n", nd ? "NO" : "yes", nd);
+                    int bad = 0;
+                    const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 40;
+                    std::vector<float> again(got.size());
+                    for (int rep = 0; rep < reps; ++rep) {
+                        CK(hipMemsetAsync(out, 0xff, got.size() * 4));
+                        hipLaunchKernelGGL(v.k, dim3(nbw), dim3(1024), sm, 0, w);
+                        CK(hipMemcpy(again.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
+                        bad += memcmp(again.data(), got.data(), got.size() * 4) != 0;
+                    }
+                    printf("   %d of %d repeats differ\n", bad, reps);
+                    {   // winners_out equals the 64 x 128 kernel's
+                        int16_t *w1, *w2; CK(hipMalloc(&w1, (size_t)M * ncell * 2)); CK(hipMalloc(&w2, (size_t)M * ncell * 2));
+                        tnp::SparseArgs x = w; x.winners_out = w1; hipLaunchKernelGGL(v.k, dim3(nbw), dim3(1024), sm, 0, x);
+                        tnp::SparseArgs y = b; y.winners_out = w2; hipLaunchKernelGGL(KQ(0), dim3(nb), dim3(1024), tnp::ra_smem_bytes(ncell), 0, y);
+                        std::vector<int16_t> h1((size_t)M * ncell), h2((size_t)M * ncell);
+                        CK(hipMemcpy(h1.data(), w1, h1.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), w2, h2.size() * 2, hipMemcpyDeviceToHost));
+                        printf("   winner tables equal: %s\n", memcmp(h1.data(), h2.data(), h1.size() * 2) ? "NO" : "yes");
+                        CK(hipFree(w1)); CK(hipFree(w2));
+                    }
+                    long long *dbgw; CK(hipMalloc(&dbgw, (size_t)nbw * 16 * 8 * 8)); CK(hipMemset(dbgw, 0, (size_t)nbw * 16 * 8 * 8));
+                    tnp::SparseArgs ws = w; ws.winners = reinterpret_cast<const int16_t *>(dbgw);
+                    time_kernel(KS(256), ws, nbw, sm, 3, 1024);
+                    std::vector<long long> hh((size_t)nbw * 16 * 8); CK(hipMemcpy(hh.data(), dbgw, hh.size() * 8, hipMemcpyDeviceToHost));
+                    const char *names[] = {"init + geometry", "votes", "winners_out", "main loop", "epilogue"};
+                    for (int ph = 0; ph < 5; ++ph) {
+                        double mn = 0, mx = 0;
+                        for (int wg = 0; wg < nbw; ++wg) {
+                            long long lo = 1ll << 62, hi = 0;
+                            for (int x = 0; x < 16; ++x) { const long long d = hh[((size_t)wg * 16 + x) * 8 + ph + 1] - hh[((size_t)wg * 16 + x) * 8 + ph]; lo = std::min(lo, d); hi = std::max(hi, d); }
+                            mn += lo; mx += hi;
+                        }
+                        printf("   phase %-16s clocks per wave: min %8.0f max %8.0f (mean over workgroups)\n", names[ph], mn / nbw, mx / nbw);
                     }
                     CK(hipFree(dbgw));
                 }

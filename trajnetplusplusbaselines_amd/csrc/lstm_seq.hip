@@ -550,7 +550,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
             fg.winners_out = w.save_winners ? w.winners : nullptr;
             rc = launch_pool_embed_sparse(w.winners, w.enc, md->C, w.row_base, md->Wp0_cell_major, md->bp[0], M,
                                           md->n * md->n, md->C, md->dims[1], 1, dst, ldo, w.partial, s,
-                                          fused_grid ? &fg : nullptr, md->Wp0_quad_major, (md->variant >> 18) & 3);
+                                          fused_grid ? &fg : nullptr, md->Wp0_quad_major);
             prof_after(PROF_GEMM1, s);
             if (rc) return rc;
             src = dst; lds = ldo; l0 = 1;

@@ -752,6 +752,9 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
     const unsigned vo = ocu * 4u;
     typedef float f4 __attribute__((ext_vector_type(4)));
     constexpr bool QUAD = QW;
+    const char *wq_base = reinterpret_cast<const char *>(a.Wp) +
+                          (size_t)min(ob * NCS + cs, (a.N1 >> 6) - 1) * (C * 64 * 4);   // a column set past N1 (N1 % 128 == 64) re-reads the last block
+    const unsigned wq_stride = (unsigned)(a.N1 >> 6) * (C * 64 * 4);
     struct WS { float f[QUAD ? 1 : C]; f4 q[QUAD ? C / 4 : 1]; };
     auto wch = [](const WS &w, int ch) -> float { if constexpr (QUAD) return w.q[ch >> 2][ch & 3]; else return w.f[ch]; };
     auto load_w = [&](WS &ws, int c) {
@@ -760,10 +763,10 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
 #pragma unroll
             for (int ch = 0; ch < (QUAD ? 1 : C); ++ch) w[ch] = 1.0f + ch;
         } else if constexpr (QUAD) {
-            // one scalar base per cell (the column block's C x 64 weights are contiguous), channel quad = immediate offset:
-            // 3 scalar instructions per cell instead of 2 per channel -- the scalar pipe is what bounds this loop
-            const int cb = min(ob * NCS + cs, (a.N1 >> 6) - 1);        // a column set past N1 (N1 % 128 == 64) re-reads the last block
-            const float *wb = a.Wp + ((size_t)c * (a.N1 >> 6) + (size_t)cb) * (C * 64);
+            // one scalar base per cell (the column block's C x 64 weights are contiguous), channel quad = immediate offset.  The
+            // scalar pipe is what bounds this loop: the base is wq_base (column block, set up once) + c * wq_stride, a 32-bit
+            // product (the launcher checks ncell * N1 * C * 4 < 2^31) -- three scalar instructions per cell
+            const char *wb = wq_base + __builtin_amdgcn_readfirstlane((unsigned)c * wq_stride);   // wave-uniform by construction; say so
             const unsigned vl = lane * 16u;
 #pragma unroll
             for (int kq = 0; kq < C / 4; ++kq)
@@ -834,8 +837,7 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
             acc[b0] = fin(w, e0, a0);
         }
     };
-    auto process = [&](WS &w, int c) {
-        const int kq = keyT[c * KS + lane];                                         // lane <-> ego of the tile
+    auto process = [&](WS &w, int kq) {                                              // kq = keyT[cell][lane]: lane <-> ego of the tile
         const int wv = (kq >= 0 && (kq & 1)) ? (kq >> 1) : -1;
         const unsigned long long mask = __ballot(wv >= 0);
         wait_w(w);
@@ -852,23 +854,30 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
         const int c = cell_of(lane);
         occ = __ballot(lane < nk && c < a.ncell && socc[c < a.ncell ? c : 0] != 0);
     }
-    auto pop = [&]() -> int { if (!occ) return -1; const int k = pop_bit(occ); return cell_of(k); };
     // Two weight sets: the next occupied cell's weights are in flight while the current cell's hits are processed; every
-    // load_w is unconditional (past the last occupied cell it re-reads the last one) so that vmcnt(C) is exact.
+    // load_w is unconditional (past the last occupied cell it re-reads the last one) so that vmcnt(C) is exact.  The visit
+    // count is known up front, so the loop carries one counter and pops without tests (scalar instructions per visited cell
+    // are what this loop pays for: 28 -> 17).
     WS wA, wB;
-    int ca = pop();
-    if constexpr (TNP_ABL(16)) ca = -1;
-    if (ca >= 0) {
+    if constexpr (TNP_ABL(16)) occ = 0ull;
+    int left = __popcll(occ);                                                        // cells still to visit
+    if (left > 0) {
+        int ca = cell_of(pop_bit(occ)), cb;
         load_w(wA, ca);
+        int ka = keyT[ca * KS + lane], kb;                                           // a cell's key row is read one cell ahead as well
         while (true) {
-            const int cb = pop();
-            load_w(wB, cb >= 0 ? cb : ca);
-            process(wA, ca);
-            if (cb < 0) break;
-            ca = pop();
-            load_w(wA, ca >= 0 ? ca : cb);
-            process(wB, cb);
-            if (ca < 0) break;
+            cb = ca;
+            if (left > 1) cb = cell_of(pop_bit(occ));
+            load_w(wB, cb);
+            kb = keyT[cb * KS + lane];
+            process(wA, ka);
+            if (--left == 0) break;
+            ca = cb;
+            if (left > 1) ca = cell_of(pop_bit(occ));
+            load_w(wA, ca);
+            ka = keyT[ca * KS + lane];
+            process(wB, kb);
+            if (--left == 0) break;
         }
         if constexpr (!TNP_ABL(1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -903,344 +912,6 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
 #undef RA_T
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Wide register-accumulator kernel (round 3): 8 waves = 8 cell groups, TWO waves per SIMD with up to 256 VGPRs each, so a
-// wave holds TE x CPL = 128 accumulators instead of 64 (same 64 Ki accumulator floats per CU as the kernel above, split
-// among half as many waves).  Two shapes:
-//   * TE = 128, CPL = 1: 128 egos x 64 columns per workgroup.  A weight register set W''[c][.][o] now serves the hits of 128
-//     egos: the L2 -> CU weight stream (0.55 GB per launch at BASELINE config 2 = 16.7 us at the L2's 34.5 TB/s) halves;
-//   * TE = 64, CPL = 2: 64 egos x 128 columns, two columns per lane.  Same stream as the kernel above, but a hit is one
-//     scalar-pipe sequence (pop, readlane, row load, register-index switches) for 16 packed FMAs instead of 8.
-// Everything else is the kernel above: winner keys built from the positions in the prologue (transposed [cell][ego], LDS
-// integer max = "last writer in ascending j wins", out-of-range / absent / padded neighbours clobber cell 0 -- here ONE
-// atomic per ego carries the largest such j instead of one per neighbour, which all hit the same LDS address), occupied
-// cells only, quad-major weights through inline-asm loads with manual vmcnt, neighbour rows through scalar loads (two
-// hits in flight per wait), partial sums of the 8 cell groups added through LDS in fixed order (group 0 + 1 + ... + 7:
-// results do not depend on the tile shape's alignment -- but the association differs from nothing: the per-ego sum is the
-// same function of the cell indices as in the kernel above, so both kernels agree bit for bit).
-// ---------------------------------------------------------------------------------------------------------
-constexpr int RW_NQ = 8, RW_RED = 32;
-template <int TE> constexpr int rw_ks() { return TE + 1; }
-static size_t rw_smem_bytes(int ncell, int TE, int OB) {
-    const size_t keys = (((size_t)ncell * (TE + 1) * 4 + 15) & ~(size_t)15) + (size_t)ncell * 4 + 6 * (size_t)TE * 4;
-    const size_t red = (size_t)RW_NQ * RW_RED * OB * 4;
-    return keys > red ? keys : red;
-}
-
-template <int C, int TE, int CPL TNP_ABL_TPARAM>
-__global__ void __launch_bounds__(64 * RW_NQ) pool_embed_regwide_kernel(const SparseArgs a) {
-    constexpr int NQ = RW_NQ, NTH = 64 * NQ, NW = NQ, OB = 64 * CPL, KS = TE + 1, NH = TE / 32, NE64 = TE / 64;
-    static_assert(TE == 64 || TE == 128, "tile");
-    static_assert(TE * CPL == 128, "128 accumulators per lane");
-    static_assert(C == 4 || C == 8 || C == 16, "channels");
-    extern __shared__ __attribute__((aligned(16))) float wsm[];
-    int *keyT = reinterpret_cast<int *>(wsm);                                        // [ncell][KS]
-    int *socc = keyT + (((size_t)a.ncell * KS + 3) & ~(size_t)3);                   // [ncell] cell may have a hit in the tile
-    int *sg = socc + a.ncell;                                                       // lo / ns / ki / pad [TE] each, then x / y
-    float *sp = reinterpret_cast<float *>(sg + 4 * TE);
-    float *red = wsm;                                                               // epilogue: [NQ][RW_RED][OB]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);                         // wave = cell group
-    const int ob = blockIdx.x % a.out_blocks, tile = blockIdx.x / a.out_blocks;     // blocks b, b+8, .. share an XCD
-    const int row0 = tile * TE;
-#ifdef TNP_EXPERIMENT_HOOKS
-    long long *dbg = nullptr;
-    if constexpr (TNP_ABL(256)) dbg = reinterpret_cast<long long *>(const_cast<int16_t *>(a.winners));
-#define RW_T(k) do { if constexpr (TNP_ABL(256)) { if (lane == 0) dbg[(blockIdx.x * 16 + q) * 8 + (k)] = (long long)__builtin_readcyclecounter(); } } while (0)
-#else
-#define RW_T(k) do { } while (0)
-#endif
-    RW_T(0);
-
-    for (int c = tid; c < a.ncell; c += NTH) socc[c] = 0;
-    {
-        const int4 m1 = {-1, -1, -1, -1};
-        const int nk4 = (a.ncell * KS + 3) / 4;
-        for (int idx = tid; idx < nk4; idx += NTH) reinterpret_cast<int4 *>(keyT)[idx] = m1;
-    }
-    if (tid < TE) {                                                                 // scene geometry of the tile's egos
-        const int row = row0 + tid;
-        int lo = 0, ns = 0, pad = 0;
-        float2 pi = {-500.0f, -500.0f};
-        if (row < a.M) {
-            lo = a.row_base[row]; ns = a.row_end[row] - lo; pad = a.row_padded[row];
-            pi = reinterpret_cast<const float2 *>(a.obs2)[row];
-            if (pi.x != pi.x || pi.y != pi.y) { pi.x = -500.0f; pi.y = -500.0f; }
-        }
-        sg[tid] = lo; sg[TE + tid] = ns; sg[2 * TE + tid] = row - lo; sg[3 * TE + tid] = pad;
-        sp[tid] = pi.x; sp[TE + tid] = pi.y;
-    }
-    __syncthreads();
-    RW_T(1);
-    if constexpr (!TNP_ABL(32)) {
-        // ---- votes: the reference's exact fp32 cell arithmetic (gridbased_pooling.py:276-288), key = 2 j + in_range ----
-        constexpr int EU = TE / NW;                                                 // egos per wave: 16 / 8
-        const float fG = (float)a.G;
-        const int e0 = q * EU;
-        const int ns_l = sg[TE + e0 + (lane & (EU - 1))];
-        const bool small = __builtin_amdgcn_readfirstlane((int)(__ballot(ns_l > 32) == 0ull)) != 0;
-        auto cell_of_pair = [&](float2 pj, float px, float py, bool &inr) -> int {
-            if (pj.x != pj.x || pj.y != pj.y) { pj.x = -500.0f; pj.y = -500.0f; }
-            const float ox = __fadd_rn(__fdiv_rn(__fsub_rn(pj.x, px), a.cell), a.half_x);
-            const float oy = __fadd_rn(__fdiv_rn(__fsub_rn(pj.y, py), a.cell), a.half_y);
-            inr = !(ox < 0.0f) && !(ox >= fG) && !(oy < 0.0f) && !(oy >= fG);
-            return inr ? ((int)ox * a.G + (int)oy) : 0;
-        };
-        if (small) {
-            // two egos per pass (lanes 0-31 / 32-63): every scene of this wave has at most 32 tracks.  All geometry reads
-            // and neighbour positions of the wave's passes are in flight together.
-            const int hi = lane >> 5, j = lane & 31;
-            int lo_[EU / 2], ns_[EU / 2], ki_[EU / 2], pad_[EU / 2];
-            float px_[EU / 2], py_[EU / 2];
-            float2 pq[EU / 2];
-#pragma unroll
-            for (int p = 0; p < EU / 2; ++p) {
-                const int e = e0 + 2 * p + hi;
-                lo_[p] = sg[e]; ns_[p] = sg[TE + e]; ki_[p] = sg[2 * TE + e]; pad_[p] = sg[3 * TE + e];
-                px_[p] = sp[e]; py_[p] = sp[TE + e];
-            }
-#pragma unroll
-            for (int p = 0; p < EU / 2; ++p)
-                pq[p] = reinterpret_cast<const float2 *>(a.obs2)[lo_[p] + (j < ns_[p] ? j : 0)];
-#pragma unroll
-            for (int p = 0; p < EU / 2; ++p) {
-                const int e = e0 + 2 * p + hi;
-                const bool valid = j < ns_[p] && j != ki_[p];
-                bool inr;
-                const int cellid = cell_of_pair(pq[p], px_[p], py_[p], inr);
-                if (valid && inr) { atomicMax(&keyT[cellid * KS + e], 2 * j + 1); socc[cellid] = 1; }
-                // neighbours that clobber cell 0 (out of range / absent; padded slots are the highest j of all): one vote
-                const unsigned long long oor = __ballot(valid && !inr);
-                const unsigned mh = hi ? (unsigned)(oor >> 32) : (unsigned)oor;
-                int k0 = mh ? 2 * (31 - __builtin_clz(mh)) : -1;
-                if (ns_[p] < pad_[p]) k0 = 2 * (pad_[p] - 1);
-                if (j == 0 && k0 >= 0) atomicMax(&keyT[e], k0);
-            }
-        } else {
-            for (int u = 0; u < EU; ++u) {
-                const int e = e0 + u;
-                const int lo = sg[e], ns = sg[TE + e], ki = sg[2 * TE + e], pad = sg[3 * TE + e];
-                const float px = sp[e], py = sp[TE + e];
-                for (int j = lane; j < ns; j += 64) {
-                    bool inr;
-                    const int cellid = cell_of_pair(reinterpret_cast<const float2 *>(a.obs2)[lo + j], px, py, inr);
-                    if (j != ki) {
-                        atomicMax(&keyT[cellid * KS + e], 2 * j + (inr ? 1 : 0));
-                        if (inr) socc[cellid] = 1;
-                    }
-                }
-                if (ns < pad && lane == 0) atomicMax(&keyT[e], 2 * (pad - 1));
-            }
-        }
-    }
-    __syncthreads();
-    RW_T(2);
-    if (a.winners_out && ob == 0) {                                                 // training: the winner table for the backward
-        for (int e = q; e < TE; e += NW) {
-            const int row = row0 + e;
-            if (row >= a.M) continue;
-            for (int c = lane; c < a.ncell; c += 64) {
-                const int kq = keyT[c * KS + e];
-                a.winners_out[(size_t)row * a.ncell + c] = (kq >= 0 && (kq & 1)) ? (int16_t)(kq >> 1) : (int16_t)-1;
-            }
-        }
-    }
-    int rb[NE64];
-#pragma unroll
-    for (int h = 0; h < NE64; ++h) { rb[h] = sg[64 * h + lane]; asm volatile("" : "+v"(rb[h])); }
-    float bias_l[CPL];                                                              // fetched here: after the cell loop its latency would be exposed
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        const int o = ob * OB + 64 * k + lane;
-        bias_l[k] = (a.bias && o < a.N1) ? a.bias[o] : 0.0f;
-        asm volatile("" : "+v"(bias_l[k]));                                         // landed before the loop (a compiler-placed vmcnt(0) inside it would drain the weight prefetch)
-    }
-    RW_T(3);
-
-    // accumulators: vector v = 32 egos x one column of this lane; TE = 128: v <-> egos 32 v .. 32 v + 31;
-    // TE = 64, CPL = 2: v = 2 * (ego half) + column
-    ra_f32x32 acc[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int i = 0; i < 32; ++i) acc[v][i] = 0.0f;
-
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    struct WS { f4 q[CPL][C / 4]; };
-    const unsigned vl = lane * 16u;
-    auto load_w = [&](WS &ws, int c) {
-        if constexpr (TNP_ABL(1)) {
-#pragma unroll
-            for (int k = 0; k < CPL; ++k)
-#pragma unroll
-                for (int kq = 0; kq < C / 4; ++kq) ws.q[k][kq] = f4{1.0f, 2.0f, 3.0f, 4.0f};
-        } else {
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-                const int cb = min(ob * CPL + k, (a.N1 >> 6) - 1);                  // a column set past N1 re-reads the last block
-                const float *wb = a.Wp + ((size_t)c * (a.N1 >> 6) + (size_t)cb) * (C * 64);
-#pragma unroll
-                for (int kq = 0; kq < C / 4; ++kq)
-                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(ws.q[k][kq]) : "v"(vl), "s"(wb), "i"(kq * 1024) : "memory");
-            }
-        }
-    };
-    // "this set has landed, the younger set may still be in flight": every load_w issues exactly CPL * C / 4 loads
-    auto wait_w = [&](WS &ws) {
-        if constexpr (TNP_ABL(1)) {
-        } else {
-            constexpr int NL = CPL * C / 4;
-            static_assert(NL == 1 || NL == 2 || NL == 4 || NL == 8, "vmcnt immediate");
-            if constexpr (NL == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if constexpr (NL == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if constexpr (NL == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-#pragma unroll
-            for (int k = 0; k < CPL; ++k)
-#pragma unroll
-                for (int kq = 0; kq < C / 4; ++kq) asm volatile("" : "+v"(ws.q[k][kq]));
-        }
-    };
-    // one hit, one column: acc += sum_ch w[ch] * e[ch] (even / odd channels in the two halves of a packed register)
-    auto fin = [&](const WS &w, int k, const typename SRow<C>::type &ev, float av) -> float {
-        f2 p = {av, 0.0f};
-#pragma unroll
-        for (int i = 0; i < C / 2; ++i) {
-            const f2 wk = {w.q[k][(2 * i) >> 2][(2 * i) & 3], w.q[k][(2 * i + 1) >> 2][(2 * i + 1) & 3]};
-            const f2 ek = {ev[2 * i], ev[2 * i + 1]};
-            p = __builtin_elementwise_fma(wk, ek, p);
-        }
-        return p.x + p.y;
-    };
-    // harness ablations of the hit chain: 4 = no neighbour-row loads, 8 = accumulator index fixed at 0 (no register-index
-    // switches), 64 = no FMAs
-    auto row = [&](typename SRow<C>::type &r, unsigned off, int ln) {
-        if constexpr (TNP_ABL(4)) asm volatile("" : "=s"(r) : "s"(__builtin_amdgcn_readlane((int)off, ln)));
-        else sload_row<C>(r, a.enc, (unsigned)__builtin_amdgcn_readlane((int)off, ln));
-    };
-    auto fin2 = [&](const WS &w, int k, const typename SRow<C>::type &ev, float av) -> float {
-        if constexpr (TNP_ABL(64)) return av + ev[0];
-        else return fin(w, k, ev, av);
-    };
-    // the hits of 32 egos (bits of `m`, lanes lane0 .. lane0 + 31 of `off`) against accumulator vectors v0 (column 0) and,
-    // for CPL = 2, v0 + 1 (column 1).  Keep the exact read / chain / write shape (see the kernel above).
-    auto half = [&](const WS &w, ra_f32x32 &accx, ra_f32x32 &accy, unsigned m, unsigned off, int lane0) {
-        while (m & (m - 1u)) {                                                      // two hits: both rows in flight before the wait
-            const int b0 = __builtin_ctz(m); m &= m - 1u;
-            const int b1 = __builtin_ctz(m); m &= m - 1u;
-            const int i0 = TNP_ABL(8) ? 0 : b0, i1 = TNP_ABL(8) ? 1 : b1;
-            typename SRow<C>::type r0, r1;
-            row(r0, off, lane0 + b0);
-            row(r1, off, lane0 + b1);
-            const float x0 = accx[i0], x1 = accx[i1];
-            float y0 = 0.0f, y1 = 0.0f;
-            if constexpr (CPL == 2) { y0 = accy[i0]; y1 = accy[i1]; }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r0), "+s"(r1));
-            accx[i0] = fin2(w, 0, r0, x0);
-            accx[i1] = fin2(w, 0, r1, x1);
-            if constexpr (CPL == 2) { accy[i0] = fin2(w, 1, r0, y0); accy[i1] = fin2(w, 1, r1, y1); }
-        }
-        if (m) {
-            const int b0 = __builtin_ctz(m);
-            const int i0 = TNP_ABL(8) ? 0 : b0;
-            typename SRow<C>::type r0;
-            row(r0, off, lane0 + b0);
-            const float x0 = accx[i0];
-            float y0 = 0.0f;
-            if constexpr (CPL == 2) y0 = accy[i0];
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r0));
-            accx[i0] = fin2(w, 0, r0, x0);
-            if constexpr (CPL == 2) accy[i0] = fin2(w, 1, r0, y0);
-        }
-    };
-    auto process = [&](WS &w, int c) {
-        int wv[NE64];
-        unsigned long long mask[NE64];
-#pragma unroll
-        for (int h = 0; h < NE64; ++h) {
-            const int kq = keyT[c * KS + 64 * h + lane];                            // lane <-> ego of the tile
-            wv[h] = (kq >= 0 && (kq & 1)) ? (kq >> 1) : -1;
-            mask[h] = __ballot(wv[h] >= 0);
-        }
-        wait_w(w);
-        if constexpr (TNP_ABL(2)) { if (mask[0] == 1234567ull) acc[0][0] += w.q[0][0][0] + w.q[CPL - 1][C / 4 - 1][3]; return; }
-#pragma unroll
-        for (int h = 0; h < NE64; ++h) {
-            const unsigned off = __umul24((unsigned)(rb[h] + wv[h]), (unsigned)(a.ldv * 4));
-            if constexpr (CPL == 1) {
-                half(w, acc[2 * h], acc[2 * h], (unsigned)mask[h], off, 0);
-                half(w, acc[2 * h + 1], acc[2 * h + 1], (unsigned)(mask[h] >> 32), off, 32);
-            } else {
-                half(w, acc[0], acc[1], (unsigned)mask[h], off, 0);
-                half(w, acc[2], acc[3], (unsigned)(mask[h] >> 32), off, 32);
-            }
-        }
-    };
-    // cells of this wave's group with a hit in the tile; group q takes cell NQ k + ((q - k) mod NQ) of every block k of NQ cells
-    const int nk = (a.ncell + NQ - 1) / NQ;                                          // <= 64: ncell <= 512
-    auto cell_of = [&](int k) { return NQ * k + ((q - k) & (NQ - 1)); };
-    unsigned long long occ;
-    {
-        const int c = cell_of(lane);
-        occ = __ballot(lane < nk && c < a.ncell && socc[c < a.ncell ? c : 0] != 0);
-    }
-    auto pop = [&]() -> int { if (!occ) return -1; const int k = pop_bit(occ); return cell_of(k); };
-    WS wA, wB;
-    int ca = pop();
-    if constexpr (TNP_ABL(16)) ca = -1;
-    if (ca >= 0) {
-        load_w(wA, ca);
-        while (true) {
-            const int cb = pop();
-            load_w(wB, cb >= 0 ? cb : ca);
-            process(wA, ca);
-            if (cb < 0) break;
-            ca = pop();
-            load_w(wA, ca >= 0 ? ca : cb);
-            process(wB, cb);
-            if (ca < 0) break;
-        }
-        if constexpr (!TNP_ABL(1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    RW_T(4);
-
-    // ---- the 8 cell groups' partial sums, 32 (ego, column-set) rows per round: every wave leaves its partials in LDS, then
-    //      wave w adds the 8 copies of rows w, w + 8, w + 16, w + 24 in fixed order (group 0 + 1 + ... + 7), bias + activation
-    if constexpr (TNP_ABL(128)) { if (acc[0][3] + acc[3][5] == 1.234e30f) a.out[tid] = 0.0f; return; }
-#pragma unroll
-    for (int r = 0; r < NH; ++r) {                                                  // round r: egos 32 r .. 32 r + 31
-        __syncthreads();                                                            // prologue data / previous round no longer read
-#pragma unroll
-        for (int k = 0; k < CPL; ++k)
-#pragma unroll
-            for (int e = 0; e < RW_RED; ++e)
-                red[(q * RW_RED + e) * OB + 64 * k + lane] = acc[CPL == 1 ? r : 2 * r + k][e];
-        __syncthreads();
-#pragma unroll
-        for (int h = 0; h < RW_RED / NW; ++h) {
-            const int e = q + NW * h;
-            const int row = row0 + RW_RED * r + e;
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-                float v = red[(size_t)e * OB + 64 * k + lane];
-#pragma unroll
-                for (int qq = 1; qq < NQ; ++qq) v += red[((size_t)qq * RW_RED + e) * OB + 64 * k + lane];
-                v += bias_l[k];
-                if (a.relu) v = fmaxf(v, 0.0f);
-                const int o = ob * OB + 64 * k + lane;
-                if (row < a.M && o < a.N1) a.out[(size_t)row * a.ldo + o] = v;
-            }
-        }
-    }
-    RW_T(5);
-#undef RW_T
-}
-
-bool regwide_supported(int C, int ncell, int TE, int OB) {
-    return (C == 4 || C == 8 || C == 16) && ncell <= 64 * RW_NQ && rw_smem_bytes(ncell, TE, OB) <= (size_t)160 * 1024;
-}
-
 bool regacc_supported(int C, int ncell) { return (C == 4 || C == 8 || C == 16) && ncell <= 64 * RA_NQ && ra_smem_bytes(ncell) <= (size_t)160 * 1024; }
 
 bool sparse_supported(int C, int N1, int ncell) {
@@ -1268,8 +939,7 @@ bool sparse_fuses_grid(int ncell, int n_max) { return ncell <= TL_MAXCELL_LDS &&
 
 int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, const int32_t *row_base,
                              const float *Wp, const float *bias, int M, int ncell, int C, int N1, int relu,
-                             float *out, int ldo, float *partial, hipStream_t s, const SparseGridFuse *fg, const float *Wq,
-                             int shape) {
+                             float *out, int ldo, float *partial, hipStream_t s, const SparseGridFuse *fg, const float *Wq) {
     if (M <= 0) return 0;
     if (!sparse_supported(C, N1, ncell)) TNP_FAIL(-1, "sparse pooling embedding: unsupported C=%d N1=%d", C, N1);
     SparseArgs a;
@@ -1277,31 +947,6 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
     a.M = M; a.ncell = ncell; a.C = C; a.N1 = N1; a.relu = relu; a.ldo = ldo;
     a.obs2 = nullptr; a.row_end = nullptr; a.row_padded = nullptr; a.G = 0; a.cell = 1.0f; a.half_x = a.half_y = 0.0f; a.winners_out = nullptr;
     const bool lean_rows = (size_t)M * ldv * sizeof(float) < ((size_t)1 << 32);   // 32-bit byte offsets of the neighbour rows
-    // shape (tnp_lstm_model.variant bits 18-19): 0 / 1 = the 64-ego x 128-column, 16-wave register-accumulator kernel (default:
-    // the fastest at BASELINE config 2), 2 = wide kernel, 128 egos x 64 columns, 3 = wide kernel, 64 egos x 128 columns with
-    // two columns per lane.  The wide kernels halve the weight stream / the scalar work per FMA but run 8 waves per CU, and
-    // this loop is bound by instruction issue per wave: 37.6 / 32.1 us against 33.2 us (tools/experiments/README.md).
-    const bool wide_ok = lean_rows && fg != nullptr && Wq != nullptr && N1 % 64 == 0 && C % 4 == 0;
-    const int wide = (shape < 2 || !wide_ok) ? 0 : shape;
-    if (wide && regwide_supported(C, ncell, wide == 2 ? 128 : 64, wide == 2 ? 64 : 128) && (wide == 2 || N1 % 128 == 0)) {
-        const int TE = wide == 2 ? 128 : 64, OB = wide == 2 ? 64 : 128;
-        a.out = out; a.Wp = Wq;
-        a.S = 1; a.cps = ncell; a.ego_tiles = (M + TE - 1) / TE; a.out_blocks = (N1 + OB - 1) / OB;
-        a.obs2 = fg->obs2; a.row_end = fg->row_end; a.row_padded = fg->row_padded; a.G = fg->G;
-        a.cell = fg->cell; a.half_x = fg->half_x; a.half_y = fg->half_y; a.winners_out = fg->winners_out;
-        const size_t wsmem = rw_smem_bytes(ncell, TE, OB);
-        const int wblocks = a.ego_tiles * a.out_blocks;
-#define RW_LAUNCH(CC, TEE, CPLL) { static bool set = false; if (!set) { hipFuncAttributes fa; \
-        TNP_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(pool_embed_regwide_kernel<CC, TEE, CPLL>))); \
-        if (fa.localSizeBytes != 0) TNP_FAIL(-3, "pool_embed_regwide_kernel: accumulators left the register file (%zu bytes of scratch)", (size_t)fa.localSizeBytes); \
-        TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
-        pool_embed_regwide_kernel<CC, TEE, CPLL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        hipLaunchKernelGGL((pool_embed_regwide_kernel<CC, TEE, CPLL>), dim3(wblocks), dim3(64 * RW_NQ), wsmem, s, a); }
-#define RW_SWITCH(CC) { if (wide == 2) RW_LAUNCH(CC, 128, 1) else RW_LAUNCH(CC, 64, 2) }
-        if (C == 4) RW_SWITCH(4) else if (C == 8) RW_SWITCH(8) else RW_SWITCH(16)
-        TNP_HIP(hipGetLastError());
-        return 0;
-    }
     if (lean_rows && regacc_supported(C, ncell)) {                                // register accumulators, 64-ego tiles
         a.out = out;
         a.S = 1; a.cps = ncell; a.ego_tiles = (M + RA_TE - 1) / RA_TE; a.out_blocks = (N1 + RA_OB - 1) / RA_OB;
@@ -1311,7 +956,8 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
         }
         const size_t rsmem = ra_smem_bytes(ncell);
         const int rblocks = a.ego_tiles * a.out_blocks;
-        const bool quad = Wq != nullptr && fg != nullptr && N1 % 64 == 0 && C % 4 == 0;
+        const bool quad = Wq != nullptr && fg != nullptr && N1 % 64 == 0 && C % 4 == 0 &&
+                          (size_t)ncell * N1 * C * 4 < ((size_t)1 << 31);   // 32-bit byte offsets of the cells' weight blocks
         if (quad) a.Wp = Wq;
 #define RA_LAUNCH(CC, FGB, QB) { static bool set = false; if (!set) { hipFuncAttributes fa; \
         TNP_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(pool_embed_regacc_kernel<CC, FGB, QB>))); \
@@ -1387,5 +1033,5 @@ extern "C" TNP_API int tnp_pool_embed_sparse_forward(const int16_t *winners, con
         TNP_FAIL(-1, "tnp_pool_embed_sparse_forward: workspace too small (need %zu bytes)", need);
     if (ldo % 4 != 0 || (reinterpret_cast<uintptr_t>(out) & 15)) TNP_FAIL(-1, "output must be 16-byte aligned, ldo %% 4 == 0");
     return tnp::launch_pool_embed_sparse(winners, values, ldv, row_base, W_cell_major, bias, M, ncell, C, N1, relu, out,
-                                         ldo, reinterpret_cast<float *>(workspace), (hipStream_t)stream, nullptr, nullptr, 0);
+                                         ldo, reinterpret_cast<float *>(workspace), (hipStream_t)stream);
 }

@@ -73,8 +73,7 @@ bool sparse_fuses_grid(int ncell, int n_max);
 int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, const int32_t *row_base,
                              const float *Wp, const float *bias, int M, int ncell, int C, int N1, int relu,
                              float *out, int ldo, float *partial, hipStream_t s, const SparseGridFuse *fg = nullptr,
-                             const float *Wq = nullptr,   // Wq: quad-major copy of the weights (tnp_lstm_model.Wp0_quad_major)
-                             int shape = 0);              // tile shape of the register-accumulator kernels (variant bits 18-19)
+                             const float *Wq = nullptr);   // Wq: quad-major copy of the weights (tnp_lstm_model.Wp0_quad_major)
 
 // ---- non-grid interaction modules (pool_nongrid.hip) -----------------------------------------
 int launch_pool_nn(const float *obs1, const float *obs2, const int32_t *scene_start, int B, int n_sel, int in_dim,

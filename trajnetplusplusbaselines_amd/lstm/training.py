@@ -292,11 +292,27 @@ class SequenceFn(torch.autograd.Function):
         grads = {}
 
         # weights of the data-gradient GEMMs, transposed once per sweep ([in, out] rows for the NT kernel)
+        def T_into(out, name):
+            """out [in, out_features] <- P[name]^T through the LDS-tiled transpose kernel (an ATen `.t().contiguous()` is a
+            strided elementwise copy: 10-23 us per weight, nine of them per sweep)"""
+            w = P[name].detach()
+            w = w if w.is_contiguous() else w.contiguous()
+            _lib.check(L.tnp_transpose(_lib.ptr(w), w.stride(0), w.shape[0], w.shape[1], _lib.ptr(out), out.stride(0), sp()),
+                       'tnp_transpose')
+            return out
+
         def T(name):
-            return P[name].detach().t().contiguous()
+            w = P[name]
+            return T_into(torch.empty(w.shape[1], w.shape[0], dtype=torch.float32, device=dev), name)
+
         # [W_ih^T ; W_hh^T]: one GEMM per step gives the gradients of the cell's input and of its previous hidden state
-        wT = {pre: torch.cat([T(pre + '.weight_ih'), T(pre + '.weight_hh')], dim=0)
-              for pre in set('decoder' if d else 'encoder' for d in decs)}
+        def cell_T(pre):
+            w_ih, w_hh = P[pre + '.weight_ih'], P[pre + '.weight_hh']
+            out = torch.empty(w_ih.shape[1] + w_hh.shape[1], w_ih.shape[0], dtype=torch.float32, device=dev)
+            T_into(out[:w_ih.shape[1]], pre + '.weight_ih')
+            T_into(out[w_ih.shape[1]:], pre + '.weight_hh')
+            return out
+        wT = {pre: cell_T(pre) for pre in set('decoder' if d else 'encoder' for d in decs)}
         has_h2n = 'hidden2normal.linear.weight' in P            # the S-GAN discriminator has no output head
         o1_all, o2_all = ctx.obs_all
         st_saves = ctx.st_saves                                  # NearestNeighborLSTM / TrajectronPooling
@@ -327,7 +343,7 @@ class SequenceFn(torch.autograd.Function):
         st_bufs = None
         if st_pool:
             Hp = pool.hidden_dim
-            st_bufs = dict(pwT=torch.cat([T('pool.pool_lstm.weight_ih'), T('pool.pool_lstm.weight_hh')], dim=0),
+            st_bufs = dict(pwT=cell_T('pool.pool_lstm'),
                            h2pT=T('pool.hidden2pool.weight'), zeros=torch.zeros(M, 2, device=dev),
                            dG=torch.empty(S, M, 4 * Hp, device=dev), dfeat=torch.empty(S, M, pool.out_dim, device=dev),
                            dph=torch.zeros(M, Hp, device=dev), dpc=torch.zeros(M, Hp, device=dev))
