@@ -262,7 +262,7 @@ def pmc_traffic(kernel_regex, extra_args):
         try:
             cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', tmp, '-o', 'p', '--',
                    sys.executable, here, '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-roofline', '--no-traffic'] + extra_args
-            subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL,
+            subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp', TNP_BENCH_PRIME_S='0'), stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, timeout=per_pass_timeout, check=False)
             vals = []
             for f in glob.glob(tmp + '/**/*counter_collection.csv', recursive=True):
@@ -399,6 +399,14 @@ def main():
         torch.cuda.synchronize()
 
     with torch.set_grad_enabled(args.train):
+        # untimed preparation before the contract's W warm-up steps: half a second of the same step, so that code objects
+        # are loaded, the caching allocator holds its blocks and the GPU has left its idle clocks (a 20-step timed region is
+        # 28 ms: measured right after process start it once read 605 k instead of 1.0 M scene-steps/s)
+        t_prime = time.perf_counter() + float(os.environ.get('TNP_BENCH_PRIME_S', '0.5'))
+        while time.perf_counter() < t_prime:
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
         for _ in range(args.warmup):
             step()
         barrier()
