@@ -428,6 +428,20 @@ TNP_API int tnp_sparse_wgrad(const float *dy, int ldy, const float *enc, int lde
 TNP_API size_t tnp_wgrad_workspace_bytes(int Mo, int No, int K);
 TNP_API int tnp_wgrad(const float *dy, int ld_dy, const float *x, int ld_x, int K, int Mo, int No, float *dw, int ld_dw,
                       float *dbias, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Several weight-gradient contractions in ONE launch (+ one reduce launch): every problem keeps the split / summation
+ * plan of its stand-alone tnp_wgrad call (bit-identical results); `problems` is a HOST array of device pointers.  An
+ * optimisation step of Social-LSTM has eight contractions, five of them tiny: grouped they fill the chip together instead
+ * of paying ~35 us of launches each. */
+typedef struct tnp_wgrad_problem {
+    const float *dy; int ld_dy;      /* [K, Mo] gradient rows  */
+    const float *x;  int ld_x;       /* [K, No] input rows     */
+    int K, Mo, No;
+    float *dw; int ld_dw;            /* [Mo, No] out           */
+    float *dbias;                    /* [Mo] column sums of dy, or NULL */
+} tnp_wgrad_problem;
+TNP_API size_t tnp_wgrad_grouped_workspace_bytes(const tnp_wgrad_problem *problems, int n);
+TNP_API int tnp_wgrad_grouped(const tnp_wgrad_problem *problems, int n, void *workspace, size_t workspace_bytes, void *stream);
 /* Backward of HiddenStateMLPPooling's max-pool (lstm/non_gridbased_pooling.py:196-239 under autograd): d_pooled [M, ldp]
  * (gradient of the max-pooled [spatial | hidden | velocity] vector) is routed to the winning slot of every (ego,
  * dimension): G [M, ms+mv] and R [M, ms+mv, 2] (routed gradient and the winner's input of the two Linear(2 -> dim)

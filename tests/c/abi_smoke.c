@@ -11,7 +11,8 @@ int main(void) {
     if (tnp_abi_version() != TNP_ABI_VERSION) { printf("abi version %d != %d\n", tnp_abi_version(), TNP_ABI_VERSION); return 1; }
     if (tnp_abi_sizeof(0) != sizeof(tnp_lstm_model) || tnp_abi_sizeof(1) != sizeof(tnp_lstm_extras) ||
         tnp_abi_sizeof(2) != sizeof(tnp_step_saves) || tnp_abi_sizeof(3) != sizeof(tnp_train_saves) ||
-        tnp_abi_sizeof(4) != sizeof(tnp_bwd_sweep)) { printf("struct sizes differ between C and the library\n"); return 2; }
+        tnp_abi_sizeof(4) != sizeof(tnp_bwd_sweep) || tnp_abi_sizeof(5) != sizeof(tnp_wgrad_problem) ||
+        tnp_abi_sizeof(6) != sizeof(tnp_adam_tensor)) { printf("struct sizes differ between C and the library\n"); return 2; }
     /* an invalid model is rejected with a message, not a crash */
     if (tnp_lstm_workspace_bytes(&m, 16, 2) != 0) { printf("invalid model accepted\n"); return 3; }
     if (tnp_last_error() == NULL || strlen(tnp_last_error()) == 0) { printf("no error message\n"); return 4; }

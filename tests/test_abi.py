@@ -96,7 +96,9 @@ def test_ctypes_mirrors_have_the_c_struct_sizes():
     import ctypes
     from trajnetplusplusbaselines_amd.lstm import training
     L = _lib.lib()
-    mirrors = [_lib.LstmModel, _lib.LstmExtras, training.StepSaves, training.TrainSaves, training.BwdSweep]
+    from trajnetplusplusbaselines_amd import optim
+    mirrors = [_lib.LstmModel, _lib.LstmExtras, training.StepSaves, training.TrainSaves, training.BwdSweep, training.WgradProblem,
+               optim.AdamTensor]
     for which, cls in enumerate(mirrors):
         assert L.tnp_abi_sizeof(which) == ctypes.sizeof(cls), cls.__name__
     assert L.tnp_abi_sizeof(99) == 0

@@ -461,3 +461,39 @@ def test_every_gradient_goes_through_the_in_backward_reducer_exactly_once(kind):
         assert torch.equal(doubled[n], plain[n] * 2.0), n
     if kind == 'social':
         assert red.seen[0] == max(red.seen)            # the sparse first-layer gradient is published first
+
+
+def test_grouped_wgrad_is_bitwise_the_stand_alone_wgrad():
+    """tnp_wgrad_grouped (all contractions of a step in one launch + one reduce) keeps every problem's split / summation plan:
+    its results equal the stand-alone tnp_wgrad calls bit for bit, bias column sums included, for shapes like the step's."""
+    import ctypes
+    from trajnetplusplusbaselines_amd import _lib
+    from trajnetplusplusbaselines_amd.lstm.training import WgradProblem
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(4096, 256, 1024, True), (3000, 512, 320, True), (3000, 512, 128, False), (4096, 5, 128, True), (4096, 62, 2, True),
+              (4096, 16, 128, True), (777, 33, 70, False)]
+    probs, keep, singles = [], [], []
+    for K, Mo, No, bias in shapes:
+        dy = torch.randn(K, Mo, generator=g).cuda()
+        x = torch.randn(K, No, generator=g).cuda()
+        dw, db = torch.empty(Mo, No, device='cuda'), (torch.empty(Mo, device='cuda') if bias else None)
+        dw1, db1 = torch.empty(Mo, No, device='cuda'), (torch.empty(Mo, device='cuda') if bias else None)
+        nb = L.tnp_wgrad_workspace_bytes(Mo, No, K)
+        ws = torch.empty(nb, dtype=torch.uint8, device='cuda')
+        _lib.check(L.tnp_wgrad(_lib.ptr(dy), Mo, _lib.ptr(x), No, K, Mo, No, _lib.ptr(dw1), No, _lib.ptr(db1), _lib.ptr(ws), nb,
+                               _lib.stream_ptr()), 'tnp_wgrad')
+        probs.append(WgradProblem(dy.data_ptr(), Mo, x.data_ptr(), No, K, Mo, No, dw.data_ptr(), No, db.data_ptr() if bias else None))
+        keep.append((dy, x, dw, db))
+        singles.append((dw1, db1))
+    table = (WgradProblem * len(probs))(*probs)
+    nb = L.tnp_wgrad_grouped_workspace_bytes(table, len(probs))
+    ws = torch.empty(nb, dtype=torch.uint8, device='cuda')
+    _lib.check(L.tnp_wgrad_grouped(table, len(probs), _lib.ptr(ws), nb, _lib.stream_ptr()), 'tnp_wgrad_grouped')
+    torch.cuda.synchronize()
+    for (dy, x, dw, db), (dw1, db1) in zip(keep, singles):
+        assert torch.equal(dw, dw1)
+        if db is not None:
+            assert torch.equal(db, db1)
+        ref = dy.double().t() @ x.double()
+        assert (dw.double() - ref).abs().max() <= 1e-3 * max(1.0, float(ref.abs().max()))

@@ -127,6 +127,9 @@ def lib():
                                    ctypes.c_int, _fp, _fp]
     L.tnp_wgrad_workspace_bytes.restype = ctypes.c_size_t
     L.tnp_wgrad_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.tnp_wgrad_grouped_workspace_bytes.restype = ctypes.c_size_t
+    L.tnp_wgrad_grouped_workspace_bytes.argtypes = [_fp, ctypes.c_int]
+    L.tnp_wgrad_grouped.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_size_t, _fp]
     L.tnp_wgrad.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int,
                             _fp, _fp, ctypes.c_size_t, _fp]
     L.tnp_pool_hiddenmlp_backward.argtypes = [_fp, _fp, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

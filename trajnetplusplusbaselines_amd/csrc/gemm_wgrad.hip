@@ -20,16 +20,17 @@ typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WG_U = 8;   // k-pairs per unrolled iteration (16 rows of K)
 
-__global__ void __launch_bounds__(256) wgrad_tn_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B,
-                                                       int ldb, int Mo, int No, int K, int kchunk,
-                                                       float *__restrict__ part, float *__restrict__ bias_part) {
+// one workgroup: region `region` (128 x 128 outputs) of split `ks` of one contraction
+__device__ __forceinline__ void wgrad_tn_block(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb, int Mo,
+                                               int No, int K, int kchunk, float *__restrict__ part,
+                                               float *__restrict__ bias_part, int region, int ks) {
     const int regions_n = (No + 127) >> 7;
-    const int rm = blockIdx.x / regions_n, rn = blockIdx.x - rm * regions_n;
+    const int rm = region / regions_n, rn = region - rm * regions_n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kh = lane >> 5;
     const int i0 = rm * 128 + (wave & 1) * 64, j0 = rn * 128 + (wave >> 1) * 64;
     if (i0 >= Mo || j0 >= No) return;           // no barriers in this kernel: idle waves just leave
     const bool m1 = i0 + 32 < Mo, n1 = j0 + 32 < No;
-    const int kb = blockIdx.y * kchunk, ke = min(K, kb + kchunk);
+    const int kb = ks * kchunk, ke = min(K, kb + kchunk);
     const int ia0 = min(i0 + li, Mo - 1), ia1 = min(i0 + 32 + li, Mo - 1);
     const int jb0 = min(j0 + li, No - 1), jb1 = min(j0 + 32 + li, No - 1);
     wg_f32x16 acc00, acc01, acc10, acc11;
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(256) wgrad_tn_kernel(const float *__restrict__
             bs0 += a0[u]; bs1 += a1[u];
         }
     }
-    float *P = part + (size_t)blockIdx.y * Mo * No;
+    float *P = part + (size_t)ks * Mo * No;
     auto store = [&](const wg_f32x16 &acc, int ib, int jb) {
         const int col = jb + li;
         if (col >= No) return;
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(256) wgrad_tn_kernel(const float *__restrict__
     if (want_bias) {
         bs0 += __shfl_xor(bs0, 32);
         bs1 += __shfl_xor(bs1, 32);
-        float *bp = bias_part + (size_t)blockIdx.y * Mo;
+        float *bp = bias_part + (size_t)ks * Mo;
         if (kh == 0) {
             if (i0 + li < Mo) bp[i0 + li] = bs0;
             if (m1 && i0 + 32 + li < Mo) bp[i0 + 32 + li] = bs1;
@@ -84,16 +85,47 @@ __global__ void __launch_bounds__(256) wgrad_tn_kernel(const float *__restrict__
     }
 }
 
+__global__ void __launch_bounds__(256) wgrad_tn_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                                       int ldb, int Mo, int No, int K, int kchunk,
+                                                       float *__restrict__ part, float *__restrict__ bias_part) {
+    wgrad_tn_block(A, lda, B, ldb, Mo, No, K, kchunk, part, bias_part, blockIdx.x, blockIdx.y);
+}
+
+// ---- grouped form: several contractions in ONE launch (+ one reduce launch) ------------------------------------------------
+// An optimisation step has eight of these (second embedding layer, the two LSTM cells' W_ih / W_hh, output head, input
+// embedding, social encoding); five are tiny (<= 64 x 128 outputs) and cost a ~27 us launch + a ~7 us reduce each for
+// microseconds of matrix work.  Here every contraction keeps exactly the plan -- split count, chunk, summation order -- of
+// its stand-alone launch (so the results are bit-identical to tnp_wgrad), and the workgroups of all of them fill the chip
+// together.
+#define WG_MAX_PROBLEMS 12
+struct WgradGroup {
+    const float *A[WG_MAX_PROBLEMS], *B[WG_MAX_PROBLEMS];
+    float *part[WG_MAX_PROBLEMS], *bias_part[WG_MAX_PROBLEMS], *out[WG_MAX_PROBLEMS], *bout[WG_MAX_PROBLEMS];
+    int lda[WG_MAX_PROBLEMS], ldb[WG_MAX_PROBLEMS], Mo[WG_MAX_PROBLEMS], No[WG_MAX_PROBLEMS], K[WG_MAX_PROBLEMS];
+    int kchunk[WG_MAX_PROBLEMS], regions[WG_MAX_PROBLEMS], SK[WG_MAX_PROBLEMS], ldo[WG_MAX_PROBLEMS];
+    int first_block[WG_MAX_PROBLEMS + 1];     // wgrad_tn_group_kernel
+    int first_rblock[WG_MAX_PROBLEMS + 1];    // wgrad_reduce_group_kernel
+    int count;
+};
+
+__global__ void __launch_bounds__(256) wgrad_tn_group_kernel(const WgradGroup g) {
+    int p = 0;
+    while (p + 1 < g.count && (int)blockIdx.x >= g.first_block[p + 1]) ++p;
+    const int local = (int)blockIdx.x - g.first_block[p];
+    const int region = local % g.regions[p], ks = local / g.regions[p];
+    wgrad_tn_block(g.A[p], g.lda[p], g.B[p], g.ldb[p], g.Mo[p], g.No[p], g.K[p], g.kchunk[p], g.part[p], g.bias_part[p], region, ks);
+}
+
 // out[e] = sum over the splits of part[s][e], ascending s.  One launch covers the weight tile and (blocks past it) the bias
 // column; eight partials are in flight before the first add (the adds stay in split order: bit-identical to a serial loop).
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ part, int SK, long n, int cols, float *__restrict__ out,
-                                                           int ldo, const float *__restrict__ bpart, long nb, float *__restrict__ bout) {
+__device__ __forceinline__ void wgrad_reduce_block(const float *__restrict__ part, int SK, long n, int cols, float *__restrict__ out,
+                                                   int ldo, const float *__restrict__ bpart, long nb, float *__restrict__ bout, long block) {
     const long nblk = (n + 255) / 256;
-    long e = (long)blockIdx.x * 256 + threadIdx.x;
+    long e = block * 256 + threadIdx.x;
     long cnt = n;
     const float *src = part;
     bool bias = false;
-    if ((long)blockIdx.x >= nblk) { e -= nblk * 256; cnt = nb; src = bpart; bias = true; }
+    if (block >= nblk) { e -= nblk * 256; cnt = nb; src = bpart; bias = true; }
     if (e >= cnt) return;
     float acc = src[e];
     constexpr int U = 8;
@@ -108,6 +140,18 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
     for (; s < SK; ++s) acc += src[(size_t)s * cnt + e];
     if (bias) bout[e] = acc;
     else out[(e / cols) * ldo + (e % cols)] = acc;
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ part, int SK, long n, int cols, float *__restrict__ out,
+                                                           int ldo, const float *__restrict__ bpart, long nb, float *__restrict__ bout) {
+    wgrad_reduce_block(part, SK, n, cols, out, ldo, bpart, nb, bout, (long)blockIdx.x);
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_group_kernel(const WgradGroup g) {
+    int p = 0;
+    while (p + 1 < g.count && (int)blockIdx.x >= g.first_rblock[p + 1]) ++p;
+    wgrad_reduce_block(g.part[p], g.SK[p], (long)g.Mo[p] * g.No[p], g.No[p], g.out[p], g.ldo[p], g.bias_part[p], (long)g.Mo[p], g.bout[p],
+                       (long)((int)blockIdx.x - g.first_rblock[p]));
 }
 
 static void wgrad_plan(int Mo, int No, int K, int &regions, int &SK, int &kchunk) {
@@ -149,5 +193,57 @@ extern "C" TNP_API int tnp_wgrad(const float *dy, int ld_dy, const float *x, int
     hipLaunchKernelGGL(tnp::wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, s, part, SK, n, No, dw, ld_dw,
                        dbias ? bpart : nullptr, (long)Mo, dbias);
     TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+
+static size_t wgrad_problem_bytes(int Mo, int No, int K) {
+    int regions, SK, kchunk;
+    tnp::wgrad_plan(Mo, No, K, regions, SK, kchunk);
+    return (((size_t)SK * Mo * No + (size_t)SK * Mo) * sizeof(float) + 255) & ~(size_t)255;
+}
+
+extern "C" TNP_API size_t tnp_wgrad_grouped_workspace_bytes(const tnp_wgrad_problem *problems, int n) {
+    size_t total = 0;
+    for (int i = 0; i < n; ++i)
+        if (problems[i].Mo > 0 && problems[i].No > 0 && problems[i].K > 0) total += wgrad_problem_bytes(problems[i].Mo, problems[i].No, problems[i].K);
+    return total;
+}
+
+extern "C" TNP_API int tnp_wgrad_grouped(const tnp_wgrad_problem *problems, int n, void *workspace, size_t workspace_bytes,
+                                         void *stream) {
+    if (n <= 0) return 0;
+    if (!problems) TNP_FAIL(-1, "tnp_wgrad_grouped: problems == NULL");
+    const size_t need = tnp_wgrad_grouped_workspace_bytes(problems, n);
+    if (!workspace || workspace_bytes < need) TNP_FAIL(-1, "tnp_wgrad_grouped: workspace too small (need %zu bytes, got %zu)", need, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    int done = 0;
+    while (done < n) {
+        tnp::WgradGroup g;
+        g.count = 0; g.first_block[0] = 0; g.first_rblock[0] = 0;
+        for (; done < n && g.count < WG_MAX_PROBLEMS; ++done) {
+            const tnp_wgrad_problem &q = problems[done];
+            if (q.Mo <= 0 || q.No <= 0) continue;
+            if (q.K <= 0 || !q.dy || !q.x || !q.dw) TNP_FAIL(-1, "tnp_wgrad_grouped: problem %d: K = %d or a NULL pointer", done, q.K);
+            const int c = g.count;
+            int regions, SK, kchunk;
+            tnp::wgrad_plan(q.Mo, q.No, q.K, regions, SK, kchunk);
+            g.A[c] = q.dy; g.lda[c] = q.ld_dy; g.B[c] = q.x; g.ldb[c] = q.ld_x; g.Mo[c] = q.Mo; g.No[c] = q.No; g.K[c] = q.K;
+            g.kchunk[c] = kchunk; g.regions[c] = regions; g.SK[c] = SK; g.out[c] = q.dw; g.ldo[c] = q.ld_dw; g.bout[c] = q.dbias;
+            g.part[c] = (float *)ws;
+            g.bias_part[c] = q.dbias ? g.part[c] + (size_t)SK * q.Mo * q.No : nullptr;
+            ws += wgrad_problem_bytes(q.Mo, q.No, q.K);
+            g.first_block[c + 1] = g.first_block[c] + regions * SK;
+            const long nel = (long)q.Mo * q.No;
+            g.first_rblock[c + 1] = g.first_rblock[c] + (int)((nel + 255) / 256) + (q.dbias ? (q.Mo + 255) / 256 : 0);
+            ++g.count;
+        }
+        if (g.count == 0) break;
+        hipLaunchKernelGGL(tnp::wgrad_tn_group_kernel, dim3(g.first_block[g.count]), dim3(256), 0, s, g);
+        TNP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(tnp::wgrad_reduce_group_kernel, dim3(g.first_rblock[g.count]), dim3(256), 0, s, g);
+        TNP_HIP(hipGetLastError());
+    }
     return 0;
 }

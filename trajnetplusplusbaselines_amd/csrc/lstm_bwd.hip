@@ -1261,6 +1261,8 @@ extern "C" TNP_API size_t tnp_abi_sizeof(int which) {
         case 2: return sizeof(tnp_step_saves);
         case 3: return sizeof(tnp_train_saves);
         case 4: return sizeof(tnp_bwd_sweep);
+        case 5: return sizeof(tnp_wgrad_problem);
+        case 6: return sizeof(tnp_adam_tensor);
         default: return 0;
     }
 }

@@ -46,6 +46,13 @@ def _off(t, floats):
     return ctypes.c_void_p(t.data_ptr() + 4 * floats)
 
 
+class WgradProblem(ctypes.Structure):
+    """mirror of ``struct tnp_wgrad_problem`` (include/trajnet_hip.h)"""
+    _fields_ = [('dy', ctypes.c_void_p), ('ld_dy', ctypes.c_int), ('x', ctypes.c_void_p), ('ld_x', ctypes.c_int),
+                ('K', ctypes.c_int), ('Mo', ctypes.c_int), ('No', ctypes.c_int), ('dw', ctypes.c_void_p), ('ld_dw', ctypes.c_int),
+                ('dbias', ctypes.c_void_p)]
+
+
 class StepSaves(ctypes.Structure):
     """mirror of ``struct tnp_step_saves`` (include/trajnet_hip.h)"""
     _fields_ = [('X', ctypes.c_void_p), ('act', ctypes.c_void_p * 2), ('gates', ctypes.c_void_p), ('enc', ctypes.c_void_p),
@@ -110,7 +117,7 @@ def _attention_param_grads(pool, P, grads, wgrad, dout_all, bufs, denc_all, h_pr
     dout = flat(dout_all)
 
     def wg(dy, x, with_bias):       # (dy^T x, column sums of dy) through the shared split-K kernel
-        wgrad('_t', dy, x, '_b' if with_bias else None)
+        wgrad('_t', dy, x, '_b' if with_bias else None, immediate=True)
         return grads.pop('_t'), (grads.pop('_b') if with_bias else None)
     # query / key paths
     dwq_eff, dbq = wg(dq, eself, True)                                   # q = Wq_eff e_self + bq
@@ -506,25 +513,46 @@ class SequenceFn(torch.autograd.Function):
                 pending.append(reduce_fn(t))
 
         wg_ws = [None]
+        wg_queue = []        # contractions waiting for the grouped launch: (name, bias_name, problem, tensors kept alive)
 
-        def wgrad(name, dy, x, bias_name):
-            # dW = dy^T x over the stacked steps, operands as stored, K split across workgroups (csrc/gemm_wgrad.hip)
+        def wgrad(name, dy, x, bias_name, immediate=False):
+            # dW = dy^T x over the stacked steps, operands as stored, K split across workgroups (csrc/gemm_wgrad.hip).
+            # Queued: all contractions of the step go to the device in ONE launch (tnp_wgrad_grouped) when flush_wgrads() runs;
+            # immediate: launched now (the attention un-folding consumes its intermediates right away).
             dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
             K, Mo, No = dy2.shape[0], dy2.shape[1], x2.shape[1]
-            nbytes = L.tnp_wgrad_workspace_bytes(Mo, No, K)
-            if wg_ws[0] is None or wg_ws[0].numel() < nbytes:
-                wg_ws[0] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             dw = torch.empty(Mo, No, device=dev)
             db = torch.empty(Mo, device=dev) if bias_name is not None else None
-            _lib.check(L.tnp_wgrad(_lib.ptr(dy2), dy2.stride(0), _lib.ptr(x2), x2.stride(0), K, Mo, No, _lib.ptr(dw), No,
-                                   _lib.ptr(db), _lib.ptr(wg_ws[0]), nbytes, sp()), 'tnp_wgrad')
             grads[name] = dw
             if bias_name is not None:
                 grads[bias_name] = db
+            if not immediate:
+                wg_queue.append((name, bias_name, WgradProblem(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), K, Mo, No,
+                                                               dw.data_ptr(), No, db.data_ptr() if db is not None else None),
+                                 (dy2, x2, dw, db)))
+                return
+            nbytes = L.tnp_wgrad_workspace_bytes(Mo, No, K)
+            if wg_ws[0] is None or wg_ws[0].numel() < nbytes:
+                wg_ws[0] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(L.tnp_wgrad(_lib.ptr(dy2), dy2.stride(0), _lib.ptr(x2), x2.stride(0), K, Mo, No, _lib.ptr(dw), No,
+                                   _lib.ptr(db), _lib.ptr(wg_ws[0]), nbytes, sp()), 'tnp_wgrad')
             if not name.startswith('_'):       # '_t' / '_b': intermediates of the attention un-folding, combined further on the
                 publish(dw)                    # compute stream -- their final forms are published at the end
                 if bias_name is not None:
                     publish(db)
+
+        def flush_wgrads():
+            if not wg_queue:
+                return
+            table = (WgradProblem * len(wg_queue))(*[q[2] for q in wg_queue])
+            nbytes = L.tnp_wgrad_grouped_workspace_bytes(table, len(wg_queue))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(L.tnp_wgrad_grouped(table, len(wg_queue), _lib.ptr(ws), nbytes, sp()), 'tnp_wgrad_grouped')
+            for name, bias_name, _, keep in wg_queue:
+                publish(keep[2])
+                if bias_name is not None:
+                    publish(keep[3])
+            del wg_queue[:]
 
         def layer_wgrad(li, name):
             if li == 0 and sparse_bwd:
@@ -604,6 +632,7 @@ class SequenceFn(torch.autograd.Function):
         if social:
             wgrad('pool.hidden_dim_encoding.weight', denc_all, h_prev_all, 'pool.hidden_dim_encoding.bias')
 
+        flush_wgrads()
         if reduce_fn is not None:      # gradients formed outside wgrad() / layer_wgrad() (torch expressions) are reduced here
             done = set(id(t) for t in pending_tensors)
             for n in ctx.param_names:
