@@ -497,3 +497,56 @@ def test_grouped_wgrad_is_bitwise_the_stand_alone_wgrad():
             assert torch.equal(db, db1)
         ref = dy.double().t() @ x.double()
         assert (dw.double() - ref).abs().max() <= 1e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_sharded_loss_with_the_real_collision_term_sums_to_the_single_process_gradient():
+    """Scene-sharded training with PredictionLoss(col_wt > 0): the NLL term is a mean over frames x scenes, the
+    collision term a sum over scenes (lstm/loss.py:85-91, :147-161); `train_step.batch_loss` scales them separately.  On one
+    GPU: the gradients of two shards (each with the batch-wide slot count), added up as a SUM all-reduce would, equal the
+    gradients of the whole batch; with the round-2 rule (everything x n_local / n_global) they do not."""
+    from trajnetplusplusbaselines_amd import parallel, synth
+    from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling, PredictionLoss
+    from trajnetplusplusbaselines_amd.lstm.train_step import batch_loss
+    torch.manual_seed(3)
+    pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=8, out_dim=64, embedding_arch='two_layer',
+                            layer_dims=[128], latent_dim=8)
+    model = LSTM(pool=pool).cuda().train()
+    xy, split = synth.ragged_crowd(6, 3, 9, seed=41, nan_frac=0.0)
+    xy = xy * 0.35                                                     # a dense crowd: primaries come within col_distance of neighbours
+    crit = PredictionLoss(col_wt=10.0, col_distance=1.0)
+    goals = torch.zeros(xy.shape[1], 2)
+
+    def grads_of(batch, sp, shard, pad_to):
+        model.zero_grad()
+        scene = batch.cuda()
+        rel, out = model(scene[:9].clone(), goals[:scene.shape[1]], sp, scene[9:20].clone(), pad_to=pad_to)
+        targets = scene[9:21] - scene[8:20]
+        loss = batch_loss(crit, rel, out, scene, targets, sp, 12, 6, shard=shard)
+        loss.backward()
+        return float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    full_loss, full = grads_of(xy, split, None, None)
+    # the collision term is live and sizeable in this batch
+    with torch.no_grad():
+        model.eval()
+        rel, out = model(xy[:9].cuda(), goals, split, xy[9:20].cuda().clone())
+        model.train()
+    total, parts = 0.0, []
+    for r in range(2):
+        sh = parallel.shard_batch(xy, goals, split, r, 2)
+        lo, hi = sh.track_range
+        l, g = grads_of(xy[:, lo:hi], sh.batch_split, (sh.n_scenes, sh.n_scenes_global), sh.pad_to)
+        total += l
+        parts.append(g)
+    assert abs(total - full_loss) <= 2e-4 * max(1.0, abs(full_loss)), (total, full_loss)
+    worst = 0.0
+    for n, g in full.items():
+        s = parts[0][n] + parts[1][n]
+        worst = max(worst, float((s - g).abs().max()) / max(1e-6, float(g.abs().max())))
+    assert worst < 2e-4, worst
+    # the collision term really contributes: without it the loss is different
+    crit0 = PredictionLoss()
+    model.zero_grad()
+    scene = xy.cuda()
+    rel, out = model(scene[:9].clone(), goals, split, scene[9:20].clone())
+    l0 = float(batch_loss(crit0, rel, out, scene, scene[9:21] - scene[8:20], split, 12, 6))
+    assert abs(full_loss - l0) > 0.05 * abs(l0) + 1.0, (full_loss, l0)

@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_group_kernel(const WgradGrou
 
 static void wgrad_plan(int Mo, int No, int K, int &regions, int &SK, int &kchunk) {
     regions = ((Mo + 127) / 128) * ((No + 127) / 128);
-    int want = (512 + regions - 1) / regions;
+    int want = (512 + regions - 1) / regions;      // ~2 workgroups per CU; 768 - 1536 measured the same (round 3)
     if (want > 128) want = 128;
     const int maxsk = (K + 255) / 256;
     if (want > maxsk) want = maxsk;
