@@ -108,6 +108,44 @@ def test_random_ragged_batches(ref, kind):
     print('%s: worst |oracle - reference| over 44 forwards = %.2e' % (kind, worst))
 
 
+def _nongrid_model(ref, kind, rng):
+    from trajnetbaselines.lstm import non_gridbased_pooling as ngp
+    torch.manual_seed(int(rng.randint(1 << 30)))
+    pool = {'nn': lambda: ngp.NearestNeighborMLP(n=4, out_dim=32),
+            'hiddenstatemlp': lambda: ngp.HiddenStateMLPPooling(hidden_dim=128, out_dim=32),
+            'attentionmlp': lambda: ngp.AttentionMLPPooling(hidden_dim=128, out_dim=32),
+            'nn_lstm': lambda: ngp.NearestNeighborLSTM(n=4, hidden_dim=64, out_dim=32),
+            'traj_pool': lambda: ngp.TrajectronPooling(hidden_dim=64, out_dim=32)}[kind]()
+    goal_flag = bool(rng.rand() < 0.3)
+    model = ref.LSTM(pool=pool, goal_flag=goal_flag).eval()
+    sd = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+    kw = dict(n=4) if kind in ('nn', 'nn_lstm') else {}
+    if kind == 'attentionmlp':
+        kw['constant'] = -10.0
+    return model, oracle.OracleModel(sd, pool_type=kind, goal_flag=goal_flag, **kw), dict(goal_flag=goal_flag)
+
+
+@pytest.mark.parametrize('kind', ['nn', 'hiddenstatemlp', 'attentionmlp', 'nn_lstm', 'traj_pool'])
+def test_random_ragged_batches_nongrid(ref, kind):
+    """The five non-grid interaction modules (lstm/non_gridbased_pooling.py): 8 fresh ragged / NaN batches each, both decoder
+    modes, reference (1 thread) vs oracle within 2e-5 (measured 2e-6), NaN pattern identical."""
+    rng = np.random.RandomState({'nn': 41, 'hiddenstatemlp': 42, 'attentionmlp': 43, 'nn_lstm': 44, 'traj_pool': 45}[kind])
+    worst = 0.0
+    for it in range(8):
+        model, om, cfg = _nongrid_model(ref, kind, rng)
+        xy, split = _ragged_batch(rng, max_scenes=6, sizes=(1, 2, 3, 5, 9, 13))
+        goals = rng.uniform(-5, 5, size=(xy.shape[1], 2)).astype(np.float32)
+        for mode in ('n_predict', 'truth'):
+            rel_r, pred_r = _run_ref(model, xy, goals, split, mode)
+            rel_o, pred_o = _run_oracle(om, xy, goals, split, mode)
+            what = '%s #%d %s %r sizes=%s' % (kind, it, mode, cfg, np.diff(split).tolist())
+            helpers.assert_close_nan(rel_o, rel_r, 2e-5, 'rel ' + what)
+            helpers.assert_close_nan(pred_o, pred_r, 2e-5, 'pred ' + what)
+            if np.isfinite(pred_r).any():
+                worst = max(worst, float(np.nanmax(np.abs(pred_o - pred_r))))
+    print('%s: worst |oracle - reference| over 16 forwards = %.2e' % (kind, worst))
+
+
 def test_config2_full_size(ref):
     """BASELINE config 2 at FULL size (Social-LSTM n=16 two_layer 1024, 64 scenes x 32 agents; synth.linear_crowd(seed=100)
     = the bench workload): reference vs oracle, positions within 2e-5 and the primaries' ADE / FDE within 1e-4 m."""
