@@ -174,6 +174,17 @@ int main(int argc, char **argv) {
                 printf("   %-36s %d of %d repeats differ from the first\n", t.name, bad, reps - 1);
             }
         }
+        {   // cost of folding track_prepare into the prologue: the product kernel + a prepare-like phase
+            std::vector<float> hh((size_t)M * 128), w21(21 * 128);
+            for (auto &v : hh) v = Nrm(rng);
+            for (auto &v : w21) v = 0.1f * Nrm(rng);
+            float *dh = dev(hh), *dw21 = dev(w21), *de; CK(hipMalloc(&de, (size_t)M * 21 * 4));
+            const float *ptrs[3] = {dh, dw21, de};
+            const float **dptrs; CK(hipMalloc(&dptrs, sizeof(ptrs))); CK(hipMemcpy(dptrs, ptrs, sizeof(ptrs), hipMemcpyHostToDevice));
+            tnp::SparseArgs pa = b; pa.winners_out = reinterpret_cast<int16_t *>(dptrs);
+            printf("%-42s %8.2f us\n", "regacc quad-major + prepare-like prologue", time_kernel(KQ(1024), pa, nb, tnp::ra_smem_bytes(ncell), 50, 1024));
+            printf("%-42s %8.2f us\n", "regacc quad-major (again)", time_kernel(KQ(0), b, nb, tnp::ra_smem_bytes(ncell), 50, 1024));
+        }
         {   // wide register-accumulator kernels (round 3): 8 waves, 128 accumulators per lane
             std::vector<float> refq(got);                                           // output of the quad-major 64 x 128 kernel
             CK(hipMemset(out, 0, got.size() * 4));

@@ -623,6 +623,39 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
 #define RA_T(k) do { } while (0)
 #endif
     RA_T(0);
+#ifdef TNP_EXPERIMENT_HOOKS
+    // harness only (ABL & 1024): what folding track_prepare into this prologue would add -- the tile's 64 state rows (H = 128)
+    // and the 21 x 128 head / encoding weights through LDS, 64 x 21 dot products, the encodings written back to global
+    // memory for this workgroup's own scalar row loads and waited for.  a.winners_out carries {h, W21, enc_out} here.
+    if constexpr (TNP_ABL(1024)) {
+        const float *const *pp = reinterpret_cast<const float *const *>(a.winners_out);
+        const float *hsrc = pp[0], *wsrc = pp[1];
+        float *eout = const_cast<float *>(pp[2]);
+        float *hs = rsm, *ws21 = rsm + TE * 132;
+        for (int i = tid; i < TE * 32; i += NTH) {                                  // 64 rows x 128 floats, float4 each
+            const int r = i >> 5, k4 = i & 31;
+            const float4 v = reinterpret_cast<const float4 *>(hsrc + (size_t)min(row0 + r, a.M - 1) * 128)[k4];
+            *reinterpret_cast<float4 *>(hs + r * 132 + 4 * k4) = v;
+        }
+        for (int i = tid; i < 21 * 32; i += NTH) {
+            const int o = i >> 5, k4 = i & 31;
+            *reinterpret_cast<float4 *>(ws21 + o * 132 + 4 * k4) = reinterpret_cast<const float4 *>(wsrc + o * 128)[k4];
+        }
+        __syncthreads();
+        for (int i = tid; i < TE * 21; i += NTH) {
+            const int r = i / 21, o = i - r * 21;
+            float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+#pragma unroll 8
+            for (int k = 0; k < 128; k += 4) {
+                const float4 hv = *reinterpret_cast<const float4 *>(hs + r * 132 + k), wv = *reinterpret_cast<const float4 *>(ws21 + o * 132 + k);
+                acc0 = fmaf(hv.x, wv.x, acc0); acc1 = fmaf(hv.y, wv.y, acc1); acc2 = fmaf(hv.z, wv.z, acc2); acc3 = fmaf(hv.w, wv.w, acc3);
+            }
+            if (row0 + r < a.M) eout[(size_t)(row0 + r) * 21 + o] = (acc0 + acc1) + (acc2 + acc3);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // the stores have reached L2 before the scalar loads
+        __syncthreads();
+    }
+#endif
 
     for (int c = tid; c < a.ncell; c += NTH) socc[c] = 0;
     {
@@ -713,7 +746,7 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
         }
         __syncthreads();
         RA_T(2);
-        if (a.winners_out && ob == 0) {                                             // training: the winner table for the backward
+        if (!TNP_ABL(1024) && a.winners_out && ob == 0) {                           // training: the winner table for the backward
             for (int e = wave; e < TE; e += NW) {
                 const int row = row0 + e;
                 if (row >= a.M) continue;
