@@ -6,6 +6,7 @@ from trajnetplusplusbaselines_amd import synth
 from trajnetplusplusbaselines_amd.lstm import (LSTM, GridBasedPooling, NearestNeighborMLP, HiddenStateMLPPooling,
                                                AttentionMLPPooling, NearestNeighborLSTM, TrajectronPooling, PredictionLoss)
 from trajnetplusplusbaselines_amd.lstm.train_step import train_batch
+from trajnetplusplusbaselines_amd.optim import Adam
 
 POOLS = {
     'vanilla': lambda: None,
@@ -34,7 +35,7 @@ for name, mk in POOLS.items():
         for _ in range(20):
             model(scene[:9], goals, split, n_predict=12)
         torch.cuda.synchronize(); fwd = (time.perf_counter() - t0) / 20
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)          # the native one-launch update (optim.py)
     crit = PredictionLoss()
     for _ in range(3):
         train_batch(model, opt, crit, scene, goals, split, 9, 12, batch_size=64)
