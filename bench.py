@@ -539,6 +539,16 @@ def main():
             if n.value > 0 and ms.value > 0:
                 avg_s = ms.value / n.value * 1e-3
                 achieved = flops / avg_s / 1e12
+                # what an event pair costs with NOTHING between the two records, on the same stream: the bracket around a launch
+                # contains this much that is not the kernel (rocprofv3's kernel durations do not), so `avg_launch_us` reads
+                # higher than the committed rocprofv3 mean of the same kernel by about this amount
+                pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+                step()
+                for e0, e1 in pairs:
+                    e0.record(); e1.record()
+                    step()                                                       # keep the stream busy as in the measured region
+                torch.cuda.synchronize()
+                empty_us = float(np.median([e0.elapsed_time(e1) for e0, e1 in pairs])) * 1e3
                 roof = dict(bound='mfma', achieved=achieved, peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                             frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=None, kernel=kname,
                             engine=('fp32 VALU FMA (same 157.3 TFLOP/s peak as the fp32 matrix cores)' if sparse
@@ -547,7 +557,11 @@ def main():
                                          else 'dense GEMM (algorithmic FLOPs = 2*M*N1*C*n*n)'),
                             launches=n.value, avg_launch_us=avg_s * 1e6, flops_per_launch=flops,
                             dense_equivalent_tflops=dense_flops / avg_s / 1e12,
-                            share_of_step=ms.value * 1e-3 / elapsed)
+                            share_of_step=ms.value * 1e-3 / elapsed,
+                            event_pair_empty_us=empty_us,
+                            event_note='avg_launch_us is the span between two HIP events around each launch; two events with nothing '
+                                       'between them already read event_pair_empty_us on this stream (about half of that sits inside a '
+                                       'bracketed launch), which is why the rocprofv3 mean of the same kernel under profiles/ is ~3 us lower')
                 if hits is not None:
                     # the (A-1)-cell bound is an upper bound of the work; this is the work that was actually there
                     mean_hits = float(np.mean(hits))
