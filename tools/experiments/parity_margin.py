@@ -1,0 +1,22 @@
+"""How far the HIP path is from the oracle on BASELINE config 2 at full size and on a ragged fuzz batch: max |difference| of
+positions / normals (the parity tests assert 2e-5 / 1e-4; this prints the margin).  python tools/experiments/parity_margin.py"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, '.')
+from oracle import oracle
+from trajnetplusplusbaselines_amd import synth
+from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling
+
+torch.manual_seed(0)
+pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=16, out_dim=256, embedding_arch='two_layer',
+                        layer_dims=[1024], latent_dim=16)
+model = LSTM(pool=pool).eval()
+om = oracle.OracleModel({k: v.numpy() for k, v in model.state_dict().items()}, pool_type='social', n=16, cell_side=0.6)
+model = model.cuda()
+for name, (xy, split) in (('config 2 (64 x 32)', synth.linear_crowd(64, 32, seed=100)), ('ragged 12 scenes', synth.ragged_crowd(12, 3, 40, seed=9))):
+    with torch.no_grad():
+        rel, pred = model(xy[:9], torch.zeros(xy.shape[1], 2), split, n_predict=12)
+    orel, opred = om.forward(xy[:9].numpy(), None, split.numpy(), n_predict=12)
+    dp = np.nanmax(np.abs(pred.cpu().numpy() - opred)); dr = np.nanmax(np.abs(rel.cpu().numpy() - orel))
+    print('%-20s max |pred - oracle| %.3e   max |rel - oracle| %.3e' % (name, dp, dr))

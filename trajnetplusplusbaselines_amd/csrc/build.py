@@ -44,7 +44,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(OUT_DIR, os.path.splitext(src)[0] + '.o')
         # exact-arithmetic units (cell indexing, float64 / float32 simulators): no fma contraction
         extra = ['-ffp-contract=off'] if src in EXACT else []
-        cmd = [hipcc()] + FLAGS + extra + ['-c', path, '-o', obj]
+        cmd = [hipcc()] + FLAGS + extra + os.environ.get('TNP_HIPCC_EXTRA', '').split() + ['-c', path, '-o', obj]
         if verbose:
             print(' '.join(cmd))
         cmds.append(cmd)
