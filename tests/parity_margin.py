@@ -1,5 +1,5 @@
 """How far the HIP path is from the oracle on BASELINE config 2 at full size and on a ragged fuzz batch: max |difference| of
-positions / normals (the parity tests assert 2e-5 / 1e-4; this prints the margin).  python tools/experiments/parity_margin.py"""
+positions / normals (the parity tests assert 2e-5 / 1e-4; this prints the margin).  python tests/parity_margin.py"""
 import sys
 import numpy as np
 import torch

@@ -75,7 +75,7 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
 // (1 ulp each), tanh(x) = 2 sigmoid(2x) - 1 (absolute error ~1e-7).  libm's expf / tanhf and an IEEE divide are 20 precise
 // transcendentals per lane = 6 k of the gates kernel's 32 k cycles; with these the step is 1 us shorter (1.6 % of the forward)
 // and the distance to the oracle does not move: max |pred - oracle| at config 2 full size 2.9e-6 against 2.4e-6 (summation
-// order dominates both; tools/experiments/parity_margin.py), all parity tests unchanged.  -DTNP_PRECISE_GATES restores libm.
+// order dominates both; tests/parity_margin.py), all parity tests unchanged.  -DTNP_PRECISE_GATES restores libm.
 #ifndef TNP_PRECISE_GATES
 __device__ __forceinline__ float sigmoidf_acc(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_acc(float x) { return fmaf(2.0f, sigmoidf_acc(2.0f * x), -1.0f); }
