@@ -4,8 +4,10 @@
 //   * pool_embed_regwide_kernel<C, 128, 1> / <C, 64, 2>: 8 waves with 128 accumulators per lane (128-ego tiles, or two
 //     columns per lane);
 //   * pool_embed_regshare_kernel<C>: 128-ego tiles on 16 waves, the two waves of a cell group share the group's weight
-//     blocks through an LDS ring filled by LDS-DMA, byte winners voted through per-half-wave tables.
-// All three are bit-identical to the product kernel on every output element.
+//     blocks through an LDS ring filled by LDS-DMA, byte winners voted through per-half-wave tables;
+//   * pool_embed_regring_kernel<C>: the product's tile and waves, every wave with a private two-slot LDS ring (LDS-DMA two
+//     cells ahead) and one weight register set.
+// All four are bit-identical to the product kernel on every output element.
 #pragma once
 
 namespace tnp {
@@ -697,5 +699,303 @@ bool regshare_supported(int C, int ncell, int n_max) {
            rs_smem_bytes(ncell, C) <= (size_t)160 * 1024;
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Ring kernel: the product kernel's tile (64 egos x 128 columns, 16 waves = 8 cell groups x 2 column sets, 64 register
+// accumulators per lane), but every wave streams its weight blocks through a PRIVATE two-slot LDS ring filled by LDS-DMA two
+// cells ahead (no inter-wave hand-off: a wave reads only what it loaded itself), and holds ONE weight register set that it
+// refills from LDS at the top of a visit.  The register-staged product kernel prefetches one cell ahead: its memory pipe runs
+// dry while a wave works through a dense cell, and stream (16.5 us) and hits (14.6 us) add up to 25 us instead of overlapping.
+// LDS: winners as bytes (17 KB, voted through per-half-wave tables as in the shared-weight kernel) + 16 x 2 x 4 KB of ring.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int RG_TE = 64, RG_OB = 128, RG_NQ = 8, RG_NCS = 2, RG_WS = RG_TE + 4, RG_RED = 32;
+static size_t rg_smem_bytes(int ncell, int C) {
+    const size_t head = (((size_t)ncell * RG_WS + (size_t)ncell * 4 + 6 * RG_TE * 4) + 15) & ~(size_t)15;
+    const size_t ring = (size_t)RG_NQ * RG_NCS * 2 * C * 64 * 4;
+    const size_t votes = (size_t)RG_NQ * RG_NCS * 2 * ncell * 4;
+    const size_t red = (size_t)RG_NQ * RG_RED * RG_OB * 4;
+    size_t body = ring > votes ? ring : votes;
+    if (red > body) body = red;
+    return head + body;
+}
+
+template <int C TNP_ABL_TPARAM>
+__global__ void __launch_bounds__(64 * RG_NQ * RG_NCS) pool_embed_regring_kernel(const SparseArgs a) {
+    constexpr int TE = RG_TE, OB = RG_OB, NQ = RG_NQ, NCS = RG_NCS, NW = NQ * NCS, NTH = 64 * NW, WS = RG_WS, SLOT = C * 64;
+    static_assert(C == 4 || C == 8 || C == 16, "channels");
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm8[];
+    unsigned char *win8 = gsm8;                                                      // [ncell][WS]: winning neighbour, 255 = none
+    int *socc = reinterpret_cast<int *>(gsm8 + (size_t)a.ncell * WS);
+    int *sg = socc + a.ncell;
+    float *sp = reinterpret_cast<float *>(sg + 4 * TE);
+    const size_t head = (((size_t)a.ncell * WS + (size_t)a.ncell * 4 + 6 * TE * 4) + 15) & ~(size_t)15;
+    float *ring = reinterpret_cast<float *>(gsm8 + head);                            // [NW][2][SLOT] (main loop)
+    int *vtab = reinterpret_cast<int *>(gsm8 + head);                                // [NW][2][ncell] (prologue)
+    float *red = reinterpret_cast<float *>(gsm8 + head);                             // [NQ][RG_RED][OB] (epilogue)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cs = wave % NCS, q = wave / NCS;
+    const int ob = blockIdx.x % a.out_blocks, tile = blockIdx.x / a.out_blocks;
+    const int row0 = tile * TE;
+    long long *dbg = nullptr;
+    if constexpr (TNP_ABL(256)) dbg = reinterpret_cast<long long *>(const_cast<int16_t *>(a.winners));
+#define RG_T(k) do { if constexpr (TNP_ABL(256)) { if (lane == 0) dbg[(blockIdx.x * 16 + wave) * 8 + (k)] = (long long)__builtin_readcyclecounter(); } } while (0)
+    RG_T(0);
+    for (int c = tid; c < a.ncell; c += NTH) socc[c] = 0;
+    {
+        const int4 ff = {-1, -1, -1, -1};
+        const int nw4 = (a.ncell * WS) / 16;
+        for (int idx = tid; idx < nw4; idx += NTH) reinterpret_cast<int4 *>(win8)[idx] = ff;
+        const int nv4 = NW * 2 * a.ncell / 4;
+        for (int idx = tid; idx < nv4; idx += NTH) reinterpret_cast<int4 *>(vtab)[idx] = ff;
+    }
+    if (tid < TE) {
+        const int row = row0 + tid;
+        int lo = 0, ns = 0, pad = 0;
+        float2 pi = {-500.0f, -500.0f};
+        if (row < a.M) {
+            lo = a.row_base[row]; ns = a.row_end[row] - lo; pad = a.row_padded[row];
+            pi = reinterpret_cast<const float2 *>(a.obs2)[row];
+            if (pi.x != pi.x || pi.y != pi.y) { pi.x = -500.0f; pi.y = -500.0f; }
+        }
+        sg[tid] = lo; sg[TE + tid] = ns; sg[2 * TE + tid] = row - lo; sg[3 * TE + tid] = pad;
+        sp[tid] = pi.x; sp[TE + tid] = pi.y;
+    }
+    __syncthreads();
+    RG_T(1);
+    if constexpr (!TNP_ABL(32)) {
+        constexpr int EU = TE / NW;                                                 // 4 egos per wave
+        const float fG = (float)a.G;
+        const int e0 = wave * EU;
+        const int ns_l = sg[TE + e0 + (lane & (EU - 1))];
+        const bool small = __builtin_amdgcn_readfirstlane((int)(__ballot(ns_l > 32) == 0ull)) != 0;
+        auto cell_of_pair = [&](float2 pj, float px, float py, bool &inr) -> int {
+            if (pj.x != pj.x || pj.y != pj.y) { pj.x = -500.0f; pj.y = -500.0f; }
+            const float ox = __fadd_rn(__fdiv_rn(__fsub_rn(pj.x, px), a.cell), a.half_x);
+            const float oy = __fadd_rn(__fdiv_rn(__fsub_rn(pj.y, py), a.cell), a.half_y);
+            inr = !(ox < 0.0f) && !(ox >= fG) && !(oy < 0.0f) && !(oy >= fG);
+            return inr ? ((int)ox * a.G + (int)oy) : 0;
+        };
+        if (small) {
+            const int hi = lane >> 5, j = lane & 31;
+            int *tab = vtab + (size_t)(wave * 2 + hi) * a.ncell;
+            int lo_[EU / 2], ns_[EU / 2], ki_[EU / 2], pad_[EU / 2];
+            float px_[EU / 2], py_[EU / 2];
+            float2 pq[EU / 2];
+#pragma unroll
+            for (int p = 0; p < EU / 2; ++p) {
+                const int e = e0 + 2 * p + hi;
+                lo_[p] = sg[e]; ns_[p] = sg[TE + e]; ki_[p] = sg[2 * TE + e]; pad_[p] = sg[3 * TE + e];
+                px_[p] = sp[e]; py_[p] = sp[TE + e];
+            }
+#pragma unroll
+            for (int p = 0; p < EU / 2; ++p)
+                pq[p] = reinterpret_cast<const float2 *>(a.obs2)[lo_[p] + (j < ns_[p] ? j : 0)];
+#pragma unroll
+            for (int p = 0; p < EU / 2; ++p) {
+                const int e = e0 + 2 * p + hi;
+                const bool valid = j < ns_[p] && j != ki_[p];
+                bool inr;
+                const int cellid = cell_of_pair(pq[p], px_[p], py_[p], inr);
+                const bool vin = valid && inr;
+                const unsigned long long oor = __ballot(valid && !inr);
+                const unsigned mh = hi ? (unsigned)(oor >> 32) : (unsigned)oor;
+                int k0 = mh ? 2 * (31 - __builtin_clz(mh)) : -1;
+                if (ns_[p] < pad_[p]) k0 = 2 * (pad_[p] - 1);
+                if (vin) atomicMax(&tab[cellid], 2 * j + 1);
+                if (j == 0 && k0 >= 0) atomicMax(&tab[0], k0);
+                const int w = vin ? tab[cellid] : -1;
+                if (vin && w == 2 * j + 1) { win8[cellid * WS + e] = (unsigned char)j; socc[cellid] = 1; }
+                if (vin) tab[cellid] = -1;
+                if (j == 0) tab[0] = -1;
+            }
+        } else {
+            int *tab = vtab + (size_t)(wave * 2) * a.ncell;
+            for (int u = 0; u < EU; ++u) {
+                const int e = e0 + u;
+                const int lo = sg[e], ns = sg[TE + e], ki = sg[2 * TE + e], pad = sg[3 * TE + e];
+                const float px = sp[e], py = sp[TE + e];
+                for (int j = lane; j < ns; j += 64) {
+                    bool inr;
+                    const int cellid = cell_of_pair(reinterpret_cast<const float2 *>(a.obs2)[lo + j], px, py, inr);
+                    if (j != ki) atomicMax(&tab[cellid], 2 * j + (inr ? 1 : 0));
+                }
+                if (ns < pad && lane == 0) atomicMax(&tab[0], 2 * (pad - 1));
+                for (int c = lane; c < a.ncell; c += 64) {
+                    const int w = tab[c];
+                    if (w >= 0) {
+                        if (w & 1) { win8[c * WS + e] = (unsigned char)(w >> 1); socc[c] = 1; }
+                        tab[c] = -1;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    RG_T(2);
+    if (!TNP_ABL(1024) && a.winners_out && ob == 0) {
+        for (int e = wave; e < TE; e += NW) {
+            const int row = row0 + e;
+            if (row >= a.M) continue;
+            for (int c = lane; c < a.ncell; c += 64) {
+                const int w = win8[c * WS + e];
+                a.winners_out[(size_t)row * a.ncell + c] = w == 255 ? (int16_t)-1 : (int16_t)w;
+            }
+        }
+    }
+    int rb = sg[lane];
+    asm volatile("" : "+v"(rb));
+    const int col2 = 2 * lane;
+    float2 bias2 = {0.0f, 0.0f};
+    if (a.bias && ob * OB + col2 + 1 < a.N1) bias2 = *reinterpret_cast<const float2 *>(a.bias + ob * OB + col2);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias2) :: "memory");                    // from here on vmcnt counts LDS-DMA batches only
+    RG_T(3);
+    ra_f32x32 accA, accB;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { accA[i] = 0.0f; accB[i] = 0.0f; }
+
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    struct WS_ { f4 q[C / 4]; };
+    float *myring = ring + (size_t)wave * 2 * SLOT;
+    const unsigned lds0 = (unsigned)(uintptr_t)myring, lds1 = lds0 + SLOT * 4;
+    const char *wq_base = reinterpret_cast<const char *>(a.Wp) + (size_t)min(ob * NCS + cs, (a.N1 >> 6) - 1) * (C * 64 * 4);
+    const unsigned wq_stride = (unsigned)(a.N1 >> 6) * (C * 64 * 4);
+    const unsigned vl = lane * 16u;
+    // LDS-DMA of the weights of cell c into slot `lds`: C / 4 instructions of 1 KB, destination lane-linear = the quad-major
+    // source order; M0 is set inside the statement (nothing else in this kernel depends on M0)
+    auto dma = [&](int c, unsigned lds) {
+        if constexpr (!TNP_ABL(1)) {
+            const char *wb = wq_base + __builtin_amdgcn_readfirstlane((unsigned)c * wq_stride);
+            if constexpr (C == 16)
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                             "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
+                             :: "v"(vl), "s"(wb), "s"(lds) : "memory");
+            else if constexpr (C == 8)
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
+                             :: "v"(vl), "s"(wb), "s"(lds) : "memory");
+            else
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vl), "s"(wb), "s"(lds) : "memory");
+        }
+    };
+    auto wait_older_dma = [&]() {                                                   // the older of the two batches in flight has landed
+        if constexpr (!TNP_ABL(1)) {
+            if constexpr (C == 16) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (C == 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        }
+    };
+    auto fin = [&](const WS_ &w, const typename SRow<C>::type &ev, float av) -> float {
+        f2 p = {av, 0.0f};
+#pragma unroll
+        for (int k = 0; k < C / 2; ++k) {
+            const f2 wk = {w.q[(2 * k) >> 2][(2 * k) & 3], w.q[(2 * k + 1) >> 2][(2 * k + 1) & 3]};
+            const f2 ek = {ev[2 * k], ev[2 * k + 1]};
+            p = __builtin_elementwise_fma(wk, ek, p);
+        }
+        return p.x + p.y;
+    };
+    auto half = [&](const WS_ &w, ra_f32x32 &acc, unsigned m, unsigned off, int lane0) {
+        while (m & (m - 1u)) {
+            const int b0 = __builtin_ctz(m); m &= m - 1u;
+            const int b1 = __builtin_ctz(m); m &= m - 1u;
+            typename SRow<C>::type e0, e1;
+            sload_row<C>(e0, a.enc, (unsigned)__builtin_amdgcn_readlane((int)off, lane0 + b0));
+            sload_row<C>(e1, a.enc, (unsigned)__builtin_amdgcn_readlane((int)off, lane0 + b1));
+            const float a0 = acc[b0], a1 = acc[b1];
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e0), "+s"(e1));
+            acc[b0] = fin(w, e0, a0);
+            acc[b1] = fin(w, e1, a1);
+        }
+        if (m) {
+            const int b0 = __builtin_ctz(m);
+            typename SRow<C>::type e0;
+            sload_row<C>(e0, a.enc, (unsigned)__builtin_amdgcn_readlane((int)off, lane0 + b0));
+            const float a0 = acc[b0];
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e0));
+            acc[b0] = fin(w, e0, a0);
+        }
+    };
+    const int nk = (a.ncell + NQ - 1) / NQ;
+    auto cell_of = [&](int k) { return NQ * k + ((q - k) & (NQ - 1)); };
+    unsigned long long occ;
+    {
+        const int c = cell_of(lane);
+        occ = __ballot(lane < nk && c < a.ncell && socc[c < a.ncell ? c : 0] != 0);
+    }
+    if constexpr (TNP_ABL(16)) occ = 0ull;
+    int left = __popcll(occ);
+    // one visit: the slot's weights into registers, the next-but-one cell's DMA into the same slot, the hits
+    auto visit = [&](const float *slot, unsigned lds, int c_dma, int key8) {
+        wait_older_dma();
+        WS_ w;
+        {
+            const f4 *src = reinterpret_cast<const f4 *>(slot) + lane;
+#pragma unroll
+            for (int kq = 0; kq < C / 4; ++kq) w.q[kq] = src[kq * 64];
+        }
+        const int wv = key8 == 255 ? -1 : key8;
+        const unsigned long long mask = __ballot(wv >= 0);
+#pragma unroll
+        for (int kq = 0; kq < C / 4; ++kq) asm volatile("" : "+v"(w.q[kq]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           // the slot has been read: it may be refilled
+        dma(c_dma, lds);
+        if constexpr (TNP_ABL(2)) { if (mask == 1234567ull) accA[0] += w.q[0][0] + w.q[C / 4 - 1][3]; return; }
+        const unsigned off = __umul24((unsigned)(rb + wv), (unsigned)(a.ldv * 4));
+        half(w, accA, (unsigned)mask, off, 0);
+        half(w, accB, (unsigned)(mask >> 32), off, 32);
+    };
+    if (left > 0) {
+        // cells of visits v, v + 1 (cA, cB); every DMA is issued unconditionally (past the end it re-reads the last cell) so that
+        // the vmcnt arithmetic is exact
+        int cA = cell_of(pop_bit(occ)), cB = cA;
+        if (left > 1) cB = cell_of(pop_bit(occ));
+        dma(cA, lds0);
+        dma(cB, lds1);
+        int kA = win8[cA * WS + lane], kB;
+        while (true) {
+            int cn = cB;
+            if (left > 2) cn = cell_of(pop_bit(occ));
+            kB = win8[cB * WS + lane];
+            visit(myring, lds0, cn, kA);
+            if (--left == 0) break;
+            cA = cn;                                                                // cell of visit v + 2
+            int cm = cA;
+            if (left > 2) cm = cell_of(pop_bit(occ));
+            kA = win8[cA * WS + lane];
+            visit(myring + SLOT, lds1, cm, kB);
+            if (--left == 0) break;
+            cB = cm;
+        }
+        if constexpr (!TNP_ABL(1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    RG_T(4);
+    if constexpr (TNP_ABL(128)) { if (accA[3] + accB[5] == 1.234e30f) a.out[tid] = 0.0f; return; }
+#pragma unroll
+    for (int r = 0; r < TE / RG_RED; ++r) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < RG_RED; ++e)
+            red[(q * RG_RED + e) * OB + cs * 64 + lane] = r == 0 ? accA[e] : accB[e];
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < RG_RED / NW; ++h) {
+            const int e = wave + NW * h;
+            float2 v = *reinterpret_cast<const float2 *>(red + (size_t)e * OB + col2);
+#pragma unroll
+            for (int qq = 1; qq < NQ; ++qq) {
+                const float2 t = *reinterpret_cast<const float2 *>(red + ((size_t)qq * RG_RED + e) * OB + col2);
+                v.x += t.x; v.y += t.y;
+            }
+            v.x += bias2.x; v.y += bias2.y;
+            if (a.relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); }
+            const int row = row0 + RG_RED * r + e;
+            if (row < a.M && ob * OB + col2 + 1 < a.N1) *reinterpret_cast<float2 *>(a.out + (size_t)row * a.ldo + ob * OB + col2) = v;
+        }
+    }
+    RG_T(5);
+#undef RG_T
+}
 
 }  // namespace tnp

@@ -244,6 +244,48 @@ int main(int argc, char **argv) {
                 }
             }
         }
+        {   // ring kernel (round 3): product tile, per-wave two-slot LDS ring filled by LDS-DMA two cells ahead
+            std::vector<float> refq(got.size());
+            CK(hipMemset(out, 0, got.size() * 4));
+            time_kernel(KQ(0), b, nb, tnp::ra_smem_bytes(ncell), 1, 1024);
+            CK(hipMemcpy(refq.data(), out, refq.size() * 4, hipMemcpyDeviceToHost));
+#define KG(abl) (kern_t)tnp::pool_embed_regring_kernel<16, abl>
+            struct GV { const char *name; kern_t k; };
+            const GV gv[] = {{"ring 64x128", KG(0)}, {"ring 64x128 no DMA (1)", KG(1)}, {"ring 64x128 no hits (2)", KG(2)},
+                             {"ring 64x128 no DMA, no hits (3)", KG(3)}, {"ring 64x128 no cell loop (16)", KG(16)},
+                             {"ring 64x128 no loop, no votes (48)", KG(48)}, {"ring 64x128 nothing (176)", KG(176)}};
+            const size_t sm = tnp::rg_smem_bytes(ncell, 16);
+            printf("ring kernel: %d workgroups, %zu bytes of LDS\n", nb, sm);
+            for (const GV &v : gv) {
+                CK(hipMemset(out, 0, got.size() * 4));
+                printf("%-42s %8.2f us\n", v.name, time_kernel(v.k, b, nb, sm, 50, 1024));
+                if (v.k == KG(0)) {
+                    CK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
+                    check(got, v.name);
+                    size_t nd = 0; for (size_t i = 0; i < got.size(); ++i) nd += memcmp(&got[i], &refq[i], 4) != 0;
+                    printf("   bit-identical to the product kernel: %s (%zu elements differ)\n", nd ? "NO" : "yes", nd);
+                    int bad = 0;
+                    const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 60;
+                    std::vector<float> again(got.size());
+                    for (int rep = 0; rep < reps; ++rep) {
+                        CK(hipMemsetAsync(out, 0xff, got.size() * 4));
+                        hipLaunchKernelGGL(v.k, dim3(nb), dim3(1024), sm, 0, b);
+                        CK(hipMemcpy(again.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
+                        bad += memcmp(again.data(), got.data(), got.size() * 4) != 0;
+                    }
+                    printf("   %d of %d repeats differ\n", bad, reps);
+                    {
+                        int16_t *w1, *w2; CK(hipMalloc(&w1, (size_t)M * ncell * 2)); CK(hipMalloc(&w2, (size_t)M * ncell * 2));
+                        tnp::SparseArgs x = b; x.winners_out = w1; hipLaunchKernelGGL(v.k, dim3(nb), dim3(1024), sm, 0, x);
+                        tnp::SparseArgs y = b; y.winners_out = w2; hipLaunchKernelGGL(KQ(0), dim3(nb), dim3(1024), tnp::ra_smem_bytes(ncell), 0, y);
+                        std::vector<int16_t> h1((size_t)M * ncell), h2((size_t)M * ncell);
+                        CK(hipMemcpy(h1.data(), w1, h1.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), w2, h2.size() * 2, hipMemcpyDeviceToHost));
+                        printf("   winner tables equal: %s\n", memcmp(h1.data(), h2.data(), h1.size() * 2) ? "NO" : "yes");
+                        CK(hipFree(w1)); CK(hipFree(w2));
+                    }
+                }
+            }
+        }
         {   // shared-weight kernel (round 3): 128 egos x 64 columns, 16 waves, weights through an LDS ring (LDS-DMA)
             std::vector<float> refq(got.size());
             CK(hipMemset(out, 0, got.size() * 4));
