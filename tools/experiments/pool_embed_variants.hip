@@ -5,9 +5,9 @@
 //     columns per lane);
 //   * pool_embed_regshare_kernel<C>: 128-ego tiles on 16 waves, the two waves of a cell group share the group's weight
 //     blocks through an LDS ring filled by LDS-DMA, byte winners voted through per-half-wave tables;
-//   * pool_embed_regring_kernel<C>: the product's tile and waves, every wave with a private two-slot LDS ring (LDS-DMA two
-//     cells ahead) and one weight register set.
-// All four are bit-identical to the product kernel on every output element.
+//   * pool_embed_regring_kernel<C, DB>: the product's tile and waves, every wave with a private two-slot LDS ring (LDS-DMA two
+//     cells ahead) and one weight register set (DB = false) or two, the next visit's read issued mid-visit (DB = true).
+// All five are bit-identical to the product kernel on every output element.
 #pragma once
 
 namespace tnp {
@@ -720,7 +720,7 @@ static size_t rg_smem_bytes(int ncell, int C) {
     return head + body;
 }
 
-template <int C TNP_ABL_TPARAM>
+template <int C, bool DB TNP_ABL_TPARAM>
 __global__ void __launch_bounds__(64 * RG_NQ * RG_NCS) pool_embed_regring_kernel(const SparseArgs a) {
     constexpr int TE = RG_TE, OB = RG_OB, NQ = RG_NQ, NCS = RG_NCS, NW = NQ * NCS, NTH = 64 * NW, WS = RG_WS, SLOT = C * 64;
     static_assert(C == 4 || C == 8 || C == 16, "channels");
@@ -926,15 +926,17 @@ __global__ void __launch_bounds__(64 * RG_NQ * RG_NCS) pool_embed_regring_kernel
     }
     if constexpr (TNP_ABL(16)) occ = 0ull;
     int left = __popcll(occ);
+    auto lds_to_regs = [&](WS_ &w, const float *slot) {
+        const f4 *src = reinterpret_cast<const f4 *>(slot) + lane;
+#pragma unroll
+        for (int kq = 0; kq < C / 4; ++kq) w.q[kq] = src[kq * 64];
+    };
+    if constexpr (!DB) {
     // one visit: the slot's weights into registers, the next-but-one cell's DMA into the same slot, the hits
     auto visit = [&](const float *slot, unsigned lds, int c_dma, int key8) {
         wait_older_dma();
         WS_ w;
-        {
-            const f4 *src = reinterpret_cast<const f4 *>(slot) + lane;
-#pragma unroll
-            for (int kq = 0; kq < C / 4; ++kq) w.q[kq] = src[kq * 64];
-        }
+        lds_to_regs(w, slot);
         const int wv = key8 == 255 ? -1 : key8;
         const unsigned long long mask = __ballot(wv >= 0);
 #pragma unroll
@@ -969,6 +971,50 @@ __global__ void __launch_bounds__(64 * RG_NQ * RG_NCS) pool_embed_regring_kernel
             cB = cm;
         }
         if constexpr (!TNP_ABL(1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    } else {
+    // double-buffered registers: the weights of visit v + 1 go from their slot into the second register set between the two
+    // halves of visit v (their LDS latency hides behind the second half's hits); the slot of visit v is refilled with visit
+    // v + 2 at the top of visit v (its reads finished a visit ago)
+    auto visit2 = [&](WS_ &w, WS_ &wn, const float *slot_next, unsigned lds_cur, int c_dma, int key8) {
+#pragma unroll
+        for (int kq = 0; kq < C / 4; ++kq) asm volatile("" : "+v"(w.q[kq]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           // this visit's registers (read a visit ago) and key row
+        dma(c_dma, lds_cur);                                                         // visit v + 2 into the slot visit v came from
+        const int wv = key8 == 255 ? -1 : key8;
+        const unsigned long long mask = __ballot(wv >= 0);
+        const unsigned off = __umul24((unsigned)(rb + wv), (unsigned)(a.ldv * 4));
+        if constexpr (!TNP_ABL(2)) half(w, accA, (unsigned)mask, off, 0);
+        wait_older_dma();                                                           // visit v + 1's DMA (issued a visit ago) has landed
+        lds_to_regs(wn, slot_next);
+        if constexpr (TNP_ABL(2)) { if (mask == 1234567ull) accA[0] += w.q[0][0] + w.q[C / 4 - 1][3]; return; }
+        half(w, accB, (unsigned)(mask >> 32), off, 32);
+    };
+    if (left > 0) {
+        int cA = cell_of(pop_bit(occ)), cB = cA;
+        if (left > 1) cB = cell_of(pop_bit(occ));
+        dma(cA, lds0);
+        dma(cB, lds1);
+        WS_ wA, wB;
+        wait_older_dma();
+        lds_to_regs(wA, myring);
+        int kA = win8[cA * WS + lane], kB;
+        while (true) {
+            int cn = cB;
+            if (left > 2) cn = cell_of(pop_bit(occ));
+            kB = win8[cB * WS + lane];
+            visit2(wA, wB, myring + SLOT, lds0, cn, kA);
+            if (--left == 0) break;
+            cA = cn;
+            int cm = cA;
+            if (left > 2) cm = cell_of(pop_bit(occ));
+            kA = win8[cA * WS + lane];
+            visit2(wB, wA, myring, lds1, cm, kB);
+            if (--left == 0) break;
+            cB = cm;
+        }
+        if constexpr (!TNP_ABL(1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     }
     RG_T(4);
     if constexpr (TNP_ABL(128)) { if (accA[3] + accB[5] == 1.234e30f) a.out[tid] = 0.0f; return; }

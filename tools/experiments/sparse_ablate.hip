@@ -249,17 +249,20 @@ int main(int argc, char **argv) {
             CK(hipMemset(out, 0, got.size() * 4));
             time_kernel(KQ(0), b, nb, tnp::ra_smem_bytes(ncell), 1, 1024);
             CK(hipMemcpy(refq.data(), out, refq.size() * 4, hipMemcpyDeviceToHost));
-#define KG(abl) (kern_t)tnp::pool_embed_regring_kernel<16, abl>
+#define KG(abl) (kern_t)tnp::pool_embed_regring_kernel<16, false, abl>
+#define KG2(abl) (kern_t)tnp::pool_embed_regring_kernel<16, true, abl>
             struct GV { const char *name; kern_t k; };
             const GV gv[] = {{"ring 64x128", KG(0)}, {"ring 64x128 no DMA (1)", KG(1)}, {"ring 64x128 no hits (2)", KG(2)},
                              {"ring 64x128 no DMA, no hits (3)", KG(3)}, {"ring 64x128 no cell loop (16)", KG(16)},
-                             {"ring 64x128 no loop, no votes (48)", KG(48)}, {"ring 64x128 nothing (176)", KG(176)}};
+                             {"ring 64x128 no loop, no votes (48)", KG(48)}, {"ring 64x128 nothing (176)", KG(176)},
+                             {"ring2 (two register sets)", KG2(0)}, {"ring2 no DMA (1)", KG2(1)}, {"ring2 no hits (2)", KG2(2)},
+                             {"ring2 no DMA, no hits (3)", KG2(3)}};
             const size_t sm = tnp::rg_smem_bytes(ncell, 16);
             printf("ring kernel: %d workgroups, %zu bytes of LDS\n", nb, sm);
             for (const GV &v : gv) {
                 CK(hipMemset(out, 0, got.size() * 4));
                 printf("%-42s %8.2f us\n", v.name, time_kernel(v.k, b, nb, sm, 50, 1024));
-                if (v.k == KG(0)) {
+                if (v.k == KG(0) || v.k == KG2(0)) {
                     CK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
                     check(got, v.name);
                     size_t nd = 0; for (size_t i = 0; i < got.size(); ++i) nd += memcmp(&got[i], &refq[i], 4) != 0;
