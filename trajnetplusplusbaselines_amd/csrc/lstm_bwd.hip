@@ -726,10 +726,12 @@ template <int C>
 __global__ void __launch_bounds__(256) sparse_wgrad_mfma_kernel(const float *__restrict__ dy, int ldy,
                                                                 const float *__restrict__ enc, int lde,
                                                                 const int2 *__restrict__ list, const int32_t *__restrict__ count,
-                                                                int R, int N1, int ncell, float *__restrict__ dWc) {
+                                                                int R, int N1, int ncell, float *__restrict__ dWc,
+                                                                const float *__restrict__ swg_zeros) {
     static_assert(C <= 16, "one 16-channel A tile");
     typedef float f4 __attribute__((ext_vector_type(4)));
-    __shared__ float red[3][16][64];
+    constexpr int NW = 4, U = 1;                                    // waves per workgroup, batches per trip (see below)
+    __shared__ float red[NW - 1][16][64];
     int c, chunk;
     {
         const int nchunk = N1 >> 6, bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
@@ -745,31 +747,41 @@ __global__ void __launch_bounds__(256) sparse_wgrad_mfma_kernel(const float *__r
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = f4{0.0f, 0.0f, 0.0f, 0.0f};
     const int nb = (cnt + 3) >> 2;                                  // batches of four hits
-    auto entry = [&](int b) -> int2 {                               // this lane's hit of batch b ((-1, -1) past the end)
-        const int k = 4 * b + g;
-        int2 e = {-1, -1};
-        if (b < nb && k < cnt) e = L[k];
-        return e;
+    // Every load is unconditional: past the end of the list the entry index is 0 and the operands come from a row of
+    // zeros (swg_zeros, a device buffer the launcher owns), chosen by ADDRESS.  A `valid ? load : 0` select is turned back
+    // into a branch around the load by the compiler, and a load under a branch is waited for at the join: round 2's kernel
+    // did that and took 286 us, this one 235 (profiles/round3_p_sparse_wgrad_sweep.md).
+    auto entry = [&](int b) -> int2 { const int k = 4 * b + g; return L[(b < nb && k < cnt) ? k : 0]; };
+    auto valid = [&](int b) -> bool { return b < nb && 4 * b + g < cnt; };
+    // (as element offsets from the operand bases, so that every lane forms its address with the same arithmetic)
+    const long za = swg_zeros - enc, zb = (swg_zeros + 4 * i) - dyc;
+    auto fetch = [&](int2 e, bool ok, float &av, f4 &bv) {
+        const long oa = (ok && i < C) ? (long)e.y * lde + i : za;
+        const long ob = ok ? (long)e.x * ldy : zb;
+        av = enc[oa];
+        bv = *reinterpret_cast<const f4 *>(dyc + ob);
     };
-    auto fetch = [&](int2 e, float &av, f4 &bv) {
-        av = 0.0f; bv = f4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (e.x >= 0) {
-            if (i < C) av = enc[(size_t)e.y * lde + i];
-            bv = *reinterpret_cast<const f4 *>(dyc + (size_t)e.x * ldy);
-        }
-    };
-    // two batches in flight: list entries of batch t + 2 and operands of batch t + 1 while batch t runs on the matrix pipe
+    // U batches per trip, three trips in flight: list entries of trip t + 2 and operands of trip t + 1 while trip t runs on
+    // the matrix pipe.  The order in which a wave adds its batches is b = wave, wave + NW, ... whatever U is.  Measured
+    // (same file): U = 2 / 4 / 8 -> 311 / 380 / 335 us, 8 / 16 waves -> 239 / 309 us, a block map that ignores the XCDs 310 us:
+    // the kernel is not short of loads in flight, it is bound by what the XCD's L2 has to fetch again (the 288 workgroups of
+    // an XCD sweep the 38912 rows at the pace of their own cell's hit density), and more in flight evicts more.
     int b = wave;
-    int2 e0 = entry(b), e1 = entry(b + 4);
-    float a0; f4 b0;
-    fetch(e0, a0, b0);
-    for (; b < nb; b += 4) {
-        const int2 e2 = entry(b + 8);
-        float a1; f4 b1;
-        fetch(e1, a1, b1);
+    int2 e1[U];
+    float a0[U]; f4 b0[U];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[q], acc[q], 0, 0, 0);
-        a0 = a1; b0 = b1; e1 = e2;
+    for (int u = 0; u < U; ++u) { fetch(entry(b + NW * u), valid(b + NW * u), a0[u], b0[u]); e1[u] = entry(b + NW * (U + u)); }
+    for (; b < nb; b += NW * U) {
+        int2 e2[U];
+        float a1[U]; f4 b1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { e2[u] = entry(b + NW * (2 * U + u)); fetch(e1[u], valid(b + NW * (U + u)), a1[u], b1[u]); }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b0[u][q], acc[q], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a0[u] = a1[u]; b0[u] = b1[u]; e1[u] = e2[u]; }
     }
     // acc[q][r]: channel 4 g + r, column 4 i + q of the chunk
     if (wave > 0) {
@@ -786,8 +798,17 @@ __global__ void __launch_bounds__(256) sparse_wgrad_mfma_kernel(const float *__r
             if (ch >= C) continue;
             f4 o;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                o[q] = (acc[q][r] + red[0][ch][4 * i + q]) + (red[1][ch][4 * i + q] + red[2][ch][4 * i + q]);
+            for (int q = 0; q < 4; ++q) {                                   // pairwise in wave order: (w0 + w1) + (w2 + w3) ...
+                float v[NW];
+                v[0] = acc[q][r];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) v[w] = red[w - 1][ch][4 * i + q];
+#pragma unroll
+                for (int st = 1; st < NW; st *= 2)
+#pragma unroll
+                    for (int j = 0; j + st < NW; j += 2 * st) v[j] += v[j + st];
+                o[q] = v[0];
+            }
             *reinterpret_cast<f4 *>(dWc + ((size_t)c * C + ch) * N1 + chunk * 64 + 4 * i) = o;
         }
     }
@@ -798,8 +819,13 @@ static int launch_sparse_wgrad(const float *dy, int ldy, const float *enc, int l
                                int ncell, int N1, float *dWc, hipStream_t s) {
     if constexpr (C <= 16) {
         if (ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(dWc) & 15) == 0) {
-            hipLaunchKernelGGL(sparse_wgrad_mfma_kernel<C>, dim3(ncell * (N1 / 64)), dim3(256), 0, s, dy, ldy, enc, lde, list, count, R, N1,
-                               ncell, dWc);
+            static float *zeros = nullptr;                                   // 64 zeros: what a past-the-end hit loads (one process, one device)
+            if (!zeros) {
+                TNP_HIP(hipMalloc(&zeros, 256));
+                TNP_HIP(hipMemset(zeros, 0, 256));
+            }
+            hipLaunchKernelGGL(sparse_wgrad_mfma_kernel<C>, dim3(ncell * (N1 / 64)), dim3(256), 0, s, dy, ldy, enc, lde, list, count, R, N1, ncell,
+                               dWc, zeros);
             TNP_HIP(hipGetLastError());
             return 0;
         }
