@@ -26,7 +26,8 @@ __device__ __forceinline__ void wgrad_tn_block(const float *__restrict__ A, int 
                                                float *__restrict__ bias_part, int region, int ks) {
     const int regions_n = (No + 127) >> 7;
     const int rm = region / regions_n, rn = region - rm * regions_n;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kh = lane >> 5;
+    const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);         // wave-uniform tile coordinates and edge tests
     const int i0 = rm * 128 + (wave & 1) * 64, j0 = rn * 128 + (wave >> 1) * 64;
     if (i0 >= Mo || j0 >= No) return;           // no barriers in this kernel: idle waves just leave
     const bool m1 = i0 + 32 < Mo, n1 = j0 + 32 < No;
@@ -38,51 +39,122 @@ __device__ __forceinline__ void wgrad_tn_block(const float *__restrict__ A, int 
     for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
     const bool want_bias = bias_part != nullptr && rn == 0 && (wave >> 1) == 0;
     float bs0 = 0.f, bs1 = 0.f;
-    for (int k = kb; k < ke; k += 2 * WG_U) {
-        float a0[WG_U], a1[WG_U], b0[WG_U], b1[WG_U];
-#pragma unroll
-        for (int u = 0; u < WG_U; ++u) {
-            const int kk = k + 2 * u + kh;
-            const bool ok = kk < ke;
-            const size_t row = (size_t)(ok ? kk : ke - 1);
-            const float *ar = A + row * lda, *br = B + row * ldb;
-            float va0 = ar[ia0], vb0 = br[jb0];
-            float va1 = m1 ? ar[ia1] : 0.f, vb1 = n1 ? br[jb1] : 0.f;
-            a0[u] = ok ? va0 : 0.f; a1[u] = ok ? va1 : 0.f;
-            b0[u] = ok ? vb0 : 0.f; b1[u] = ok ? vb1 : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < WG_U; ++u) {
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc00, 0, 0, 0);
-            if (n1) acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc01, 0, 0, 0);
-            if (m1) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc10, 0, 0, 0);
-            if (m1 && n1) acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc11, 0, 0, 0);
-            bs0 += a0[u]; bs1 += a1[u];
-        }
-    }
-    float *P = part + (size_t)ks * Mo * No;
-    auto store = [&](const wg_f32x16 &acc, int ib, int jb) {
-        const int col = jb + li;
-        if (col >= No) return;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = ib + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row < Mo) P[(size_t)row * No + col] = acc[r];
+    auto finish = [&]() {
+        float *P = part + (size_t)ks * Mo * No;
+        auto store = [&](const wg_f32x16 &acc, int ib, int jb) {
+            const int col = jb + li;
+            if (col >= No) return;
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = ib + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < Mo) P[(size_t)row * No + col] = acc[r];
+            }
+        };
+        store(acc00, i0, j0);
+        if (n1) store(acc01, i0, j0 + 32);
+        if (m1) store(acc10, i0 + 32, j0);
+        if (m1 && n1) store(acc11, i0 + 32, j0 + 32);
+        if (want_bias) {
+            bs0 += __shfl_xor(bs0, 32);
+            bs1 += __shfl_xor(bs1, 32);
+            float *bp = bias_part + (size_t)ks * Mo;
+            if (kh == 0) {
+                if (i0 + li < Mo) bp[i0 + li] = bs0;
+                if (m1 && i0 + 32 + li < Mo) bp[i0 + 32 + li] = bs1;
+            }
         }
     };
-    store(acc00, i0, j0);
-    if (n1) store(acc01, i0, j0 + 32);
-    if (m1) store(acc10, i0 + 32, j0);
-    if (m1 && n1) store(acc11, i0 + 32, j0 + 32);
-    if (want_bias) {
-        bs0 += __shfl_xor(bs0, 32);
-        bs1 += __shfl_xor(bs1, 32);
-        float *bp = bias_part + (size_t)ks * Mo;
-        if (kh == 0) {
-            if (i0 + li < Mo) bp[i0 + li] = bs0;
-            if (m1 && i0 + 32 + li < Mo) bp[i0 + 32 + li] = bs1;
+    if (m1 && n1 && ((ke - kb) % (2 * WG_U)) == 0) {
+        // Whole stages of a block with both halves present (every split but a ragged last one): two operand stages of 16
+        // rows of K, the 32 loads of stage s + 1 issued before the 32 MFMAs of stage s.  The loads are inline asm with a
+        // hand-placed s_waitcnt: written as plain C++ the compiler (a) hoists the bias adds of a stage above its MFMAs, which
+        // drags the wait for ALL outstanding loads in front of them, and (b) parks the accumulators in VGPRs across the
+        // back edge (64 v_accvgpr_write per trip) -- 574 us for the grouped launch of config 2 without any prefetch (every
+        // 16 rows of K paid a memory round trip in front of 2048 cycles of matrix work), 450 us with the C++ prefetch.
+        // Addresses: scalar base of row k (wave-uniform) + a per-lane byte offset that never changes.
+        // Same order of the additions as the edge loop below: bit-identical results.
+        const unsigned oa0 = (unsigned)(kh * lda + ia0) * 4u, oa1 = (unsigned)(kh * lda + ia1) * 4u;
+        const unsigned ob0 = (unsigned)(kh * ldb + jb0) * 4u, ob1 = (unsigned)(kh * ldb + jb1) * 4u;
+        const float *ab = A + (size_t)kb * lda, *bb = B + (size_t)kb * ldb;
+        float a0[2][WG_U], a1[2][WG_U], b0[2][WG_U], b1[2][WG_U];
+#define WG_LD(dst, off, base) asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory")
+        int rem = (ke - kb) / (2 * WG_U);                     // stages not yet requested (<= 0: look-ahead past the end)
+        auto load = [&](int st) {                             // past the last stage: the last one again (valid memory, never used)
+#pragma unroll
+            for (int u = 0; u < WG_U; ++u) {
+                const float *pa = ab + (size_t)(2 * u) * lda, *pb = bb + (size_t)(2 * u) * ldb;
+                WG_LD(a0[st][u], oa0, pa); WG_LD(b0[st][u], ob0, pb);
+                WG_LD(a1[st][u], oa1, pa); WG_LD(b1[st][u], ob1, pb);
+            }
+            --rem;                                            // ab / bb: the next stage to request, if there is one
+            ab += rem > 0 ? (size_t)(2 * WG_U) * lda : 0; bb += rem > 0 ? (size_t)(2 * WG_U) * ldb : 0;
+        };
+#undef WG_LD
+        static_assert(WG_U == 8, "the wait statements name eight registers per operand");
+#define WG_R8(x) "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+        auto wait = [&](int st, bool more) {                 // stage st has landed (`more`: the next stage's 32 loads stay in flight)
+            if (more) asm volatile("s_waitcnt vmcnt(32)" : WG_R8(a0[st]), WG_R8(b0[st]));
+            else asm volatile("s_waitcnt vmcnt(0)" : WG_R8(a0[st]), WG_R8(b0[st]));
+            asm volatile("" : WG_R8(a1[st]), WG_R8(b1[st]));
+        };
+#undef WG_R8
+        auto mma = [&](int st) {
+#pragma unroll
+            for (int u = 0; u < WG_U; ++u) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[st][u], b0[st][u], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[st][u], b1[st][u], acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[st][u], b0[st][u], acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[st][u], b1[st][u], acc11, 0, 0, 0);
+            }
+            if (want_bias) {
+#pragma unroll
+                for (int u = 0; u < WG_U; ++u) { bs0 += a0[st][u]; bs1 += a1[st][u]; }
+            }
+        };
+        // one back edge, no exit from the middle, no branch in the body (anything else and the accumulators get copied
+        // between VGPRs and AGPRs around every stage, or a stage's registers are moved before their wait)
+        const int stages = rem, pairs = stages >> 1;
+        if (stages > 0) {
+            load(0);
+            for (int p = 0; p < pairs; ++p) {
+                load(1);
+                wait(0, true);
+                mma(0);
+                load(0);
+                wait(1, true);
+                mma(1);
+            }
+            wait(0, false);                                   // drains the look-ahead loads too
+            if (stages & 1) mma(0);
+        }
+        finish();                       // (not shared with the edge path: a join would keep both paths' accumulators alive)
+        return;
+    }
+    {
+        for (int k = kb; k < ke; k += 2 * WG_U) {
+            float a0[WG_U], a1[WG_U], b0[WG_U], b1[WG_U];
+#pragma unroll
+            for (int u = 0; u < WG_U; ++u) {
+                const int kk = k + 2 * u + kh;
+                const bool ok = kk < ke;
+                const size_t row = (size_t)(ok ? kk : ke - 1);
+                const float *ar = A + row * lda, *br = B + row * ldb;
+                float va0 = ar[ia0], vb0 = br[jb0];
+                float va1 = m1 ? ar[ia1] : 0.f, vb1 = n1 ? br[jb1] : 0.f;
+                a0[u] = ok ? va0 : 0.f; a1[u] = ok ? va1 : 0.f;
+                b0[u] = ok ? vb0 : 0.f; b1[u] = ok ? vb1 : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < WG_U; ++u) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc00, 0, 0, 0);
+                if (n1) acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc01, 0, 0, 0);
+                if (m1) acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc10, 0, 0, 0);
+                if (m1 && n1) acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc11, 0, 0, 0);
+                bs0 += a0[u]; bs1 += a1[u];
+            }
         }
     }
+    finish();
 }
 
 __global__ void __launch_bounds__(256) wgrad_tn_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B,
@@ -103,15 +175,16 @@ struct WgradGroup {
     float *part[WG_MAX_PROBLEMS], *bias_part[WG_MAX_PROBLEMS], *out[WG_MAX_PROBLEMS], *bout[WG_MAX_PROBLEMS];
     int lda[WG_MAX_PROBLEMS], ldb[WG_MAX_PROBLEMS], Mo[WG_MAX_PROBLEMS], No[WG_MAX_PROBLEMS], K[WG_MAX_PROBLEMS];
     int kchunk[WG_MAX_PROBLEMS], regions[WG_MAX_PROBLEMS], SK[WG_MAX_PROBLEMS], ldo[WG_MAX_PROBLEMS];
-    int first_block[WG_MAX_PROBLEMS + 1];     // wgrad_tn_group_kernel
+    int first_block[WG_MAX_PROBLEMS + 1];     // wgrad_tn_group_kernel: block ranges of problems tn_order[0], tn_order[1], ...
+    int tn_order[WG_MAX_PROBLEMS];            // longest workgroups first (the launch ends with the short ones: no long tail)
     int first_rblock[WG_MAX_PROBLEMS + 1];    // wgrad_reduce_group_kernel
     int count;
 };
 
 __global__ void __launch_bounds__(256) wgrad_tn_group_kernel(const WgradGroup g) {
-    int p = 0;
-    while (p + 1 < g.count && (int)blockIdx.x >= g.first_block[p + 1]) ++p;
-    const int local = (int)blockIdx.x - g.first_block[p];
+    int q = 0;
+    while (q + 1 < g.count && (int)blockIdx.x >= g.first_block[q + 1]) ++q;
+    const int local = (int)blockIdx.x - g.first_block[q], p = g.tn_order[q];
     const int region = local % g.regions[p], ks = local / g.regions[p];
     wgrad_tn_block(g.A[p], g.lda[p], g.B[p], g.ldb[p], g.Mo[p], g.No[p], g.K[p], g.kchunk[p], g.part[p], g.bias_part[p], region, ks);
 }
@@ -234,12 +307,29 @@ extern "C" TNP_API int tnp_wgrad_grouped(const tnp_wgrad_problem *problems, int 
             g.part[c] = (float *)ws;
             g.bias_part[c] = q.dbias ? g.part[c] + (size_t)SK * q.Mo * q.No : nullptr;
             ws += wgrad_problem_bytes(q.Mo, q.No, q.K);
-            g.first_block[c + 1] = g.first_block[c] + regions * SK;
             const long nel = (long)q.Mo * q.No;
             g.first_rblock[c + 1] = g.first_rblock[c] + (int)((nel + 255) / 256) + (q.dbias ? (q.Mo + 255) / 256 : 0);
             ++g.count;
         }
         if (g.count == 0) break;
+        // block order of the contraction launch: problems by the estimated duration of one of their workgroups, longest
+        // first (rows of K per split; x 3 for blocks that take the edge loop, which has no operand prefetch).  With the
+        // queue order the five tiny contractions came last and their 50-us edge-loop workgroups ran on an empty chip
+        // (1.2 of 2 waves per SIMD resident on average, profiles/round3_q_pmc_train.md).  Plans, partial buffers and the
+        // reduce launch are untouched: results do not depend on the order.
+        {
+            long cost[WG_MAX_PROBLEMS];
+            for (int c = 0; c < g.count; ++c) {
+                const bool edge = g.Mo[c] % 64 != 0 || g.No[c] % 64 != 0;
+                cost[c] = (long)g.kchunk[c] * (edge ? 3 : 1);
+                g.tn_order[c] = c;
+            }
+            for (int a = 1; a < g.count; ++a)                       // insertion sort, stable: equal costs keep the queue order
+                for (int b = a; b > 0 && cost[g.tn_order[b]] > cost[g.tn_order[b - 1]]; --b) {
+                    const int t = g.tn_order[b]; g.tn_order[b] = g.tn_order[b - 1]; g.tn_order[b - 1] = t;
+                }
+            for (int c = 0; c < g.count; ++c) g.first_block[c + 1] = g.first_block[c] + g.regions[g.tn_order[c]] * g.SK[g.tn_order[c]];
+        }
         hipLaunchKernelGGL(tnp::wgrad_tn_group_kernel, dim3(g.first_block[g.count]), dim3(256), 0, s, g);
         TNP_HIP(hipGetLastError());
         hipLaunchKernelGGL(tnp::wgrad_reduce_group_kernel, dim3(g.first_rblock[g.count]), dim3(256), 0, s, g);

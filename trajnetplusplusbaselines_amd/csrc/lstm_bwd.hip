@@ -592,6 +592,7 @@ static int launch_dgrid_cells(const float *dy, int ldy, const float *Wc, const i
 // consumes them (social_scatter_backward_cells8_kernel) adds the copies in slice order, so nothing is atomic and the order
 // is fixed.  A wave owns whole 16-ego groups (g = wave, wave + 4, ...): no barrier and no cross-wave reduction in the loop.
 // ---------------------------------------------------------------------------------------------------------
+template <int TT>                                                             // TT = N1 / 128 when that is 8 (straight-line code), 0 = any
 __global__ void __launch_bounds__(256) dgrid_cells_xcd_kernel(const float *__restrict__ dy, int ldy, const float *__restrict__ Wc,
                                                               const int2 *__restrict__ list, const int32_t *__restrict__ count,
                                                               int R, int nseg, int seg, int M, int C, int ncell, int N1,
@@ -603,12 +604,21 @@ __global__ void __launch_bounds__(256) dgrid_cells_xcd_kernel(const float *__res
     const int ngroups = (cnt + 15) >> 4;
     const int2 *L = list + (size_t)c * R + (size_t)seg * M;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane & 15, kq = lane >> 4;
-    const int ncol = N1 >> 3, T = ncol >> 4, k0 = x * ncol;
-    for (int q = tid; q < T * 64; q += 256) {                                   // T <= 8 for N1 <= 1024: one or two loads per thread
-        const int t = q >> 6, l = q & 63, ch = l & 15, kk = l >> 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ch < C) v = *reinterpret_cast<const float4 *>(Wc + ((size_t)c * C + ch) * N1 + k0 + 16 * t + 4 * kk);
-        xcd_lds[q] = v;
+    const int ncol = N1 >> 3, T = TT ? TT : ncol >> 4, k0 = x * ncol;
+    // T <= 8 for N1 <= 1024: one or two 16-byte loads per thread, both in flight before the first is stored (channels
+    // >= C read channel 0 and store zeros: a load under `if (ch < C)` is waited for where the branch joins)
+    for (int q0 = tid; q0 < T * 64; q0 += 512) {
+        float4 v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = q0 + 256 * h, t = (q < T * 64 ? q : q0) >> 6, l = q & 63, ch = l & 15, kk = l >> 4;
+            v[h] = *reinterpret_cast<const float4 *>(Wc + ((size_t)c * C + (ch < C ? ch : 0)) * N1 + k0 + 16 * t + 4 * kk);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = q0 + 256 * h;
+            if (q < T * 64) xcd_lds[q] = ((q & 15) < C) ? v[h] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     __syncthreads();
     const int row_off = seg * M;
@@ -639,12 +649,15 @@ __global__ void __launch_bounds__(256) dgrid_cells_xcd_kernel(const float *__res
         rows_of(g + 8, rl2, ro2);
         if (g + 4 < ngroups) load_a(a1, rl1, 0);
         floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
+        int bl = lane;
+        asm volatile("" : "+v"(bl));                                  // re-read the weights per group: hoisted out of the loop they
+                                                                      // cost 32 registers = one wave per SIMD (3 instead of 4)
         for (int t0 = 0; t0 < T; t0 += 8) {
             if (t0 > 0) load_a(a0, rl0, t0);                          // N1 > 1024: further K batches of this group, not prefetched
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (t0 + u < T) {
-                    const float4 b = xcd_lds[(t0 + u) * 64 + lane];
+                    const float4 b = xcd_lds[(t0 + u) * 64 + bl];
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].x, b.x, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].y, b.y, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u].z, b.z, acc, 0, 0, 0);
@@ -709,8 +722,12 @@ static bool dgrid_xcd_ok(int C, int N1) { return C <= 16 && N1 % 128 == 0; }
 static int launch_dgrid_cells_xcd(const float *dy, int ldy, const float *Wc, const int2 *list, const int32_t *count, int R, int nseg,
                                   int seg, int M, int C, int ncell, int N1, float *dcell8, hipStream_t s) {
     const size_t lds = (size_t)(N1 / 8 / 16) * 64 * sizeof(float4);
-    hipLaunchKernelGGL(dgrid_cells_xcd_kernel, dim3(ncell * 8), dim3(256), lds, s, dy, ldy, Wc, list, count, R, nseg, seg, M, C, ncell, N1,
-                       dcell8);
+    if (N1 == 1024)
+        hipLaunchKernelGGL(dgrid_cells_xcd_kernel<8>, dim3(ncell * 8), dim3(256), lds, s, dy, ldy, Wc, list, count, R, nseg, seg, M, C, ncell,
+                           N1, dcell8);
+    else
+        hipLaunchKernelGGL(dgrid_cells_xcd_kernel<0>, dim3(ncell * 8), dim3(256), lds, s, dy, ldy, Wc, list, count, R, nseg, seg, M, C, ncell,
+                           N1, dcell8);
     TNP_HIP(hipGetLastError());
     return 0;
 }
