@@ -717,6 +717,74 @@ __global__ void __launch_bounds__(256) social_scatter_backward_cells8_kernel(con
     }
 }
 
+// social_scatter_backward_cells8_kernel + state_grad_combine_kernel in one launch (C <= 16, C % 4 == 0, H = 64 HK): the
+// wave that forms denc[j][:] also forms dh[j][:] = dxh[j][:] + pass[j][:] + denc[j][:] . Wh -- the operands of the second
+// half are requested before the gathers of the first, so the launch costs what the scatter alone did (7.8 us; the combine
+// kernel was another 4.9 us per step).  Both halves keep the arithmetic and the order of the kernels they replace.
+template <int HK>
+__global__ void __launch_bounds__(256) social_scatter_combine_kernel(const float *__restrict__ dcell8, const int32_t *__restrict__ cells,
+                                                                     const int32_t *__restrict__ row_base,
+                                                                     const int32_t *__restrict__ row_count, int M, int n_max, int C,
+                                                                     int ncell, float *__restrict__ denc,
+                                                                     const float *__restrict__ dxh, int ld,
+                                                                     const float *__restrict__ pass, const float *__restrict__ whT,
+                                                                     float *__restrict__ out) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, sub = lane >> 4, ch = lane & 15;
+    if (j >= M) return;
+    constexpr int H = 64 * HK;
+    float v0[HK], v1[HK];
+    float4 wv[HK][4];
+#pragma unroll
+    for (int t = 0; t < HK; ++t) {
+        const int k = lane + 64 * t;
+        v0[t] = dxh[(size_t)j * ld + k]; v1[t] = pass[(size_t)j * H + k];
+        const float4 *w4 = reinterpret_cast<const float4 *>(whT + (size_t)k * C);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wv[t][c] = w4[c < C / 4 ? c : 0];
+    }
+    const int lo = row_base[j], ns = row_count[j], jj = j - lo;
+    const size_t slice = (size_t)M * ncell * C;
+    float acc = 0.0f;
+    for (int i0 = lo + sub; i0 < lo + ns; i0 += 16) {
+        int cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + 4 * u; cc[u] = i < lo + ns ? cells[(size_t)i * n_max + jj] : -1; }
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = cc[u] >= 0 && ch < C;
+            const float *p = dcell8 + ((size_t)(ok ? i0 + 4 * u : lo) * ncell + (ok ? cc[u] : 0)) * C + (ch < C ? ch : 0);
+#pragma unroll
+            for (int xx = 0; xx < 8; ++xx) v[u][xx] = ok ? p[xx * slice] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (cc[u] >= 0 && ch < C) {
+                float sum = v[u][0];
+#pragma unroll
+                for (int xx = 1; xx < 8; ++xx) sum += v[u][xx];
+                acc += sum;
+            }
+    }
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    if (sub == 0 && ch < C) denc[(size_t)j * C + ch] = acc;
+    float d[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) d[c] = __shfl(acc, c);                           // lane c (sub 0) holds denc[j][c]
+#pragma unroll
+    for (int t = 0; t < HK; ++t) {
+        float a = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C / 4) {
+                a = fmaf(d[4 * c], wv[t][c].x, a); a = fmaf(d[4 * c + 1], wv[t][c].y, a);
+                a = fmaf(d[4 * c + 2], wv[t][c].z, a); a = fmaf(d[4 * c + 3], wv[t][c].w, a);
+            }
+        out[(size_t)j * H + lane + 64 * t] = (v0[t] + v1[t]) + a;
+    }
+}
+
 static bool dgrid_xcd_ok(int C, int N1) { return C <= 16 && N1 % 128 == 0; }
 
 static int launch_dgrid_cells_xcd(const float *dy, int ldy, const float *Wc, const int2 *list, const int32_t *count, int R, int nseg,
@@ -1174,6 +1242,7 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
         }
         // ---- grid embedding MLP + scatter + social encoding backward ----
         const float *extra = nullptr, *social_denc = nullptr;
+        bool combined = false;                  // a->dh of this step already formed (social_scatter_combine_kernel)
         if (grid) {
             if (a->grid_all) {   // the dense grid is the only intermediate that is recomputed
                 TNP_RC(tnp_pool_grid_forward(md->pool_type, o1, o2, social ? sv->enc_all + r * C : nullptr, C, a->scene_start, a->B,
@@ -1205,9 +1274,18 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
                     if (tnp::dgrid_xcd_ok(C, N1) && (reinterpret_cast<uintptr_t>(dy0) & 15) == 0) {
                         TNP_RC(tnp::launch_dgrid_cells_xcd(dy0, N1, a->w_cell_major, reinterpret_cast<const int2 *>(a->ego_list), a->ego_count,
                                                            S * M, S, st, M, C, ncell, N1, w.dcell, s));
-                        hipLaunchKernelGGL(tnp::social_scatter_backward_cells8_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s,
-                                           w.dcell, a->cells_all + r * a->n_max, a->row_base, a->row_count, M, a->n_max, C, ncell, denc);
-                        TNP_HIP(hipGetLastError());
+                        if ((H == 64 || H == 128) && (C & 3) == 0 && !extra) {      // scatter + state-gradient combine in one launch
+                            auto k = H == 64 ? tnp::social_scatter_combine_kernel<1> : tnp::social_scatter_combine_kernel<2>;
+                            hipLaunchKernelGGL(k, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, w.dcell, a->cells_all + r * a->n_max,
+                                               a->row_base, a->row_count, M, a->n_max, C, ncell, denc, w.dxh + I, LDX, w.dh_pass, a->whT,
+                                               a->dh);
+                            TNP_HIP(hipGetLastError());
+                            combined = true;
+                        } else {
+                            hipLaunchKernelGGL(tnp::social_scatter_backward_cells8_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s,
+                                               w.dcell, a->cells_all + r * a->n_max, a->row_base, a->row_count, M, a->n_max, C, ncell, denc);
+                            TNP_HIP(hipGetLastError());
+                        }
                     } else {
                     TNP_RC(tnp_social_dgrid_cells(dy0, N1, a->w_cell_major, a->ego_list, a->ego_count, S * M, st, M, C, ncell, N1,
                                                   w.dcell, stream));
@@ -1286,9 +1364,11 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
                 extra = w.tmp_h;
             }
         }
-        hipLaunchKernelGGL(tnp::state_grad_combine_kernel, dim3((unsigned)((MH + 255) / 256)), dim3(256), 0, s, w.dxh + I, LDX,
-                           w.dh_pass, extra, M, H, a->dh, social_denc, a->whT, C);
-        TNP_HIP(hipGetLastError());
+        if (!combined) {
+            hipLaunchKernelGGL(tnp::state_grad_combine_kernel, dim3((unsigned)((MH + 255) / 256)), dim3(256), 0, s, w.dxh + I, LDX,
+                               w.dh_pass, extra, M, H, a->dh, social_denc, a->whT, C);
+            TNP_HIP(hipGetLastError());
+        }
         float *t = dc_cur; dc_cur = dc_nxt; dc_nxt = t;
     }
     if (dc_cur != a->dc) TNP_HIP(hipMemcpyAsync(a->dc, dc_cur, MH * 4, hipMemcpyDeviceToDevice, s));
