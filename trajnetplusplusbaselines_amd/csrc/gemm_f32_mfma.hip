@@ -215,6 +215,24 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[AN], i
                     g.C[(size_t)row * g.ldc + col] = v;
                 }
             }
+            if (g.nseg > 0) {
+                for (int si = 0; si < g.nseg; ++si) {
+                    const GemmArgs::EpiSeg &sg = g.seg[si];
+                    const int c = col - sg.col0;
+                    if (c < 0 || c >= sg.n) continue;
+                    float ak[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1);
+                        ak[r] = sg.act[(size_t)row * sg.ld_act + c];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (row < g.M) sg.out[(size_t)row * sg.ld_out + c] = ak[r] > 0.0f ? acc[an][r] + b : 0.0f;
+                    }
+                }
+            }
         }
     } else {
         const int H = g.H;

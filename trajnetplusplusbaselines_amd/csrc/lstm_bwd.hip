@@ -971,20 +971,6 @@ __global__ void __launch_bounds__(256) state_grad_combine_kernel(const float *__
     out[q] = v;
 }
 
-// The ReLU masks of one step's data gradient in one launch: input embedding, goal embedding and the (ReLU-output)
-// interaction vector.  Segment s of a row: out_s[m, c] = act_s[m, c] > 0 ? grad_s[m, c] : 0.
-struct MaskSeg { const float *grad; int ldg; const float *act; int lda; float *out; int n; };
-__global__ void __launch_bounds__(256) relu_mask3_kernel(MaskSeg s0, MaskSeg s1, MaskSeg s2, int M) {
-    const int W = s0.n + s1.n + s2.n;
-    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= (long)M * W) return;
-    const int m = (int)(q / W);
-    int c = (int)(q - (long)m * W);
-    const MaskSeg *sg = &s0;
-    if (c >= s0.n) { c -= s0.n; sg = &s1; if (c >= s1.n) { c -= s1.n; sg = &s2; } }
-    sg->out[(size_t)m * sg->n + c] = sg->act[(size_t)m * sg->lda + c] > 0.0f ? sg->grad[(size_t)m * sg->ldg + c] : 0.0f;
-}
-
 struct SweepScratch {
     float *dh_tot, *dh_pass, *dxh, *dc_alt, *d_in, *tmp_h, *dgrid, *dcell, *d_pooled, *at_u, *at_deh, *at_dself;
     float *st_tot, *st_pass, *st_dxh, *st_dc_alt;
@@ -1223,22 +1209,26 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
         }
         const float *wT = st >= a->n_enc ? a->wT_dec : a->wT_enc;
         if (!wT) TNP_FAIL(-1, "tnp_lstm_backward_sweep: transposed cell weights missing for step %d", st);
-        TNP_RC(tnp_linear_forward(dG, 4 * H, wT, 4 * H, nullptr, w.dxh, LDX, M, LDX, 4 * H, 0, 0, stream));   // [dG.W_ih | dG.W_hh]
-        // ---- input / goal embedding backward (X holds the ReLU outputs) ----
+        // ---- [dG.W_ih | dG.W_hh] -> dxh, and on the same launch's epilogue the input / goal embedding backward (X holds
+        // the ReLU outputs) and the ReLU mask of a ReLU-output interaction vector: three masked copies of column ranges of
+        // dxh (GemmArgs::seg; a relu_mask3 launch per step before) ----
         const float *Xs = sv->X_all + r * I;
         // gradient and forward value of the interaction vector: pooled columns of X, or (pool_to_input=False) the vector
         // that was added to the hidden operand -- its gradient is the hidden operand's
         const float *pgrad = to_hidden ? w.dxh + I : w.dxh + P0;
         const float *pact = to_hidden ? sv->pvec_all + r * H : Xs + P0;
         const int pact_ld = to_hidden ? H : I;
-        {   // ReLU masks of the input / goal embedding and of a ReLU-output interaction vector, one launch
-            tnp::MaskSeg s0 = {w.dxh, LDX, Xs, I, a->de_all + r * (E - 2), E - 2};
-            tnp::MaskSeg s1 = {w.dxh + E, LDX, Xs + E, I, GD ? a->dgoal_all + r * (GD - 2) : nullptr, GD ? GD - 2 : 0};
+        {
+            tnp::GemmArgs g = {};
+            g.A1 = dG; g.lda1 = 4 * H; g.K1 = 4 * H; g.B1 = wT; g.ldb1 = 4 * H;
+            g.M = M; g.N = LDX; g.C = w.dxh; g.ldc = LDX;
+            int ns = 0;
+            g.seg[ns++] = {0, E - 2, Xs, I, a->de_all + r * (E - 2), E - 2};
+            if (GD) g.seg[ns++] = {E, GD - 2, Xs + E, I, a->dgoal_all + r * (GD - 2), GD - 2};
             float *pout = a->nn_pool ? a->dnn_all + r * Pw : (grid ? a->dy_all[md->n_layers - 1] + r * Pw : nullptr);
-            tnp::MaskSeg s2 = {pgrad, LDX, pact, pact_ld, pout, pout ? Pw : 0};
-            const long tot = (long)M * (s0.n + s1.n + s2.n);
-            hipLaunchKernelGGL(tnp::relu_mask3_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, s0, s1, s2, M);
-            TNP_HIP(hipGetLastError());
+            if (pout) g.seg[ns++] = {to_hidden ? I : P0, Pw, pact, pact_ld, pout, Pw};
+            g.nseg = ns;
+            TNP_RC(tnp::launch_linear(g, 0, s));
         }
         // ---- grid embedding MLP + scatter + social encoding backward ----
         const float *extra = nullptr, *social_denc = nullptr;

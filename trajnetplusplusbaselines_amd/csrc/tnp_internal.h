@@ -39,6 +39,12 @@ struct GemmArgs {
     // EPI_BIAS, optional: C[row, col] = mask_act[row, col] > 0 ? value : 0 -- the ReLU backward of the layer below fused into
     // the data-gradient GEMM (what a separate relu_mask launch did)
     const float *mask_act; int ld_mask;
+    // EPI_BIAS, optional: up to three masked COPIES of column ranges of the result (the value itself still goes to C):
+    // seg[i].out[row, col - col0] = seg[i].act[row, col - col0] > 0 ? value : 0 for col0 <= col < col0 + n -- the ReLU
+    // backwards of the input / goal embeddings and of the interaction vector, which read the data-gradient GEMM's output
+    // (lstm_bwd.hip: what a relu_mask3 launch did after it)
+    struct EpiSeg { int col0, n; const float *act; int ld_act; float *out; int ld_out; };
+    EpiSeg seg[3]; int nseg;
 };
 
 // generic dense layer (variant selects the tile configuration)
