@@ -14,7 +14,7 @@ model = bench.build_model(cfg, dev)
 xy, split = synth.linear_crowd(cfg['scenes'], cfg['agents'], seed=100)
 scene = xy.to(dev)
 goals = torch.zeros(xy.shape[1], 2, device=dev)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+opt = bench.make_adam(model.parameters()) if hasattr(bench, 'make_adam') else torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
 crit = PredictionLoss()
 for _ in range(3):
     train_batch(model, opt, crit, scene, goals, split, 9, 12, batch_size=cfg['scenes'])
@@ -33,7 +33,17 @@ def phases():
 torch.cuda.synchronize()
 acc = [phases() for _ in range(5)][1:]
 print('host ms  forward %.2f  loss %.2f  backward %.2f  adam %.2f  wait-for-gpu %.2f' % tuple(sum(c) / len(c) for c in zip(*acc)))
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     train_batch(model, opt, crit, scene, goals, split, 9, 12, batch_size=cfg['scenes'])
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by='self_cuda_time_total', row_limit=45, max_name_column_width=60))
+
+# every ATen op that launches something, with the innermost frame of this repository that issued it
+import collections
+seen = collections.Counter()
+for ev in prof.events():
+    if ev.device_time_total > 0 and ev.name.startswith('aten::') and ev.cpu_parent is not None and not ev.cpu_parent.name.startswith('aten::'):
+        where = [f for f in (ev.stack or []) if 'trajnetplusplusbaselines_amd' in f or 'bench.py' in f]
+        seen[(ev.name, where[0].split('/')[-1] if where else '?')] += 1
+for (name, where), n in sorted(seen.items(), key=lambda kv: kv[0][1]):
+    print('%3d x %-28s %s' % (n, name, where))

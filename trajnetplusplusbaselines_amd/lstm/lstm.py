@@ -72,7 +72,7 @@ class LSTM(torch.nn.Module):
     _ENCODER_ONLY = False
 
     # device-side caches (workspace, re-laid-out weight copies): rebuilt lazily, never pickled / deep-copied
-    _CACHES = ('_ws', '_cell_major', '_quad_major', '_dummy_head', '_grad_reduce_fn')
+    _CACHES = ('_ws', '_cell_major', '_quad_major', '_dummy_head', '_grad_reduce_fn', '_desc_cache', '_plist_cache')
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -93,14 +93,79 @@ class LSTM(torch.nn.Module):
     def _normal_head(self):
         return self.hidden2normal.linear.weight, self.hidden2normal.linear.bias
 
+    def _named_parameter_lists(self):
+        """(names, parameters) in ``named_parameters()`` order.  The module-tree walk costs ~35 us and the training forward
+        needs the list twice per call, in front of its first kernel: it is kept while every module is still the same
+        object in the same place with the same number of parameters, and every parameter the same object."""
+        c = self.__dict__.get('_plist_cache')
+        if c is not None and all(d.get(k) is child for d, k, child in c['links']) \
+                and all(len(d) == n for d, n in c['sizes']) and all(d.get(k) is q for d, k, q in c['where']):
+            return c['names'], c['params']
+        names, params = [], []
+        for n, q in self.named_parameters():
+            names.append(n)
+            params.append(q)
+        mods = list(self.modules())
+        ids = set(id(q) for q in params)
+        self.__dict__['_plist_cache'] = dict(
+            names=names, params=params,
+            links=[(parent._modules, name, child) for parent in mods for name, child in parent._modules.items()],
+            sizes=[(mod._parameters, len(mod._parameters)) for mod in mods],
+            where=[(mod._parameters, name, q) for mod in mods for name, q in mod._parameters.items() if id(q) in ids])
+        return names, params
+
+    def _descriptor_signature(self):
+        pool = self.pool
+        grid = None
+        if pool is not None and hasattr(pool, 'embedding_layers'):
+            grid = (pool.type_, pool.n, pool.cell_side, pool.pooling_dim, pool.out_dim, pool.pool_size, pool.blur_size,
+                    float(pool.constant), getattr(pool, 'front', None))
+        return (self.embedding_dim, self.hidden_dim, bool(self.goal_flag), self.goal_dim, int(self.kernel_variant),
+                bool(self.pool_to_input), bool(self.sparse_embedding), id(pool), grid)
+
     def _descriptor(self):
+        """(tnp_lstm_model, the tensors it points into, device).  Filling the struct costs ~80 us of host time in front of
+        the first kernel of every call, so it is kept: a call whose configuration is unchanged and whose parameters are
+        all still the same objects in the same modules at the same addresses (Adam updates in place) gets a copy of the
+        stored struct.  Only
+        the two re-laid-out copies of the first embedding layer follow the parameter's VALUE; they are refreshed on every
+        call (_cell_major_weight / _quad_major_weight compare the parameter's version counter).  A descriptor that points
+        into anything but parameters (AttentionMLPPooling.folded, the S-GAN discriminator's dummy head) or belongs to a
+        non-grid interaction module is rebuilt every time."""
+        c = self.__dict__.get('_desc_cache')
+        if c is not None and c['sig'] == self._descriptor_signature() \
+                and all(d.get(k) is child for d, k, child in c['links']) \
+                and all(d.get(k) is t and t.data_ptr() == ptr for d, k, t, ptr in c['watched']):
+            m = _lib.LstmModel.from_buffer_copy(c['m'])      # callers may edit their copy (training.py clears the head)
+            keep = c['keep']
+            if c['relaid'] is not None:
+                w, quad = c['relaid']
+                cm = self._cell_major_weight(w, self.pool)
+                keep = keep + [cm]
+                m.Wp0_cell_major = ctypes.c_void_p(cm.data_ptr())
+                if quad:
+                    qm = self._quad_major_weight(w, self.pool)
+                    keep.append(qm)
+                    m.Wp0_quad_major = ctypes.c_void_p(qm.data_ptr())
+            return m, keep, c['dev']
+        return self._build_descriptor()
+
+    def _build_descriptor(self):
         dev = self.encoder.weight_ih.device
         if dev.type != 'cuda':
             raise RuntimeError('LSTM parameters live on %s: move the model to a ROCm device (model.to("cuda")); '
                                'the MI355X path has no CPU fallback' % dev)
         keep = []
+        owners = {id(q): (mod._parameters, name) for mod in self.modules() for name, q in mod._parameters.items()
+                  if q is not None}
+        watched, cacheable, relaid = [], [True], [None]
 
         def P(t):
+            o = owners.get(id(t))
+            if o is None or t.dtype != torch.float32 or not t.is_contiguous():
+                cacheable[0] = False                          # a computed tensor, or one that is converted below
+            else:
+                watched.append((o[0], o[1], t, t.data_ptr()))
             t = t.detach()
             if t.dtype != torch.float32 or not t.is_contiguous():
                 t = t.float().contiguous()
@@ -177,12 +242,29 @@ class LSTM(torch.nn.Module):
                 m.Wh, m.bh = P(pool.hidden_dim_encoding.weight), P(pool.hidden_dim_encoding.bias)
                 if self.sparse_embedding and float(pool.constant) == 0.0 and pool.pooling_dim in (4, 8, 16, 32) \
                         and layers[0].weight.shape[0] % 4 == 0:
-                    m.Wp0_cell_major = P(self._cell_major_weight(layers[0].weight, pool))
-                    if layers[0].weight.shape[0] % 64 == 0 and pool.pooling_dim % 4 == 0:
-                        m.Wp0_quad_major = P(self._quad_major_weight(layers[0].weight, pool))
+                    # (not through P: these follow the parameter's value and are refreshed by _descriptor on every call)
+                    quad = layers[0].weight.shape[0] % 64 == 0 and pool.pooling_dim % 4 == 0
+                    relaid[0] = (layers[0].weight, quad)
         m.variant = int(self.kernel_variant)
         if pool is not None and not self.pool_to_input:
             m.variant |= 1 << 17   # interaction vector added to the hidden state (lstm/lstm.py:150-151)
+        grid_or_none = pool is None or hasattr(pool, 'embedding_layers')
+        self.__dict__['_desc_cache'] = None
+        if cacheable[0] and grid_or_none:
+            # (the module tree as it is now: a replaced sub-module invalidates the stored struct like a moved parameter does)
+            links = [(parent._modules, name, child) for parent in self.modules() for name, child in parent._modules.items()]
+            self.__dict__['_desc_cache'] = dict(sig=self._descriptor_signature(), watched=watched, links=links, m=m,
+                                                keep=list(keep), dev=dev, relaid=relaid[0])
+        if relaid[0] is not None:
+            w, quad = relaid[0]
+            m = _lib.LstmModel.from_buffer_copy(m)
+            cm = self._cell_major_weight(w, pool)
+            keep.append(cm)
+            m.Wp0_cell_major = ctypes.c_void_p(cm.data_ptr())
+            if quad:
+                qm = self._quad_major_weight(w, pool)
+                keep.append(qm)
+                m.Wp0_quad_major = ctypes.c_void_p(qm.data_ptr())
         return m, keep, dev
 
     def _cell_major_weight(self, weight, pool):

@@ -278,7 +278,7 @@ class SequenceFn(torch.autograd.Function):
         ctx.win_all = win_all
         ctx.w_cell_major = model._cell_major_weight(layers[0].weight, pool) if win_all is not None else None
         ctx.pos_offset = 1 if T_obs == 2 else 0
-        ctx.param_names = [n for n, _ in model.named_parameters()]
+        ctx.param_names = _param_lists(model)[0]
         ctx.save_for_backward(*params)
         ctx.T_obs = T_obs
         return normals, pos_all, h_all[S].clone()
@@ -658,8 +658,16 @@ class SequenceFn(torch.autograd.Function):
         return tuple(out)
 
 
+def _param_lists(model):
+    """(names, parameters) of the model in named_parameters() order (kept by our LSTM between calls)"""
+    if hasattr(model, '_named_parameter_lists'):
+        return model._named_parameter_lists()
+    named = list(model.named_parameters())
+    return [n for n, _ in named], [q for _, q in named]
+
+
 def run_sequence_with_grad(model, observed, goals, batch_split, truth, T_dec, opts=None):
     """(rel_pred, pred, h_last) attached to the autograd graph of the model's parameters (and of `observed` when
     opts['input_grad'] is set and it requires grad)."""
-    params = [p for _, p in model.named_parameters()]
+    params = _param_lists(model)[1]
     return SequenceFn.apply(model, observed, goals, batch_split, truth, T_dec, opts, *params)

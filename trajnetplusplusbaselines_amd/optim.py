@@ -24,6 +24,15 @@ class Adam(torch.optim.Optimizer):
             raise ValueError('invalid Adam hyper-parameters')
         super(Adam, self).__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
+    def zero_grad(self, set_to_none=True):
+        """torch.optim.Optimizer.zero_grad without its per-call bookkeeping (profiler range, foreach grouping): this runs
+        in front of the first kernel of every optimisation step, while the GPU is idle.  Same effect."""
+        if not set_to_none:
+            return super(Adam, self).zero_grad(set_to_none=False)
+        for group in self.param_groups:
+            for p in group['params']:
+                p.grad = None
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
