@@ -197,6 +197,23 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[AN], i
             float b;
             if (pbias) b = pbias[an];
             else { b = g.bias1 ? g.bias1[col] : 0.0f; if (g.bias2) b += g.bias2[col]; }
+            // masked copies (GemmArgs::seg): a column belongs to at most one segment; pick it per lane and request its
+            // sixteen activation values BEFORE the stores of the value itself, so that their round trip runs under them
+            const float *sact = nullptr; float *sout = nullptr;
+            int sc = 0, lda_s = 0, ldo_s = 0;
+            for (int si = 0; si < g.nseg; ++si) {
+                const GemmArgs::EpiSeg &sg = g.seg[si];
+                const int c = col - sg.col0;
+                if (c >= 0 && c < sg.n) { sact = sg.act; sout = sg.out; sc = c; lda_s = sg.ld_act; ldo_s = sg.ld_out; }
+            }
+            float ak[16];
+            if (g.nseg > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1);
+                    ak[r] = sout ? sact[(size_t)row * lda_s + sc] : 0.0f;
+                }
+            }
             float mk[16];
             if (g.mask_act) {                                   // all sixteen mask operands in flight before the first use
 #pragma unroll
@@ -215,22 +232,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[AN], i
                     g.C[(size_t)row * g.ldc + col] = v;
                 }
             }
-            if (g.nseg > 0) {
-                for (int si = 0; si < g.nseg; ++si) {
-                    const GemmArgs::EpiSeg &sg = g.seg[si];
-                    const int c = col - sg.col0;
-                    if (c < 0 || c >= sg.n) continue;
-                    float ak[16];
+            if (g.nseg > 0 && sout) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1);
-                        ak[r] = sg.act[(size_t)row * sg.ld_act + c];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = rbase + (r & 3) + 8 * (r >> 2);
-                        if (row < g.M) sg.out[(size_t)row * sg.ld_out + c] = ak[r] > 0.0f ? acc[an][r] + b : 0.0f;
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < g.M) sout[(size_t)row * ldo_s + sc] = ak[r] > 0.0f ? acc[an][r] + b : 0.0f;
                 }
             }
         }
