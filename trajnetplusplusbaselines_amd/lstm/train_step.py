@@ -42,10 +42,6 @@ def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batc
             src = torch.distributed.get_global_rank(group, 0) if group is not None else 0
             torch.distributed.broadcast_object_list(box, src=src, group=group)
             start_length = int(box[0])
-    if buckets is not None:
-        buckets.zero()
-    else:
-        optimizer.zero_grad()
     empty = n_local <= 0 or int(split[-1]) <= 0
     if empty and not distributed:
         raise ValueError('empty batch')
@@ -54,8 +50,10 @@ def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batc
         batch_scene = (t * torch.tensor([0.1, 0.05])).expand(-1, 1, 2).contiguous()
         batch_scene_goal, split, n_local = torch.zeros(1, 2), torch.tensor([0, 1]), 0
     batch_scene = batch_scene.to(dev)
-    observed = batch_scene[start_length:obs_length].clone()
-    prediction_truth = batch_scene[obs_length:obs_length + pred_length - 1].clone()
+    # (the reference clones both slices, lstm/trainer.py:251-252; its forward pass writes into neither and neither does
+    # ours -- two copies less in front of the first kernel)
+    observed = batch_scene[start_length:obs_length]
+    prediction_truth = batch_scene[obs_length:obs_length + pred_length - 1]
     targets = batch_scene[obs_length:obs_length + pred_length] - batch_scene[obs_length - 1:obs_length + pred_length - 1]
     in_backward = distributed and overlap and hasattr(model, '_grad_reduce_fn')
     if distributed and n_global_scenes is None and empty:
@@ -68,6 +66,12 @@ def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batc
         rel_outputs, outputs = model(observed, batch_scene_goal, split, prediction_truth, pad_to=pad_to)
         loss = batch_loss(criterion, rel_outputs, outputs, batch_scene, targets, split, pred_length, batch_size,
                           shard=(n_local, n_global) if distributed else None)
+        # gradients are cleared between the forward pass and backward(), where the reference does it (lstm/trainer.py:266):
+        # by then the forward kernels are queued and the host's time is free
+        if buckets is not None:
+            buckets.zero()
+        else:
+            optimizer.zero_grad()
         loss.backward()
     finally:
         if in_backward:
