@@ -157,7 +157,10 @@ def test_sparse_first_layer_backward_equals_dense_backward(latent_dim, n, layer)
 
 
 @pytest.mark.parametrize('K,Mo,No', [(1000, 5, 128), (777, 62, 2), (4099, 512, 320), (38912, 256, 288), (33, 130, 70),
-                                     (2048, 16, 128)])
+                                     (2048, 16, 128),
+                                     # whole 64 x 64 blocks with 1, 2, 3 and 5 operand stages per split (the pipelined loop's
+                                     # prologue / pair / odd-tail paths) and a long one with whole stages everywhere
+                                     (16, 64, 64), (32, 128, 64), (48, 64, 128), (80, 128, 128), (8192, 192, 256)])
 def test_wgrad_split_k_matches_fp64(K, Mo, No):
     """tnp_wgrad (dy^T x with K split across workgroups + bias column sums) against an fp64 product, ragged shapes,
     strided operands; two runs are bit-identical (fixed reduction order)."""

@@ -676,8 +676,12 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
     const size_t MH = (size_t)M * H;
     // training: the states of all steps stay in the caller's [steps + 1, M, H] buffers instead of the ping-pong pair
     float *hcur = sv ? sv->h_all : w.h[0];
-    TNP_HIP(hipMemsetAsync(hcur, 0, MH * 4, s));  // lstm.py:207-210
-    TNP_HIP(hipMemsetAsync(sv ? sv->c_all : w.c, 0, MH * 4, s));
+    if (!sv && w.c > w.h[0]) {      // lstm.py:207-210; h[0], h[1], c lie one after the other in the workspace: one fill, not two
+        TNP_HIP(hipMemsetAsync(hcur, 0, (size_t)(reinterpret_cast<char *>(w.c + MH) - reinterpret_cast<char *>(w.h[0])), s));
+    } else {
+        TNP_HIP(hipMemsetAsync(hcur, 0, MH * 4, s));
+        TNP_HIP(hipMemsetAsync(sv ? sv->c_all : w.c, 0, MH * 4, s));
+    }
     if (w.ph[0]) {  // pool.reset() (lstm/lstm.py:213-216): zero interaction-encoder state, all tracks "present"
         TNP_HIP(hipMemsetAsync((sv && stateful) ? sv->ph_all : w.ph[0], 0, (size_t)M * md->dims[0] * 4, s));
         TNP_HIP(hipMemsetAsync((sv && stateful) ? sv->pc_all : w.pc, 0, (size_t)M * md->dims[0] * 4, s));
