@@ -924,7 +924,12 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
     if (variant == 0) variant = (big_tiles >= 192) ? 12 : 24;
     switch (variant) {
         case 12: TNP_TRY_FAST(2, 2, 1, 1, 32, EPI_BIAS); break;  // 64x64, 4 waves
-        case 24: TNP_TRY_PIPE(1, 2, 2, 1, 32, EPI_BIAS); break;  // pipelined: 32x64, split-K 2
+        case 24:
+            TNP_TRY_PIPE(1, 2, 2, 1, 32, EPI_BIAS);              // pipelined: 32x64, split-K 2
+            // K a multiple of 96 but not of 64 (the directional grid: 2 x 12 x 12 = 288 inputs): split-K 3 keeps the
+            // pipelined kernel instead of falling to the masked general one
+            TNP_TRY_PIPE(1, 2, 3, 1, 32, EPI_BIAS);
+            break;
         default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d (0 = automatic, 12, 24)", variant);
     }
     // shape not eligible for the fast path: masked general kernel

@@ -904,11 +904,15 @@ static int launch_sparse_wgrad(const float *dy, int ldy, const float *enc, int l
                                int ncell, int N1, float *dWc, hipStream_t s) {
     if constexpr (C <= 16) {
         if (ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(dWc) & 15) == 0) {
-            static float *zeros = nullptr;                                   // 64 zeros: what a past-the-end hit loads (one process, one device)
-            if (!zeros) {
-                TNP_HIP(hipMalloc(&zeros, 256));
-                TNP_HIP(hipMemset(zeros, 0, 256));
+            static float *zeros_of[64] = {};                                 // per device: 64 zeros, what a past-the-end hit loads
+            int dev_id = 0;
+            TNP_HIP(hipGetDevice(&dev_id));
+            if (dev_id < 0 || dev_id >= 64) TNP_FAIL(-1, "tnp_sparse_wgrad: device ordinal %d", dev_id);
+            if (!zeros_of[dev_id]) {
+                TNP_HIP(hipMalloc(&zeros_of[dev_id], 256));
+                TNP_HIP(hipMemset(zeros_of[dev_id], 0, 256));
             }
+            float *zeros = zeros_of[dev_id];
             hipLaunchKernelGGL(sparse_wgrad_mfma_kernel<C>, dim3(ncell * (N1 / 64)), dim3(256), 0, s, dy, ldy, enc, lde, list, count, R, N1, ncell,
                                dWc, zeros);
             TNP_HIP(hipGetLastError());
