@@ -1,5 +1,7 @@
 #!/bin/bash
-# sparse_wgrad_mfma sweep: pipeline depth (TNP_SWG_U), waves per workgroup (TNP_SWG_NW), block map (TNP_SWG_MAP)
+# sparse_wgrad_mfma sweep: pipeline depth (TNP_SWG_U), waves per workgroup (TNP_SWG_NW), block map (TNP_SWG_MAP).
+# History: the three environment knobs existed only in the working tree that ran this sweep (the library reads no environment
+# variables); results in profiles/round3_p_sparse_wgrad_sweep.md.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out/r3p; export TMPDIR=/tmp; R=$PWD
 run() {
