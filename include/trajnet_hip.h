@@ -86,7 +86,7 @@ TNP_API int tnp_pool_pair_cells(const float *obs2, const int32_t *row_base, cons
  * Dense layer on the matrix cores: torch.nn.Linear (+ReLU) as used by the grid embedding
  * MLPs (lstm/gridbased_pooling.py:308-335).   C[M,N] = act(A[M,K] @ W[N,K]^T + bias)
  * fp32-in / fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products.
- *   variant: 0 = automatic tile selection; 12 / 24 pin one of the two fast kernels
+ *   variant: 0 = automatic tile selection; 12 / 24 / 25 / 26 pin one of the fast kernels' tile shapes
  * ----------------------------------------------------------------------------------------- */
 TNP_API int tnp_linear_forward(const float *A, int lda, const float *W, int ldw, const float *bias, float *C,
                        int ldc, int M, int N, int K, int relu, int variant, void *stream);

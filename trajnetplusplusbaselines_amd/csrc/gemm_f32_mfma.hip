@@ -915,13 +915,29 @@ static int launch_pipe(GemmArgs g, hipStream_t s) {
 #define TNP_TRY_PIPE(WM, WN, WK, AN, BK, EPI) \
     if (fast_ok(g, WK, BK)) return launch_pipe<WM, WN, WK, AN, BK, EPI>(g, s)
 
+static int compute_units() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) n = cu;
+        else n = 256;
+    }
+    return n;
+}
+
 int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
     GemmArgs g = g_in;
     check_vec(g);
     const long big_tiles = (long)((g.M + 127) / 128) * ((g.N + 63) / 64);
     // tile selection measured on MI355X (profiles/round1_b_variant_sweep.jsonl): 64x64 tiles when they fill the chip, else
     // the pipelined 32x64 split-K 2 kernel; `variant` pins one of the two (12 / 24), anything else is an error
-    if (variant == 0) variant = (big_tiles >= 192) ? 12 : 24;
+    if (variant == 0) {
+        variant = (big_tiles >= 192) ? 12 : 24;
+        // 32x64 tiles that need a second round of workgroups while 32x128 tiles fit in one (the backward data-gradient GEMM,
+        // N = 448: 448 against 256 workgroups on 256 CUs): 22.8 -> 18.0 us (tools/experiments/run_r3v.sh)
+        const long b64 = (long)((g.M + 31) / 32) * ((g.N + 63) / 64), b128 = (long)((g.M + 31) / 32) * ((g.N + 127) / 128);
+        if (variant == 24 && b64 > compute_units() && b128 <= compute_units() && fast_ok(g, 1, 32)) variant = 25;
+    }
     switch (variant) {
         case 12: TNP_TRY_FAST(2, 2, 1, 1, 32, EPI_BIAS); break;  // 64x64, 4 waves
         case 24:
@@ -930,7 +946,9 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
             // pipelined kernel instead of falling to the masked general one
             TNP_TRY_PIPE(1, 2, 3, 1, 32, EPI_BIAS);
             break;
-        default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d (0 = automatic, 12, 24)", variant);
+        case 25: TNP_TRY_PIPE(1, 4, 1, 1, 32, EPI_BIAS); break;  // pipelined: 32x128, four waves over the whole K
+        case 26: TNP_TRY_PIPE(1, 2, 2, 2, 32, EPI_BIAS); break;  // pipelined: 32x128, split-K 2, two blocks per wave
+        default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d (0 = automatic, 12, 24, 25, 26)", variant);
     }
     // shape not eligible for the fast path: masked general kernel
     if (big_tiles >= 192) return launch_general<4, 2, 1, 1, 32, EPI_BIAS>(g, s);
