@@ -229,7 +229,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_group_kernel(const WgradGrou
 
 static void wgrad_plan(int Mo, int No, int K, int &regions, int &SK, int &kchunk) {
     regions = ((Mo + 127) / 128) * ((No + 127) / 128);
-    int want = (512 + regions - 1) / regions;      // ~2 workgroups per CU; 768 - 1536 measured the same (round 3)
+    int want = (512 + regions - 1) / regions;      // ~2 workgroups per CU; in the grouped launch 256 - 512 measure the same
+                                                   // (365 us), 768 / 1024 / 2048: 384 / 389 / 410 us (tools/experiments/run_r3w.sh)
     if (want > 128) want = 128;
     const int maxsk = (K + 255) / 256;
     if (want > maxsk) want = maxsk;
