@@ -477,6 +477,14 @@ TNP_API int tnp_colsum_prod(const float *G, const float *R, long rows, int cols,
                             size_t workspace_bytes, void *stream);
 /* out [cols, rows] = in [rows, cols]^T (LDS-tiled; operands of the weight-gradient GEMMs) */
 TNP_API int tnp_transpose(const float *in, int ld_in, int rows, int cols, float *out, int ld_out, void *stream);
+/* the same for several matrices in ONE launch (the backward sweep transposes six weight matrices per optimisation step:
+ * six launches of a few microseconds of work each) */
+typedef struct tnp_transpose_problem {
+    const float *in; int ld_in;      /* [rows, cols] */
+    int rows, cols;
+    float *out; int ld_out;          /* [cols, rows] */
+} tnp_transpose_problem;
+TNP_API int tnp_transpose_grouped(const tnp_transpose_problem *problems, int n, void *stream);
 /* gradient of the directional grid's values (v_j - v_i, lstm/gridbased_pooling.py:118-143) with respect to the tracks'
  * velocities: dvel [M,2]; needed when the positions fed to the sequence carry gradient (S-GAN discriminator input) */
 TNP_API int tnp_directional_scatter_backward(const float *dgrid, int ldg, const int32_t *cells,

@@ -98,7 +98,7 @@ def test_ctypes_mirrors_have_the_c_struct_sizes():
     L = _lib.lib()
     from trajnetplusplusbaselines_amd import optim
     mirrors = [_lib.LstmModel, _lib.LstmExtras, training.StepSaves, training.TrainSaves, training.BwdSweep, training.WgradProblem,
-               optim.AdamTensor]
+               optim.AdamTensor, training.TransposeProblem]
     for which, cls in enumerate(mirrors):
         assert L.tnp_abi_sizeof(which) == ctypes.sizeof(cls), cls.__name__
     assert L.tnp_abi_sizeof(99) == 0

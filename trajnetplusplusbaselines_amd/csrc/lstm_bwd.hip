@@ -286,6 +286,37 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float *__restrict_
     }
 }
 
+#define TR_MAX_PROBLEMS 12
+struct TransposeGroup {
+    const float *in[TR_MAX_PROBLEMS];
+    float *out[TR_MAX_PROBLEMS];
+    int ld_in[TR_MAX_PROBLEMS], ld_out[TR_MAX_PROBLEMS], R[TR_MAX_PROBLEMS], C[TR_MAX_PROBLEMS], tiles_x[TR_MAX_PROBLEMS];
+    int first_block[TR_MAX_PROBLEMS + 1];
+    int count;
+};
+
+// transpose_kernel for several matrices: block -> (problem, 64 x 64 tile)
+__global__ void __launch_bounds__(256) transpose_group_kernel(const TransposeGroup g) {
+    __shared__ float tile[64][65];
+    int p = 0;
+    while (p + 1 < g.count && (int)blockIdx.x >= g.first_block[p + 1]) ++p;
+    const int local = (int)blockIdx.x - g.first_block[p];
+    const int c0 = (local % g.tiles_x[p]) * 64, r0 = (local / g.tiles_x[p]) * 64;
+    const float *__restrict__ in = g.in[p];
+    float *__restrict__ out = g.out[p];
+    const int R = g.R[p], C = g.C[p], ld_in = g.ld_in[p], ld_out = g.ld_out[p];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = ty; k < 64; k += 4) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < R && c < C) ? in[(size_t)r * ld_in + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < C && r < R) out[(size_t)c * ld_out + r] = tile[tx][k];
+    }
+}
+
 
 // ---- sparse backward of the first grid-embedding layer (social pooling) ------------------------------------------
 // Forward (pool_embed_sparse.hip): y1[i, :] = sum over the occupied cells c of ego i of  W'[c][ch][:] * enc[winner(i,c), ch]
@@ -1027,6 +1058,29 @@ static void plan_sweep(const tnp_bwd_sweep *a, void *base, SweepScratch &w) {
 
 }  // namespace tnp
 
+extern "C" TNP_API int tnp_transpose_grouped(const tnp_transpose_problem *problems, int n, void *stream) {
+    if (n <= 0) return 0;
+    if (!problems) TNP_FAIL(-1, "tnp_transpose_grouped: problems == NULL");
+    int done = 0;
+    while (done < n) {
+        tnp::TransposeGroup g;
+        g.count = 0; g.first_block[0] = 0;
+        for (; done < n && g.count < TR_MAX_PROBLEMS; ++done) {
+            const tnp_transpose_problem &q = problems[done];
+            if (q.rows <= 0 || q.cols <= 0) continue;
+            if (!q.in || !q.out) TNP_FAIL(-1, "tnp_transpose_grouped: problem %d: NULL pointer", done);
+            const int c = g.count++;
+            g.in[c] = q.in; g.out[c] = q.out; g.ld_in[c] = q.ld_in; g.ld_out[c] = q.ld_out; g.R[c] = q.rows; g.C[c] = q.cols;
+            g.tiles_x[c] = (q.cols + 63) / 64;
+            g.first_block[c + 1] = g.first_block[c] + g.tiles_x[c] * ((q.rows + 63) / 64);
+        }
+        if (g.count == 0) break;
+        hipLaunchKernelGGL(tnp::transpose_group_kernel, dim3(g.first_block[g.count]), dim3(256), 0, (hipStream_t)stream, g);
+        TNP_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
 extern "C" TNP_API int tnp_transpose(const float *in, int ld_in, int rows, int cols, float *out, int ld_out, void *stream) {
     if (rows <= 0 || cols <= 0) return 0;
     hipLaunchKernelGGL(tnp::transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, in,
@@ -1380,6 +1434,7 @@ extern "C" TNP_API size_t tnp_abi_sizeof(int which) {
         case 4: return sizeof(tnp_bwd_sweep);
         case 5: return sizeof(tnp_wgrad_problem);
         case 6: return sizeof(tnp_adam_tensor);
+        case 7: return sizeof(tnp_transpose_problem);
         default: return 0;
     }
 }

@@ -53,6 +53,12 @@ class WgradProblem(ctypes.Structure):
                 ('dbias', ctypes.c_void_p)]
 
 
+class TransposeProblem(ctypes.Structure):
+    """mirror of ``struct tnp_transpose_problem`` (include/trajnet_hip.h)"""
+    _fields_ = [('src', ctypes.c_void_p), ('ld_in', ctypes.c_int), ('rows', ctypes.c_int), ('cols', ctypes.c_int),
+                ('out', ctypes.c_void_p), ('ld_out', ctypes.c_int)]
+
+
 class StepSaves(ctypes.Structure):
     """mirror of ``struct tnp_step_saves`` (include/trajnet_hip.h)"""
     _fields_ = [('X', ctypes.c_void_p), ('act', ctypes.c_void_p * 2), ('gates', ctypes.c_void_p), ('enc', ctypes.c_void_p),
@@ -299,14 +305,23 @@ class SequenceFn(torch.autograd.Function):
         grads = {}
 
         # weights of the data-gradient GEMMs, transposed once per sweep ([in, out] rows for the NT kernel)
+        tq, tq_keep = [], []
+
         def T_into(out, name):
             """out [in, out_features] <- P[name]^T through the LDS-tiled transpose kernel (an ATen `.t().contiguous()` is a
-            strided elementwise copy: 10-23 us per weight, nine of them per sweep)"""
+            strided elementwise copy: 10-23 us per weight, nine of them per sweep).  Queued: every transpose of the sweep
+            goes out in ONE launch (flush_transposes, before the first kernel that reads one)."""
             w = P[name].detach()
             w = w if w.is_contiguous() else w.contiguous()
-            _lib.check(L.tnp_transpose(_lib.ptr(w), w.stride(0), w.shape[0], w.shape[1], _lib.ptr(out), out.stride(0), sp()),
-                       'tnp_transpose')
+            tq.append(TransposeProblem(w.data_ptr(), w.stride(0), w.shape[0], w.shape[1], out.data_ptr(), out.stride(0)))
+            tq_keep.append(w)
             return out
+
+        def flush_transposes():
+            if tq:
+                table = (TransposeProblem * len(tq))(*tq)
+                _lib.check(L.tnp_transpose_grouped(table, len(tq), sp()), 'tnp_transpose_grouped')
+                del tq[:]
 
         def T(name):
             w = P[name]
@@ -457,6 +472,8 @@ class SequenceFn(torch.autograd.Function):
         need = L.tnp_lstm_backward_scratch_bytes(ctypes.byref(sw))
         scratch = torch.empty(need, dtype=torch.uint8, device=dev)
 
+        flush_transposes()             # every transposed weight of the sweep: one launch
+
         def sweep(hi, lo):
             if hi >= lo:
                 _lib.check(L.tnp_lstm_backward_sweep(ctypes.byref(sw), hi, lo, _lib.ptr(scratch), need, sp()), 'backward_sweep')
@@ -472,7 +489,9 @@ class SequenceFn(torch.autograd.Function):
             _lib.check(L.tnp_relu_mask(_lib.ptr(dh), H, _lib.ptr(ctx_act), nc, M, nc, _lib.ptr(dctx), nc, sp()), 'relu_mask')
             grads['mlp_decoder_context.0.weight'] = _mm(dctx.t(), h_enc.t())
             grads['mlp_decoder_context.0.bias'] = dctx.sum(0)
-            dh.copy_(_lin(dctx, T('mlp_decoder_context.0.weight')))
+            w_ctx_T = T('mlp_decoder_context.0.weight')
+            flush_transposes()
+            dh.copy_(_lin(dctx, w_ctx_T))
             sweep(s_noise - 1, 0)
         del keep, sv_keep
         if GD:    # direction to the goal, the goal embedding's input (all steps at once)
