@@ -267,6 +267,21 @@ class SceneIndex(object):
         check(lib().tnp_mark_primaries(ptr(self.starts), self.B, self.M, ptr(self.primary), stream_ptr()),
               'tnp_mark_primaries')
 
+    def stacked_rows(self, S):
+        """(row_base, row_count) of S copies of the batch stacked along the rows (row r of step s is row s M + r): what the
+        backward sweep's whole-sweep pair-cell launch indexes with.  Built on the host once per (batch structure, S) -- five
+        small device kernels per optimisation step otherwise (arange, scale, add, copy, repeat)."""
+        got = self.__dict__.setdefault('_stacked', {}).get(S)
+        if got is None:
+            base = self.row_base.to('cpu', torch.int64)
+            off = (torch.arange(S, dtype=torch.int64) * self.M)[:, None]
+            rb = (off + base[None]).reshape(-1).to(torch.int32).to(self.row_base.device)
+            rc = self.row_count.to('cpu').repeat(S).to(self.row_base.device)
+            if len(self._stacked) > 4:
+                self._stacked.clear()
+            got = self._stacked[S] = (rb, rc)
+        return got
+
     @classmethod
     def get(cls, batch_split, device, pad_to=None):
         if isinstance(batch_split, (list, tuple)):

@@ -404,9 +404,7 @@ class SequenceFn(torch.autograd.Function):
                 if sparse_bwd:
                     # pair cells of every step in one launch, then per (step, cell) the egos with a neighbour in that cell
                     R, ncell = S * M, G * G
-                    step_off = (torch.arange(S, device=dev, dtype=torch.int32) * M)[:, None]
-                    rb_all = (step_off + row_base[None]).reshape(-1).contiguous()
-                    rc_all = row_count.repeat(S)
+                    rb_all, rc_all = idx.stacked_rows(S)
                     cells_all = torch.empty(S, M, idx.n_max, dtype=torch.int32, device=dev)
                     _lib.check(L.tnp_pool_pair_cells(_lib.ptr(o2_all), _lib.ptr(rb_all), _lib.ptr(rc_all), R, idx.n_max, G,
                                                      cell, half_x, half_y, _lib.ptr(cells_all), sp()), 'pair_cells')
@@ -416,10 +414,12 @@ class SequenceFn(torch.autograd.Function):
                     ego_count = torch.empty(ncell, S, dtype=torch.int32, device=dev)
                     _lib.check(L.tnp_pair_ego_lists(_lib.ptr(cells_all), R, M, idx.n_max, ncell, _lib.ptr(occ), _lib.ptr(occ_t),
                                                     _lib.ptr(ego_list), _lib.ptr(ego_count), sp()), 'ego_lists')
-                    del occ, occ_t, rb_all, rc_all
+                    del occ, occ_t
 
-        dh = _lib.f32c(d_hlast, dev).clone() if d_hlast is not None else torch.zeros(M, H, device=dev)
-        dc = torch.zeros(M, H, device=dev)
+        if d_hlast is not None:
+            dh, dc = _lib.f32c(d_hlast, dev).clone(), torch.zeros(M, H, device=dev)
+        else:
+            dh, dc = torch.zeros(2, M, H, device=dev).unbind(0)          # one fill
         dvel_pool_all = torch.empty(S, M, 2, device=dev) if directional_in else None
 
         # ---- the reverse sweep: one driver call (two around the S-GAN noise hook), csrc/lstm_bwd.hip ----
