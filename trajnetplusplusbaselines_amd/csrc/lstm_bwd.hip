@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float *__restrict_
     }
 }
 
-#define TR_MAX_PROBLEMS 12
+#define TR_MAX_PROBLEMS 32
 struct TransposeGroup {
     const float *in[TR_MAX_PROBLEMS];
     float *out[TR_MAX_PROBLEMS];

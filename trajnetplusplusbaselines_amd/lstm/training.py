@@ -585,7 +585,15 @@ class SequenceFn(torch.autograd.Function):
                 dwc = torch.empty(ncell, C, N1, device=dev)
                 _lib.check(L.tnp_sparse_wgrad(_lib.ptr(dy_all[0]), N1, _lib.ptr(enc_all), C, _lib.ptr(hits), _lib.ptr(count),
                                               R, C, ncell, N1, _lib.ptr(dwc), sp()), 'sparse_wgrad')
-                grads[name + '.weight'] = dwc.permute(2, 1, 0).reshape(N1, C * ncell)   # back to the parameter's layout (a copy)
+                # back to the parameter's layout: g[n][ch ncell + cell] = dW'[cell][ch][n] is one strided transpose per
+                # channel ([ncell, N1] rows C N1 apart -> [N1, ncell] columns of g), all of them in one launch (an ATen
+                # permute + reshape copy: 22 us)
+                gw = torch.empty(N1, C * ncell, device=dev)
+                table = (TransposeProblem * C)(*[
+                    TransposeProblem(dwc.data_ptr() + 4 * ch * N1, C * N1, ncell, N1, gw.data_ptr() + 4 * ch * ncell, C * ncell)
+                    for ch in range(C)])
+                _lib.check(L.tnp_transpose_grouped(table, C, sp()), 'tnp_transpose_grouped')
+                grads[name + '.weight'] = gw
                 publish(grads[name + '.weight'])
                 grads[name + '.bias'] = dy_all[0].reshape(-1, N1).sum(0)
                 publish(grads[name + '.bias'])
