@@ -74,3 +74,44 @@ def test_unaligned_and_odd_sizes():
     Adam([p], lr=1e-2).step()
     torch.optim.Adam([q], lr=1e-2).step()
     assert torch.allclose(p, q, rtol=2e-6, atol=1e-7)
+
+
+def test_updated_tensors_are_marked_as_modified():
+    """the kernel writes through raw pointers: Tensor._version (what autograd's saved-tensor checks and our re-laid-out
+    weight copies are keyed on) must still move"""
+    from trajnetplusplusbaselines_amd.optim import Adam
+    ps = _params(9)[:3]
+    opt = Adam(ps, lr=1e-3)
+    before = [p._version for p in ps]
+    for p in ps:
+        p.grad = torch.ones_like(p)
+    opt.step()
+    assert all(p._version > v for p, v in zip(ps, before))
+    assert all(opt.state[p]['exp_avg']._version > 0 for p in ps)
+
+
+def test_social_lstm_trains_like_with_torch_adam():
+    """Three optimisation steps of Social-LSTM (sparse first layer: the forward runs on cell- / quad-major COPIES of the first
+    embedding layer that are rebuilt when the parameter's version changes) with the native Adam and with torch.optim.Adam:
+    same losses, same parameters.  A stale copy shows from the second step on."""
+    import copy
+    from trajnetplusplusbaselines_amd import synth
+    from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling, PredictionLoss
+    from trajnetplusplusbaselines_amd.lstm.train_step import train_batch
+    from trajnetplusplusbaselines_amd.optim import Adam
+    torch.manual_seed(5)
+    pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=8, out_dim=64, embedding_arch='two_layer',
+                            layer_dims=[128], latent_dim=16)
+    m1 = LSTM(pool=pool).cuda()
+    m2 = copy.deepcopy(m1)
+    o1, o2 = Adam(m1.parameters(), lr=2e-2, weight_decay=1e-4), torch.optim.Adam(m2.parameters(), lr=2e-2, weight_decay=1e-4)
+    xy, split = synth.ragged_crowd(6, 3, 9, seed=12)
+    xy = xy.cuda()
+    goals = torch.zeros(xy.shape[1], 2, device='cuda')
+    l1 = [train_batch(m1, o1, PredictionLoss(), xy, goals, split, 9, 12) for _ in range(3)]
+    l2 = [train_batch(m2, o2, PredictionLoss(), xy, goals, split, 9, 12) for _ in range(3)]
+    assert l1[0] == l2[0]
+    assert abs(l1[1] - l2[1]) <= 2e-4 * max(1.0, abs(l2[1])) and abs(l1[2] - l2[2]) <= 5e-4 * max(1.0, abs(l2[2])), (l1, l2)
+    assert abs(l2[1] - l2[0]) > 1e-2 * abs(l2[0])             # the step is large enough for a stale forward to show
+    for (n, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-4), (n, float((a - b).abs().max()))

@@ -64,4 +64,7 @@ class Adam(torch.optim.Optimizer):
                     _lib.check(L.tnp_adam_step(table, len(items), step, float(group['lr']), float(group['betas'][0]),
                                                float(group['betas'][1]), float(group['eps']), float(group['weight_decay']),
                                                _lib.stream_ptr()), 'tnp_adam_step')
+                # the kernel wrote through raw pointers: tell autograd (and everything keyed on Tensor._version, e.g. the
+                # re-laid-out copies of the first embedding layer, lstm/lstm.py) that these tensors changed in place
+                torch.autograd.graph.increment_version([t for p, _, m, v in items for t in (p, m, v)])
         return loss
