@@ -475,6 +475,14 @@ TNP_API int tnp_pool_hiddenmlp_backward(const float *obs1, const float *obs2, co
 TNP_API size_t tnp_colsum_prod_workspace_bytes(long rows, int cols);
 TNP_API int tnp_colsum_prod(const float *G, const float *R, long rows, int cols, float *dW, float *db, void *workspace,
                             size_t workspace_bytes, void *stream);
+/* The two re-laid-out copies of the first grid-embedding layer W [N1, C n n] (torch.nn.Linear weight,
+ * lstm/gridbased_pooling.py:308-335) that tnp_lstm_model carries, in one launch:
+ *   w_cell_major [ncell][C][N1]:               W'[c][ch][o]                      = W[o][ch ncell + c]
+ *   w_quad_major [ncell][N1/64][C/4][64][4]:   W''[c][o/64][ch/4][o%64][ch%4]    = W[o][ch ncell + c]   (NULL: not wanted;
+ *                                              needs N1 % 64 == 0 and C % 4 == 0)
+ * Rebuild both whenever the parameter changes (every optimiser step while training). */
+TNP_API int tnp_pool_embed_weight_layouts(const float *W, int ldw, int N1, int C, int ncell, float *w_cell_major,
+                                          float *w_quad_major, void *stream);
 /* out [cols, rows] = in [rows, cols]^T (LDS-tiled; operands of the weight-gradient GEMMs) */
 TNP_API int tnp_transpose(const float *in, int ld_in, int rows, int cols, float *out, int ld_out, void *stream);
 /* the same for several matrices in ONE launch (the backward sweep transposes six weight matrices per optimisation step:

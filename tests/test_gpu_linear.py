@@ -71,3 +71,22 @@ def test_transpose_grouped_matches_torch():
     _lib.check(_lib.lib().tnp_transpose_grouped(table, len(shapes), _lib.stream_ptr()), 'tnp_transpose_grouped')
     for a, o in zip(srcs, outs):
         assert torch.equal(o[:, :a.shape[0]], a.t()) and bool((o[:, a.shape[0]:] == -7.0).all())
+
+
+@pytest.mark.parametrize('N1,C,G', [(1024, 16, 12), (128, 8, 8), (100, 4, 3), (192, 6, 5), (64, 32, 16)])
+def test_weight_layouts_match_the_permutes(N1, C, G):
+    """tnp_pool_embed_weight_layouts: the cell-major and quad-major copies of the first embedding layer against the tensor
+    expressions INTEGRATION.md gives for them (strided source, ragged shapes; no quad-major copy when the shape rules it out)."""
+    ncell = G * G
+    rng = np.random.RandomState(N1 + C)
+    full = torch.tensor(rng.randn(N1, C * ncell + 8).astype(np.float32)).cuda()
+    W = full[:, 4:4 + C * ncell]
+    quad = N1 % 64 == 0 and C % 4 == 0
+    cm = torch.full((ncell, C, N1), float('nan'), device='cuda')
+    qm = torch.full((ncell, N1 // 64, C // 4, 64, 4), float('nan'), device='cuda') if quad else None
+    _lib.check(_lib.lib().tnp_pool_embed_weight_layouts(_lib.ptr(W), W.stride(0), N1, C, ncell, _lib.ptr(cm), _lib.ptr(qm),
+                                                        _lib.stream_ptr()), 'tnp_pool_embed_weight_layouts')
+    Wc = W.contiguous()
+    assert torch.equal(cm, Wc.view(N1, C, ncell).permute(2, 1, 0).contiguous())
+    if quad:
+        assert torch.equal(qm, Wc.view(N1 // 64, 64, C // 4, 4, ncell).permute(4, 0, 2, 1, 3).contiguous())

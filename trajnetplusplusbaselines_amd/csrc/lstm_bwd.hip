@@ -317,6 +317,37 @@ __global__ void __launch_bounds__(256) transpose_group_kernel(const TransposeGro
     }
 }
 
+// W [N1][C ncell] -> cell-major W'[c][ch][o] and (optional) quad-major W''[c][o/64][ch/4][o%64][ch%4] (tnp_lstm_model).
+// Workgroup (cell block of 32, column block of 64 outputs, channel quad q): the 4 x 64 x 32 values go through LDS once; reads
+// run along the cells (contiguous in W), writes along the outputs (contiguous in both copies).
+__global__ void __launch_bounds__(256) weight_layouts_kernel(const float *__restrict__ W, int ldw, int N1, int C, int ncell,
+                                                            float *__restrict__ Wc, float *__restrict__ Wq) {
+    __shared__ float t[4][64][33];                                   // [ch % 4][o % 64][cell % 32]
+    const int c0 = blockIdx.x * 32, o0 = blockIdx.y * 64, q = blockIdx.z;
+    const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;       // 8 rows of 32 lanes
+    for (int k = 0; k < 4; ++k) {
+        const int ch = 4 * q + k;
+        for (int r = ly; r < 64; r += 8) {
+            const int o = o0 + r, c = c0 + lx;
+            t[k][r][lx] = (ch < C && o < N1 && c < ncell) ? W[(size_t)o * ldw + (size_t)ch * ncell + c] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int ox = tid & 63, cy = tid >> 6;                          // 4 cells per pass, 64 outputs per cell
+    for (int cc = cy; cc < 32; cc += 4) {
+        const int c = c0 + cc, o = o0 + ox;
+        if (c >= ncell || o >= N1) continue;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = t[k][ox][cc];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * q + k < C) Wc[((size_t)c * C + 4 * q + k) * N1 + o] = v[k];
+        if (Wq)       // N1 % 64 == 0, C % 4 == 0 (checked by the launcher): a lane's four channels are 16 contiguous bytes
+            *reinterpret_cast<float4 *>(Wq + ((((size_t)c * (N1 >> 6) + (o >> 6)) * (C >> 2) + q) * 64 + (o & 63)) * 4) =
+                make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
 
 // ---- sparse backward of the first grid-embedding layer (social pooling) ------------------------------------------
 // Forward (pool_embed_sparse.hip): y1[i, :] = sum over the occupied cells c of ego i of  W'[c][ch][:] * enc[winner(i,c), ch]
@@ -1057,6 +1088,20 @@ static void plan_sweep(const tnp_bwd_sweep *a, void *base, SweepScratch &w) {
 }
 
 }  // namespace tnp
+
+extern "C" TNP_API int tnp_pool_embed_weight_layouts(const float *W, int ldw, int N1, int C, int ncell, float *w_cell_major,
+                                                     float *w_quad_major, void *stream) {
+    if (N1 <= 0 || C <= 0 || ncell <= 0) return 0;
+    if (!W || !w_cell_major) TNP_FAIL(-1, "tnp_pool_embed_weight_layouts: NULL pointer");
+    if (ldw < C * ncell) TNP_FAIL(-1, "tnp_pool_embed_weight_layouts: ldw %d < C n n = %d", ldw, C * ncell);
+    if (w_quad_major && (N1 % 64 != 0 || C % 4 != 0 || (reinterpret_cast<uintptr_t>(w_quad_major) & 15) != 0))
+        TNP_FAIL(-1, "tnp_pool_embed_weight_layouts: the quad-major copy needs N1 %% 64 == 0, C %% 4 == 0 and a 16-byte aligned "
+                     "buffer (N1 %d, C %d)", N1, C);
+    hipLaunchKernelGGL(tnp::weight_layouts_kernel, dim3((ncell + 31) / 32, (N1 + 63) / 64, (C + 3) / 4), dim3(256), 0,
+                       (hipStream_t)stream, W, ldw, N1, C, ncell, w_cell_major, w_quad_major);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" TNP_API int tnp_transpose_grouped(const tnp_transpose_problem *problems, int n, void *stream) {
     if (n <= 0) return 0;

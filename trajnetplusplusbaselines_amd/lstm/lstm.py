@@ -267,25 +267,32 @@ class LSTM(torch.nn.Module):
                 m.Wp0_quad_major = ctypes.c_void_p(qm.data_ptr())
         return m, keep, dev
 
-    def _cell_major_weight(self, weight, pool):
-        """W'[c][ch][o] = W[o][ch*n*n + c]: cell-major copy of the first embedding layer for the sparse kernel
-        (pool_embed_sparse.hip); rebuilt only when the parameter changes (data_ptr / in-place version)."""
+    def _relaid_weights(self, weight, pool):
+        """The copies of the first embedding layer the sparse kernels read (include/trajnet_hip.h, tnp_lstm_model):
+        cell-major W'[c][ch][o] = W[o][ch*n*n + c] (pool_embed_sparse.hip, the sparse backward) and, when the shape allows
+        it, quad-major W''[c][o/64][ch/4][o%64][ch%4] (what the register-accumulator kernel streams: a wave's C x 64 weights
+        of a cell are one contiguous block).  Both from ONE native launch (tnp_pool_embed_weight_layouts), rebuilt only
+        when the parameter changes (data_ptr / in-place version)."""
         key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device))
         if self._cell_major is None or self._cell_major[0] != key:
-            n1 = weight.shape[0]
-            w = weight.detach().float().view(n1, pool.pooling_dim, pool.n * pool.n).permute(2, 1, 0).contiguous()
-            self._cell_major = (key, w)
-        return self._cell_major[1]
+            n1, C, ncell = weight.shape[0], pool.pooling_dim, pool.n * pool.n
+            w = weight.detach()
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                w = w.float().contiguous()
+            quad = n1 % 64 == 0 and C % 4 == 0
+            cm = torch.empty(ncell, C, n1, dtype=torch.float32, device=w.device)
+            qm = torch.empty(ncell, n1 // 64, C // 4, 64, 4, dtype=torch.float32, device=w.device) if quad else None
+            _lib.check(_lib.lib().tnp_pool_embed_weight_layouts(_lib.ptr(w), w.stride(0), n1, C, ncell, _lib.ptr(cm),
+                                                                _lib.ptr(qm), _lib.stream_ptr()), 'tnp_pool_embed_weight_layouts')
+            self._cell_major = (key, cm)
+            self._quad_major = (key, qm)
+        return self._cell_major[1], self._quad_major[1]
+
+    def _cell_major_weight(self, weight, pool):
+        return self._relaid_weights(weight, pool)[0]
 
     def _quad_major_weight(self, weight, pool):
-        """W''[c][o/64][ch/4][o%64][ch%4] = W[o][ch*n*n + c]: the layout the register-accumulator sparse kernel streams
-        (a wave's C x 64 weights of a cell are one contiguous block: one scalar base per cell, 16-byte loads per lane)."""
-        key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device))
-        if getattr(self, '_quad_major', None) is None or self._quad_major[0] != key:
-            n1, C = weight.shape[0], pool.pooling_dim
-            w = weight.detach().float().view(n1 // 64, 64, C // 4, 4, pool.n * pool.n).permute(4, 0, 2, 1, 3).contiguous()
-            self._quad_major = (key, w)
-        return self._quad_major[1]
+        return self._relaid_weights(weight, pool)[1]
 
     def _workspace(self, m, M, B, dev):
         need = _lib.lib().tnp_lstm_workspace_bytes(ctypes.byref(m), M, B)
