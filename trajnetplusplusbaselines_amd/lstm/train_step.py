@@ -66,7 +66,12 @@ def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batc
         rel_outputs, outputs = model(observed, batch_scene_goal, split, prediction_truth, pad_to=pad_to)
         loss = batch_loss(criterion, rel_outputs, outputs, batch_scene, targets, split, pred_length, batch_size,
                           shard=(n_local, n_global) if distributed else None)
-        # gradients are cleared between the forward pass and backward(), where the reference does it (lstm/trainer.py:266):
+        # The loss value leaves for the host NOW (pinned buffer + event), not through a blocking read after optimizer.step():
+        # it is final once the forward pass is, so the caller gets its float back when the HOST has queued the step and
+        # prepares the next batch while the GPU still runs this step's backward pass and optimiser update -- the reference's
+        # loss.item() at the end of the step (lstm/trainer.py:268) leaves the GPU idle for that long at every step.
+        read_back = _LossReadBack(loss)
+        # gradients are cleared between the forward pass and backward(), where the reference does it (lstm/trainer.py:264):
         # by then the forward kernels are queued and the host's time is free
         if buckets is not None:
             buckets.zero()
@@ -78,7 +83,6 @@ def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batc
             # also on an exception (NaN check, out of memory ...): a reducer left attached would all-reduce from inside
             # the next, unrelated backward pass of this model
             model._grad_reduce_fn = None              # gradients were summed over the ranks inside the backward pass
-    loss_value = loss.detach()
     if in_backward:
         pass
     elif buckets is not None:
@@ -87,7 +91,32 @@ def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batc
     elif distributed:
         parallel.allreduce_gradients(list(model.parameters()), group=group)
     optimizer.step()
-    return float(loss_value)
+    return read_back.value()
+
+
+class _LossReadBack(object):
+    """float(loss) without waiting for work queued after the loss: an asynchronous copy into pinned host memory and an event.
+    (One pinned scalar per device, reused: `value()` of step N is read before step N + 1 records its own.)"""
+    _pinned = {}
+
+    def __init__(self, loss):
+        self.loss, self.event = loss.detach(), None
+        if self.loss.is_cuda:
+            dev = self.loss.device
+            buf = self._pinned.get(dev)
+            if buf is None:
+                buf = self._pinned[dev] = torch.empty((), dtype=torch.float32, pin_memory=True)
+            self.buf = buf
+            with torch.cuda.device(dev):
+                buf.copy_(self.loss.float(), non_blocking=True)
+                self.event = torch.cuda.Event()
+                self.event.record()
+
+    def value(self):
+        if self.event is None:
+            return float(self.loss)
+        self.event.synchronize()
+        return float(self.buf)
 
 
 def batch_loss(criterion, rel_outputs, outputs, batch_scene, targets, split, pred_length, batch_size, shard=None):

@@ -3,6 +3,7 @@
 import torch
 
 from ..lstm.loss import gan_d_loss, gan_g_loss, variety_loss
+from ..lstm.train_step import _LossReadBack
 
 
 def loss_criterion(model, criterion, rel_output_list, targets, batch_split, scores_fake, scores_real, step_type,
@@ -20,7 +21,8 @@ def train_batch(model, g_optimizer, d_optimizer, criterion, batch_scene, batch_s
                 obs_length=9, pred_length=12, start_length=0):
     """batch_scene [obs+pred, M, 2], step_type 'g' | 'd' (reference sgan/trainer.py:258-300).  `criterion` must keep the
     batch dimension (PredictionLoss(keep_batch_dim=True)), as the reference's top-k loss needs per-scene values."""
-    model.train()
+    if not model.training:
+        model.train()
     dev = next(model.parameters()).device
     batch_scene = batch_scene.to(dev)
     seq_length = obs_length + pred_length
@@ -31,8 +33,9 @@ def train_batch(model, g_optimizer, d_optimizer, criterion, batch_scene, batch_s
                                                                step_type=step_type, pred_length=pred_length)
     loss = loss_criterion(model, criterion, rel_output_list, targets, batch_split, scores_fake, scores_real, step_type,
                           pred_length)
+    read_back = _LossReadBack(loss)      # the value is final here: it travels to the host while backward + update run
     opt = g_optimizer if step_type == 'g' else d_optimizer
     opt.zero_grad()
     loss.backward()
     opt.step()
-    return float(loss.detach())
+    return read_back.value()
