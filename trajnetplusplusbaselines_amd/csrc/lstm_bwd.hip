@@ -470,22 +470,50 @@ template <typename T, bool OCC>
 __global__ void __launch_bounds__(256) hits_transpose_kernel(const T *__restrict__ table, const int32_t *__restrict__ row_base,
                                                              int R, int M, int ncell, int32_t *__restrict__ hit_t) {
     __shared__ int32_t tile[64][65];
-    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int k = ty; k < 64; k += 4) {
-        const int r = r0 + k, c = c0 + tx;
-        int v = -1;
-        if (r < R && c < ncell) {
-            const int w = table[(size_t)r * ncell + c];
-            if (OCC) {
-                if (w) v = r;
-            } else if (w >= 0) {
-                const int i = r % M;
-                v = r - i + row_base[i] + w;
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
+    // read: four table entries per load (8 bytes of int16 / 4 bytes of uint8), 16 threads per row, four rows per thread, all
+    // four loads (and their row_base entries) in flight together -- entry by entry this kernel ran at 1 TB/s.  The vector
+    // loads need the row segment aligned: ncell a multiple of 4 and a 16-byte aligned table (else entry by entry).
+    const bool vec = (ncell & 3) == 0 && (reinterpret_cast<uintptr_t>(table) & 15) == 0;
+    const int q = tid & 15, rr = tid >> 4;                           // column quad, row within a group of 16
+    T e[4][4];
+    int base[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + rr + 16 * k, c = c0 + 4 * q;
+        const int rc = r < R ? r : R - 1;
+        base[k] = 0;
+        if (!OCC) { const int i = rc % M; base[k] = rc - i + row_base[i]; }
+        if (vec && c + 3 < ncell) {
+            if (sizeof(T) == 2) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(table + (size_t)rc * ncell + c);
+                e[k][0] = (T)(v.x & 0xffff); e[k][1] = (T)(v.x >> 16); e[k][2] = (T)(v.y & 0xffff); e[k][3] = (T)(v.y >> 16);
+            } else {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(table + (size_t)rc * ncell + c);
+                e[k][0] = (T)(v & 0xff); e[k][1] = (T)((v >> 8) & 0xff); e[k][2] = (T)((v >> 16) & 0xff); e[k][3] = (T)(v >> 24);
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[k][j] = table[(size_t)rc * ncell + (c + j < ncell ? c + j : ncell - 1)];
         }
-        tile[k][tx] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + rr + 16 * k;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + 4 * q + j;
+            int v = -1;
+            if (r < R && c < ncell) {
+                const int w = (int)e[k][j];
+                if (OCC) { if (w) v = r; }
+                else if (w >= 0) v = base[k] + w;
+            }
+            tile[rr + 16 * k][4 * q + j] = v;
+        }
     }
     __syncthreads();
+    const int tx = tid & 63, ty = tid >> 6;
     for (int k = ty; k < 64; k += 4) {
         const int c = c0 + k, r = r0 + tx;
         if (r < R && c < ncell) hit_t[(size_t)c * R + r] = tile[tx][k];
