@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(256) hits_transpose_kernel(const T *__restrict
 
 // compact list of a cell's hits in ascending row order, per segment of `seg` rows (one segment = the whole sweep for the
 // weight gradient, one step for the ego lists): list[c][y*seg + k] = (ego row, entry), count[c*nseg + y]
-template <int NW>
+template <int NW, int KEEP>
 __global__ void __launch_bounds__(64 * NW) hits_compact_kernel(const int32_t *__restrict__ hit_t, int R, int seg,
                                                                int2 *__restrict__ list, int32_t *__restrict__ count) {
     // Two passes without a barrier inside the loops (the first version synchronised the workgroup twice per 256 rows: 152
@@ -538,6 +538,34 @@ __global__ void __launch_bounds__(64 * NW) hits_compact_kernel(const int32_t *__
     const int k0 = wave * per, k1 = min(seg, k0 + per);
     constexpr int UN = 8;                                     // rows are fetched UN x 64 at a time: the loads of a batch are
     int mine = 0;                                             // independent, so one memory round trip serves 512 rows
+    if (KEEP > 0 && per <= 64 * KEEP) {
+        // the wave's whole slice fits in registers (whole-sweep list of config 2: 38 rows per lane): ONE read, every load in
+        // flight at once, the second pass works on the registers (two passes over memory in batches of eight were ~ten
+        // dependent round trips per wave: 23 us for 22 MB)
+        constexpr int KK = KEEP > 0 ? KEEP : 1;
+        int e[KK];
+#pragma unroll
+        for (int u = 0; u < KK; ++u) {
+            const int k = k0 + 64 * u + lane;
+            const int v = src[k < k1 ? k : (k1 > k0 ? k1 - 1 : 0)];
+            e[u] = k < k1 ? v : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < KK; ++u) mine += __popcll(__ballot(e[u] >= 0));
+        if (lane == 0) wcnt[wave] = mine;
+        __syncthreads();
+        int off = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) { const int w = wcnt[q]; if (q < wave) off += w; total += w; }
+#pragma unroll
+        for (int u = 0; u < KK; ++u) {
+            const unsigned long long m = __ballot(e[u] >= 0);
+            if (e[u] >= 0) dst[off + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(y * seg + k0 + 64 * u + lane, e[u]);
+            off += __popcll(m);
+        }
+        if (tid == 0) count[c * gridDim.y + y] = total;
+        return;
+    }
     for (int base = k0; base < k1; base += 64 * UN) {
         int e[UN];
 #pragma unroll
@@ -643,10 +671,10 @@ static int launch_hit_lists(bool occ, const void *table, const int32_t *row_base
                            ncell, hit_t);
     TNP_HIP(hipGetLastError());
     if (seg > 8192)
-        hipLaunchKernelGGL(hits_compact_kernel<16>, dim3(ncell, R / seg), dim3(1024), 0, s, hit_t, R, seg,
+        hipLaunchKernelGGL((hits_compact_kernel<16, 40>), dim3(ncell, R / seg), dim3(1024), 0, s, hit_t, R, seg,
                            reinterpret_cast<int2 *>(list), count);
     else
-        hipLaunchKernelGGL(hits_compact_kernel<4>, dim3(ncell, R / seg), dim3(256), 0, s, hit_t, R, seg,
+        hipLaunchKernelGGL((hits_compact_kernel<4, 8>), dim3(ncell, R / seg), dim3(256), 0, s, hit_t, R, seg,
                            reinterpret_cast<int2 *>(list), count);
     TNP_HIP(hipGetLastError());
     return 0;
