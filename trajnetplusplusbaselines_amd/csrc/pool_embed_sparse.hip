@@ -273,6 +273,11 @@ __device__ __forceinline__ int pop_bit(unsigned long long &mask) {
     asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(b));
     return b;
 }
+__device__ __forceinline__ int pop_bit32(unsigned &mask) {
+    const int b = __builtin_ctz(mask);
+    asm("s_bitset0_b32 %0, %1" : "+s"(mask) : "s"(b));
+    return b;
+}
 
 template <int C> struct SRow;
 template <> struct SRow<4> { typedef float type __attribute__((ext_vector_type(4))); };
@@ -850,9 +855,12 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
     };
     // the hits of one half of the tile (32 egos, bits of `m`) against the accumulator vector of that half
     auto half = [&](const WS &w, ra_f32x32 &acc, unsigned m, unsigned off, int lane0) {
-        while (m & (m - 1u)) {                                                      // two hits: both rows in flight before the wait
-            const int b0 = __builtin_ctz(m); m &= m - 1u;
-            const int b1 = __builtin_ctz(m); m &= m - 1u;
+        // (pops as s_ff1 + s_bitset0 and a hit counter for the loop test: `m &= m - 1` twice plus `m & (m - 1)` are seven
+        // scalar instructions per pair of hits, this is six less one)
+        int left = __popc(m);
+        for (; left >= 2; left -= 2) {                                              // two hits: both rows in flight before the wait
+            const int b0 = pop_bit32(m);
+            const int b1 = pop_bit32(m);
             typename SRow<C>::type e0, e1;
             sload_row<C>(e0, a.enc, (unsigned)__builtin_amdgcn_readlane((int)off, lane0 + b0));
             sload_row<C>(e1, a.enc, (unsigned)__builtin_amdgcn_readlane((int)off, lane0 + b1));
@@ -861,7 +869,7 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
             acc[b0] = fin(w, e0, a0);
             acc[b1] = fin(w, e1, a1);
         }
-        if (m) {
+        if (left) {
             const int b0 = __builtin_ctz(m);
             typename SRow<C>::type e0;
             sload_row<C>(e0, a.enc, (unsigned)__builtin_amdgcn_readlane((int)off, lane0 + b0));
