@@ -96,19 +96,14 @@ def train_batch(model, optimizer, criterion, batch_scene, batch_scene_goal, batc
 
 class _LossReadBack(object):
     """float(loss) without waiting for work queued after the loss: an asynchronous copy into pinned host memory and an event.
-    (One pinned scalar per device, reused: `value()` of step N is read before step N + 1 records its own.)"""
-    _pinned = {}
+    (The pinned scalar comes from torch's caching host allocator: a few microseconds after the first call.)"""
 
     def __init__(self, loss):
-        self.loss, self.event = loss.detach(), None
+        self.loss, self.event, self.buf = loss.detach(), None, None
         if self.loss.is_cuda:
-            dev = self.loss.device
-            buf = self._pinned.get(dev)
-            if buf is None:
-                buf = self._pinned[dev] = torch.empty((), dtype=torch.float32, pin_memory=True)
-            self.buf = buf
-            with torch.cuda.device(dev):
-                buf.copy_(self.loss.float(), non_blocking=True)
+            with torch.cuda.device(self.loss.device):
+                self.buf = torch.empty((), dtype=torch.float32, pin_memory=True)
+                self.buf.copy_(self.loss.float(), non_blocking=True)
                 self.event = torch.cuda.Event()
                 self.event.record()
 
