@@ -553,3 +553,16 @@ def test_sharded_loss_with_the_real_collision_term_sums_to_the_single_process_gr
     rel, out = model(scene[:9].clone(), goals, split, scene[9:20].clone())
     l0 = float(batch_loss(crit0, rel, out, scene, scene[9:21] - scene[8:20], split, 12, 6))
     assert abs(full_loss - l0) > 0.05 * abs(l0) + 1.0, (full_loss, l0)
+
+
+def test_loss_read_back_is_the_value_at_record_time():
+    """train_step._LossReadBack: the value travels to the host when it is recorded -- later in-place changes of the tensor
+    (or any amount of work queued behind it) do not change what value() returns"""
+    from trajnetplusplusbaselines_amd.lstm.train_step import _LossReadBack
+    t = torch.full((), 3.25, device='cuda')
+    rb = _LossReadBack(t)
+    big = torch.randn(4096, 4096, device='cuda')
+    for _ in range(4):
+        big = big @ big.t() * 1e-4
+    t.add_(1.0)
+    assert rb.value() == 3.25 and float(t) == 4.25

@@ -41,3 +41,12 @@ def test_native_adam_has_torch_adams_interface():
     p[0].grad = torch.zeros(3, 2)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         ours.step()
+
+
+def test_loss_read_back_on_host_tensors():
+    """train_step._LossReadBack: a host tensor is read directly (the pinned-buffer + event path needs a device)"""
+    import torch
+    from trajnetplusplusbaselines_amd.lstm.train_step import _LossReadBack
+    loss = (torch.tensor([1.5, 2.0], requires_grad=True) * 2).sum()
+    rb = _LossReadBack(loss)
+    assert rb.event is None and rb.value() == 7.0
