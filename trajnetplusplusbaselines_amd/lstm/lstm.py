@@ -355,6 +355,14 @@ class LSTM(torch.nn.Module):
             if self.pool is not None and not trainable_pool:
                 raise NotImplementedError('training (backward) through %s is not available on the MI355X path yet; '
                                           'use model.eval() / torch.no_grad() for inference' % type(self.pool).__name__)
+            if torch.compiler.is_compiling() and (pad_to is None or isinstance(pad_to, int)) \
+                    and getattr(self, '_grad_reduce_fn', None) is None:
+                # under torch.compile the training sequence is ONE dispatcher op with its backward behind a handle
+                # (ops.py: trajnet::lstm_sequence_train / lstm_sequence_backward) -- no graph break
+                rel_pred, pred, _, _ = torch.ops.trajnet.lstm_sequence_train(
+                    observed, goals, torch.as_tensor(batch_split), prediction_truth, T_dec, int(pad_to or 0), self._op_handle,
+                    list(self.parameters()))
+                return rel_pred, pred
             from .training import run_sequence_with_grad
             opts = {'pad_to': pad_to, 'reduce_fn': getattr(self, '_grad_reduce_fn', None)}
             rel_pred, pred, _ = run_sequence_with_grad(self, observed, goals, batch_split, prediction_truth, T_dec, opts)

@@ -3,10 +3,12 @@ returning torch.Tensor on the current HIP stream, no host sync, errors surfaced 
 
 The ops live in the ``trajnet`` namespace (``torch.ops.trajnet.linear`` ...).  Each has a fake (meta) implementation, so
 ``torch.compile`` / ``FakeTensorMode`` can trace through them, and ``trajnet::linear`` carries its autograd formula.  The
-recurrent sequence itself is ``trajnet::lstm_sequence`` for inference (``LSTM.forward`` routes through it while
-``torch.compile`` traces, so an eval-mode model compiles without a graph break); the TRAINING sequence keeps its
-``torch.autograd.Function`` (lstm/training.py) because its saved state is a set of per-step buffers owned by the module,
-not tensors an op schema can describe -- ``torch.compile`` graph-breaks there.  The implementations are the same ctypes calls the
+recurrent sequence itself is ``trajnet::lstm_sequence`` for inference and ``trajnet::lstm_sequence_train`` +
+``trajnet::lstm_sequence_backward`` for training (``LSTM.forward`` routes through them while ``torch.compile`` traces, so a
+model compiles without a graph break in either mode).  The training pair wraps the same forward / backward code as the
+eager ``torch.autograd.Function`` (lstm/training.py); what that Function keeps on its ctx -- per-step buffers, index
+objects, not tensors an op schema can describe -- stays in this module behind an integer handle that travels through the
+graph as a tensor.  The implementations are the same ctypes calls the
 module classes make -- the ops add dispatcher visibility, not another code path -- and there is no CPU kernel: a host
 tensor raises, as everywhere in this package.
 
@@ -17,7 +19,11 @@ tensor raises, as everywhere in this package.
     constant_velocity(last, prev, n_predict)                                            -> fp64 [n_predict, N, 2]
     sf_rollout(state, scene_start, n_max, n_predict, v0, sigma, tau)                    -> fp64 [n_predict, M, 2]
     lstm_sequence(observed, goals?, batch_split, truth?, t_dec, pad_to, model, params)  -> (fp32 [S, M, 5], fp32 [S', M, 2])
+    lstm_sequence_train(same arguments)             -> (fp32 [S, M, 5], fp32 [S', M, 2], fp32 [M, H], int64 handle)   (+ autograd)
+    lstm_sequence_backward(handle, d_rel, d_pred, d_hlast, params)                      -> list of parameter gradients
 """
+import collections
+import itertools
 import weakref
 from typing import List, Optional, Tuple
 
@@ -229,3 +235,88 @@ def _(observed, goals, batch_split, truth, t_dec, pad_to, model, params):
     dev = params[0].device if len(params) else observed.device
     return (torch.empty((S, M, 5), dtype=torch.float32, device=dev),
             torch.empty((S + (1 if t_obs == 2 else 0), M, 2), dtype=torch.float32, device=dev))
+
+
+# ---- the training sequence: forward with saves + backward sweep behind an opaque handle ---------------------------------
+class _SavedSequence(object):
+    """what torch.autograd.Function's ctx is to lstm/training.py's SequenceFn: attribute bag + save_for_backward"""
+    saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+_SAVED = collections.OrderedDict()     # handle -> _SavedSequence; bounded: a forward whose backward never runs must not leak
+_SAVED_MAX = 16
+_next_handle = itertools.count(1)
+
+
+@torch.library.custom_op('trajnet::lstm_sequence_train', mutates_args=())
+def lstm_sequence_train(observed: torch.Tensor, goals: Optional[torch.Tensor], batch_split: torch.Tensor,
+                        truth: Optional[torch.Tensor], t_dec: int, pad_to: int, model: int,
+                        params: List[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """LSTM.forward in training mode (teacher forcing / free running, reference lstm/lstm.py:170-264) with everything its
+    backward sweep needs kept behind ``handle`` (an int64 scalar on the host): (rel_pred, pred, h_last, handle).  Same code
+    as the eager autograd.Function (lstm/training.py SequenceFn.forward).  Differences of this path: gradients with respect
+    to the observed positions are not formed, and parameters the forward never touches get ZERO gradients (the eager
+    Function returns None for them, so that optimisers skip them)."""
+    m = _MODELS.get(model)
+    if m is None:
+        raise RuntimeError('trajnet::lstm_sequence_train: unknown model handle (the module was garbage collected)')
+    from .lstm.training import SequenceFn
+    ctx = _SavedSequence()
+    opts = {'pad_to': int(pad_to) if pad_to > 0 else None}
+    with torch.no_grad():
+        rel, pred, h_last = SequenceFn.forward(ctx, m, observed, goals, batch_split, truth, int(t_dec), opts,
+                                               *[p.detach() for p in params])
+    h = next(_next_handle)
+    _SAVED[h] = ctx
+    while len(_SAVED) > _SAVED_MAX:
+        _SAVED.popitem(last=False)
+    return rel, pred, h_last, torch.tensor(h, dtype=torch.int64)
+
+
+@lstm_sequence_train.register_fake
+def _(observed, goals, batch_split, truth, t_dec, pad_to, model, params):
+    t_obs, M = observed.shape[0], observed.shape[1]
+    S = t_obs - 1 + t_dec
+    dev = params[0].device if len(params) else observed.device
+    m = _MODELS.get(model)
+    H = m.hidden_dim if m is not None else 128
+    return (torch.empty((S, M, 5), dtype=torch.float32, device=dev),
+            torch.empty((S + (1 if t_obs == 2 else 0), M, 2), dtype=torch.float32, device=dev),
+            torch.empty((M, H), dtype=torch.float32, device=dev), torch.empty((), dtype=torch.int64))
+
+
+@torch.library.custom_op('trajnet::lstm_sequence_backward', mutates_args=())
+def lstm_sequence_backward(handle: torch.Tensor, d_rel: torch.Tensor, d_pred: torch.Tensor, d_hlast: torch.Tensor,
+                           params: List[torch.Tensor]) -> List[torch.Tensor]:
+    """the backward sweep of the sequence ``handle`` names (lstm/training.py SequenceFn.backward): one gradient per entry of
+    ``params`` (zeros where the forward did not use the parameter).  A handle serves one backward."""
+    ctx = _SAVED.pop(int(handle), None)
+    if ctx is None:
+        raise RuntimeError('trajnet::lstm_sequence_backward: the saved state of this forward pass is gone (its backward has '
+                           'already run, or more than %d forward passes were started since)' % _SAVED_MAX)
+    from .lstm.training import SequenceFn
+    out = SequenceFn.backward(ctx, d_rel, d_pred, d_hlast)
+    grads = out[len(out) - len(params):]
+    return [g if g is not None else torch.zeros_like(p) for g, p in zip(grads, params)]
+
+
+@lstm_sequence_backward.register_fake
+def _(handle, d_rel, d_pred, d_hlast, params):
+    return [torch.empty_like(p) for p in params]
+
+
+def _train_setup_context(ctx, inputs, output):
+    ctx.handle = output[3]
+    ctx.params = inputs[7]
+    ctx.n_inputs = len(inputs)
+
+
+def _train_backward(ctx, d_rel, d_pred, d_hlast, d_handle):
+    grads = torch.ops.trajnet.lstm_sequence_backward(ctx.handle, d_rel, d_pred, d_hlast, ctx.params)
+    return (None,) * (ctx.n_inputs - 1) + (grads,)
+
+
+torch.library.register_autograd('trajnet::lstm_sequence_train', _train_backward, setup_context=_train_setup_context)
