@@ -196,7 +196,11 @@ __global__ void __launch_bounds__(256) pool_hiddenmlp_gather_kernel(const int32_
 
 // dW[k, c] = sum_rows G[row, k] * R[row, k, c] (c = 0, 1), db[k] = sum_rows G[row, k]: gradients of a Linear(2 -> cols)
 // whose input differs per output unit (the max-pool's winner).  Two deterministic stages: row chunks, then chunks.
-constexpr int CS_ROWS = 2048;
+// Row chunks of 256: at config 2 (38 912 rows, 64 columns) chunks of 2048 rows were 19 workgroups, each lane a chain of 512
+// dependent round trips, and the second stage one more chain over the chunks -- 216 us for 30 MB.  Now 152 workgroups per column
+// block with eight rows in flight per lane, and a second stage that gives every output 64 lanes (chunks strided over the
+// lanes, fixed-order shuffle tree): deterministic as before.
+constexpr int CS_ROWS = 256;
 __global__ void __launch_bounds__(256) colsum_prod_kernel(const float *__restrict__ G, const float *__restrict__ R, long rows, int cols,
                                                           float *__restrict__ part) {
     __shared__ float red[4][64][3];
@@ -204,17 +208,25 @@ __global__ void __launch_bounds__(256) colsum_prod_kernel(const float *__restric
     const long r0 = (long)blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
     float a0 = 0.0f, a1 = 0.0f, ab = 0.0f;
     if (c < cols) {
-        if (G) {
-            for (long r = r0 + sub; r < r1; r += 4) {
-                const float g = G[r * cols + c];
-                a0 = fmaf(g, R[(r * cols + c) * 2], a0);
-                a1 = fmaf(g, R[(r * cols + c) * 2 + 1], a1);
-                ab += g;
+        constexpr int U = 8;
+        for (long rb = r0 + sub; rb < r1; rb += 4 * U) {
+            float g[U], x0[U], x1[U], x2[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long r = rb + 4 * u, rc = r < r1 ? r : r1 - 1;      // past the chunk: its last row, weighted 0 below
+                if (G) {
+                    g[u] = G[rc * cols + c];
+                    x0[u] = R[(rc * cols + c) * 2]; x1[u] = R[(rc * cols + c) * 2 + 1]; x2[u] = 0.0f;
+                } else {   // R = [rows, cols, 3]: per-row sums already formed (attention: every slot contributes)
+                    const float *p = R + (rc * cols + c) * 3;
+                    g[u] = 1.0f; x0[u] = p[0]; x1[u] = p[1]; x2[u] = p[2];
+                }
             }
-        } else {   // R = [rows, cols, 3]: per-row sums already formed (attention: every slot contributes)
-            for (long r = r0 + sub; r < r1; r += 4) {
-                const float *p = R + (r * cols + c) * 3;
-                a0 += p[0]; a1 += p[1]; ab += p[2];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (rb + 4 * u >= r1) continue;
+                if (G) { a0 = fmaf(g[u], x0[u], a0); a1 = fmaf(g[u], x1[u], a1); ab += g[u]; }
+                else { a0 += x0[u]; a1 += x1[u]; ab += x2[u]; }
             }
         }
     }
@@ -226,14 +238,19 @@ __global__ void __launch_bounds__(256) colsum_prod_kernel(const float *__restric
             part[((size_t)blockIdx.y * cols + c) * 3 + q] = (red[0][l][q] + red[1][l][q]) + (red[2][l][q] + red[3][l][q]);
     }
 }
+// one wave per output element: lane l adds chunks l, l + 64, ... in ascending order, then a fixed shuffle tree
 __global__ void __launch_bounds__(256) colsum_reduce_kernel(const float *__restrict__ part, int nchunks, int cols, float *__restrict__ dW,
                                                             float *__restrict__ db) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (e >= cols * 3) return;
     float acc = 0.0f;
-    for (int ch = 0; ch < nchunks; ++ch) acc += part[(size_t)ch * cols * 3 + e];
-    const int c = e / 3, q = e - c * 3;
-    if (q < 2) dW[c * 2 + q] = acc; else db[c] = acc;
+    for (int ch = lane; ch < nchunks; ch += 64) acc += part[(size_t)ch * cols * 3 + e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+        const int c = e / 3, q = e - c * 3;
+        if (q < 2) dW[c * 2 + q] = acc; else db[c] = acc;
+    }
 }
 
 int launch_pool_nn(const float *obs1, const float *obs2, const int32_t *scene_start, int B, int n_sel, int in_dim,
@@ -755,7 +772,7 @@ extern "C" TNP_API int tnp_colsum_prod(const float *G, const float *R, long rows
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(tnp::colsum_prod_kernel, dim3((cols + 63) / 64, nchunks), dim3(256), 0, s, G, R, rows, cols, (float *)workspace);
     TNP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(tnp::colsum_reduce_kernel, dim3((cols * 3 + 255) / 256), dim3(256), 0, s, (const float *)workspace, nchunks, cols,
+    hipLaunchKernelGGL(tnp::colsum_reduce_kernel, dim3((cols * 3 + 3) / 4), dim3(256), 0, s, (const float *)workspace, nchunks, cols,
                        dW, db);
     TNP_HIP(hipGetLastError());
     return 0;
