@@ -332,10 +332,24 @@ __global__ void __launch_bounds__(64) pool_attn_pair_kernel(const float *__restr
                                                             const float *__restrict__ bv, float fill,
                                                             const float *__restrict__ u, int ldu,
                                                             float *__restrict__ ebar, int lde) {
-    extern __shared__ float att_sc[];                      // [n_scene] scores of the current ego
+    extern __shared__ float att_sc[];                      // [n_max] scores of the current ego | [ns][4] x, y, vx, vy | [ns][mh]
     const int lo = scene_start[blockIdx.x], hi = scene_start[blockIdx.x + 1];
     const int D = ms + mh + mv, lane = threadIdx.x;
     const float scale = 1.0f / sqrtf((float)D);
+    // the scene's tracks once into LDS: the two passes over the neighbours below were a chain of 2 x ns global round trips
+    // per ego (87 us per step at config 2, one wave per SIMD)
+    float *s_xy = att_sc + ((n_max + 3) & ~3), *s_h = s_xy + 4 * (hi - lo);        // (16-byte aligned: float4 reads)
+    for (int j = lane; j < hi - lo; j += 64) {
+        const float x = obs2[2 * (lo + j)], y = obs2[2 * (lo + j) + 1];
+        s_xy[4 * j] = x; s_xy[4 * j + 1] = y; s_xy[4 * j + 2] = x - obs1[2 * (lo + j)]; s_xy[4 * j + 3] = y - obs1[2 * (lo + j) + 1];
+    }
+    for (int q = lane; q < (hi - lo) * mh; q += 64) {
+        const int j = q / mh, k = q - j * mh;
+        float h = henc[(size_t)(lo + j) * ldh + k];
+        if (henc_relu) h = h > 0.0f ? h : 0.0f;
+        s_h[q] = h;
+    }
+    __syncthreads();
     const int npad = (scene_slots ? scene_slots[blockIdx.x] : n_max) - (hi - lo);   // virtual padded slots: [fill.., 0.., fill..]
     float w0[ATT_MAXD_PER_LANE], w1[ATT_MAXD_PER_LANE], b0[ATT_MAXD_PER_LANE];
 #pragma unroll
@@ -353,13 +367,13 @@ __global__ void __launch_bounds__(64) pool_attn_pair_kernel(const float *__restr
         for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) { const int k = lane + 64 * t; ui[t] = k < D ? u[(size_t)i * ldu + k] : 0.0f; }
         const float ci = u[(size_t)i * ldu + D];
         auto embed = [&](int j, float (&e)[ATT_MAXD_PER_LANE]) {
-            const float xj = obs2[2 * j], yj = obs2[2 * j + 1];
-            const float vxj = xj - obs1[2 * j], vyj = yj - obs1[2 * j + 1];
+            const float4 pj = *reinterpret_cast<const float4 *>(s_xy + 4 * (j - lo));
+            const float xj = pj.x, yj = pj.y, vxj = pj.z, vyj = pj.w;
 #pragma unroll
             for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) {
                 const int k = lane + 64 * t;
                 float h = 0.0f;
-                if (k >= ms && k < ms + mh) { h = henc[(size_t)j * ldh + (k - ms)]; if (henc_relu) h = h > 0.0f ? h : 0.0f; }
+                if (k >= ms && k < ms + mh) h = s_h[(j - lo) * mh + (k - ms)];
                 e[t] = k < D ? attn_embed(k, ms, mh, fill, xi, yi, vxi, vyi, xj, yj, vxj, vyj, h, w0[t], w1[t], b0[t]) : 0.0f;
             }
         };
@@ -442,10 +456,22 @@ __global__ void __launch_bounds__(64) pool_attn_pair_backward_kernel(const float
                                                                      const float *__restrict__ debar, int ldd,
                                                                      float *__restrict__ du, float *__restrict__ A3,
                                                                      float *__restrict__ dEh, float *__restrict__ ebar, int lde) {
-    extern __shared__ float att_sc[];                      // [2][n_scene]: softmax weights, then da
+    extern __shared__ float att_sc[];                      // [2][n_max]: softmax weights, then da | [ns][4] x, y, vx, vy | [ns][mh]
     const int lo = scene_start[blockIdx.x], hi = scene_start[blockIdx.x + 1], ns = hi - lo;
     float *att_a = att_sc, *att_da = att_sc + n_max;
     const int D = ms + mh + mv, GD = ms + mv, lane = threadIdx.x;
+    // the scene's tracks once into LDS (see pool_attn_pair_kernel)
+    float *s_xy = att_sc + ((2 * n_max + 3) & ~3), *s_h = s_xy + 4 * ns;
+    for (int j = lane; j < ns; j += 64) {
+        const float x = obs2[2 * (lo + j)], y = obs2[2 * (lo + j) + 1];
+        s_xy[4 * j] = x; s_xy[4 * j + 1] = y; s_xy[4 * j + 2] = x - obs1[2 * (lo + j)]; s_xy[4 * j + 3] = y - obs1[2 * (lo + j) + 1];
+    }
+    for (int q = lane; q < ns * mh; q += 64) {
+        const int j = q / mh, k = q - j * mh;
+        const float h = henc[(size_t)(lo + j) * ldh + k];
+        s_h[q] = h > 0.0f ? h : 0.0f;
+    }
+    __syncthreads();
     const float scale = 1.0f / sqrtf((float)D);
     const int npad = (scene_slots ? scene_slots[blockIdx.x] : n_max) - ns;
     float w0[ATT_MAXD_PER_LANE], w1[ATT_MAXD_PER_LANE], b0[ATT_MAXD_PER_LANE];
@@ -475,14 +501,14 @@ __global__ void __launch_bounds__(64) pool_attn_pair_backward_kernel(const float
         const float ci = u[(size_t)i * ldu + D];
         // embedding of slot j and, for the spatial / velocity units, the inputs and whether the unit passes a gradient
         auto embed = [&](int j, float (&e)[ATT_MAXD_PER_LANE], float (&rx)[ATT_MAXD_PER_LANE], float (&ry)[ATT_MAXD_PER_LANE]) {
-            const float xj = obs2[2 * j], yj = obs2[2 * j + 1];
-            const float vxj = xj - obs1[2 * j], vyj = yj - obs1[2 * j + 1];
+            const float4 pj = *reinterpret_cast<const float4 *>(s_xy + 4 * (j - lo));
+            const float xj = pj.x, yj = pj.y, vxj = pj.z, vyj = pj.w;
 #pragma unroll
             for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) {
                 const int k = lane + 64 * t;
                 float h = 0.0f;
                 rx[t] = 0.0f; ry[t] = 0.0f;
-                if (k >= ms && k < ms + mh) { h = henc[(size_t)j * ldh + (k - ms)]; h = h > 0.0f ? h : 0.0f; }
+                if (k >= ms && k < ms + mh) h = s_h[(j - lo) * mh + (k - ms)];
                 else if (k < ms) { rx[t] = xj - xi; ry[t] = yj - yi; }
                 else if (k < D) { rx[t] = (vxj - vxi) * 4.0f; ry[t] = (vyj - vyi) * 4.0f; }
                 e[t] = k < D ? attn_embed(k, ms, mh, fill, xi, yi, vxi, vyi, xj, yj, vxj, vyj, h, w0[t], w1[t], b0[t]) : 0.0f;
@@ -627,8 +653,9 @@ int launch_pool_attn_pair(const float *obs1, const float *obs2, const float *hen
     if (B <= 0) return 0;
     const int D = ms + mh + mv;
     if (D > 64 * ATT_MAXD_PER_LANE) TNP_FAIL(-1, "AttentionMLPPooling: mlp_dim %d > %d", D, 64 * ATT_MAXD_PER_LANE);
-    if (n_max < 1 || (size_t)n_max * 4 > 60000) TNP_FAIL(-1, "AttentionMLPPooling: n_max %d out of range", n_max);
-    hipLaunchKernelGGL(pool_attn_pair_kernel, dim3(B, 16), dim3(64), (size_t)n_max * sizeof(float), s, obs1, obs2, henc, ldh,
+    const size_t lds = ((size_t)((n_max + 3) & ~3) + (size_t)n_max * (4 + (mh > 0 ? mh : 0))) * sizeof(float);   // scores + the scene's tracks (n_scene <= n_max)
+    if (n_max < 1 || lds > 60000) TNP_FAIL(-1, "AttentionMLPPooling: n_max %d (x mlp_dim_hidden %d) out of range", n_max, mh);
+    hipLaunchKernelGGL(pool_attn_pair_kernel, dim3(B, 16), dim3(64), lds, s, obs1, obs2, henc, ldh,
                        henc_relu, scene_start, n_max, scene_slots, ms, mv, mh, Ws, bs, Wv, bv, fill, u, ldu, ebar, lde);
     TNP_HIP(hipGetLastError());
     return 0;
@@ -787,9 +814,10 @@ extern "C" TNP_API int tnp_pool_attn_pair_backward(const float *obs1, const floa
     if (B <= 0) return 0;
     const int D = ms + mh + mv;
     if (D > 64 * tnp::ATT_MAXD_PER_LANE) TNP_FAIL(-1, "AttentionMLPPooling: mlp_dim %d > %d", D, 64 * tnp::ATT_MAXD_PER_LANE);
-    if (n_max < 1 || (size_t)n_max * 8 > 60000) TNP_FAIL(-1, "AttentionMLPPooling: n_max %d out of range", n_max);
+    const size_t lds = ((size_t)((2 * n_max + 3) & ~3) + (size_t)n_max * (4 + (mh > 0 ? mh : 0))) * sizeof(float);
+    if (n_max < 1 || lds > 60000) TNP_FAIL(-1, "AttentionMLPPooling: n_max %d (x mlp_dim_hidden %d) out of range", n_max, mh);
     if (ldu < D + 1) TNP_FAIL(-1, "tnp_pool_attn_pair_backward: ldu %d < mlp_dim + 1", ldu);
-    hipLaunchKernelGGL(tnp::pool_attn_pair_backward_kernel, dim3(B, 16), dim3(64), (size_t)n_max * 2 * sizeof(float),
+    hipLaunchKernelGGL(tnp::pool_attn_pair_backward_kernel, dim3(B, 16), dim3(64), lds,
                        (hipStream_t)stream, obs1, obs2, hidden_emb_pre, ldh, scene_start, n_max, scene_slots, ms, mv, mh, W_spatial, b_spatial,
                        W_vel, b_vel, fill, u, ldu, d_ebar, ldd, du, A3, dEh, ebar, lde);
     TNP_HIP(hipGetLastError());
