@@ -459,7 +459,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
     const int H = md->H;
     if (md->pool_type == TNP_POOL_NN) {          // NearestNeighborMLP straight into the pooled columns of X
         int rc = launch_pool_nn(w.obs1, w.obs2, scene_start, B, md->n, md->C, md->Wp[0], md->bp[0], md->P / md->n,
-                                w.pdst, w.pld, s, w.nn_attrs_save);
+                                w.pdst, w.pld, s, w.nn_attrs_save, n_max);
         if (rc) return rc;
     } else if (md->pool_type == TNP_POOL_HIDDENMLP) {   // pair embeddings + max-pool, then the projection GEMM
         const int ms = md->dims[0], mv = md->dims[1], mh = md->dims[2];
@@ -481,7 +481,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
         int rc;
         if (md->pool_type == TNP_POOL_NNLSTM)
             rc = launch_pool_nn(w.obs1, w.obs2, scene_start, B, md->n, 4, md->Wp[0], md->bp[0], md->P / md->n, w.y[0], md->P, s,
-                                w.nn_attrs_save);
+                                w.nn_attrs_save, n_max);
         else
             rc = launch_pool_traj(w.obs1, w.obs2, M, md->Wp[0], md->bp[0], md->P, w.y[0], md->P, w.scratch, s, w.traj_in_save);
         if (rc) return rc;

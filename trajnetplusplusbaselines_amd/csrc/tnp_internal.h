@@ -83,7 +83,8 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
 
 // ---- non-grid interaction modules (pool_nongrid.hip) -----------------------------------------
 int launch_pool_nn(const float *obs1, const float *obs2, const int32_t *scene_start, int B, int n_sel, int in_dim,
-                   const float *W, const float *bias, int d, float *out, int ldo, hipStream_t s, float *attrs = nullptr);
+                   const float *W, const float *bias, int d, float *out, int ldo, hipStream_t s, float *attrs = nullptr,
+                   int n_max_hint = 0);   // largest scene if the caller knows it (0: unknown -> the lane-per-ego kernel)
 int launch_pool_hiddenmlp(const float *obs1, const float *obs2, const float *henc, int ldh, int henc_relu,
                           const int32_t *scene_start, int B, int ms, int mv, int mh, const float *Ws, const float *bs,
                           const float *Wv, const float *bv, float *pooled, int ldp, hipStream_t s);
