@@ -798,6 +798,15 @@ ORC_API void orc_constant_velocity(const double *xy, int T, int N, int n_predict
 
 ORC_API int orc_abi_version(void) { return 1; }
 
+/* OpenMP thread count of the following calls (bench.py's cpu_baseline times the port at several counts and reports
+ * the best one with the count it was measured at); returns the previous maximum.  No-op without OpenMP. */
+#ifdef _OPENMP
+#include <omp.h>
+ORC_API int orc_set_threads(int n) { int prev = omp_get_max_threads(); if (n > 0) omp_set_num_threads(n); return prev; }
+#else
+ORC_API int orc_set_threads(int n) { (void)n; return 1; }
+#endif
+
 /* ------------------------------------------------------------------------- *
  * Losses, lstm/loss.py.  inputs [T,M,5], targets [T,M,2]; primaries = rows split[s].
  * ------------------------------------------------------------------------- */

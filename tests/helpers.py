@@ -126,3 +126,46 @@ def primary_loss_autograd(mode, inputs, targets, batch_split, background_rate, k
         return (values.mean(dim=0) if keep_batch_dim else values.mean()) * scale
     sq = ((inp[:, :2] - tgt) ** 2).reshape(T, B, 2)
     return (sq.mean(dim=0).mean(dim=1) if keep_batch_dim else sq.mean()) * (scale * 2.0)
+
+
+# ---- sketches of large gradient tensors (tests/golden/train_full.npz, config4_train_full.npz; oracle/gen_golden_r4.py) ----
+SKETCH_FULL_BELOW = 70_000
+
+
+def sketch(a, samples=16384):
+    """A [rows, cols] tensor too large to store in a fixture, reduced to: row sums, column sums, two seeded Gaussian
+    projections (a @ R[cols, 8] and L[8, rows] @ a, fp64) and `samples` entries at seeded positions.  Every element enters
+    the projections with a non-zero weight, so a wrong element anywhere moves them."""
+    a = np.asarray(a, dtype=np.float64)
+    a = a.reshape(a.shape[0], -1)
+    rows, cols = a.shape
+    rng = np.random.RandomState(rows * 7919 + cols)
+    R = rng.standard_normal((cols, 8))
+    L = rng.standard_normal((8, rows))
+    idx = rng.randint(0, rows * cols, size=min(samples, rows * cols))
+    return {'rowsum': a.sum(1), 'colsum': a.sum(0), 'projR': a @ R, 'projL': L @ a, 'absmax': np.float64(np.abs(a).max()),
+            'samples': a.reshape(-1)[idx].astype(np.float32)}
+
+
+def assert_matches_stored(z, key, got, rtol, what=''):
+    """Compare a tensor with what oracle/gen_golden_r4.py:store_tensor kept under `key` (the full copy, or its sketch);
+    errors are relative to the stored tensor's largest magnitude (sketch parts: to the part's own largest magnitude).
+    Returns the worst relative error."""
+    got = np.asarray(got, dtype=np.float64)
+    if key in z.files:
+        want = z[key].astype(np.float64)
+        scale = max(1e-12, float(np.abs(want).max()))
+        err = float(np.abs(got.reshape(want.shape) - want).max()) / scale
+        assert err < rtol, '%s %s: relative error %.2e (scale %.2e)' % (what, key, err, scale)
+        return err
+    mine = sketch(got)
+    worst = 0.0
+    for part in ('rowsum', 'colsum', 'projR', 'projL', 'samples'):
+        want = z[key + '@' + part].astype(np.float64)
+        # sums of many entries: scale by the tensor's magnitude times sqrt(terms) so that cancellation does not inflate it
+        terms = got.size / max(1, want.size) if part != 'samples' else 1
+        scale = max(1e-12, float(z[key + '@absmax']) * np.sqrt(terms), float(np.abs(want).max()))
+        err = float(np.abs(mine[part].astype(np.float64) - want).max()) / scale
+        worst = max(worst, err)
+        assert err < rtol, '%s %s@%s: relative error %.2e (scale %.2e)' % (what, key, part, err, scale)
+    return worst

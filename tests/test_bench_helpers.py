@@ -23,3 +23,14 @@ def test_occupied_cells_counter_matches_oracle_grids():
             g = oracle.grid('occupancy', pos[None, lo:hi].astype(np.float32), pos[None, lo:hi].astype(np.float32), n=n, cell_side=cs)
             want += int((np.asarray(g) != 0).sum())
         assert cnt == want
+
+
+def test_training_pin_constants_match_the_reference_fixture():
+    """bench.py's training leg fails unless its first optimisation step reproduces the reference's loss on the same batch
+    and weights: the constants it compares with are the fixture's (tests/golden/train_full.npz, oracle/gen_golden_r4.py)."""
+    import os
+    from tests import helpers
+    z = np.load(os.path.join(helpers.GOLDEN, 'train_full.npz'))
+    assert bench.TRAIN_PIN_SEED == int(z['seed']) and int(z['synth_seed']) == 100
+    assert abs(bench.TRAIN_PIN_LOSS - float(z['synth_loss'])) < 1e-5
+    assert abs(float(z['curve_losses'][0]) - float(z['synth_loss'])) < 1e-9

@@ -222,3 +222,36 @@ def test_independent_orca_restatements_agree():
     assert np.array_equal(nb, wnb)
     assert np.isfinite(got).all() and got.shape == want.shape
     assert np.abs(got - want).max() < 2e-4
+
+
+@pytest.mark.gpu
+def test_gpu_rollouts_against_the_independent_numpy_restatement_at_config5_density():
+    """The GPU output against oracle/classical_numpy.py -- the restatement that does NOT include csrc/classical_core.h -- at
+    BASELINE config 5's density (scenes of 128 agents on 8 m x 8 m, as bench.py --config classical draws them): an independent
+    check of the kernels' arithmetic, not of the shared header.  Social force: float64, 1e-8; Kalman (EM + smoother, float64): 1e-7.  ORCA: float32 on both
+    sides with a few operations ordered differently, so the first step's neighbour sets must be identical and positions
+    agree to accumulated float32 rounding; a neighbour at exactly neighborDist can flip and move an agent by ~1e-2 -- such
+    agents are counted (at most 2 % of them), not hidden."""
+    from oracle import classical_numpy as cn
+    from trajnetplusplusbaselines_amd.classical import socialforce, orca, kalman
+    scenes, agents = 2, 128
+    pos, vel, goals, speed, sizes = crowd(scenes, agents, 11)
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    st = np.concatenate([pos, vel, goals], axis=1)
+    got = socialforce.rollout_batch(st, sizes)
+    want = cn.sf_rollout(st, starts)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-8)
+    got, nbr = orca.rollout_batch(pos, vel, speed, goals, sizes, want_neighbors=True)
+    want, wnbr = cn.orca_rollout(pos, vel, goals, speed, 1.3 * speed, starts, want_neighbors=True)
+    assert np.array_equal(nbr, wnbr)                       # integer neighbour indices of the first step: identical
+    err = np.abs(got.astype(np.float64) - want).max(axis=(0, 2))
+    flipped = int((err > 5e-4).sum())
+    assert flipped <= max(1, len(err) // 50) and np.isfinite(got).all(), (flipped, float(err.max()))
+    print('ORCA vs numpy at 128 agents per scene: max |d| %.2e, agents beyond 5e-4: %d of %d' % (err.max(), flipped, len(err)))
+    rng = np.random.RandomState(13)
+    n = 256
+    t = np.arange(9)[None, :, None]
+    obs = rng.randn(n, 1, 2) + rng.randn(n, 1, 2) * 0.4 * t + rng.randn(n, 9, 2) * 0.03
+    z = rng.standard_normal((n, 5, 13, 6))
+    np.testing.assert_allclose(kalman.predict_batch(obs, 12, noise=z), cn.kalman_predict(obs, z)[:, 1:], rtol=0, atol=1e-7)

@@ -116,7 +116,7 @@ def test_training_curve_matches_reference():
     print('losses', losses, 'ref', z['losses'].tolist(), 'dADE %.2e dFDE %.2e' % (np.abs(a0 - a1).max(), np.abs(f0 - f1).max()))
 
 
-@pytest.mark.parametrize('latent_dim,n,layer', [(16, 12, 192), (4, 8, 64), (8, 16, 128), (32, 6, 256)])
+@pytest.mark.parametrize('latent_dim,n,layer', [(16, 12, 192), (4, 8, 64), (8, 16, 128), (32, 6, 256), (16, 16, 1024)])
 def test_sparse_first_layer_backward_equals_dense_backward(latent_dim, n, layer):
     """The social first-layer gradients computed from the winner tables (tnp_social_dgrid_cells, tnp_sparse_wgrad)
     equal the dense GEMM backward on a crowd with duplicates, empty cells and ragged scenes, for every channel count
@@ -566,3 +566,88 @@ def test_loss_read_back_is_the_value_at_record_time():
         big = big @ big.t() * 1e-4
     t.add_(1.0)
     assert rb.value() == 3.25 and float(t) == 4.25
+
+
+# ---- the training path at BASELINE config 2's FULL size, against the reference's own autograd (train_full.npz) ----------------
+
+def _train_full():
+    return np.load(os.path.join(helpers.GOLDEN, 'train_full.npz'))
+
+
+def _full_size_model():
+    """helpers.real_model: the headline Social-LSTM (n=16, two_layer 1024, latent_dim 16) under the fixture's seed; the
+    per-tensor weight sums stored by the reference run are checked."""
+    model, _ = helpers.real_model('cuda')
+    z = _train_full()
+    for k, v in model.state_dict().items():
+        assert abs(v.double().sum().item() - float(z['wsum_' + k])) < 1e-9, 'seeded weight differs from the reference run: ' + k
+    return model.train(), z
+
+
+def _full_batch(z, tag):
+    if tag == 'synth':
+        from trajnetplusplusbaselines_amd import synth
+        return synth.linear_crowd(64, 32, seed=int(z['synth_seed']))
+    r = np.load(os.path.join(helpers.GOLDEN, 'real_cases.npz'))
+    return torch.tensor(r[tag + '_raw_xy'], dtype=torch.float32), torch.tensor(r[tag + '_split'])
+
+
+@pytest.mark.parametrize('tag', ['synth', 'hotel', 'students'])
+def test_full_size_gradients_match_reference_autograd(tag):
+    """Trainer.train_batch's loss (lstm/trainer.py:252-265) back-propagated through the HEADLINE model -- layer_dims=[1024],
+    C=16, n=16: the configuration whose backward runs dgrid_cells_xcd_kernel<8> (the N1 == 1024 specialisation),
+    sparse_wgrad_mfma_kernel<16> and the grouped weight-gradient launch at K = 19 x 2048 -- on the bench's 64 x 32 batch and
+    on the real scenes of real_cases.npz (ragged, up to 68 agents, NaN tracks), against the reference's autograd:
+    loss 2e-5, primaries' outputs 5e-5, every parameter gradient within 1e-4 of its largest magnitude (measured ~1e-6),
+    the 16.8 MB first-layer gradient through its sketch (row / column sums, seeded projections, 16 k sampled entries)."""
+    from trajnetplusplusbaselines_amd.lstm import PredictionLoss
+    model, z = _full_size_model()
+    xy, split = _full_batch(z, tag)
+    M = xy.shape[1]
+    observed, truth = xy[:9].clone(), xy[9:20].clone()
+    targets = (xy[9:21] - xy[8:20]).cuda()
+    rel, pred = model(observed, torch.zeros(M, 2), split, truth)
+    loss = PredictionLoss()(rel[-12:], targets, split) * (split.numel() - 1)
+    np.testing.assert_allclose(float(loss), float(z[tag + '_loss']), rtol=2e-5)
+    prim = split[:-1].cuda()
+    helpers.assert_close_nan(rel.detach()[:, prim].cpu().numpy(), z[tag + '_rel_prim'], 5e-5, 'rel (primaries)')
+    helpers.assert_close_nan(pred.detach()[:, prim].cpu().numpy(), z[tag + '_pred_prim'], 5e-5, 'pred (primaries)')
+    loss.backward()
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if (tag + '_nograd_' + name) in z.files:
+            assert p.grad is None, name + ': the reference leaves this gradient None'
+            continue
+        assert p.grad is not None, name
+        worst = max(worst, helpers.assert_matches_stored(z, tag + '_grad_' + name, p.grad.cpu().numpy(), 1e-4, tag))
+    print(tag, 'worst relative gradient error %.2e' % worst)
+
+
+def test_full_size_training_curve_matches_reference():
+    """Four optimisation steps of the headline model (train_step.train_batch == Trainer.train_batch; Adam lr 1e-3, weight_decay
+    1e-4 as lstm/trainer.py:497), alternating the 64 x 32 synthetic batch and the hotel scenes: the reference's loss trajectory
+    (149.6 -> 32.1 -> 118.6 -> 16.4) within 1e-4 relative, trained weights within half an Adam step."""
+    from trajnetplusplusbaselines_amd.lstm import PredictionLoss
+    from trajnetplusplusbaselines_amd.lstm.train_step import train_batch
+    for make_opt in (lambda ps: torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-4), None):
+        model, z = _full_size_model()
+        if make_opt is None:
+            from trajnetplusplusbaselines_amd import optim
+            opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)      # the one-launch update bench.py times
+        else:
+            opt = make_opt(model.parameters())
+        batches = [_full_batch(z, 'synth'), _full_batch(z, 'hotel')]
+        losses = []
+        for it in range(4):
+            xy, split = batches[it % 2]
+            losses.append(train_batch(model, opt, PredictionLoss(), xy, torch.zeros(xy.shape[1], 2), split, 9, 12))
+        np.testing.assert_allclose(losses, z['curve_losses'], rtol=1e-4)
+        for k, v in model.state_dict().items():
+            got = v.cpu().numpy()
+            if ('curve_final_' + k) in z.files:
+                assert np.abs(got - z['curve_final_' + k]).max() < 5e-4, k
+            else:       # sketched: sampled entries within half a step, sums within half a step times the number of terms' root
+                s = helpers.sketch(got)
+                assert np.abs(s['samples'] - z['curve_final_' + k + '@samples']).max() < 5e-4, k
+                assert np.abs(s['rowsum'] - z['curve_final_' + k + '@rowsum']).max() < 5e-4 * np.sqrt(got.size / got.shape[0]) * 4, k
+        print('losses', losses, 'reference', z['curve_losses'].tolist())

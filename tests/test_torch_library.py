@@ -123,7 +123,7 @@ def test_lstm_sequence_op_and_torch_compile_without_graph_break():
 @pytest.mark.gpu
 def test_training_sequence_ops_and_torch_compile_without_graph_break():
     """trajnet::lstm_sequence_train / lstm_sequence_backward: the same numbers as the eager autograd.Function (outputs bit
-    for bit, parameter gradients bit for bit where the Function returns one, zeros where it returns None), opcheck's schema /
+    for bit, parameter gradients bit for bit where the Function returns one, None where it returns None), opcheck's schema /
     fake-tensor / autograd-registration tests, and a TRAIN-mode model compiles with fullgraph=True through AOT autograd."""
     from trajnetplusplusbaselines_amd import ops as tops, synth
     from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling
@@ -166,7 +166,7 @@ def test_training_sequence_ops_and_torch_compile_without_graph_break():
     for n, p in model.named_parameters():
         want = g_eager[n]
         if want is None:
-            assert p.grad is None or not bool(p.grad.any()), n
+            assert p.grad is None, n + ': unused parameters keep grad = None under torch.compile as in eager mode'
         else:
             assert p.grad is not None and torch.equal(p.grad, want), n
     # a handle serves one backward

@@ -261,22 +261,30 @@ class SceneIndex(object):
                 self.slots = slots.to(torch.int32).to(device)
         self.starts = split.to(torch.int32).to(device)
         # first row / size of every row's scene (training backward): built on the host, one copy, no device-side sync later
-        self.row_base = torch.repeat_interleave(split[:-1], sizes).to(torch.int32).to(device)
-        self.row_count = torch.repeat_interleave(sizes, sizes).to(torch.int32).to(device)
+        # (the host copies stay: stacked_rows() builds the whole-sweep tables from them without reading the device back)
+        self._row_base_host = torch.repeat_interleave(split[:-1], sizes).to(torch.int32)
+        self._row_count_host = torch.repeat_interleave(sizes, sizes).to(torch.int32)
+        self.row_base = self._row_base_host.to(device)
+        self.row_count = self._row_count_host.to(device)
         self.primary = torch.empty(max(self.M, 1), dtype=torch.uint8, device=device)
         check(lib().tnp_mark_primaries(ptr(self.starts), self.B, self.M, ptr(self.primary), stream_ptr()),
               'tnp_mark_primaries')
 
     def stacked_rows(self, S):
         """(row_base, row_count) of S copies of the batch stacked along the rows (row r of step s is row s M + r): what the
-        backward sweep's whole-sweep pair-cell launch indexes with.  Built on the host once per (batch structure, S) -- five
-        small device kernels per optimisation step otherwise (arange, scale, add, copy, repeat)."""
+        backward sweep's whole-sweep pair-cell launch indexes with.  Built from the HOST copies of the tables once per
+        (batch structure, S): no device read-back (a real trainer has a new batch_split every step, and a D2H copy here
+        would drain the forward's queue in the middle of the backward pass), two small pinned H2D copies."""
         got = self.__dict__.setdefault('_stacked', {}).get(S)
         if got is None:
-            base = self.row_base.to('cpu', torch.int64)
-            off = (torch.arange(S, dtype=torch.int64) * self.M)[:, None]
-            rb = (off + base[None]).reshape(-1).to(torch.int32).to(self.row_base.device)
-            rc = self.row_count.to('cpu').repeat(S).to(self.row_base.device)
+            dev = self.row_base.device
+            off = (torch.arange(S, dtype=torch.int32) * self.M)[:, None]
+            rb = (off + self._row_base_host[None]).reshape(-1)
+            rc = self._row_count_host.repeat(S)
+            if dev.type == 'cuda':
+                rb, rc = rb.pin_memory().to(dev, non_blocking=True), rc.pin_memory().to(dev, non_blocking=True)
+            else:
+                rb, rc = rb.to(dev), rc.to(dev)
             if len(self._stacked) > 4:
                 self._stacked.clear()
             got = self._stacked[S] = (rb, rc)

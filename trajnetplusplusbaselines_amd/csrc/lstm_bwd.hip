@@ -925,12 +925,18 @@ static int launch_dgrid_cells_xcd(const float *dy, int ldy, const float *Wc, con
 // VALU form above needs the encoding row of every hit in SGPRs, and those 4.7 M scalar loads of 2.5 MB of randomly addressed
 // rows (scalar-cache misses) are what held it at 313 us against a 68 us arithmetic floor.  Hits are taken in list order,
 // four per MFMA, batches b = wave, wave + 4, ... per wave, the four waves' tiles added in fixed order: deterministic.
+// 64 zeros: what a past-the-end hit of sparse_wgrad_mfma_kernel loads.  A zero-initialised device global of the code object:
+// present on every device the library is loaded on, no allocation, no fill on any stream, nothing to order a first launch
+// against (a lazily hipMalloc'ed + NULL-stream hipMemset buffer was not ordered before a launch on a non-blocking stream,
+// not thread-safe and not capturable -- ADVICE round 3).
+__device__ __attribute__((aligned(256))) float g_swg_zeros[64] = {};
+
 template <int C>
 __global__ void __launch_bounds__(256) sparse_wgrad_mfma_kernel(const float *__restrict__ dy, int ldy,
                                                                 const float *__restrict__ enc, int lde,
                                                                 const int2 *__restrict__ list, const int32_t *__restrict__ count,
-                                                                int R, int N1, int ncell, float *__restrict__ dWc,
-                                                                const float *__restrict__ swg_zeros) {
+                                                                int R, int N1, int ncell, float *__restrict__ dWc) {
+    const float *swg_zeros = g_swg_zeros;
     static_assert(C <= 16, "one 16-channel A tile");
     typedef float f4 __attribute__((ext_vector_type(4)));
     constexpr int NW = 4, U = 1;                                    // waves per workgroup, batches per trip (see below)
@@ -951,7 +957,7 @@ __global__ void __launch_bounds__(256) sparse_wgrad_mfma_kernel(const float *__r
     for (int q = 0; q < 4; ++q) acc[q] = f4{0.0f, 0.0f, 0.0f, 0.0f};
     const int nb = (cnt + 3) >> 2;                                  // batches of four hits
     // Every load is unconditional: past the end of the list the entry index is 0 and the operands come from a row of
-    // zeros (swg_zeros, a device buffer the launcher owns), chosen by ADDRESS.  A `valid ? load : 0` select is turned back
+    // zeros (g_swg_zeros, a zero-initialised device global), chosen by ADDRESS.  A `valid ? load : 0` select is turned back
     // into a branch around the load by the compiler, and a load under a branch is waited for at the join: round 2's kernel
     // did that and took 286 us, this one 235 (profiles/round3_p_sparse_wgrad_sweep.md).
     auto entry = [&](int b) -> int2 { const int k = 4 * b + g; return L[(b < nb && k < cnt) ? k : 0]; };
@@ -1022,17 +1028,8 @@ static int launch_sparse_wgrad(const float *dy, int ldy, const float *enc, int l
                                int ncell, int N1, float *dWc, hipStream_t s) {
     if constexpr (C <= 16) {
         if (ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(dWc) & 15) == 0) {
-            static float *zeros_of[64] = {};                                 // per device: 64 zeros, what a past-the-end hit loads
-            int dev_id = 0;
-            TNP_HIP(hipGetDevice(&dev_id));
-            if (dev_id < 0 || dev_id >= 64) TNP_FAIL(-1, "tnp_sparse_wgrad: device ordinal %d", dev_id);
-            if (!zeros_of[dev_id]) {
-                TNP_HIP(hipMalloc(&zeros_of[dev_id], 256));
-                TNP_HIP(hipMemset(zeros_of[dev_id], 0, 256));
-            }
-            float *zeros = zeros_of[dev_id];
             hipLaunchKernelGGL(sparse_wgrad_mfma_kernel<C>, dim3(ncell * (N1 / 64)), dim3(256), 0, s, dy, ldy, enc, lde, list, count, R, N1, ncell,
-                               dWc, zeros);
+                               dWc);
             TNP_HIP(hipGetLastError());
             return 0;
         }

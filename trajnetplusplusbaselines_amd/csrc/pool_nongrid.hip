@@ -415,6 +415,7 @@ __global__ void __launch_bounds__(256) pool_attn_self_kernel(const float *__rest
 }
 
 constexpr int ATT_MAXD_PER_LANE = 4;   // D <= 256
+constexpr size_t ATT_MAX_LDS = (size_t)160 * 1024;   // a scene's tracks are staged in LDS (the whole CU's when needed)
 
 // one wave per ego (blockIdx.x = scene, blockIdx.y strides over its egos); lane <-> dims lane, lane + 64, ...
 __global__ void __launch_bounds__(64) pool_attn_pair_kernel(const float *__restrict__ obs1, const float *__restrict__ obs2,
@@ -756,7 +757,12 @@ int launch_pool_attn_pair(const float *obs1, const float *obs2, const float *hen
     const int D = ms + mh + mv;
     if (D > 64 * ATT_MAXD_PER_LANE) TNP_FAIL(-1, "AttentionMLPPooling: mlp_dim %d > %d", D, 64 * ATT_MAXD_PER_LANE);
     const size_t lds = ((size_t)((n_max + 3) & ~3) + (size_t)n_max * (4 + (mh > 0 ? mh : 0))) * sizeof(float);   // scores + the scene's tracks (n_scene <= n_max)
-    if (n_max < 1 || lds > 60000) TNP_FAIL(-1, "AttentionMLPPooling: n_max %d (x mlp_dim_hidden %d) out of range", n_max, mh);
+    // (a scene's tracks are staged in LDS: up to the CU's whole 160 KB, i.e. ~400 tracks per scene at mlp_dim_hidden = 96)
+    if (n_max < 1 || lds > ATT_MAX_LDS) TNP_FAIL(-1, "AttentionMLPPooling: a scene of %d slots (x mlp_dim_hidden %d) needs %zu bytes of LDS, limit %zu", n_max, mh, lds, ATT_MAX_LDS);
+    if (lds > 60000) {
+        static bool raised = false;     // idempotent: a race only repeats the call
+        if (!raised) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pool_attn_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_MAX_LDS)); raised = true; }
+    }
     // one wave per ego up to 64 egos per scene (two egos per wave left one wave per SIMD: 59 -> 35 us at config 2)
     hipLaunchKernelGGL(pool_attn_pair_kernel, dim3(B, n_max < 64 ? n_max : 64), dim3(64), lds, s, obs1, obs2, henc, ldh,
                        henc_relu, scene_start, n_max, scene_slots, ms, mv, mh, Ws, bs, Wv, bv, fill, u, ldu, ebar, lde);
@@ -918,7 +924,11 @@ extern "C" TNP_API int tnp_pool_attn_pair_backward(const float *obs1, const floa
     const int D = ms + mh + mv;
     if (D > 64 * tnp::ATT_MAXD_PER_LANE) TNP_FAIL(-1, "AttentionMLPPooling: mlp_dim %d > %d", D, 64 * tnp::ATT_MAXD_PER_LANE);
     const size_t lds = ((size_t)((2 * n_max + 3) & ~3) + (size_t)n_max * (4 + (mh > 0 ? mh : 0))) * sizeof(float);
-    if (n_max < 1 || lds > 60000) TNP_FAIL(-1, "AttentionMLPPooling: n_max %d (x mlp_dim_hidden %d) out of range", n_max, mh);
+    if (n_max < 1 || lds > tnp::ATT_MAX_LDS) TNP_FAIL(-1, "AttentionMLPPooling: a scene of %d slots (x mlp_dim_hidden %d) needs %zu bytes of LDS, limit %zu", n_max, mh, lds, tnp::ATT_MAX_LDS);
+    if (lds > 60000) {
+        static bool raised = false;
+        if (!raised) { TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tnp::pool_attn_pair_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tnp::ATT_MAX_LDS)); raised = true; }
+    }
     if (ldu < D + 1) TNP_FAIL(-1, "tnp_pool_attn_pair_backward: ldu %d < mlp_dim + 1", ldu);
     hipLaunchKernelGGL(tnp::pool_attn_pair_backward_kernel, dim3(B, n_max < 64 ? n_max : 64), dim3(64), lds,
                        (hipStream_t)stream, obs1, obs2, hidden_emb_pre, ldh, scene_start, n_max, scene_slots, ms, mv, mh, W_spatial, b_spatial,

@@ -359,9 +359,12 @@ class LSTM(torch.nn.Module):
                     and getattr(self, '_grad_reduce_fn', None) is None:
                 # under torch.compile the training sequence is ONE dispatcher op with its backward behind a handle
                 # (ops.py: trajnet::lstm_sequence_train / lstm_sequence_backward) -- no graph break
+                # only the parameters the sequence touches enter the graph: the others keep .grad = None, as in eager mode
+                from .training import unused_parameter_names
+                skip = set(unused_parameter_names(self, T_dec))
                 rel_pred, pred, _, _ = torch.ops.trajnet.lstm_sequence_train(
                     observed, goals, torch.as_tensor(batch_split), prediction_truth, T_dec, int(pad_to or 0), self._op_handle,
-                    list(self.parameters()))
+                    [p for n, p in self.named_parameters() if n not in skip])
                 return rel_pred, pred
             from .training import run_sequence_with_grad
             opts = {'pad_to': pad_to, 'reduce_fn': getattr(self, '_grad_reduce_fn', None)}

@@ -685,6 +685,29 @@ class SequenceFn(torch.autograd.Function):
         return tuple(out)
 
 
+def unused_parameter_names(model, T_dec):
+    """Names of the parameters LSTM.forward never touches for this module configuration and call: the reference's autograd
+    leaves their ``.grad`` None (so Adam + weight decay does not move them), and so does SequenceFn.backward.  Static
+    rules, checked against what the backward sweep actually returns in tests/test_gpu_training.py:
+      goal_embedding.*                       unless goal_flag (lstm/lstm.py:132-139)
+      decoder.*                              in an encoder-only run (T_dec == 0: the S-GAN discriminator)
+      pool.pool_lstm.*, pool.hidden2pool.*   of a grid module with embedding_arch='lstm_layer' (its forward is
+                                             Linear + ReLU, lstm/gridbased_pooling.py:94-110 never calls lstm_forward)
+      mlp_decoder_context.*                  (S-GAN generator) only used with a noise vector -- not on the LSTM.forward path"""
+    unused = []
+    grid_lstm_layer = hasattr(model.pool, 'embedding_layers') and getattr(model.pool, 'embedding_arch', None) == 'lstm_layer'
+    for n, _ in model.named_parameters():
+        if n.startswith('goal_embedding.') and not model.goal_flag:
+            unused.append(n)
+        elif n.startswith('decoder.') and T_dec == 0:
+            unused.append(n)
+        elif grid_lstm_layer and (n.startswith('pool.pool_lstm.') or n.startswith('pool.hidden2pool.')):
+            unused.append(n)
+        elif n.startswith('mlp_decoder_context.'):
+            unused.append(n)
+    return unused
+
+
 def _param_lists(model):
     """(names, parameters) of the model in named_parameters() order (kept by our LSTM between calls)"""
     if hasattr(model, '_named_parameter_lists'):

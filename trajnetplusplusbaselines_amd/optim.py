@@ -19,7 +19,16 @@ class AdamTensor(ctypes.Structure):
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, *, foreach=None,
+                 maximize=False, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False):
+        # torch.optim.Adam's remaining keyword arguments are accepted at their defaults (a trainer that spells them out
+        # keeps working); the variants themselves are not built
+        for name, val in (('amsgrad', amsgrad), ('maximize', maximize), ('capturable', capturable),
+                          ('differentiable', differentiable), ('decoupled_weight_decay', decoupled_weight_decay)):
+            if val:
+                raise NotImplementedError('tnp Adam: %s=True is not implemented (use torch.optim.Adam)' % name)
+        if isinstance(lr, torch.Tensor):
+            raise NotImplementedError('tnp Adam: a tensor lr is not implemented')
         if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
             raise ValueError('invalid Adam hyper-parameters')
         super(Adam, self).__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
@@ -48,6 +57,10 @@ class Adam(torch.optim.Optimizer):
                 _lib.require_device(p, 'parameter')
                 if p.dtype != torch.float32 or not p.is_contiguous() or p.grad.is_sparse:
                     raise RuntimeError('tnp Adam: float32 contiguous dense parameters only')
+                if p.grad.dtype != torch.float32 or p.grad.device != p.device:
+                    # the kernel reads raw float pointers on the parameter's device
+                    raise RuntimeError('tnp Adam: gradient is %s on %s, parameter is float32 on %s'
+                                       % (p.grad.dtype, p.grad.device, p.device))
                 state = self.state[p]
                 if len(state) == 0:
                     state['step'] = torch.tensor(0.0, dtype=torch.float32)            # host tensor, like torch's default
