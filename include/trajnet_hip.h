@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNP_ABI_VERSION 5
+#define TNP_ABI_VERSION 6
 #define TNP_API __attribute__((visibility("default")))
 
 /* pooling types: GridBasedPooling(type_=...)  lstm/gridbased_pooling.py:16-19,55-66 */
@@ -81,6 +81,18 @@ TNP_API int tnp_pool_grid_forward(int type, const float *obs1, const float *obs2
  * its cell).  row_base / row_count [M]: first row and size of the row's scene; out [M, n_max] int32, -1 = no cell. */
 TNP_API int tnp_pool_pair_cells(const float *obs2, const int32_t *row_base, const int32_t *row_count, int M, int n_max,
                         int n, float cell, float half_x, float half_y, int32_t *out, void *stream);
+/* The same table as autograd sees it (what the training path uses).  The grid leaves occupancy() through
+ * lp_pool2d(x, 1, 1) = sign(x) * relu(|x|) (lstm/gridbased_pooling.py:304), whose derivative at x == 0 is zero: a cell whose
+ * final value is exactly 0 passes no gradient -- cell (0, 0) whenever its last writer is an out-of-range / absent / padded
+ * neighbour and constant == 0 (they write `constant` there, :281-282), so the genuine neighbours in that cell get nothing.
+ * cells [M, n_max]: the raw cell or -1 (no gradient); winner [M, n_max] (may be NULL): slot of the last writer of the
+ * pair's cell (whose value is the cell's value; -2: the cell holds a non-zero `constant`, -1 with cells == -1).
+ * row_padded [M] (NULL: pad_default for every row) = slots the row's scene is padded to (lstm/lstm.py:29);
+ * raw_scratch [M, n_max] int32, a buffer different from `cells`. */
+TNP_API int tnp_pool_pair_cells_autograd(const float *obs2, const int32_t *row_base, const int32_t *row_count,
+                                         const int32_t *row_padded, int pad_default, int M, int n_max, int n, float cell,
+                                         float half_x, float half_y, float constant, int32_t *raw_scratch, int32_t *cells,
+                                         int32_t *winner, void *stream);
 
 /* -------------------------------------------------------------------------------------------
  * Dense layer on the matrix cores: torch.nn.Linear (+ReLU) as used by the grid embedding
@@ -281,7 +293,8 @@ TNP_API int tnp_lstm_step(const tnp_lstm_model *model, int decoder, const float 
  *                          tracks (their state is copied through, lstm/lstm.py:158-166)
  *   tnp_relu_mask:         out = dy * (act > 0) on column slices (leading dimensions given)
  *   tnp_social_scatter_backward: d(social encoding)[j] = sum over the egos i of j's scene of dgrid[i, :, cell(i,j)]
- *                          with cells from tnp_pool_pair_cells (every in-range neighbour)
+ *                          with cells from tnp_pool_pair_cells_autograd (every in-range neighbour of a cell whose value
+ *                          is not the constant 0, SURVEY.md 8a quirk 4 + lp_pool2d's zero derivative at 0)
  * ----------------------------------------------------------------------------------------- */
 typedef struct tnp_step_saves {
     float *X;
@@ -343,7 +356,8 @@ typedef struct tnp_bwd_sweep {
     const float *whT;                /* social: hidden_dim_encoding.weight^T [H, C] */
     const float *w_cell_major;       /* social_sparse */
     const int32_t *row_base, *row_count;            /* [M] first row / size of each track's scene */
-    const int32_t *cells_all, *ego_list, *ego_count; /* social_sparse: [S,M,n_max], [n*n,S*M,2], [n*n,S] */
+    const int32_t *cells_all, *ego_list, *ego_count; /* cells_all [S,M,n_max]: tnp_pool_pair_cells_autograd over the stacked steps
+                                                      * (social, directional_in); social_sparse: ego lists [n*n,S*M,2], [n*n,S] */
     float *dlin_all, *dG_all, *de_all, *dgoal_all;  /* [S,M,5], [S,M,4H], [S,M,E-2], [S,M,goal_dim-2] */
     float *dy_all[3];                /* [S,M,dims[l+1]] gradient of embedding layer l's pre-activation */
     float *denc_all, *dnn_all;       /* [S,M,C] social; [S,M,P] TNP_POOL_NN */
@@ -372,6 +386,7 @@ typedef struct tnp_bwd_sweep {
     int32_t stateful;
     const float *st_pwT, *st_h2pT, *st_zeros;
     float *st_dG_all, *st_dfeat_all, *st_dph, *st_dpc;
+    const int32_t *cellwin_all;      /* directional_in: [S,M,n_max] winner table of tnp_pool_pair_cells_autograd, or NULL */
 } tnp_bwd_sweep;
 /* sizeof() of the structs of this header as the library was compiled (which: 0 tnp_lstm_model, 1 tnp_lstm_extras,
  * 2 tnp_step_saves, 3 tnp_train_saves, 4 tnp_bwd_sweep; 0 for any other value) -- lets a binding check its mirrors */
@@ -494,8 +509,9 @@ typedef struct tnp_transpose_problem {
 } tnp_transpose_problem;
 TNP_API int tnp_transpose_grouped(const tnp_transpose_problem *problems, int n, void *stream);
 /* gradient of the directional grid's values (v_j - v_i, lstm/gridbased_pooling.py:118-143) with respect to the tracks'
- * velocities: dvel [M,2]; needed when the positions fed to the sequence carry gradient (S-GAN discriminator input) */
-TNP_API int tnp_directional_scatter_backward(const float *dgrid, int ldg, const int32_t *cells,
+ * velocities: dvel [M,2]; needed when the positions fed to the sequence carry gradient (S-GAN discriminator input).
+ * cells / winner: tnp_pool_pair_cells_autograd's tables (winner may be NULL: no per-channel zero-value mask) */
+TNP_API int tnp_directional_scatter_backward(const float *dgrid, int ldg, const int32_t *cells, const int32_t *winner,
                                              const int32_t *row_base, const int32_t *row_count, const float *obs1,
                                              const float *obs2, int M, int n_max, int ncell, float *dvel, void *stream);
 

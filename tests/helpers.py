@@ -169,3 +169,40 @@ def assert_matches_stored(z, key, got, rtol, what=''):
         worst = max(worst, err)
         assert err < rtol, '%s %s@%s: relative error %.2e (scale %.2e)' % (what, key, part, err, scale)
     return worst
+
+
+# ---- the grid scatter's backward as autograd defines it (tests/golden/scatter_grad.npz, oracle/gen_golden_r4.py) ----
+def pair_cells_autograd_numpy(obs2, n, cell_side, constant):
+    """Pure-numpy statement of the rule tnp_pool_pair_cells_autograd implements, for ONE padded scene obs2 [N, 2] (NaN =
+    absent / padded slot).  Returns (cells [N, N], winner [N, N]) indexed [ego, neighbour slot]: the cell of the pair, or -1
+    when the pair receives no gradient -- self, absent, out of range, or standing in a cell whose final value is the constant
+    0 (cell 0 whose last writer is an out-of-range / absent slot: lp_pool2d(x, 1, 1) has a zero derivative at 0, reference
+    lstm/gridbased_pooling.py:281-304); winner = slot of the cell's last writer (-2: the cell holds a non-zero constant)."""
+    N = obs2.shape[0]
+    pos = np.where(np.isnan(obs2).any(axis=1, keepdims=True), np.float32(-500.0), obs2).astype(np.float32)
+    cs, half = np.float32(cell_side), np.float32(n / 2)
+    cells = -np.ones((N, N), dtype=np.int64)
+    winner = -np.ones((N, N), dtype=np.int64)
+    for i in range(N):
+        raw = -np.ones(N, dtype=np.int64)
+        for j in range(N):
+            if j == i:
+                continue
+            o = (pos[j] - pos[i]) / cs + half
+            if (o >= 0).all() and (o < n).all():
+                raw[j] = int(o[0]) * n + int(o[1])
+        others = [j for j in range(N) if j != i]
+        for j in others:
+            c = raw[j]
+            if c < 0:
+                continue
+            later = [k for k in others if k > j]
+            writers = [k for k in later if raw[k] == c or (c == 0 and raw[k] < 0)]
+            last = max(writers) if writers else j
+            if raw[last] < 0:                      # cell 0 clobbered by an out-of-range / absent slot
+                if constant == 0:
+                    continue
+                cells[i, j], winner[i, j] = c, -2
+            else:
+                cells[i, j], winner[i, j] = c, last
+    return cells, winner

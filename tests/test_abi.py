@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 12
     for name in names:
         assert hasattr(L, name), name
-    assert L.tnp_abi_version() == _lib.ABI_VERSION == 5   # 2: tnp_lstm_model gained Wx / bx; 3: tnp_step_saves gained winners; 4: scene_slots; 5: Wp0_quad_major
+    assert L.tnp_abi_version() == _lib.ABI_VERSION == 6   # 2: tnp_lstm_model gained Wx / bx; 3: tnp_step_saves gained winners; 4: scene_slots; 5: Wp0_quad_major; 6: tnp_pool_pair_cells_autograd, tnp_bwd_sweep.cellwin_all
 
 
 def test_struct_layout_matches_header_size():

@@ -1,5 +1,7 @@
 """GPU parity of the recurrent path (tnp_lstm_forward / tnp_lstm_step) against the reference's golden outputs,
 against the CPU oracle at BASELINE config sizes, and through size-independent properties."""
+import os
+
 import numpy as np
 import pytest
 import torch

@@ -182,3 +182,30 @@ def test_duplicate_cells_single_threaded_reference():
     enc = helpers.social_enc(dict(hidden=z['hidden'], Wh=z['Wh'], bh=z['bh']))
     g = oracle.grid('social', z['obs1'], z['obs2'], enc, n=12, cell_side=0.6)
     np.testing.assert_allclose(g, z['grid_social'], rtol=0, atol=2e-6)    # a wrong winner would be off by O(1)
+
+
+def test_scatter_backward_rule_matches_reference_autograd():
+    """The rule the training kernels implement for the grid scatter's backward (helpers.pair_cells_autograd_numpy: every
+    in-range neighbour receives its cell's gradient, duplicates included, EXCEPT in a cell whose final value is the constant 0
+    -- cell (0, 0) clobbered by an out-of-range / absent / padded slot, where lp_pool2d's derivative is zero) against the
+    reference's autograd on dense crowds (tests/golden/scatter_grad.npz): per-pair gradients of the scattered values, exact."""
+    import os
+    z = np.load(os.path.join(helpers.GOLDEN, 'scatter_grad.npz'))
+    masked_total = 0
+    for k in range(int(z['num_cases'])):
+        pre = 's%d_' % k
+        obs2, dgrid, want = z[pre + 'obs2'], z[pre + 'dgrid'], z[pre + 'dvalues']
+        n, cs, const = int(z[pre + 'n']), float(z[pre + 'cell_side']), float(z[pre + 'constant'])
+        B, N = obs2.shape[:2]
+        got = np.zeros_like(want)
+        for b in range(B):
+            cells, _ = helpers.pair_cells_autograd_numpy(obs2[b], n, cs, const)
+            raw, _ = helpers.pair_cells_autograd_numpy(obs2[b], n, cs, 1.0)      # constant != 0: nothing is masked
+            masked_total += int(((raw >= 0) & (cells < 0)).sum())
+            for i in range(N):
+                for j in range(N):
+                    if j != i and cells[i, j] >= 0:
+                        c = cells[i, j]
+                        got[b, i, j - (j > i)] = dgrid[b * N + i, :, c // n, c % n]
+        np.testing.assert_array_equal(got, want)
+    assert masked_total > 0, 'the fixture must contain in-range pairs in a clobbered cell (0, 0)'

@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'trajnet_hip.h')
 
 POOL_NONE, POOL_OCCUPANCY, POOL_DIRECTIONAL, POOL_SOCIAL = -1, 0, 1, 2
 POOL_NN, POOL_HIDDENMLP, POOL_ATTNMLP, POOL_NNLSTM, POOL_TRAJ = 4, 5, 6, 7, 8
-ABI_VERSION = 5   # TNP_ABI_VERSION of include/trajnet_hip.h this binding was written against
+ABI_VERSION = 6   # TNP_ABI_VERSION of include/trajnet_hip.h this binding was written against
 POOL_TYPES = {None: POOL_NONE, 'occupancy': POOL_OCCUPANCY, 'directional': POOL_DIRECTIONAL, 'social': POOL_SOCIAL}
 
 _fp = ctypes.c_void_p
@@ -144,7 +144,7 @@ def lib():
     L.tnp_pool_attn_self_backward.argtypes = [_fp, _fp, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, _fp, _fp, _fp, _fp, _fp]
     L.tnp_transpose.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]
-    L.tnp_directional_scatter_backward.argtypes = [_fp, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int,
+    L.tnp_directional_scatter_backward.argtypes = [_fp, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, _fp, _fp]
     L.tnp_pool_traj_forward.argtypes = [_fp, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp]
     L.tnp_pool_attn_self.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -175,6 +175,8 @@ def lib():
                                      ctypes.c_double, ctypes.c_double, _fp, _fp]
     L.tnp_pool_pair_cells.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_float, _fp, _fp]
+    L.tnp_pool_pair_cells_autograd.argtypes = [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _fp, _fp, _fp, _fp]
     if L.tnp_abi_version() != ABI_VERSION:
         raise RuntimeError('libtrajnet_hip.so ABI version mismatch')
     _LIB = L
@@ -241,6 +243,7 @@ class SceneIndex(object):
             raise ValueError('batch_split must start at 0')
         self.n_max = int(sizes.max()) if self.B > 0 else 0
         self.slots = None
+        self._slots_host, self._sizes_host = None, sizes
         if isinstance(pad_to, numbers.Integral):
             pad_to = int(pad_to)
         if pad_to is not None:
@@ -259,6 +262,7 @@ class SceneIndex(object):
             self.n_max = int(slots.max()) if self.B > 0 else 0
             if not isinstance(pad_to, int):
                 self.slots = slots.to(torch.int32).to(device)
+                self._slots_host = slots.to(torch.int64)
         self.starts = split.to(torch.int32).to(device)
         # first row / size of every row's scene (training backward): built on the host, one copy, no device-side sync later
         # (the host copies stay: stacked_rows() builds the whole-sweep tables from them without reading the device back)
@@ -271,23 +275,27 @@ class SceneIndex(object):
               'tnp_mark_primaries')
 
     def stacked_rows(self, S):
-        """(row_base, row_count) of S copies of the batch stacked along the rows (row r of step s is row s M + r): what the
-        backward sweep's whole-sweep pair-cell launch indexes with.  Built from the HOST copies of the tables once per
-        (batch structure, S): no device read-back (a real trainer has a new batch_split every step, and a D2H copy here
-        would drain the forward's queue in the middle of the backward pass), two small pinned H2D copies."""
+        """(row_base, row_count, row_padded) of S copies of the batch stacked along the rows (row r of step s is row s M + r):
+        what the backward sweep's whole-sweep pair-cell launch indexes with; row_padded = slots the row's scene is padded to,
+        None when every scene is padded to ``n_max``.  Built from the HOST copies of the tables once per (batch structure, S):
+        no device read-back (a real trainer has a new batch_split every step, and a D2H copy here would drain the forward's
+        queue in the middle of the backward pass), small pinned H2D copies."""
         got = self.__dict__.setdefault('_stacked', {}).get(S)
         if got is None:
             dev = self.row_base.device
             off = (torch.arange(S, dtype=torch.int32) * self.M)[:, None]
-            rb = (off + self._row_base_host[None]).reshape(-1)
-            rc = self._row_count_host.repeat(S)
+            tabs = [(off + self._row_base_host[None]).reshape(-1), self._row_count_host.repeat(S)]
+            if self._slots_host is not None:
+                tabs.append(torch.repeat_interleave(self._slots_host, self._sizes_host).to(torch.int32).repeat(S))
             if dev.type == 'cuda':
-                rb, rc = rb.pin_memory().to(dev, non_blocking=True), rc.pin_memory().to(dev, non_blocking=True)
+                tabs = [t.pin_memory().to(dev, non_blocking=True) for t in tabs]
             else:
-                rb, rc = rb.to(dev), rc.to(dev)
+                tabs = [t.to(dev) for t in tabs]
+            if len(tabs) == 2:
+                tabs.append(None)
             if len(self._stacked) > 4:
                 self._stacked.clear()
-            got = self._stacked[S] = (rb, rc)
+            got = self._stacked[S] = tuple(tabs)
         return got
 
     @classmethod

@@ -236,9 +236,13 @@ __global__ void __launch_bounds__(256) social_scatter_backward_kernel(const floa
 // 118-143: value(i, j) = nan_to_num(v_j - v_i) scattered to cell(i, j); autograd gives every in-range pair its cell's
 // gradient and nothing through the integer cell index).  thread <-> track t:
 //   dvel[t] = sum_i dgrid[i, :, cell(i,t)]  (t as neighbour of ego i)  -  sum_j dgrid[t, :, cell(t,j)]  (t as ego)
-// over the pairs of t's scene whose two velocities are finite.
+// over the pairs of t's scene whose two velocities are finite.  `cells` comes from tnp_pool_pair_cells_autograd (a cell
+// whose value is the constant 0 passes nothing); with its `winner` table the second consequence of lp_pool2d's zero
+// derivative at 0 is applied per channel: the cell's value is its WINNER's nan_to_num(v_w - v_i), and where that is exactly
+// 0 (a winner without a finite velocity: both channels) no pair of the cell receives that channel's gradient.
 __global__ void __launch_bounds__(256) directional_scatter_backward_kernel(const float *__restrict__ dgrid, int ldg,
                                                                            const int32_t *__restrict__ cells,
+                                                                           const int32_t *__restrict__ winner,
                                                                            const int32_t *__restrict__ row_base,
                                                                            const int32_t *__restrict__ row_count,
                                                                            const float *__restrict__ obs1,
@@ -252,14 +256,36 @@ __global__ void __launch_bounds__(256) directional_scatter_backward_kernel(const
         const float a = obs1[2 * r], b = obs1[2 * r + 1], c = obs2[2 * r], d = obs2[2 * r + 1];
         return (a == a) && (b == b) && (c == c) && (d == d);
     };
+    // channel mask of ego row `e`'s cell that pair slot `slot` stands in: 1 where the winner's value is non-zero
+    auto pass = [&](int e, int slot, bool &px, bool &py) {
+        px = py = true;
+        if (!winner) return;
+        const int w = winner[(size_t)e * n_max + slot];
+        if (w < 0) return;                                           // -2: the cell holds a non-zero constant
+        const int wr = row_base[e] + w;
+        float vx = (obs2[2 * wr] - obs1[2 * wr]) - (obs2[2 * e] - obs1[2 * e]);
+        float vy = (obs2[2 * wr + 1] - obs1[2 * wr + 1]) - (obs2[2 * e + 1] - obs1[2 * e + 1]);
+        if (vx != vx) vx = 0.0f;                                     // nan_to_num, gridbased_pooling.py:140
+        if (vy != vy) vy = 0.0f;
+        px = vx != 0.0f; py = vy != 0.0f;
+    };
     float ax = 0.0f, ay = 0.0f;
     if (finite_vel(t)) {
         for (int i = lo + lane; i < lo + ns; i += 64) {
             if (i == t || !finite_vel(i)) continue;
+            bool px, py;
             const int c1 = cells[(size_t)i * n_max + tt];
-            if (c1 >= 0) { ax += dgrid[(size_t)i * ldg + c1]; ay += dgrid[(size_t)i * ldg + ncell + c1]; }
+            if (c1 >= 0) {
+                pass(i, tt, px, py);
+                if (px) ax += dgrid[(size_t)i * ldg + c1];
+                if (py) ay += dgrid[(size_t)i * ldg + ncell + c1];
+            }
             const int c2 = cells[(size_t)t * n_max + (i - lo)];
-            if (c2 >= 0) { ax -= dgrid[(size_t)t * ldg + c2]; ay -= dgrid[(size_t)t * ldg + ncell + c2]; }
+            if (c2 >= 0) {
+                pass(t, i - lo, px, py);
+                if (px) ax -= dgrid[(size_t)t * ldg + c2];
+                if (py) ay -= dgrid[(size_t)t * ldg + ncell + c2];
+            }
         }
     }
 #pragma unroll
@@ -1187,13 +1213,13 @@ extern "C" TNP_API int tnp_transpose(const float *in, int ld_in, int rows, int c
     return 0;
 }
 
-extern "C" TNP_API int tnp_directional_scatter_backward(const float *dgrid, int ldg, const int32_t *cells,
+extern "C" TNP_API int tnp_directional_scatter_backward(const float *dgrid, int ldg, const int32_t *cells, const int32_t *winner,
                                                         const int32_t *row_base, const int32_t *row_count,
                                                         const float *obs1, const float *obs2, int M, int n_max, int ncell,
                                                         float *dvel, void *stream) {
     if (M <= 0) return 0;
     hipLaunchKernelGGL(tnp::directional_scatter_backward_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       dgrid, ldg, cells, row_base, row_count, obs1, obs2, M, n_max, ncell, dvel);
+                       dgrid, ldg, cells, winner, row_base, row_count, obs1, obs2, M, n_max, ncell, dvel);
     TNP_HIP(hipGetLastError());
     return 0;
 }
@@ -1335,6 +1361,9 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
         TNP_FAIL(-1, "tnp_lstm_backward_sweep: pool type %d has no backward", md->pool_type);
     const bool to_hidden = md->pool_type != TNP_POOL_NONE && ((md->variant >> 17) & 1);   // LSTM(pool_to_input=False)
     if (to_hidden && !sv->pvec_all) TNP_FAIL(-1, "tnp_lstm_backward_sweep: pool_to_input=False needs saves->pvec_all");
+    if ((social || (grid && a->directional_in)) && !a->cells_all)
+        TNP_FAIL(-1, "tnp_lstm_backward_sweep: cells_all (tnp_pool_pair_cells_autograd over the stacked steps) is required for the "
+                     "social scatter's backward and for directional input gradients");
     tnp::SweepScratch w;
     tnp::plan_sweep(a, scratch, w);
     if (!scratch || scratch_bytes < w.bytes)
@@ -1409,10 +1438,10 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
             const float *dy0 = a->dy_all[0] + r * N1;
             if (a->directional_in) {
                 TNP_RC(tnp_linear_forward(dy0, N1, a->layT[0], N1, nullptr, w.dgrid, md->dims[0], M, md->dims[0], N1, 0, 0, stream));
-                TNP_RC(tnp_pool_pair_cells(o2, a->row_base, a->row_count, M, a->n_max, md->n, md->cell, md->half_x, md->half_y,
-                                           w.cells, stream));
-                TNP_RC(tnp_directional_scatter_backward(w.dgrid, md->dims[0], w.cells, a->row_base, a->row_count, o1, o2, M,
-                                                        a->n_max, ncell, a->dvel_pool_all + r * 2, stream));
+                // pair cells as autograd sees them, all steps at once by the caller (tnp_pool_pair_cells_autograd)
+                TNP_RC(tnp_directional_scatter_backward(w.dgrid, md->dims[0], a->cells_all + r * a->n_max,
+                                                        a->cellwin_all ? a->cellwin_all + r * a->n_max : nullptr, a->row_base,
+                                                        a->row_count, o1, o2, M, a->n_max, ncell, a->dvel_pool_all + r * 2, stream));
             }
             if (social) {
                 float *denc = a->denc_all + r * C;
@@ -1439,12 +1468,10 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
                                                              a->n_max, C, ncell, denc, stream));
                     }
                 } else {
-                    TNP_RC(tnp_pool_pair_cells(o2, a->row_base, a->row_count, M, a->n_max, md->n, md->cell, md->half_x,
-                                               md->half_y, w.cells, stream));
                     TNP_RC(tnp_linear_forward(dy0, N1, a->layT[0], N1, nullptr, w.dgrid, md->dims[0], M, md->dims[0], N1, 0, 0,
                                               stream));
-                    TNP_RC(tnp_social_scatter_backward(w.dgrid, md->dims[0], w.cells, a->row_base, a->row_count, M, a->n_max, C,
-                                                       ncell, denc, stream));
+                    TNP_RC(tnp_social_scatter_backward(w.dgrid, md->dims[0], a->cells_all + r * a->n_max, a->row_base, a->row_count,
+                                                       M, a->n_max, C, ncell, denc, stream));
                 }
                 social_denc = denc;     // its contribution to dh (denc . Wh) is formed inside the combine kernel
             }

@@ -105,7 +105,8 @@ class BwdSweep(ctypes.Structure):
                 ('at_dq_all', ctypes.c_void_p), ('at_ebar_all', ctypes.c_void_p), ('at_du_all', ctypes.c_void_p),
                 ('at_A_all', ctypes.c_void_p), ('stateful', ctypes.c_int32), ('st_pwT', ctypes.c_void_p),
                 ('st_h2pT', ctypes.c_void_p), ('st_zeros', ctypes.c_void_p), ('st_dG_all', ctypes.c_void_p),
-                ('st_dfeat_all', ctypes.c_void_p), ('st_dph', ctypes.c_void_p), ('st_dpc', ctypes.c_void_p)]
+                ('st_dfeat_all', ctypes.c_void_p), ('st_dph', ctypes.c_void_p), ('st_dpc', ctypes.c_void_p),
+                ('cellwin_all', ctypes.c_void_p)]
 
 
 def _attention_param_grads(pool, P, grads, wgrad, dout_all, bufs, denc_all, h_prev_all, rows, L, dev, sp):
@@ -399,15 +400,25 @@ class SequenceFn(torch.autograd.Function):
             G, cell, half_x, half_y = pool._geometry()
             C = pool.pooling_dim
             grid_all = torch.empty(S, M, C * G * G, device=dev) if not sparse_bwd else None
+            cells_all = cellwin_all = None
             if social or directional_in:
                 row_base, row_count = idx.row_base, idx.row_count
+                # pair cells of every step in one launch, AS AUTOGRAD SEES THEM (tnp_pool_pair_cells_autograd): every in-range
+                # neighbour receives its cell's gradient (duplicates included), except in a cell whose final value is the
+                # constant 0 -- cell (0, 0) clobbered by an out-of-range / absent / padded neighbour: lp_pool2d(x, 1, 1) has a
+                # zero derivative there (reference gridbased_pooling.py:304)
+                R, ncell = S * M, G * G
+                rb_all, rc_all, rp_all = idx.stacked_rows(S)
+                cells_raw = torch.empty(S, M, idx.n_max, dtype=torch.int32, device=dev)
+                cells_all = torch.empty(S, M, idx.n_max, dtype=torch.int32, device=dev)
+                cellwin_all = torch.empty(S, M, idx.n_max, dtype=torch.int32, device=dev) if directional_in else None
+                _lib.check(L.tnp_pool_pair_cells_autograd(_lib.ptr(o2_all), _lib.ptr(rb_all), _lib.ptr(rc_all), _lib.ptr(rp_all),
+                                                          idx.n_max, R, idx.n_max, G, cell, half_x, half_y, float(pool.constant),
+                                                          _lib.ptr(cells_raw), _lib.ptr(cells_all), _lib.ptr(cellwin_all), sp()),
+                           'pair_cells_autograd')
+                del cells_raw
                 if sparse_bwd:
-                    # pair cells of every step in one launch, then per (step, cell) the egos with a neighbour in that cell
-                    R, ncell = S * M, G * G
-                    rb_all, rc_all = idx.stacked_rows(S)
-                    cells_all = torch.empty(S, M, idx.n_max, dtype=torch.int32, device=dev)
-                    _lib.check(L.tnp_pool_pair_cells(_lib.ptr(o2_all), _lib.ptr(rb_all), _lib.ptr(rc_all), R, idx.n_max, G,
-                                                     cell, half_x, half_y, _lib.ptr(cells_all), sp()), 'pair_cells')
+                    # per (step, cell) the egos with a neighbour in that cell
                     occ = torch.empty(R, ncell, dtype=torch.uint8, device=dev)
                     occ_t = torch.empty(ncell, R, dtype=torch.int32, device=dev)
                     ego_list = torch.empty(ncell, R, 2, dtype=torch.int32, device=dev)
@@ -458,8 +469,11 @@ class SequenceFn(torch.autograd.Function):
             sw.at_ebar_all, sw.at_du_all, sw.at_A_all = (at_bufs[k].data_ptr() for k in ('ebar', 'du', 'A'))
         if hm_pool:
             sw.hidden_mlp, sw.hm_G_all, sw.hm_R_all = 1, hm_G_all.data_ptr(), hm_R_all.data_ptr()
+        if grid_pool and cells_all is not None:
+            sw.cells_all = cells_all.data_ptr()
+            sw.cellwin_all = cellwin_all.data_ptr() if cellwin_all is not None else None
         if social and sparse_bwd:
-            sw.cells_all, sw.ego_list, sw.ego_count = cells_all.data_ptr(), ego_list.data_ptr(), ego_count.data_ptr()
+            sw.ego_list, sw.ego_count = ego_list.data_ptr(), ego_count.data_ptr()
         sw.dlin_all, sw.dG_all, sw.de_all = dlin_all.data_ptr(), dG_all.data_ptr(), de_all.data_ptr()
         sw.dgoal_all = dgoal_all.data_ptr() if GD else None
         for li, t in enumerate(dy_all):

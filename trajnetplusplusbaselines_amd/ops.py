@@ -280,11 +280,17 @@ def lstm_sequence_train(observed: torch.Tensor, goals: Optional[torch.Tensor], b
     # `params` is what the caller wants gradients for (LSTM.forward passes the parameters the sequence touches,
     # training.unused_parameter_names() stay out of the graph and keep .grad = None as in eager mode); the sequence itself
     # runs on the module's own parameters
+    from .lstm.training import unused_parameter_names
     names, own = _param_lists(m)
-    by_ptr = {q.data_ptr(): n for n, q in zip(names, own)}
-    ctx.grad_names = [by_ptr.get(p.data_ptr()) for p in params]
-    if any(n is None for n in ctx.grad_names):
-        raise RuntimeError('trajnet::lstm_sequence_train: `params` must be parameters of the module behind the handle')
+    skip = set(unused_parameter_names(m, int(t_dec)))
+    used = [n for n in names if n not in skip]
+    if len(params) == len(used):            # what LSTM.forward passes (positional: opcheck hands in copies of the tensors)
+        ctx.grad_names = used
+    elif len(params) == len(names):         # every parameter of the module, in named_parameters() order
+        ctx.grad_names = list(names)
+    else:
+        raise RuntimeError('trajnet::lstm_sequence_train: `params` must be the module\'s parameters in named_parameters() order, '
+                           'all %d of them or the %d the sequence touches (got %d)' % (len(names), len(used), len(params)))
     with torch.no_grad():
         rel, pred, h_last = SequenceFn.forward(ctx, m, observed, goals, batch_split, truth, int(t_dec), opts,
                                                *[p.detach() for p in own])
