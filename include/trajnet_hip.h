@@ -258,6 +258,10 @@ typedef struct tnp_lstm_extras {
     float *loss_values;
     int32_t loss_steps, loss_mode;
     float loss_background_rate;
+    /* VAE (vae/vae.py:89-107, add_noise): after the last encoder step the hidden state is multiplied element by element
+     * with h_scale [M,H] (= vae_decoder(z)), the cell state is kept; NULL = no such hook.  Exclusive with the noise interface.
+     * (k modes = k replicas of the scenes, each replica's rows carrying its own multiplier.) */
+    const float *h_scale;
 } tnp_lstm_extras;
 TNP_API int tnp_lstm_forward_ex(const tnp_lstm_model *model, const float *observed, int T_obs, int M,
                         const float *goals, const int32_t *scene_start, const uint8_t *primary_flag,

@@ -45,7 +45,7 @@ class LstmExtras(ctypes.Structure):
     """mirror of ``struct tnp_lstm_extras``"""
     _fields_ = [('W_ctx', _fp), ('b_ctx', _fp), ('noise', _fp), ('noise_dim', ctypes.c_int32), ('noise_group_tracks', ctypes.c_int32),
                 ('h_final', _fp), ('loss_targets', _fp), ('loss_values', _fp), ('loss_steps', ctypes.c_int32),
-                ('loss_mode', ctypes.c_int32), ('loss_background_rate', ctypes.c_float)]
+                ('loss_mode', ctypes.c_int32), ('loss_background_rate', ctypes.c_float), ('h_scale', _fp)]
 
 
 _LIB = None

@@ -610,6 +610,14 @@ static void fill_prep_common(PrepArgs &p, const tnp_lstm_model *md, const Worksp
     p.enc = wants_enc ? w.enc : nullptr;
 }
 
+// y[q] = x[q] * g[q] on float4 groups (H % 4 == 0)
+__global__ void scale_rows_kernel(float *__restrict__ y, const float *__restrict__ x, const float *__restrict__ g, long n4) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n4) return;
+    const float4 a = reinterpret_cast<const float4 *>(x)[q], b = reinterpret_cast<const float4 *>(g)[q];
+    reinterpret_cast<float4 *>(y)[q] = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+
 // h[:, H-nd:H] = z (one noise vector shared by all tracks, sgan/sgan.py:213-216)
 // group > 0: tracks [g*group, (g+1)*group) carry noise vector g (several generator samples batched as replicated scenes)
 __global__ void noise_broadcast_kernel(float *h, int M, int H, int nd, const float *z, int group) {
@@ -666,6 +674,8 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
     const bool noisy = ex && ex->noise_dim > 0;
     if (noisy && (ex->noise_dim >= md->H || !ex->W_ctx || !ex->b_ctx || !ex->noise || ex->noise_group_tracks < 0))
         TNP_FAIL(-1, "tnp_lstm_forward_ex: bad noise interface (noise_dim %d)", ex->noise_dim);
+    const bool scaled = ex && ex->h_scale != nullptr;      // VAE: h <- h * vae_decoder(z) between encoder and decoder
+    if (noisy && scaled) TNP_FAIL(-1, "tnp_lstm_forward_ex: the noise interface and h_scale are exclusive");
     Workspace w;
     plan_workspace(md, M, workspace, w);
     if (workspace == nullptr || workspace_bytes < w.bytes)
@@ -755,7 +765,7 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
                 p.use_pos2 = 1;
             }
         }
-        if (noisy && p.have_next && st == T_obs - 1) {
+        if ((noisy || scaled) && p.have_next && st == T_obs - 1) {
             // S-GAN generator (sgan/sgan.py:200-221, 366): the last encoder step is finished on the clean hidden state,
             // then h <- [relu(W_ctx h + b_ctx) | z] for every track, then the first decoder step is prepared
             PrepArgs pa = p;
@@ -770,6 +780,11 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
                 clean = sv->h_clean;
                 noisy = hcur;
             }
+            if (scaled) {   // VAE add_noise (vae/vae.py:101-105): hidden <- hidden * vae_decoder(z), cell state unchanged
+                const long tot4 = (long)MH / 4;
+                hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((tot4 + 255) / 256)), dim3(256), 0, s, noisy, clean, ex->h_scale, tot4);
+                TNP_HIP(hipGetLastError());
+            } else {
             GemmArgs g;
             memset(&g, 0, sizeof(g));
             g.A1 = clean; g.lda1 = H; g.K1 = H;
@@ -781,6 +796,7 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
             hipLaunchKernelGGL(noise_broadcast_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, noisy, M, H,
                                ex->noise_dim, ex->noise, ex->noise_group_tracks);
             TNP_HIP(hipGetLastError());
+            }
             if (!sv) cur ^= 1;
             hcur = noisy;
             p.h = hcur;

@@ -409,7 +409,7 @@ class LSTM(torch.nn.Module):
         return rel_pred, pred, (out if keep else out[0])
 
     def _run_sequence(self, observed, goals, batch_split, truth, T_dec, w_ctx=None, b_ctx=None, noise=None,
-                      want_h_final=False, pad_to=None, fused_loss=None):
+                      want_h_final=False, pad_to=None, fused_loss=None, h_scale=None):
         """tnp_lstm_forward(_ex): T_obs-1 encoder steps + T_dec decoder steps; optional S-GAN hooks.
         ``fused_loss`` = (targets [T_loss, M, 2], mode, background_rate): the per-primary loss values of the last T_loss
         outputs are evaluated inside the sequence (returned in place of h_final as [T_loss, M] rows)."""
@@ -437,6 +437,11 @@ class LSTM(torch.nn.Module):
                 if M % groups:
                     raise ValueError('%d noise vectors for %d tracks' % (groups, M))
                 ex.noise_group_tracks = M // groups
+        if h_scale is not None:      # VAE: hidden <- hidden * h_scale [M, H] after the last encoder step
+            h_scale = _lib.f32c(h_scale, dev)
+            if tuple(h_scale.shape) != (M, self.hidden_dim):
+                raise ValueError('h_scale must be [%d, %d]' % (M, self.hidden_dim))
+            ex.h_scale = _lib.ptr(h_scale)
         if want_h_final:
             h_final = torch.empty(M, self.hidden_dim, dtype=torch.float32, device=dev)
             ex.h_final = _lib.ptr(h_final)

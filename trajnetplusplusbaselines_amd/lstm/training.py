@@ -194,6 +194,10 @@ class SequenceFn(torch.autograd.Function):
                                'the MI355X path has no CPU fallback' % dev)
         opts = opts or {}
         noise = opts.get('noise')
+        h_scale = None
+        if opts.get('h_scale_arg'):        # VAE: the [M, H] multiplier rides behind the parameters (it needs a gradient)
+            h_scale, params = params[-1], params[:-1]
+        ctx.has_h_scale = h_scale is not None
         ctx.reduce_fn = opts.get('reduce_fn')
         ctx.input_grad = bool(opts.get('input_grad')) and observed.requires_grad
         if ctx.input_grad and T_dec != 0:
@@ -267,6 +271,15 @@ class SequenceFn(torch.autograd.Function):
                 if M % groups:
                     raise ValueError('%d noise vectors for %d tracks' % (groups, M))
                 ex.noise_group_tracks = M // groups
+        if h_scale is not None:      # VAE add_noise (vae/vae.py:89-107): hidden <- hidden * vae_decoder(z) after the encoder
+            if noise is not None:
+                raise ValueError('noise and h_scale are exclusive')
+            g_scale = _lib.f32c(h_scale.detach(), dev)
+            if tuple(g_scale.shape) != (M, H):
+                raise ValueError('h_scale must be [M, H] = [%d, %d], got %s' % (M, H, tuple(g_scale.shape)))
+            h_enc = torch.empty(M, H, device=dev)
+            sv.h_clean = h_enc.data_ptr()
+            ex.h_scale = _lib.ptr(g_scale)
         # the whole sequence (encoder + decoder steps, feedback of the predicted positions) is one driver call
         _lib.check(L.tnp_lstm_forward_train(
             ctypes.byref(m), _lib.ptr(observed), T_obs, M, _lib.ptr(goals_t), _lib.ptr(idx.starts), _lib.ptr(idx.primary),
@@ -275,6 +288,9 @@ class SequenceFn(torch.autograd.Function):
         if noise is not None:
             s_noise = T_obs - 1
             ctx.noise_at = (s_noise, h_enc, h_all[s_noise][:, :H - nd].contiguous())
+        ctx.scale_at = None
+        if h_scale is not None and T_dec > 0:
+            ctx.scale_at = (T_obs - 1, h_enc, g_scale)
         decs = [0] * (T_obs - 1) + [1] * T_dec
         del keep
         ctx.model, ctx.idx, ctx.goals = model, idx, goals_t
@@ -445,8 +461,9 @@ class SequenceFn(torch.autograd.Function):
         sw.S, sw.M, sw.B, sw.n_max, sw.n_enc, sw.pos_offset = S, M, idx.B, idx.n_max, n_enc, ctx.pos_offset
         sw.nn_pool, sw.social_sparse, sw.directional_in = int(nn_pool), int(social and sparse_bwd), int(directional_in)
         sw.h_override_step = -1
-        if ctx.noise_at is not None:
-            sw.h_override_step, sw.h_override = ctx.noise_at[0] - 1, ctx.noise_at[1].data_ptr()
+        hook_at = ctx.noise_at if ctx.noise_at is not None else ctx.scale_at
+        if hook_at is not None:
+            sw.h_override_step, sw.h_override = hook_at[0] - 1, hook_at[1].data_ptr()
         sw.scene_start = idx.starts.data_ptr()
         sw.scene_slots = idx.slots.data_ptr() if idx.slots is not None else None
         sw.d_rel = d_rel.data_ptr() if d_rel is not None else None
@@ -492,7 +509,15 @@ class SequenceFn(torch.autograd.Function):
             if hi >= lo:
                 _lib.check(L.tnp_lstm_backward_sweep(ctypes.byref(sw), hi, lo, _lib.ptr(scratch), need, sp()), 'backward_sweep')
 
-        if ctx.noise_at is None:
+        d_h_scale = None
+        if ctx.scale_at is not None:
+            # backward of the VAE hook h_dec = h_enc * g: d g = dh * h_enc, d h_enc = dh * g (the cell state passes through)
+            s_hook, h_enc, g_scale = ctx.scale_at
+            sweep(S - 1, s_hook)
+            d_h_scale = dh * h_enc
+            dh.mul_(g_scale)
+            sweep(s_hook - 1, 0)
+        elif ctx.noise_at is None:
             sweep(S - 1, 0)
         else:
             s_noise, h_enc, ctx_act = ctx.noise_at
@@ -616,9 +641,9 @@ class SequenceFn(torch.autograd.Function):
         if lay_names:
             layer_wgrad(0, lay_names[0])     # first: the largest gradient (16.8 MB at config 2) gets the longest overlap
         h_out_all, h_prev_all = h_all[1:], h_all[:-1]
-        if ctx.noise_at is not None:     # the last encoder step's output is the hidden state BEFORE the noise was added
+        if hook_at is not None:     # the last encoder step's output is the hidden state BEFORE the noise was added / the scaling
             h_out_all = h_out_all.clone()
-            h_out_all[ctx.noise_at[0] - 1] = ctx.noise_at[1]
+            h_out_all[hook_at[0] - 1] = hook_at[1]
         if has_h2n:
             wgrad('hidden2normal.linear.weight', dlin_all, h_out_all, 'hidden2normal.linear.bias')
         n_enc = sum(1 for d in decs if not d)
@@ -696,6 +721,8 @@ class SequenceFn(torch.autograd.Function):
         out = [None, d_obs, None, None, None, None, None]
         for n in ctx.param_names:
             out.append(grads.get(n))
+        if ctx.has_h_scale:
+            out.append(d_h_scale if d_h_scale is not None else torch.zeros(M, H, device=dev))
         return tuple(out)
 
 
@@ -734,4 +761,7 @@ def run_sequence_with_grad(model, observed, goals, batch_split, truth, T_dec, op
     """(rel_pred, pred, h_last) attached to the autograd graph of the model's parameters (and of `observed` when
     opts['input_grad'] is set and it requires grad)."""
     params = _param_lists(model)[1]
+    if opts is not None and opts.get('h_scale') is not None:      # VAE: a differentiable [M, H] multiplier of the encoder's state
+        opts = dict(opts, h_scale_arg=True)
+        return SequenceFn.apply(model, observed, goals, batch_split, truth, T_dec, opts, *params, opts['h_scale'])
     return SequenceFn.apply(model, observed, goals, batch_split, truth, T_dec, opts, *params)
