@@ -359,6 +359,105 @@ def strong_scaling_leg(args, device, rank, world, barrier, global_scenes=256):
                               overlap='in-backward (parallel.GradReducer)' if world > 1 else None))
 
 
+def sgan_strong_leg(args, device, rank, world, barrier, global_scenes=128):
+    """BASELINE config 4 as a strong-scaling leg of the default run: S-GAN (directional n=12 generator + discriminator, k = 3,
+    noise_dim 16) on ONE batch of 128 scenes x 32 agents sharded over the ranks; SGAN.forward (teacher-forced 'g' mode: 3
+    generator samples + real / fake scores) and one discriminator step + one generator step (variety loss + adversarial loss,
+    gradients of the updated network SUM-reduced over the ranks, sgan/train_step.py)."""
+    import random
+    import torch.distributed as dist
+    from trajnetplusplusbaselines_amd import parallel
+    from trajnetplusplusbaselines_amd.lstm import PredictionLoss
+    from trajnetplusplusbaselines_amd.sgan.train_step import train_batch as sgan_train_batch
+    cfg = CONFIGS['sgan']
+    model = build_model(cfg, device)
+    gxy, gsplit = synth.linear_crowd(global_scenes, cfg['agents'], seed=44)
+    shard = parallel.shard_batch(gxy, torch.zeros(gxy.shape[1], 2), gsplit, rank, world)
+    lo, hi = shard.track_range
+    xy, split = gxy[:, lo:hi].contiguous().to(device), shard.batch_split
+    goals = torch.zeros(xy.shape[1], 2, device=device)
+    torch.manual_seed(1234)          # the same noise vectors and noisy labels on every rank
+    random.seed(1234)
+
+    def timed(fn, steps, warm):
+        for _ in range(warm):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    steps = max(5, min(args.steps, 30))
+    model.eval()
+    with torch.no_grad():
+        t_inf = timed(lambda: model(xy[:9], goals, split, prediction_truth=xy[9:21], step_type='g', pred_length=12,
+                                    pad_to=shard.pad_to), steps, 3)
+    model.train()
+    g_opt, d_opt = make_adam(model.generator.parameters()), make_adam(model.discriminator.parameters())
+    crit = PredictionLoss(keep_batch_dim=True)
+    t_steps = max(3, min(args.steps, 10))
+
+    def dg():
+        for st in ('d', 'g'):
+            sgan_train_batch(model, g_opt, d_opt, crit, xy, goals, split, st, n_global_scenes=shard.n_scenes_global,
+                             pad_to=shard.pad_to)
+    with torch.enable_grad():
+        t_tr = timed(dg, t_steps, 2)
+    rec = 3 * 19 + 2 * 20            # recurrent steps of one SGAN.forward: 3 generator samples + 2 discriminator encodings
+    return dict(workload='%s, ONE batch of %d scenes x %d agents sharded over %d GPU(s)' % (cfg['name'], global_scenes, cfg['agents'], world),
+                scaling='strong', n_gpus=world, global_scenes=global_scenes, scenes_this_rank=shard.n_scenes,
+                recurrent_steps_per_forward=rec,
+                inference=dict(value=global_scenes * 21 * steps / t_inf, unit='scene-steps/s (one SGAN.forward = 21 frames per scene)',
+                               steps=steps, ms_per_step=t_inf / steps * 1e3),
+                training=dict(value=global_scenes * 21 * t_steps / t_tr, unit='scene-steps/s (one d step + one g step = 21 frames per scene)',
+                              steps=t_steps, ms_per_step=t_tr / t_steps * 1e3,
+                              allreduce_bytes=(sum(p.numel() * 4 for p in model.parameters()) if world > 1 else 0)))
+
+
+def classical_leg(device, scenes=4096, agents=128):
+    """BASELINE config 5 inside the default run (N = 1): one timed pass of the three classical rollouts over 4096 scenes x
+    128 agents, inputs resident in HBM (bench.py --config classical has the full line with roofline and cpu_baseline)."""
+    S, A = scenes, agents
+    rng = np.random.RandomState(11)
+    M = S * A
+    pos = rng.rand(M, 2) * 8 - 4
+    vel = rng.randn(M, 2) * 0.6
+    goals = pos + vel * 4.8 + rng.randn(M, 2) * 0.2
+    speed = np.linalg.norm(vel, axis=1)
+    t = np.arange(9)[None, :, None]
+    obs = pos[:, None, :] + vel[:, None, :] * 0.4 * (t - 8) + rng.randn(M, 9, 2) * 0.03
+    z = rng.standard_normal((M, 5, 13, 6))
+    dv = lambda a, dt: torch.tensor(np.ascontiguousarray(a, dtype=dt), device=device)
+    d = dict(st=dv(np.concatenate([pos, vel, goals], axis=1), np.float64), starts=dv(np.arange(S + 1) * A, np.int32),
+             pos=dv(pos, np.float32), vel=dv(vel, np.float32), goals=dv(goals, np.float64), speed=dv(speed, np.float64),
+             vmax=dv(1.3 * speed, np.float32), obs=dv(obs, np.float64), z=dv(z, np.float64))
+    out_sf = torch.empty(12, M, 2, dtype=torch.float64, device=device)
+    out_orca = torch.empty(12, M, 2, dtype=torch.float32, device=device)
+    out_k = torch.empty(M, 13, 2, dtype=torch.float64, device=device)
+    L, P, sp = _lib.lib(), _lib.ptr, _lib.stream_ptr
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for timed in (False, True):
+        ev[0].record()
+        _lib.check(L.tnp_sf_rollout(P(d['st']), P(d['starts']), S, M, A, 12 * 8, 8, 0.5, 2.1, 0.3, 1.0 / 20, P(out_sf), sp()), 'sf')
+        ev[1].record()
+        _lib.check(L.tnp_orca_rollout(P(d['pos']), P(d['vel']), P(d['goals']), P(d['speed']), P(d['vmax']), P(d['starts']), S, M, A,
+                                      8 * 12 + 1, 8, 1.0 / 20, 1.5, 10, 1.5, 0.4, P(out_orca), None, sp()), 'orca')
+        ev[2].record()
+        _lib.check(L.tnp_kalman_predict(P(d['obs']), M, 9, 10, 13, 5, P(d['z']), 1e-5, 0.05 ** 2, P(out_k), sp()), 'kalman')
+        ev[3].record()
+        torch.cuda.synchronize()
+    per = {k: ev[i].elapsed_time(ev[i + 1]) for i, k in enumerate(('socialforce', 'orca', 'kalman'))}
+    tot = sum(per.values())
+    return dict(workload='classical.socialforce + ORCA + Kalman, %d scenes x %d agents, 9 obs + 12 pred, second pass timed' % (S, A),
+                ms_per_predictor=per, scene_steps_per_s_per_predictor={k: S * 21 / (v * 1e-3) for k, v in per.items()},
+                value=S * 21 / (tot * 1e-3), unit='scene-steps/s (all three predictors over the batch)',
+                finite=bool(torch.isfinite(out_sf).all() and torch.isfinite(out_orca).all() and torch.isfinite(out_k).all()))
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: run this script under `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>` (what the contract's command line does) and
@@ -623,6 +722,17 @@ def main():
             strong3 = strong_scaling_leg(args, device, rank, world, barrier)
         except Exception as exc:
             strong3 = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:300]))
+    strong4 = classical5 = None
+    if strong3 is not None and 'error' not in strong3:
+        try:
+            strong4 = sgan_strong_leg(args, device, rank, world, barrier)
+        except Exception as exc:
+            strong4 = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:300]))
+        if world == 1:
+            try:
+                classical5 = classical_leg(device)
+            except Exception as exc:
+                classical5 = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:300]))
 
     with torch.set_grad_enabled(args.train):
         # ---- roofline leg: same region again with HIP events around every launch of the dominant kernel ----
@@ -764,6 +874,8 @@ def main():
             'sustained': sustained,
             'training': training,
             'strong_scaling_config3': strong3,
+            'strong_scaling_config4_sgan': strong4,
+            'classical_config5': classical5,
         }
         if world == 1 and not args.no_cpu_baseline and not is_sgan:
             out['cpu_baseline'] = cpu_baseline(cfg, xy, split)

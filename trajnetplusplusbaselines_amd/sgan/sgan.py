@@ -46,6 +46,9 @@ class LSTMGenerator(LSTM):
         self.no_noise = no_noise
         self.noise_type = noise_type
         self.mlp_decoder_context = make_mlp([self.hidden_dim, self.hidden_dim - self.noise_dim])
+        #: slots the reference would pad the scenes to when this call holds a SHARD of a larger batch (_lib.SceneIndex);
+        #: None = the largest scene of the call.  Set by SGAN.forward(pad_to=...) / sgan.train_step for sharded training
+        self.pad_to = None
 
     def forward(self, observed, goals, batch_split, prediction_truth=None, n_predict=None, noise=None):
         """reference sgan/sgan.py:302-399.  `noise` ([noise_dim]) may be given explicitly; by default it is drawn with
@@ -62,20 +65,24 @@ class LSTMGenerator(LSTM):
         if self.no_noise:
             if training:
                 from ..lstm.training import run_sequence_with_grad
-                rel, pred, _ = run_sequence_with_grad(self, observed, goals, batch_split, truth, T_dec)
+                rel, pred, _ = run_sequence_with_grad(self, observed, goals, batch_split, truth, T_dec, {'pad_to': self._pad(batch_split)})
                 return rel, pred
-            rel, pred, _ = self._run_sequence(observed, goals, batch_split, truth, T_dec)
+            rel, pred, _ = self._run_sequence(observed, goals, batch_split, truth, T_dec, pad_to=self._pad(batch_split))
             return rel, pred
         if noise is None:
             noise = get_noise((self.noise_dim,), self.noise_type, device='cpu')
         if training:   # autograd through the sequence incl. the noise / context MLP (lstm/training.py)
             from ..lstm.training import run_sequence_with_grad
-            rel, pred, _ = run_sequence_with_grad(self, observed, goals, batch_split, truth, T_dec, {'noise': noise})
+            rel, pred, _ = run_sequence_with_grad(self, observed, goals, batch_split, truth, T_dec,
+                                                  {'noise': noise, 'pad_to': self._pad(batch_split)})
             return rel, pred
         lin = self.mlp_decoder_context[0]
         rel, pred, _ = self._run_sequence(observed, goals, batch_split, truth, T_dec, w_ctx=lin.weight, b_ctx=lin.bias,
-                                          noise=noise)
+                                          noise=noise, pad_to=self._pad(batch_split))
         return rel, pred
+
+    def _pad(self, batch_split):
+        return getattr(self, 'pad_to', None)
 
     def sample_k(self, observed, goals, batch_split, prediction_truth=None, n_predict=None, k=1):
         """k independent samples (the k `generator(...)` calls of reference sgan/sgan.py:94-100) as ONE sequence over k
@@ -118,6 +125,7 @@ class LSTMDiscriminator(LSTM):
                                                 pool_to_input=pool_to_input, goal_dim=goal_dim, goal_flag=goal_flag)
         self.real_classifier = make_mlp([self.hidden_dim, int(self.hidden_dim / 2), int(self.hidden_dim / 4), 1])
         self._dummy_head = None
+        self.pad_to = None            # see LSTMGenerator.pad_to
 
     # the C descriptor wants a decoder cell and a Hidden2Normal head; an encoder-only run never uses the first and
     # discards the output of the second, so hand it the encoder and a zero head
@@ -138,11 +146,12 @@ class LSTMDiscriminator(LSTM):
             # generator, for the positions themselves (lstm/training.py, opts input_grad)
             from ..lstm.training import run_sequence_with_grad
             frames = torch.cat([observed.to(dev, torch.float32), prediction.to(dev, torch.float32)], dim=0)
-            _, _, h = run_sequence_with_grad(self, frames, goals, batch_split, None, 0, {'input_grad': True})
+            _, _, h = run_sequence_with_grad(self, frames, goals, batch_split, None, 0,
+                                             {'input_grad': True, 'pad_to': getattr(self, 'pad_to', None)})
             prim = _lib.SceneIndex.get(batch_split, dev).starts[:-1].long()   # cached on the device: no host sync
             return self.real_classifier(h[prim])
         frames = torch.cat([_lib.f32c(observed, dev), _lib.f32c(prediction, dev)], dim=0)
-        _, _, h = self._run_sequence(frames, goals, batch_split, None, 0, want_h_final=True)
+        _, _, h = self._run_sequence(frames, goals, batch_split, None, 0, want_h_final=True, pad_to=getattr(self, 'pad_to', None))
         x = h[_lib.SceneIndex.get(batch_split, dev).starts[:-1].long()]
         for layer in self.real_classifier:
             if isinstance(layer, nn.Linear):
@@ -178,8 +187,10 @@ class SGAN(torch.nn.Module):
         self.skip_generator_graph_on_d = True
 
     def forward(self, observed, goals, batch_split, prediction_truth=None, n_predict=None, step_type='g',
-                pred_length=12):
-        """reference sgan/sgan.py:78-132: k generator samples, then real / fake discriminator scores."""
+                pred_length=12, pad_to=None):
+        """reference sgan/sgan.py:78-132: k generator samples, then real / fake discriminator scores.  ``pad_to``
+        (extension): the batch-wide slot count when this call holds a shard of a larger batch (parallel.shard_batch)."""
+        self.generator.pad_to = self.discriminator.pad_to = pad_to
         n_samples = 1 if step_type == 'd' else self.k           # the reference breaks out of its loop on a 'd' step
         # a discriminator step only updates the discriminator (sgan/trainer.py:286-300 steps d_optimizer): its generator
         # sample needs no autograd graph (the reference builds one and throws the generator's gradients away)
