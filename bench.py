@@ -118,8 +118,14 @@ def cpu_baseline(cfg, xy, split, budget_s=20.0):
             break
     if set_threads is not None:
         set_threads(int(max_threads))
+    # `cores` = the thread count the port actually scales to: the smallest one within 5 % of the best time (a 256-thread run
+    # that is no faster than the 16-thread run used 16 cores' worth of the host)
+    for e in sorted(sweep, key=lambda e: e['threads']):
+        if e['seconds_per_forward'] <= 1.05 * best:
+            best, best_threads = e['seconds_per_forward'], e['threads']
+            break
     return dict(value=scenes * 21 / best, unit='scene-steps/s', cores=best_threads, kind='port',
-                sample='full forwards of the same %d-scene batch at %s OpenMP threads (best: %d threads), '
+                sample='full forwards of the same %d-scene batch at %s OpenMP threads (reported: %d threads = the smallest count within 5 %% of the best time), '
                        'oracle/trajnet_oracle.c with OpenMP over tracks in the Linear layers' % (
                            scenes, '/'.join(str(e['threads']) for e in sweep), best_threads),
                 seconds_per_forward=best, host_cores=cores, thread_sweep=sweep,

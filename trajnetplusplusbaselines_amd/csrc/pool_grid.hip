@@ -189,6 +189,7 @@ __global__ void pair_cells_mask_kernel(const int32_t *__restrict__ raw, const in
     const int row = q / n_max, j = q - row * n_max;
     const int c = raw[q];
     int res = c, win = -1;
+    if (c > 0 && !winner) { cells[q] = c; return; }                  // only cell 0 can be clobbered; no winner wanted: done
     if (c >= 0) {
         const int base = row_base[row], ns = row_count[row], self = row - base;
         const int pad = row_padded ? row_padded[row] : pad_default;
