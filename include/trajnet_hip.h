@@ -391,6 +391,8 @@ typedef struct tnp_bwd_sweep {
     const float *st_pwT, *st_h2pT, *st_zeros;
     float *st_dG_all, *st_dfeat_all, *st_dph, *st_dpc;
     const int32_t *cellwin_all;      /* directional_in: [S,M,n_max] winner table of tnp_pool_pair_cells_autograd, or NULL */
+    int32_t *hm_wslot_all;           /* TNP_POOL_HIDDENMLP, optional out: [S,M,ms+mv] winning rows (position gradients), or NULL */
+    float *at_posrec_all;            /* TNP_POOL_ATTNMLP, optional out: [S,M,n_max,4] per-pair position-gradient records, or NULL */
 } tnp_bwd_sweep;
 /* sizeof() of the structs of this header as the library was compiled (which: 0 tnp_lstm_model, 1 tnp_lstm_extras,
  * 2 tnp_step_saves, 3 tnp_train_saves, 4 tnp_bwd_sweep; 0 for any other value) -- lets a binding check its mirrors */
@@ -480,7 +482,7 @@ TNP_API int tnp_pool_attn_pair_backward(const float *obs1, const float *obs2, co
                                         const int32_t *scene_start, int B, int n_max, const int32_t *scene_slots, int ms,
                                         int mv, int mh, const float *W_spatial, const float *b_spatial, const float *W_vel,
                                         const float *b_vel, float fill, const float *u, int ldu, const float *d_ebar, int ldd, float *du, float *A3,
-                                        float *dEh, float *ebar, int lde, void *stream);
+                                        float *dEh, float *ebar, int lde, float *pos_rec, void *stream);
 TNP_API int tnp_pool_attn_self_backward(const float *obs1, const float *obs2, const float *hidden_emb_pre, int ldh,
                                         const int32_t *row_base, const int32_t *row_count, int M, int n_max, int ms, int mv,
                                         int mh, const float *b_spatial, const float *b_vel, const float *de_self, int ldd,
@@ -490,7 +492,29 @@ TNP_API int tnp_pool_hiddenmlp_backward(const float *obs1, const float *obs2, co
                                         const int32_t *scene_start, const int32_t *row_base, const int32_t *row_count, int B,
                                         int M, int ms, int mv, int mh, const float *W_spatial, const float *b_spatial,
                                         const float *W_vel, const float *b_vel, const float *d_pooled, int ldp, float *G,
-                                        float *R, float *d_hidden_emb_pre, int32_t *winner_scratch, void *stream);
+                                        float *R, float *d_hidden_emb_pre, int32_t *winner_scratch, int32_t *winner_slots,
+                                        void *stream);
+/* Gradients with respect to the POSITIONS through the non-grid interaction modules -- needed when the frames fed to the
+ * sequence carry gradient (the S-GAN discriminator scoring the generator's prediction, sgan/sgan.py:512-576 under autograd;
+ * the reference trainer gives the discriminator a copy of the generator's module, sgan/trainer.py:590-592).  Rows are the
+ * stacked steps (R = steps * M) with their scenes in row_base / row_count [R]; d_obs1 / d_obs2 [R, 2] out.
+ *   tnp_pool_nn_pos_backward: NearestNeighborMLP / NearestNeighborLSTM features (lstm/non_gridbased_pooling.py:98-147): the
+ *     top-n selection carries no gradient, the gathered [rel pos | rel vel] attributes do (NaN components excluded);
+ *     d_pre [R, n*d] = gradient of the embedding's pre-activation, W [d, input_dim]; sel_scratch [R, n] int32,
+ *     ga_scratch [R, n, 4].
+ *   tnp_pool_hiddenmlp_pos_backward: HiddenStateMLPPooling (:196-239): the max-pool routes dimension kk's gradient G [R, ms+mv]
+ *     to the slot winner_slots [R, ms+mv] (row index RELATIVE TO ITS OWN STEP's first row when M_step > 0 -- what the
+ *     backward sweep leaves in hm_wslot_all -- or -1; tnp_pool_hiddenmlp_backward's optional last output). */
+TNP_API int tnp_pool_nn_pos_backward(const float *obs1, const float *obs2, const int32_t *row_base, const int32_t *row_count,
+                                     int R, int n_max, int n_sel, int in_dim, const float *W, int d, const float *d_pre, int ldd,
+                                     int32_t *sel_scratch, float *ga_scratch, float *d_obs1, float *d_obs2, void *stream);
+/*   tnp_pool_pair_pos_gather: AttentionMLPPooling (:297-351): tnp_pool_attn_pair_backward's optional `pos_rec` [R, n_max, 4] holds
+ *     per (ego, slot) the gradient of the pair's relative position and relative velocity; gathered per row here. */
+TNP_API int tnp_pool_pair_pos_gather(const float *pair_records, const int32_t *row_base, const int32_t *row_count, int R, int n_max,
+                                     float *d_obs1, float *d_obs2, void *stream);
+TNP_API int tnp_pool_hiddenmlp_pos_backward(const float *G, const int32_t *winner_slots, const float *W_spatial,
+                                            const float *W_vel, const int32_t *row_base, const int32_t *row_count, int R,
+                                            int M_step, int ms, int mv, float *d_obs1, float *d_obs2, void *stream);
 TNP_API size_t tnp_colsum_prod_workspace_bytes(long rows, int cols);
 TNP_API int tnp_colsum_prod(const float *G, const float *R, long rows, int cols, float *dW, float *db, void *workspace,
                             size_t workspace_bytes, void *stream);

@@ -54,10 +54,18 @@ def _worker(rank, world, port, ret):
         p1.grad = torch.full((5, 3), float(rank + 1))
         p2.grad = torch.full((7,), 10.0 * (rank + 1))
         n_msgs = parallel.allreduce_gradients([p1, p2, p3], bucket_bytes=16)
-        reducer = parallel.GradReducer()                      # the in-backward form: asynchronous, one handle per gradient
+        reducer = parallel.GradReducer(coalesce_below=0)      # the in-backward form: asynchronous, one handle per gradient
         t1, t2 = torch.full((6,), float(rank + 1)), torch.full((3, 2), 10.0 * (rank + 1))
         handles = [reducer(t1), reducer(t2)]
         for h in handles:
+            h.wait()
+        # small gradients coalesced into one flattened message, a large one on its own
+        red2 = parallel.GradReducer(coalesce_below=64)
+        s1, s2, big = torch.full((5,), float(rank + 1)), torch.full((2, 3), 2.0 * (rank + 1)), torch.full((40,), 3.0 * (rank + 1))
+        hs = [red2(s1), red2(big), red2(s2)]
+        hs.append(red2.flush())
+        assert red2.flush() is None
+        for h in hs:
             h.wait()
         if rank == 0:
             ret['full'] = full.numpy()
@@ -68,6 +76,7 @@ def _worker(rank, world, port, ret):
             ret['n_msgs'] = n_msgs
             ret['p3_none'] = p3.grad is None
             ret['reducer'] = (t1.tolist(), t2.reshape(-1).tolist(), reducer.messages, reducer.bytes)
+            ret['coalesced'] = (s1.tolist(), s2.reshape(-1).tolist(), big.tolist(), red2.messages, red2.bytes)
     finally:
         dist.destroy_process_group()
 
@@ -94,6 +103,7 @@ def test_two_rank_scene_sharding_matches_single_process():
     assert np.all(ret['g1'] == 3.0) and np.all(ret['g2'] == 30.0)
     assert ret['n_msgs'] == 2 and ret['p3_none']
     assert ret['reducer'] == ([3.0] * 6, [30.0] * 6, 2, 48)
+    assert ret['coalesced'] == ([3.0] * 5, [6.0] * 6, [9.0] * 40, 2, (5 + 6 + 40) * 4)      # two messages for three tensors
 
 
 @pytest.mark.parametrize('balance', ['scenes', 'tracks', 'pairs'])

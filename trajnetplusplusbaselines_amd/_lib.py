@@ -134,13 +134,18 @@ def lib():
                             _fp, _fp, ctypes.c_size_t, _fp]
     L.tnp_pool_hiddenmlp_backward.argtypes = [_fp, _fp, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, _fp, _fp, _fp, _fp,
-                                              _fp]
+                                              _fp, _fp]
+    L.tnp_pool_nn_pos_backward.argtypes = [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
+                                           ctypes.c_int, _fp, ctypes.c_int, _fp, _fp, _fp, _fp, _fp]
+    L.tnp_pool_hiddenmlp_pos_backward.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, _fp, _fp, _fp]
     L.tnp_colsum_prod_workspace_bytes.restype = ctypes.c_size_t
     L.tnp_colsum_prod_workspace_bytes.argtypes = [ctypes.c_long, ctypes.c_int]
     L.tnp_colsum_prod.argtypes = [_fp, _fp, ctypes.c_long, ctypes.c_int, _fp, _fp, _fp, ctypes.c_size_t, _fp]
     L.tnp_pool_attn_pair_backward.argtypes = [_fp, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, ctypes.c_float, _fp, ctypes.c_int,
-                                              _fp, ctypes.c_int, _fp, _fp, _fp, _fp, ctypes.c_int, _fp]
+                                              _fp, ctypes.c_int, _fp, _fp, _fp, _fp, ctypes.c_int, _fp, _fp]
+    L.tnp_pool_pair_pos_gather.argtypes = [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]
     L.tnp_pool_attn_self_backward.argtypes = [_fp, _fp, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, _fp, _fp, _fp, _fp, _fp]
     L.tnp_transpose.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]

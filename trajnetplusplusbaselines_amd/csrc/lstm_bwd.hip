@@ -1485,7 +1485,7 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
             TNP_RC(tnp_pool_hiddenmlp_backward(o1, o2, mh > 0 ? sv->enc_all + r * mh : nullptr, mh, a->scene_start, a->row_base,
                                                a->row_count, a->B, M, ms, mv, mh, md->Wp[0], md->bp[0], md->Wp[1], md->bp[1],
                                                w.d_pooled, D, a->hm_G_all + r * GDm, a->hm_R_all + r * GDm * 2, denc, w.widx,
-                                               stream));
+                                               a->hm_wslot_all ? a->hm_wslot_all + r * GDm : nullptr, stream));
             if (mh > 0) {
                 TNP_RC(tnp_linear_forward(denc, mh, a->whT, mh, nullptr, w.tmp_h, H, M, H, mh, 0, 0, stream));
                 extra = w.tmp_h;
@@ -1524,7 +1524,8 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
             float *dus = a->at_du_all + r * LU;
             TNP_RC(tnp_pool_attn_pair_backward(o1, o2, hpre, mh, a->scene_start, a->B, a->n_max, a->scene_slots, ms, mv, mh, md->Wp[0], md->bp[0],
                                                md->Wp[1], md->bp[1], md->constant, w.at_u, LU, w.d_pooled, D, dus,
-                                               a->at_A_all + r * GDm * 3, w.at_deh, a->at_ebar_all + r * D, D, stream));
+                                               a->at_A_all + r * GDm * 3, w.at_deh, a->at_ebar_all + r * D, D,
+                                               a->at_posrec_all ? a->at_posrec_all + r * a->n_max * 4 : nullptr, stream));
             float *dqs = a->at_dq_all + r * D;
             TNP_RC(tnp_linear_forward(dus, LU, a->at_WuT, LU, nullptr, dqs, D, M, D, LU, 0, 0, stream));               // dq = Wu^T du
             TNP_RC(tnp_linear_forward(dqs, D, a->at_WqT, D, nullptr, w.d_pooled, D, M, D, D, 0, 0, stream));           // de_self

@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) pool_hiddenmlp_backward_kernel(const floa
                                                                       const float *__restrict__ Wv, const float *__restrict__ bv,
                                                                       const float *__restrict__ dpool, int ldp,
                                                                       float *__restrict__ G, float *__restrict__ R,
-                                                                      int32_t *__restrict__ widx) {
+                                                                      int32_t *__restrict__ widx, int32_t *__restrict__ wslot) {
     const int lo = scene_start[blockIdx.x], hi = scene_start[blockIdx.x + 1];
     const int D = ms + mh + mv, GD = ms + mv;
     for (int k = threadIdx.x; k < D; k += blockDim.x) {
@@ -249,6 +249,7 @@ __global__ void __launch_bounds__(256) pool_hiddenmlp_backward_kernel(const floa
                 G[(size_t)i * GD + kk] = g;
                 R[((size_t)i * GD + kk) * 2] = active ? brx : 0.0f;
                 R[((size_t)i * GD + kk) * 2 + 1] = active ? bry : 0.0f;
+                if (wslot) wslot[(size_t)i * GD + kk] = active ? bj : -1;     // position gradients: which slot the gradient is routed to
             }
         }
     }
@@ -340,6 +341,179 @@ __global__ void __launch_bounds__(256) colsum_reduce_kernel(const float *__restr
     if (lane == 0) {
         const int c = e / 3, q = e - c * 3;
         if (q < 2) dW[c * 2 + q] = acc; else db[c] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Gradients with respect to the POSITIONS through the non-grid interaction modules (needed when the frames fed to the
+// sequence carry gradient: the S-GAN discriminator scoring the generator's prediction, sgan/sgan.py:512-576 under autograd).
+// Rows are the stacked steps (row r = step * M + track); row_base / row_count give a row's scene.
+// ---------------------------------------------------------------------------------------------------------
+// NearestNeighborMLP features (lstm/non_gridbased_pooling.py:98-147): the selection of the n nearest neighbours carries no
+// gradient (indices), the gathered attributes [rel pos | rel vel] do, NaN components excluded (nan_to_num).  One wave per
+// ego: the selection of pool_nn_wave_kernel recomputed (same order: ascending distance, the earlier index wins ties), then
+// per slot k   ga[c] = sum_q dpre[i, k d + q] W[q, c]   masked like the attribute was.  Records: sel [R, n] (row or -1),
+// ga [R, n, 4].
+__global__ void __launch_bounds__(256) nn_pos_pairs_kernel(const float *__restrict__ obs1, const float *__restrict__ obs2,
+                                                           const int32_t *__restrict__ row_base, const int32_t *__restrict__ row_count,
+                                                           int R, int n_sel, int in_dim, const float *__restrict__ W, int d,
+                                                           const float *__restrict__ dpre, int ldd, int32_t *__restrict__ sel_out,
+                                                           float *__restrict__ ga_out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= R) return;
+    const int lo = row_base[i], ns = row_count[i], hi = lo + ns;
+    const float xi = obs2[2 * i], yi = obs2[2 * i + 1];
+    const float vxi = xi - obs1[2 * i], vyi = yi - obs1[2 * i + 1];
+    float dist[NN_WAVE_T];
+#pragma unroll
+    for (int t = 0; t < NN_WAVE_T; ++t) {
+        const int j = lo + lane + 64 * t;
+        dist[t] = INFINITY;
+        if (64 * t < ns) {
+            const int jc = j < hi ? j : hi - 1;
+            const float dx = obs2[2 * jc] - xi, dy = obs2[2 * jc + 1] - yi;
+            float dd = sqrtf(dx * dx + dy * dy);
+            if (dd != dd) dd = 1000.0f;
+            if (j < hi && j != i) dist[t] = dd;
+        }
+    }
+    int sel[NN_MAX_SEL];
+#pragma unroll
+    for (int k = 0; k < NN_MAX_SEL; ++k) {
+        sel[k] = -1;
+        if (k >= n_sel) continue;
+        float bd = INFINITY;
+        int bj = 0x7fffffff;
+#pragma unroll
+        for (int t = 0; t < NN_WAVE_T; ++t)
+            if (dist[t] < bd) { bd = dist[t]; bj = lo + lane + 64 * t; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float od = __shfl_xor(bd, off, 64);
+            const int oj = __shfl_xor(bj, off, 64);
+            if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+        }
+        if (bd < INFINITY) {
+            sel[k] = bj;
+#pragma unroll
+            for (int t = 0; t < NN_WAVE_T; ++t)
+                if (lo + lane + 64 * t == bj) dist[t] = INFINITY;
+        }
+    }
+    // lane <-> (slot k, attribute c)
+    for (int e = lane; e < n_sel * 4; e += 64) {
+        const int k = e >> 2, c = e & 3;
+        int j = -1;
+#pragma unroll
+        for (int kk = 0; kk < NN_MAX_SEL; ++kk)
+            if (kk == k) j = sel[kk];
+        float g = 0.0f;
+        if (j >= 0 && c < in_dim) {
+            float v;
+            if (c == 0) v = obs2[2 * j] - xi;
+            else if (c == 1) v = obs2[2 * j + 1] - yi;
+            else if (c == 2) v = (obs2[2 * j] - obs1[2 * j]) - vxi;
+            else v = (obs2[2 * j + 1] - obs1[2 * j + 1]) - vyi;
+            if (v == v) {                                            // nan_to_num: a NaN attribute passes nothing
+                for (int q = 0; q < d; ++q) g = fmaf(dpre[(size_t)i * ldd + k * d + q], W[q * in_dim + c], g);
+            }
+        }
+        ga_out[((size_t)i * n_sel + k) * 4 + c] = g;
+        if (c == 0) sel_out[(size_t)i * n_sel + k] = j;
+    }
+}
+
+// d obs2[t] = sum over the pairs (i, k) that selected t of (ga.pos + ga.vel)  -  sum over t's own slots of the same;
+// d obs1[t] = -(sum of ga.vel as neighbour) + (sum of ga.vel as ego).  One wave per row t, fixed shuffle tree.
+__global__ void __launch_bounds__(256) nn_pos_gather_kernel(const int32_t *__restrict__ sel, const float *__restrict__ ga,
+                                                            const int32_t *__restrict__ row_base, const int32_t *__restrict__ row_count,
+                                                            int R, int n_sel, float *__restrict__ d1, float *__restrict__ d2) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= R) return;
+    const int lo = row_base[t], ns = row_count[t];
+    float px = 0.0f, py = 0.0f, vx = 0.0f, vy = 0.0f;
+    for (int e = lane; e < ns * n_sel; e += 64) {
+        const int i = lo + e / n_sel, k = e - (e / n_sel) * n_sel;
+        const int j = sel[(size_t)i * n_sel + k];
+        if (j < 0) continue;
+        const float *g = ga + ((size_t)i * n_sel + k) * 4;
+        float sgn = 0.0f;
+        if (j == t) sgn += 1.0f;
+        if (i == t) sgn -= 1.0f;
+        if (sgn != 0.0f) { px = fmaf(sgn, g[0], px); py = fmaf(sgn, g[1], py); vx = fmaf(sgn, g[2], vx); vy = fmaf(sgn, g[3], vy); }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        px += __shfl_xor(px, off); py += __shfl_xor(py, off); vx += __shfl_xor(vx, off); vy += __shfl_xor(vy, off);
+    }
+    if (lane == 0) {
+        d2[2 * t] = px + vx; d2[2 * t + 1] = py + vy;
+        d1[2 * t] = -vx; d1[2 * t + 1] = -vy;
+    }
+}
+
+// Per-pair records rec [R, n_max, 4] = (d rel pos x, y, d rel vel x, y) of (ego row i, slot j of its scene) -- AttentionMLPPooling's
+// pair kernel leaves them -- gathered per row t: + as the neighbour (slot t - lo of every ego i), - as the ego (all its slots).
+__global__ void __launch_bounds__(256) pair_pos_gather_kernel(const float *__restrict__ rec, const int32_t *__restrict__ row_base,
+                                                              const int32_t *__restrict__ row_count, int R, int n_max,
+                                                              float *__restrict__ d1, float *__restrict__ d2) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= R) return;
+    const int lo = row_base[t], ns = row_count[t], tt = t - lo;
+    float px = 0.0f, py = 0.0f, vx = 0.0f, vy = 0.0f;
+    for (int q = lane; q < ns; q += 64) {
+        const float4 a = *reinterpret_cast<const float4 *>(rec + ((size_t)(lo + q) * n_max + tt) * 4);     // ego lo + q sees t
+        const float4 b = *reinterpret_cast<const float4 *>(rec + ((size_t)t * n_max + q) * 4);             // t sees slot q
+        px += a.x - b.x; py += a.y - b.y; vx += a.z - b.z; vy += a.w - b.w;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        px += __shfl_xor(px, off); py += __shfl_xor(py, off); vx += __shfl_xor(vx, off); vy += __shfl_xor(vy, off);
+    }
+    if (lane == 0) {
+        d2[2 * t] = px + vx; d2[2 * t + 1] = py + vy;
+        d1[2 * t] = -vx; d1[2 * t + 1] = -vy;
+    }
+}
+
+// HiddenStateMLPPooling (lstm/non_gridbased_pooling.py:196-239): the max-pool routes the gradient of pooled dimension kk to
+// ONE slot (tnp_pool_hiddenmlp_backward: G [R, ms+mv] routed gradient of the pre-activation, wslot [R, ms+mv] the winning
+// row or -1); its input is the relative position (spatial part) or 4 x the relative velocity (velocity part), so
+//   d obs2[winner] += G W[kk, :] (x4 for the velocity part), d obs2[ego] -= the same, d obs1 the velocity part negated.
+// One wave per row t, lanes over (ego of the scene, dimension).
+__global__ void __launch_bounds__(256) hiddenmlp_pos_gather_kernel(const float *__restrict__ G, const int32_t *__restrict__ wslot,
+                                                                   const float *__restrict__ Ws, const float *__restrict__ Wv,
+                                                                   const int32_t *__restrict__ row_base, const int32_t *__restrict__ row_count,
+                                                                   int R, int M_step, int ms, int mv, float *__restrict__ d1,
+                                                                   float *__restrict__ d2) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= R) return;
+    const int lo = row_base[t], ns = row_count[t], GD = ms + mv;
+    const int off = M_step > 0 ? (t / M_step) * M_step : 0;          // winner rows are relative to their own step
+    float px = 0.0f, py = 0.0f, vx = 0.0f, vy = 0.0f;
+    for (int e = lane; e < ns * GD; e += 64) {
+        const int i = lo + e / GD, kk = e - (e / GD) * GD;
+        const int j = wslot[(size_t)i * GD + kk];
+        if (j < 0) continue;
+        float sgn = 0.0f;
+        if (j + off == t) sgn += 1.0f;
+        if (i == t) sgn -= 1.0f;
+        if (sgn == 0.0f) continue;
+        const float g = sgn * G[(size_t)i * GD + kk];
+        if (kk < ms) { px = fmaf(g, Ws[2 * kk], px); py = fmaf(g, Ws[2 * kk + 1], py); }
+        else { const int q = kk - ms; vx = fmaf(g * 4.0f, Wv[2 * q], vx); vy = fmaf(g * 4.0f, Wv[2 * q + 1], vy); }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        px += __shfl_xor(px, off); py += __shfl_xor(py, off); vx += __shfl_xor(vx, off); vy += __shfl_xor(vy, off);
+    }
+    if (lane == 0) {
+        d2[2 * t] = px + vx; d2[2 * t + 1] = py + vy;
+        d1[2 * t] = -vx; d1[2 * t + 1] = -vy;
     }
 }
 
@@ -550,7 +724,8 @@ __global__ void __launch_bounds__(64) pool_attn_pair_backward_kernel(const float
                                                                      const float *__restrict__ u, int ldu,
                                                                      const float *__restrict__ debar, int ldd,
                                                                      float *__restrict__ du, float *__restrict__ A3,
-                                                                     float *__restrict__ dEh, float *__restrict__ ebar, int lde) {
+                                                                     float *__restrict__ dEh, float *__restrict__ ebar, int lde,
+                                                                     float *__restrict__ pos_rec) {
     extern __shared__ float att_sc[];                      // [2][n_max]: softmax weights, then da | [ns][4] x, y, vx, vy | [ns][mh]
     const int lo = scene_start[blockIdx.x], hi = scene_start[blockIdx.x + 1], ns = hi - lo;
     float *att_a = att_sc, *att_da = att_sc + n_max;
@@ -663,6 +838,23 @@ __global__ void __launch_bounds__(64) pool_attn_pair_backward_kernel(const float
                     a1[t] = fmaf(de, ry[t], a1[t]);
                     ab[t] += de;
                 }
+            }
+            if (pos_rec) {
+                // position gradients (the frames carry gradient: S-GAN discriminator in a generator step): the pair's
+                // embedding inputs are the relative position (spatial units) and 4 x the relative velocity (velocity units)
+                float gpx = 0.0f, gpy = 0.0f, gvx = 0.0f, gvy = 0.0f;
+#pragma unroll
+                for (int t = 0; t < ATT_MAXD_PER_LANE; ++t) {
+                    const int k = lane + 64 * t;
+                    if (k >= D || (k >= ms && k < ms + mh)) continue;
+                    if (!(e[t] > 0.0f && rx[t] == rx[t] && ry[t] == ry[t])) continue;
+                    const float de = fmaf(a, db[t], ds * ui[t]);
+                    if (k < ms) { gpx = fmaf(de, w0[t], gpx); gpy = fmaf(de, w1[t], gpy); }
+                    else { gvx = fmaf(de * 4.0f, w0[t], gvx); gvy = fmaf(de * 4.0f, w1[t], gvy); }
+                }
+                gpx = wave_sum(gpx); gpy = wave_sum(gpy); gvx = wave_sum(gvx); gvy = wave_sum(gvy);
+                if (lane == 0)
+                    *reinterpret_cast<float4 *>(pos_rec + ((size_t)i * n_max + (j - lo)) * 4) = make_float4(gpx, gpy, gvx, gvy);
             }
         }
         if (npad > 0) {
@@ -877,7 +1069,8 @@ extern "C" TNP_API int tnp_pool_hiddenmlp_backward(const float *obs1, const floa
                                                    const int32_t *row_count, int B, int M, int ms, int mv, int mh,
                                                    const float *W_spatial, const float *b_spatial, const float *W_vel,
                                                    const float *b_vel, const float *d_pooled, int ldp, float *G, float *R,
-                                                   float *d_hidden_emb_pre, int32_t *winner_scratch, void *stream) {
+                                                   float *d_hidden_emb_pre, int32_t *winner_scratch, int32_t *winner_slots,
+                                                   void *stream) {
     if (B <= 0 || M <= 0) return 0;
     if (mh > 0 && (!hidden_emb_pre || !d_hidden_emb_pre || !winner_scratch))
         TNP_FAIL(-1, "tnp_pool_hiddenmlp_backward: hidden-embedding buffers missing");
@@ -885,13 +1078,49 @@ extern "C" TNP_API int tnp_pool_hiddenmlp_backward(const float *obs1, const floa
     const int threads = D <= 64 ? 64 : (D <= 128 ? 128 : 256);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(tnp::pool_hiddenmlp_backward_kernel, dim3(B, 32), dim3(threads), 0, s, obs1, obs2, hidden_emb_pre, ldh,
-                       scene_start, ms, mv, mh, W_spatial, b_spatial, W_vel, b_vel, d_pooled, ldp, G, R, winner_scratch);
+                       scene_start, ms, mv, mh, W_spatial, b_spatial, W_vel, b_vel, d_pooled, ldp, G, R, winner_scratch, winner_slots);
     TNP_HIP(hipGetLastError());
     if (mh > 0) {
         hipLaunchKernelGGL(tnp::pool_hiddenmlp_gather_kernel, dim3((M + 3) / 4), dim3(256), 0, s, winner_scratch, d_pooled, ldp,
                            row_base, row_count, M, ms, mh, d_hidden_emb_pre);
         TNP_HIP(hipGetLastError());
     }
+    return 0;
+}
+
+extern "C" TNP_API int tnp_pool_nn_pos_backward(const float *obs1, const float *obs2, const int32_t *row_base,
+                                                const int32_t *row_count, int R, int n_max, int n_sel, int in_dim, const float *W,
+                                                int d, const float *d_pre, int ldd, int32_t *sel_scratch, float *ga_scratch,
+                                                float *d_obs1, float *d_obs2, void *stream) {
+    if (R <= 0) return 0;
+    if (n_sel < 1 || n_sel > tnp::NN_MAX_SEL || (in_dim != 2 && in_dim != 4)) TNP_FAIL(-1, "tnp_pool_nn_pos_backward: n = %d, input_dim = %d", n_sel, in_dim);
+    if (n_max > 64 * tnp::NN_WAVE_T) TNP_FAIL(-1, "tnp_pool_nn_pos_backward: scenes of more than %d tracks", 64 * tnp::NN_WAVE_T);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tnp::nn_pos_pairs_kernel, dim3((R + 3) / 4), dim3(256), 0, s, obs1, obs2, row_base, row_count, R, n_sel, in_dim, W,
+                       d, d_pre, ldd, sel_scratch, ga_scratch);
+    TNP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(tnp::nn_pos_gather_kernel, dim3((R + 3) / 4), dim3(256), 0, s, sel_scratch, ga_scratch, row_base, row_count, R,
+                       n_sel, d_obs1, d_obs2);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" TNP_API int tnp_pool_pair_pos_gather(const float *pair_records, const int32_t *row_base, const int32_t *row_count, int R,
+                                                int n_max, float *d_obs1, float *d_obs2, void *stream) {
+    if (R <= 0) return 0;
+    hipLaunchKernelGGL(tnp::pair_pos_gather_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, pair_records, row_base,
+                       row_count, R, n_max, d_obs1, d_obs2);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" TNP_API int tnp_pool_hiddenmlp_pos_backward(const float *G, const int32_t *winner_slots, const float *W_spatial,
+                                                       const float *W_vel, const int32_t *row_base, const int32_t *row_count, int R,
+                                                       int M_step, int ms, int mv, float *d_obs1, float *d_obs2, void *stream) {
+    if (R <= 0) return 0;
+    hipLaunchKernelGGL(tnp::hiddenmlp_pos_gather_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, G, winner_slots, W_spatial,
+                       W_vel, row_base, row_count, R, M_step, ms, mv, d_obs1, d_obs2);
+    TNP_HIP(hipGetLastError());
     return 0;
 }
 
@@ -919,7 +1148,8 @@ extern "C" TNP_API int tnp_pool_attn_pair_backward(const float *obs1, const floa
                                                    int ms, int mv, int mh,
                                                    const float *W_spatial, const float *b_spatial, const float *W_vel,
                                                    const float *b_vel, float fill, const float *u, int ldu, const float *d_ebar,
-                                                   int ldd, float *du, float *A3, float *dEh, float *ebar, int lde, void *stream) {
+                                                   int ldd, float *du, float *A3, float *dEh, float *ebar, int lde, float *pos_rec,
+                                                   void *stream) {
     if (B <= 0) return 0;
     const int D = ms + mh + mv;
     if (D > 64 * tnp::ATT_MAXD_PER_LANE) TNP_FAIL(-1, "AttentionMLPPooling: mlp_dim %d > %d", D, 64 * tnp::ATT_MAXD_PER_LANE);
@@ -932,7 +1162,7 @@ extern "C" TNP_API int tnp_pool_attn_pair_backward(const float *obs1, const floa
     if (ldu < D + 1) TNP_FAIL(-1, "tnp_pool_attn_pair_backward: ldu %d < mlp_dim + 1", ldu);
     hipLaunchKernelGGL(tnp::pool_attn_pair_backward_kernel, dim3(B, n_max < 64 ? n_max : 64), dim3(64), lds,
                        (hipStream_t)stream, obs1, obs2, hidden_emb_pre, ldh, scene_start, n_max, scene_slots, ms, mv, mh, W_spatial, b_spatial,
-                       W_vel, b_vel, fill, u, ldu, d_ebar, ldd, du, A3, dEh, ebar, lde);
+                       W_vel, b_vel, fill, u, ldu, d_ebar, ldd, du, A3, dEh, ebar, lde, pos_rec);
     TNP_HIP(hipGetLastError());
     return 0;
 }

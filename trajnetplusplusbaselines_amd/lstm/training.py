@@ -106,7 +106,7 @@ class BwdSweep(ctypes.Structure):
                 ('at_A_all', ctypes.c_void_p), ('stateful', ctypes.c_int32), ('st_pwT', ctypes.c_void_p),
                 ('st_h2pT', ctypes.c_void_p), ('st_zeros', ctypes.c_void_p), ('st_dG_all', ctypes.c_void_p),
                 ('st_dfeat_all', ctypes.c_void_p), ('st_dph', ctypes.c_void_p), ('st_dpc', ctypes.c_void_p),
-                ('cellwin_all', ctypes.c_void_p)]
+                ('cellwin_all', ctypes.c_void_p), ('hm_wslot_all', ctypes.c_void_p), ('at_posrec_all', ctypes.c_void_p)]
 
 
 def _attention_param_grads(pool, P, grads, wgrad, dout_all, bufs, denc_all, h_prev_all, rows, L, dev, sp):
@@ -158,6 +158,55 @@ def _attention_param_grads(pool, P, grads, wgrad, dout_all, bufs, denc_all, h_pr
     grads['pool.spatial_embedding.0.weight'], grads['pool.spatial_embedding.0.bias'] = dW2[:ms], db2[:ms]
     if mv:
         grads['pool.vel_embedding.0.weight'], grads['pool.vel_embedding.0.bias'] = dW2[ms:], db2[ms:]
+
+
+def _nongrid_position_grads(pool, P, S, M, idx, o1_all, o2_all, dnn_all, st_bufs, st_saves, hm_G_all, hm_wslot_all, L, dev, sp,
+                            at_posrec_all=None):
+    """(d obs1, d obs2) [S, M, 2]: what autograd sends to the positions THROUGH a non-grid interaction module (the frames of an
+    S-GAN discriminator carry gradient in a generator step; the reference's trainer gives the discriminator a copy of the
+    generator's module, sgan/trainer.py:590-592).  NearestNeighborMLP / NearestNeighborLSTM: through the gathered
+    [rel pos | rel vel] attributes of the selected neighbours (the selection itself has no gradient); TrajectronPooling: through
+    the ego's [pos, vel] and the whole-batch sum over the other visible tracks; HiddenStateMLPPooling: through the relative
+    position / velocity of the slot each max-pooled dimension was routed to; AttentionMLPPooling: through the relative position /
+    velocity of every (ego, slot) pair (records left by the sweep's pair kernel)."""
+    name = type(pool).__name__
+    R = S * M
+    d_o1 = torch.empty(S, M, 2, device=dev)
+    d_o2 = torch.empty(S, M, 2, device=dev)
+    rb_all, rc_all, _ = idx.stacked_rows(S)
+    if name in ('NearestNeighborMLP', 'NearestNeighborLSTM'):
+        n = pool.n
+        in_dim = pool.input_dim if name == 'NearestNeighborMLP' else 4
+        W = _lib.f32c(P['pool.embedding.0.weight'].detach(), dev)
+        d = W.shape[0]
+        dpre = dnn_all if name == 'NearestNeighborMLP' else st_bufs['dfeat']         # gradient of the embedding's pre-activation
+        sel = torch.empty(R, n, dtype=torch.int32, device=dev)
+        ga = torch.empty(R, n, 4, device=dev)
+        _lib.check(L.tnp_pool_nn_pos_backward(_lib.ptr(o1_all), _lib.ptr(o2_all), _lib.ptr(rb_all), _lib.ptr(rc_all), R, idx.n_max, n,
+                                              in_dim, _lib.ptr(W), d, _lib.ptr(dpre), n * d, _lib.ptr(sel), _lib.ptr(ga),
+                                              _lib.ptr(d_o1), _lib.ptr(d_o2), sp()), 'tnp_pool_nn_pos_backward')
+    elif name == 'TrajectronPooling':
+        # features = [pos_i, vel_i | sum over the OTHER visible tracks of the whole batch of (pos_j, vel_j)] (:513-529)
+        W = P['pool.embedding.0.weight'].detach()                                   # [P, 8]
+        din = _mm(st_bufs['dfeat'].reshape(R, -1), W.t()).reshape(S, M, 8)          # dfeat . W on the fp32 matrix cores
+        vis = (torch.isfinite(o1_all).all(dim=2) & torch.isfinite(o2_all).all(dim=2)).unsqueeze(2).to(din.dtype)
+        own, ssum = din[..., :4] * vis, din[..., 4:] * vis
+        d4 = own + (ssum.sum(dim=1, keepdim=True) - ssum) * vis
+        d_o2 = d4[..., :2] + d4[..., 2:]
+        d_o1 = -d4[..., 2:]
+    elif name == 'HiddenStateMLPPooling':
+        Ws = _lib.f32c(P['pool.spatial_embedding.0.weight'].detach(), dev)
+        Wv = _lib.f32c(P['pool.vel_embedding.0.weight'].detach(), dev) if pool.mlp_dim_vel else Ws
+        _lib.check(L.tnp_pool_hiddenmlp_pos_backward(_lib.ptr(hm_G_all), _lib.ptr(hm_wslot_all), _lib.ptr(Ws), _lib.ptr(Wv),
+                                                     _lib.ptr(rb_all), _lib.ptr(rc_all), R, M, pool.mlp_dim_spatial, pool.mlp_dim_vel,
+                                                     _lib.ptr(d_o1), _lib.ptr(d_o2), sp()), 'tnp_pool_hiddenmlp_pos_backward')
+    elif name == 'AttentionMLPPooling':
+        # the pair kernel of the sweep left d(rel pos), d(rel vel) per (ego, slot); the ego's own slot cancels (rel = 0)
+        _lib.check(L.tnp_pool_pair_pos_gather(_lib.ptr(at_posrec_all), _lib.ptr(rb_all), _lib.ptr(rc_all), R, idx.n_max,
+                                              _lib.ptr(d_o1), _lib.ptr(d_o2), sp()), 'tnp_pool_pair_pos_gather')
+    else:
+        raise NotImplementedError('position gradients through %s' % name)
+    return d_o1, d_o2
 
 
 def _train_saves(h_all, c_all, X_all, gates_all, act_all, enc_all, attrs_all, win_all, o1_all, o2_all, st=None):
@@ -365,8 +414,7 @@ class SequenceFn(torch.autograd.Function):
         social = grid_pool and pool.type_ == 'social'
         dnn_all = torch.empty(S, M, pool.out_dim, device=dev) if nn_pool else None
         directional_in = ctx.input_grad and grid_pool and pool.type_ == 'directional'
-        if ctx.input_grad and (nn_pool or hm_pool or at_pool or st_pool):
-            raise NotImplementedError('position gradients through %s' % type(pool).__name__)
+        pos_grad_pool = ctx.input_grad and (nn_pool or hm_pool or at_pool or st_pool)   # position gradients through a non-grid module
         sparse_bwd = ctx.win_all is not None      # first layer's gradients from the winner tables (csrc/lstm_bwd.hip)
         layT = [T(n + '.weight') if (li > 0 or ((social or directional_in) and not sparse_bwd)) else None
                 for li, n in enumerate(lay_names)]
@@ -480,12 +528,20 @@ class SequenceFn(torch.autograd.Function):
             sw.stateful = 1
             sw.st_pwT, sw.st_h2pT, sw.st_zeros = (st_bufs[k].data_ptr() for k in ('pwT', 'h2pT', 'zeros'))
             sw.st_dG_all, sw.st_dfeat_all, sw.st_dph, sw.st_dpc = (st_bufs[k].data_ptr() for k in ('dG', 'dfeat', 'dph', 'dpc'))
+        at_posrec_all = None
         if at_pool:
+            if pos_grad_pool:
+                at_posrec_all = torch.empty(S, M, idx.n_max, 4, device=dev)
+                sw.at_posrec_all = at_posrec_all.data_ptr()
             sw.attention, sw.at_WuT, sw.at_WqT = 1, at_wuT.data_ptr(), at_wqT.data_ptr()
             sw.at_eself_all, sw.at_q_all, sw.at_dq_all = (at_bufs[k].data_ptr() for k in ('eself', 'q', 'dq'))
             sw.at_ebar_all, sw.at_du_all, sw.at_A_all = (at_bufs[k].data_ptr() for k in ('ebar', 'du', 'A'))
+        hm_wslot_all = None
         if hm_pool:
             sw.hidden_mlp, sw.hm_G_all, sw.hm_R_all = 1, hm_G_all.data_ptr(), hm_R_all.data_ptr()
+            if pos_grad_pool:
+                hm_wslot_all = torch.empty(S, M, pool.mlp_dim_spatial + pool.mlp_dim_vel, dtype=torch.int32, device=dev)
+                sw.hm_wslot_all = hm_wslot_all.data_ptr()
         if grid_pool and cells_all is not None:
             sw.cells_all = cells_all.data_ptr()
             sw.cellwin_all = cellwin_all.data_ptr() if cellwin_all is not None else None
@@ -547,6 +603,12 @@ class SequenceFn(torch.autograd.Function):
             d_obs = torch.zeros(ctx.T_obs, M, 2, device=dev)
             d_obs[1:S + 1] += dvel
             d_obs[0:S] -= dvel
+            if pos_grad_pool:
+                # the interaction module sees the positions as well (obs1 = frame s, obs2 = frame s + 1 of step s)
+                d_o1, d_o2 = _nongrid_position_grads(pool, P, S, M, idx, o1_all, o2_all, dnn_all, st_bufs if st_pool else None,
+                                                     st_saves, hm_G_all, hm_wslot_all, L, dev, sp, at_posrec_all)
+                d_obs[1:S + 1] += d_o2
+                d_obs[0:S] += d_o1
             if GD:   # the goal embedding sees the unit vector from the goal to the current position (lstm/lstm.py:132-139)
                 goal_wT4 = torch.zeros(4, GD - 2, device=dev)
                 goal_wT4[:2] = P['goal_embedding.input_embeddings.0.weight'].detach().t()
@@ -712,6 +774,10 @@ class SequenceFn(torch.autograd.Function):
                         grads[n] = base
                     done.add(id(base))
                     publish(base)
+            if hasattr(reduce_fn, 'flush'):        # the small gradients travel as ONE flattened message (GradReducer)
+                w = reduce_fn.flush()
+                if w is not None:
+                    pending.append(w)
             for w in pending:
                 w.wait()                  # the compute stream waits for RCCL's stream; no host synchronisation
         for dst_name, src_name in hh_clones:

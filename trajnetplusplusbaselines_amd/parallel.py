@@ -219,15 +219,54 @@ class GradReducer(object):
     (stream-level wait, no host block) before it hands the gradients to autograd, so ``p.grad`` is already the sum over
     ranks when ``loss.backward()`` returns."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, coalesce_below=1 << 20):
+        """``coalesce_below`` (bytes): gradients smaller than this are not sent one by one -- a ring all-reduce of a few KB
+        is pure latency (tens of microseconds each, serialised on RCCL's stream: the thirteen small tensors of Social-LSTM
+        would finish ~0.4 ms after the last weight-gradient GEMM) -- but collected and sent as ONE flattened message by
+        ``flush()``, which the backward pass calls after its last gradient is enqueued.  0 = every tensor on its own."""
         self.group = group
+        self.coalesce_below = int(coalesce_below)
         self.messages = 0
         self.bytes = 0
+        self._small = []
 
     def __call__(self, tensor):
-        self.messages += 1
         self.bytes += tensor.numel() * tensor.element_size()
+        if tensor.numel() * tensor.element_size() < self.coalesce_below and tensor.dtype == torch.float32:
+            self._small.append(tensor)
+            return _Done()
+        self.messages += 1
         return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def flush(self):
+        """Send the collected small gradients as one flattened SUM all-reduce; returns a handle whose ``wait()`` makes the
+        current stream wait for it and copies the sums back into the tensors (or None when nothing was collected)."""
+        if not self._small:
+            return None
+        tensors, self._small = self._small, []
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        self.messages += 1
+        return _FlatWork(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, tensors)
+
+
+class _Done(object):
+    """handle of a gradient that travels with the coalesced message (GradReducer.flush)"""
+
+    def wait(self):
+        return True
+
+
+class _FlatWork(object):
+    def __init__(self, work, flat, tensors):
+        self.work, self.flat, self.tensors = work, flat, tensors
+
+    def wait(self):
+        self.work.wait()
+        off = 0
+        for t in self.tensors:
+            t.copy_(self.flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        return True
 
 
 def max_over_ranks(value, device=None, group=None):

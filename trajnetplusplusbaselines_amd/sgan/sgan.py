@@ -1,9 +1,11 @@
 """S-GAN on MI355X (reference sgan/sgan.py:46-630): the generator is the LSTM forecaster of lstm/lstm.py with a noise
 interface between encoder and decoder, the discriminator an encoder LSTM over observed + predicted frames followed
 by a small MLP on the primaries' hidden state.  Both run on the same HIP sequence driver (tnp_lstm_forward_ex);
-class names, constructor arguments, state_dict keys and return values mirror the reference.  Forward and training: the
-generator trains through every interaction module lstm/training.py supports (grid and non-grid); a generator step whose
-DISCRIMINATOR pools with a non-grid module still raises (position gradients through those modules, training.py)."""
+class names, constructor arguments, state_dict keys and return values mirror the reference.  Forward and training: generator
+and discriminator train through every interaction module of the reference (grid and non-grid), incl. the generator step
+that back-propagates from the scores through the discriminator's interaction module into the predicted positions
+(lstm/training.py: tnp_pool_*_pos_backward / tnp_directional_scatter_backward) -- the reference's trainer gives the
+discriminator a deep copy of the generator's module (sgan/trainer.py:566-592)."""
 import numpy as np
 import torch
 import torch.nn as nn
