@@ -334,6 +334,8 @@ struct Workspace {
     int32_t *row_end;                             // sparse path: one past the last row of every row's scene
     int32_t *row_padded;                          // sparse path: slots the reference pads the row's scene to
     int fuse_grid, save_winners;                  // winner tile built inside the sparse kernel; table wanted by the caller
+    unsigned *chain_flags;                        // chained last-embedding-layer + gates launch: arrival counters (+ give-up word)
+    unsigned chain_epoch;                         // steps launched since the counters were zeroed
     size_t bytes;
 };
 
@@ -357,6 +359,9 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     w.h[0] = (float *)take((size_t)M * H * 4);
     w.h[1] = (float *)take((size_t)M * H * 4);
     w.c = (float *)take((size_t)M * H * 4);
+    // (right behind h[0], h[1], c: the one fill that zeroes the state at the start of a forward pass zeroes these as well)
+    w.chain_flags = (unsigned *)take(((size_t)(M + 31) / 32 + 16) * sizeof(unsigned));
+    w.chain_epoch = 0;
     w.obs1 = (float *)take((size_t)M * 2 * 4);
     w.obs2 = (float *)take((size_t)M * 2 * 4);
     w.X = (float *)take((size_t)M * w.I * 4);
@@ -450,6 +455,22 @@ __global__ void add_rows_kernel(float *__restrict__ y, const float *__restrict__
     const float4 b = reinterpret_cast<const float4 *>(x)[q];
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     reinterpret_cast<float4 *>(y)[q] = a;
+}
+
+// the LSTM gates GEMM of one step: [X | h] x [W_ih | W_hh]^T + LSTMCell pointwise + masked state update
+static void fill_gates_args(GemmArgs &g, const tnp_lstm_model *md, int decoder, const Workspace &w, const float *h_in, float *h_out,
+                            const float *c_in, float *c_out, int M) {
+    const int H = md->H;
+    memset(&g, 0, sizeof(g));
+    g.A1 = w.X; g.lda1 = w.I; g.K1 = w.I;
+    g.A2 = w.to_hidden ? w.hplus : h_in; g.lda2 = H; g.K2 = H;
+    g.B1 = decoder ? md->dec_Wih : md->enc_Wih; g.ldb1 = w.I;
+    g.B2 = decoder ? md->dec_Whh : md->enc_Whh; g.ldb2 = H;
+    g.bias1 = decoder ? md->dec_bih : md->enc_bih;
+    g.bias2 = decoder ? md->dec_bhh : md->enc_bhh;
+    g.M = M; g.N = 4 * H; g.H = H;
+    g.h_in = h_in; g.h_out = h_out; g.c_in = c_in; g.c_out = c_out; g.mask = w.mask;
+    g.gates_out = w.gates_save;
 }
 
 // pool + gates of one step; obs/mask/X[:,0:E+GD]/enc already prepared
@@ -567,6 +588,17 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
             if (last) { g.C = w.pdst; g.ldc = w.pld; }
             else { g.C = w.y[l & 1]; g.ldc = md->dims[l + 1]; }
             const int cls = (l == 0) ? PROF_GEMM1 : PROF_ALL_GEMM;
+            // the last layer feeds the LSTM input directly: chained with the gates GEMM in one launch when the shapes allow
+            // it (gemm_f32_mfma.hip: launch_chain_l2_gates -- experimental, enabled by TNP_CHAIN=1, measured slower; variant bit 18 forbids it)
+            if (last && !w.to_hidden && ((md->variant >> 18) & 1) == 0 && ((md->variant >> 8) & 0xff) == 0 &&
+                (l > 0 || (md->variant & 0xff) == 0)) {
+                GemmArgs gg;
+                fill_gates_args(gg, md, decoder, w, h_in, h_out, c_in, c_out, M);
+                prof_before(cls, s);
+                rc = launch_chain_l2_gates(g, gg, w.chain_flags, w.chain_epoch + 1, s);
+                if (rc == 0) { prof_after(cls, s); ++w.chain_epoch; return 0; }
+                if (rc < 0) return rc;
+            }
             prof_before(cls, s);
             rc = launch_linear(g, (l == 0) ? (md->variant & 0xff) : 0, s);
             prof_after(cls, s);
@@ -582,15 +614,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
         hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((tot4 + 255) / 256)), dim3(256), 0, s, w.hplus, h_in, tot4);
         TNP_HIP(hipGetLastError());
     }
-    g.A1 = w.X; g.lda1 = w.I; g.K1 = w.I;
-    g.A2 = w.to_hidden ? w.hplus : h_in; g.lda2 = H; g.K2 = H;
-    g.B1 = decoder ? md->dec_Wih : md->enc_Wih; g.ldb1 = w.I;
-    g.B2 = decoder ? md->dec_Whh : md->enc_Whh; g.ldb2 = H;
-    g.bias1 = decoder ? md->dec_bih : md->enc_bih;
-    g.bias2 = decoder ? md->dec_bhh : md->enc_bhh;
-    g.M = M; g.N = 4 * H; g.H = H;
-    g.h_in = h_in; g.h_out = h_out; g.c_in = c_in; g.c_out = c_out; g.mask = w.mask;
-    g.gates_out = w.gates_save;
+    fill_gates_args(g, md, decoder, w, h_in, h_out, c_in, c_out, M);
     prof_before(PROF_ALL_GEMM, s);
     int rc = launch_lstm_gates(g, (md->variant >> 8) & 0xff, s);
     prof_after(PROF_ALL_GEMM, s);
@@ -686,11 +710,13 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
     const size_t MH = (size_t)M * H;
     // training: the states of all steps stay in the caller's [steps + 1, M, H] buffers instead of the ping-pong pair
     float *hcur = sv ? sv->h_all : w.h[0];
-    if (!sv && w.c > w.h[0]) {      // lstm.py:207-210; h[0], h[1], c lie one after the other in the workspace: one fill, not two
-        TNP_HIP(hipMemsetAsync(hcur, 0, (size_t)(reinterpret_cast<char *>(w.c + MH) - reinterpret_cast<char *>(w.h[0])), s));
+    const size_t flag_bytes = ((size_t)(M + 31) / 32 + 16) * sizeof(unsigned);
+    if (!sv && w.c > w.h[0]) {      // lstm.py:207-210; h[0], h[1], c, the chain counters lie one after the other: one fill
+        TNP_HIP(hipMemsetAsync(hcur, 0, (size_t)(reinterpret_cast<char *>(w.chain_flags) + flag_bytes - reinterpret_cast<char *>(w.h[0])), s));
     } else {
         TNP_HIP(hipMemsetAsync(hcur, 0, MH * 4, s));
         TNP_HIP(hipMemsetAsync(sv ? sv->c_all : w.c, 0, MH * 4, s));
+        TNP_HIP(hipMemsetAsync(w.chain_flags, 0, flag_bytes, s));
     }
     if (w.ph[0]) {  // pool.reset() (lstm/lstm.py:213-216): zero interaction-encoder state, all tracks "present"
         TNP_HIP(hipMemsetAsync((sv && stateful) ? sv->ph_all : w.ph[0], 0, (size_t)M * md->dims[0] * 4, s));
@@ -871,6 +897,7 @@ static int lstm_step_impl(const tnp_lstm_model *md, int decoder, const float *h_
         if (sv->winners && w.sparse) { w.winners = sv->winners; w.save_winners = 1; }
     }
     if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s, w.row_end, w.row_padded, scene_slots, n_max); if (rc) return rc; }
+    TNP_HIP(hipMemsetAsync(w.chain_flags, 0, ((size_t)(M + 31) / 32 + 16) * sizeof(unsigned), s));   // chained launch: fresh counters
     PrepArgs p;
     fill_prep_common(p, md, w, M);
     p.h = h_in; p.goals = goals;

@@ -51,6 +51,10 @@ struct GemmArgs {
 int launch_linear(const GemmArgs &g, int variant, hipStream_t s);
 // fused LSTM gates GEMM + cell update
 int launch_lstm_gates(const GemmArgs &g, int variant, hipStream_t s);
+// last embedding layer (producer) + LSTM gates (consumer) in ONE launch with per-row-tile arrival counters (gemm_f32_mfma.hip):
+// flags = [ceil(M/32) + 1] unsigned zeroed at the start of the forward pass, epoch = 1, 2, ... per step.  Returns 1 when the
+// pair of shapes is not eligible (the caller then launches the two kernels on their own).
+int launch_chain_l2_gates(const GemmArgs &producer, const GemmArgs &gates, unsigned *flags, unsigned epoch, hipStream_t s);
 
 // ---- grid pooling ---------------------------------------------------------------------------
 struct GridArgs {
