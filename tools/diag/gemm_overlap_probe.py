@@ -52,3 +52,16 @@ print('second-layer-shaped GEMM alone      %.2f us' % a)
 print('gates-shaped GEMM alone             %.2f us' % b)
 print('both, one stream (serial)           %.2f us per pair' % ab)
 print('both, two streams (concurrent)      %.2f us per pair' % cc)
+
+
+def launch_v(x, w, b, y, stream, variant):
+    _lib.check(L.tnp_linear_forward(_lib.ptr(x), x.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(b), _lib.ptr(y), y.stride(0),
+                                    x.shape[0], w.shape[0], x.shape[1], 1, variant, stream), 'linear')
+
+
+for v in (24, 27, 28, 25, 26):
+    try:
+        t = timed(lambda: launch_v(x1, w1, b1, y1, c(p0), v))
+        print('second-layer shape, variant %d: %.2f us' % (v, t))
+    except Exception as e:
+        print('variant', v, 'failed:', str(e)[:100])

@@ -1041,7 +1041,9 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
             break;
         case 25: TNP_TRY_PIPE(1, 4, 1, 1, 32, EPI_BIAS); break;  // pipelined: 32x128, four waves over the whole K
         case 26: TNP_TRY_PIPE(1, 2, 2, 2, 32, EPI_BIAS); break;  // pipelined: 32x128, split-K 2, two blocks per wave
-        default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d (0 = automatic, 12, 24, 25, 26)", variant);
+        case 27: TNP_TRY_PIPE(1, 1, 4, 1, 16, EPI_BIAS); break;  // probe: 32x32, split-K 4, 61 KB: two INDEPENDENT workgroups per CU
+        case 28: TNP_TRY_PIPE(1, 1, 4, 1, 32, EPI_BIAS); break;  // probe: 32x32, split-K 4, K tile 32 (110 KB: one per CU)
+        default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d (0 = automatic, 12, 24, 25, 26, 27, 28)", variant);
     }
     // shape not eligible for the fast path: masked general kernel
     if (big_tiles >= 192) return launch_general<4, 2, 1, 1, 32, EPI_BIAS>(g, s);
