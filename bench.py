@@ -638,6 +638,34 @@ def main():
         sustained = dict(value=scenes_total * 21 * n_sus / t_s, unit='scene-steps/s', forwards=n_sus, seconds=t_s,
                          ms_per_step=t_s / n_sus * 1e3)
 
+    # ---- two batches in flight: the SAME forward on two HIP streams, alternating between two different 64-scene batches (what
+    #      LSTMPredictor.predict_batches does for an evaluation set).  NOT the headline: `value` keeps one batch in flight. ----
+    in_flight2 = None
+    if not args.train and not is_sgan and not args.no_sustain and not args.no_roofline and not strong:
+        xy_b, split_b = synth.linear_crowd(cfg['scenes'], cfg['agents'], seed=1000 + rank)
+        obs_pair = [observed, xy_b[:9].to(device)]
+        split_pair = [split, split_b]
+        s_pair = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+        n2 = max(args.steps, 200)
+        with torch.no_grad():
+            for i in range(8):
+                with torch.cuda.stream(s_pair[i & 1]):
+                    model(obs_pair[i & 1], goals, split_pair[i & 1], n_predict=12, pad_to=pad_to)
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(n2):
+                with torch.cuda.stream(s_pair[i & 1]):
+                    model(obs_pair[i & 1], goals, split_pair[i & 1], n_predict=12, pad_to=pad_to)
+            barrier()
+            t2 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if distributed:
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        t2 = float(t2.item())
+        in_flight2 = dict(value=scenes_total * 21 * n2 / t2, unit='scene-steps/s', forwards=n2, ms_per_step=t2 / n2 * 1e3,
+                          note='two independent batches of the headline shape in flight on two HIP streams (alternating): the '
+                               'kernels of one forward fill the per-kernel prologue / epilogue gaps of the other.  Reported beside '
+                               'the headline, which keeps ONE batch in flight.')
+
     # ---- training leg: the optimisation step of the same model on the same shard, all-reduce included at N > 1 ----
     training = None
     training_failed = False
@@ -878,6 +906,7 @@ def main():
             'roofline': roof,
             'step_roofline': step_roof,
             'sustained': sustained,
+            'two_batches_in_flight': in_flight2,
             'training': training,
             'strong_scaling_config3': strong3,
             'strong_scaling_config4_sgan': strong4,

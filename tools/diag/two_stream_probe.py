@@ -1,0 +1,45 @@
+"""Throughput of the headline forward with ONE batch in flight (the bench's definition) against TWO independent batches in
+flight on two HIP streams (what an evaluator over many batches could do): do kernels of different forwards fill each other's
+stalls?  Each model instance has its own workspace; the two batches are different crowds."""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from trajnetplusplusbaselines_amd import synth
+from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling
+
+
+def build():
+    torch.manual_seed(0)
+    pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=16, out_dim=256, embedding_arch='two_layer',
+                            layer_dims=[1024], latent_dim=16)
+    return LSTM(pool=pool).eval().cuda()
+
+
+models = [build(), build()]
+batches = []
+for k in range(2):
+    xy, split = synth.linear_crowd(64, 32, seed=100 + k)
+    batches.append((xy[:9].cuda(), torch.zeros(xy.shape[1], 2).cuda(), split))
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+
+def run(n, two):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for i in range(n):
+            k = i & 1
+            if two:
+                with torch.cuda.stream(streams[k]):
+                    models[k](*batches[k], n_predict=12)
+            else:
+                models[k](*batches[k], n_predict=12)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+for two in (False, True, False, True):
+    run(20, two)
+    t = run(200, two)
+    print('%s: %.3f ms per forward, %.0f scene-steps/s' % ('two batches in flight (2 streams)' if two else 'one batch in flight           ', t * 1e3, 64 * 21 / t))

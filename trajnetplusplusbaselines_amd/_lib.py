@@ -220,6 +220,22 @@ def f32c(t, device=None):
     return t.contiguous()
 
 
+class StreamMark(object):
+    """Remembers on which stream a cached device object was produced: ``join()`` makes the CURRENT stream wait for that point
+    when it is a different stream (nothing otherwise, the common case).  Lets caches that are filled by kernels -- the
+    re-laid-out weight copies, the scene index tables -- be used by forward passes on several streams."""
+
+    def __init__(self):
+        self.stream = torch.cuda.current_stream()
+        self.event = torch.cuda.Event()
+        self.event.record(self.stream)
+
+    def join(self):
+        cur = torch.cuda.current_stream()
+        if cur != self.stream:
+            cur.wait_event(self.event)
+
+
 class SceneIndex(object):
     """int32 scene starts + per-track primary flags + the reference's padded slot counts (lstm/lstm.py:29).
 
@@ -278,6 +294,7 @@ class SceneIndex(object):
         self.primary = torch.empty(max(self.M, 1), dtype=torch.uint8, device=device)
         check(lib().tnp_mark_primaries(ptr(self.starts), self.B, self.M, ptr(self.primary), stream_ptr()),
               'tnp_mark_primaries')
+        self._mark = StreamMark() if torch.device(device).type == 'cuda' else None     # built on this stream (see get())
 
     def stacked_rows(self, S):
         """(row_base, row_count, row_padded) of S copies of the batch stacked along the rows (row r of step s is row s M + r):
@@ -300,8 +317,10 @@ class SceneIndex(object):
                 tabs.append(None)
             if len(self._stacked) > 4:
                 self._stacked.clear()
-            got = self._stacked[S] = tuple(tabs)
-        return got
+            got = self._stacked[S] = tuple(tabs) + (StreamMark() if dev.type == 'cuda' else None,)
+        if got[3] is not None:
+            got[3].join()
+        return got[:3]
 
     @classmethod
     def get(cls, batch_split, device, pad_to=None):
@@ -319,6 +338,8 @@ class SceneIndex(object):
                 cls._cache.clear()
             idx = cls(host, device, pad_to)
             cls._cache[key] = idx
+        if idx._mark is not None:
+            idx._mark.join()           # a cached index built on another stream: wait for its tables
         return idx
 
 

@@ -284,8 +284,10 @@ class LSTM(torch.nn.Module):
             qm = torch.empty(ncell, n1 // 64, C // 4, 64, 4, dtype=torch.float32, device=w.device) if quad else None
             _lib.check(_lib.lib().tnp_pool_embed_weight_layouts(_lib.ptr(w), w.stride(0), n1, C, ncell, _lib.ptr(cm),
                                                                 _lib.ptr(qm), _lib.stream_ptr()), 'tnp_pool_embed_weight_layouts')
-            self._cell_major = (key, cm)
+            # built on THIS stream: a forward pass on another stream (two batches in flight) must wait for the launch above
+            self._cell_major = (key, cm, _lib.StreamMark())
             self._quad_major = (key, qm)
+        self._cell_major[2].join()
         return self._cell_major[1], self._quad_major[1]
 
     def _cell_major_weight(self, weight, pool):
@@ -298,9 +300,15 @@ class LSTM(torch.nn.Module):
         need = _lib.lib().tnp_lstm_workspace_bytes(ctypes.byref(m), M, B)
         if need == 0:
             _lib.check(-1, 'tnp_lstm_workspace_bytes')
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        return self._ws, need
+        # one workspace per STREAM: forward passes of this model on different streams (two batches in flight) must not share
+        # the recurrent state and scratch buffers
+        if not isinstance(self._ws, dict):
+            self._ws = {}
+        sk = torch.cuda.current_stream(dev).cuda_stream
+        ws = self._ws.get(sk)
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = self._ws[sk] = torch.empty(need, dtype=torch.uint8, device=dev)
+        return ws, need
 
     # ---- one recurrent step (reference lstm/lstm.py:91-168) -------------------------------------------
     def step(self, lstm, hidden_cell_state, obs1, obs2, goals, batch_split, pad_to=None):
@@ -530,17 +538,64 @@ class LSTMPredictor(object):
         if not xys:
             return []
         xy, split = trajdata.batch_scenes(xys)
-        results = [dict() for _ in xys]
         with torch.no_grad():
             obs = torch.tensor(xy, dtype=torch.float32)
             goal = torch.tensor(np.concatenate(goals, axis=0), dtype=torch.float32)
             batch_split = torch.tensor(split, dtype=torch.int64)
-            for num_p in range(modes):
-                _, output = self.model(obs, goal, batch_split, n_predict=n_predict, pad_to='scene')
-                output = output.cpu().numpy()
-                for s in range(len(xys)):
-                    out = output[:, split[s]:split[s + 1]]
-                    if normalize:
-                        out = trajdata.inverse_scene(out, *frames[s])
-                    results[s][num_p] = [out[-n_predict:, 0], out[-n_predict:, 1:]]
+            outputs = [self.model(obs, goal, batch_split, n_predict=n_predict, pad_to='scene')[1] for _ in range(modes)]
+        return self._unpack(outputs, split, frames, normalize, n_predict)
+
+    @staticmethod
+    def _unpack(outputs, split, frames, normalize, n_predict):
+        """device outputs of the `modes` forward passes of one batch -> the per-scene multimodal_outputs dicts"""
+        results = [dict() for _ in range(len(split) - 1)]
+        for num_p, output in enumerate(outputs):
+            output = output.cpu().numpy()
+            for s in range(len(split) - 1):
+                out = output[:, split[s]:split[s + 1]]
+                if normalize:
+                    out = trajdata.inverse_scene(out, *frames[s])
+                results[s][num_p] = [out[-n_predict:, 0], out[-n_predict:, 1:]]
         return results
+
+    def predict_batches(self, batches, n_predict=12, modes=1, obs_length=9, start_length=0, args=None, in_flight=2):
+        """``predict_batch`` over MANY batches (an evaluation set cut into chunks of scenes) with ``in_flight`` of them on the
+        GPU at a time, each on its own HIP stream: the kernels of one recurrent step run in lockstep with a fixed prologue /
+        epilogue each, and the kernels of another, independent forward pass fill those gaps (two 64 x 32 Social-LSTM batches in
+        flight: 1.16 ms per forward against 1.31 ms one after the other, tools/diag/two_stream_probe.py).  Results are those
+        of ``predict_batch`` on every batch, bit for bit: per-stream workspaces, stream-aware caches (_lib.StreamMark).
+        Returns a list (batch order) of ``predict_batch`` results."""
+        self.model.eval()
+        normalize = bool(getattr(args, 'normalize_scene', False))
+        dev = next(self.model.parameters()).device
+        streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(in_flight)))]
+        start = torch.cuda.Event()
+        start.record(torch.cuda.current_stream(dev))
+        pending = []
+        for bi, scenes in enumerate(batches):
+            xys, goals, frames = [], [], []
+            for paths, scene_goal in scenes:
+                xy = trajdata.paths_to_xy(paths)
+                if xy.shape[0] < obs_length:
+                    raise ValueError('scene has %d frames, need at least obs_length=%d' % (xy.shape[0], obs_length))
+                scene_goal = np.zeros((xy.shape[1], 2)) if scene_goal is None else np.asarray(scene_goal)
+                if normalize:
+                    xy, rotation, center, scene_goal = trajdata.center_scene(xy, obs_length, goals=scene_goal)
+                    frames.append((rotation, center))
+                xys.append(np.asarray(xy)[start_length:obs_length])
+                goals.append(scene_goal)
+            if not xys:
+                pending.append(None)
+                continue
+            xy, split = trajdata.batch_scenes(xys)
+            st = streams[bi % len(streams)]
+            st.wait_event(start)                                   # whatever the caller had queued before this call
+            with torch.no_grad(), torch.cuda.stream(st):
+                obs = torch.tensor(xy, dtype=torch.float32)
+                goal = torch.tensor(np.concatenate(goals, axis=0), dtype=torch.float32)
+                batch_split = torch.tensor(split, dtype=torch.int64)
+                outputs = [self.model(obs, goal, batch_split, n_predict=n_predict, pad_to='scene')[1] for _ in range(modes)]
+            pending.append((outputs, split, frames))
+        for st in streams:
+            st.synchronize()
+        return [[] if item is None else self._unpack(item[0], item[1], item[2], normalize, n_predict) for item in pending]
