@@ -645,26 +645,29 @@ def main():
         xy_b, split_b = synth.linear_crowd(cfg['scenes'], cfg['agents'], seed=1000 + rank)
         obs_pair = [observed, xy_b[:9].to(device)]
         split_pair = [split, split_b]
-        s_pair = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
-        n2 = max(args.steps, 200)
-        with torch.no_grad():
-            for i in range(8):
-                with torch.cuda.stream(s_pair[i & 1]):
-                    model(obs_pair[i & 1], goals, split_pair[i & 1], n_predict=12, pad_to=pad_to)
-            barrier()
-            t0 = time.perf_counter()
-            for i in range(n2):
-                with torch.cuda.stream(s_pair[i & 1]):
-                    model(obs_pair[i & 1], goals, split_pair[i & 1], n_predict=12, pad_to=pad_to)
-            barrier()
-            t2 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-        if distributed:
-            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-        t2 = float(t2.item())
-        in_flight2 = dict(value=scenes_total * 21 * n2 / t2, unit='scene-steps/s', forwards=n2, ms_per_step=t2 / n2 * 1e3,
-                          note='two independent batches of the headline shape in flight on two HIP streams (alternating): the '
-                               'kernels of one forward fill the per-kernel prologue / epilogue gaps of the other.  Reported beside '
-                               'the headline, which keeps ONE batch in flight.')
+        in_flight2 = dict(unit='scene-steps/s',
+                          note='N independent batches of the headline shape in flight on N HIP streams (alternating between two crowds): '
+                               'the kernels of one forward fill the per-kernel prologue / epilogue gaps of the others '
+                               '(LSTMPredictor.predict_batches).  Reported beside the headline, which keeps ONE batch in flight.')
+        for nfl in (2, 4):
+            s_n = [torch.cuda.Stream(device=device) for _ in range(nfl)]
+            n2 = max(args.steps, 200)
+            with torch.no_grad():
+                for i in range(2 * nfl):
+                    with torch.cuda.stream(s_n[i % nfl]):
+                        model(obs_pair[i & 1], goals, split_pair[i & 1], n_predict=12, pad_to=pad_to)
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(n2):
+                    with torch.cuda.stream(s_n[i % nfl]):
+                        model(obs_pair[i & 1], goals, split_pair[i & 1], n_predict=12, pad_to=pad_to)
+                barrier()
+                t2 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            if distributed:
+                dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            t2 = float(t2.item())
+            in_flight2['in_flight_%d' % nfl] = dict(value=scenes_total * 21 * n2 / t2, forwards=n2, ms_per_step=t2 / n2 * 1e3)
+        in_flight2['value'] = in_flight2['in_flight_2']['value']
 
     # ---- training leg: the optimisation step of the same model on the same shard, all-reduce included at N > 1 ----
     training = None
@@ -906,7 +909,7 @@ def main():
             'roofline': roof,
             'step_roofline': step_roof,
             'sustained': sustained,
-            'two_batches_in_flight': in_flight2,
+            'batches_in_flight': in_flight2,
             'training': training,
             'strong_scaling_config3': strong3,
             'strong_scaling_config4_sgan': strong4,

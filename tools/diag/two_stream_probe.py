@@ -43,3 +43,47 @@ for two in (False, True, False, True):
     run(20, two)
     t = run(200, two)
     print('%s: %.3f ms per forward, %.0f scene-steps/s' % ('two batches in flight (2 streams)' if two else 'one batch in flight           ', t * 1e3, 64 * 21 / t))
+
+# ---- the SAME 64-scene batch as two 32-scene halves on two streams (scenes are independent) vs as one batch ----
+obs, goals, split = batches[0]
+h = 32 * 32
+half = torch.arange(0, h + 1, 32)
+parts = [(obs[:, :h].contiguous(), goals[:h], half), (obs[:, h:].contiguous(), goals[h:], half)]
+m = models[0]
+
+
+def run_halves(n, nstreams):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for i in range(n):
+            for k in range(2):
+                if nstreams == 2:
+                    with torch.cuda.stream(streams[k]):
+                        m(*parts[k], n_predict=12, pad_to=32)
+                else:
+                    m(*parts[k], n_predict=12, pad_to=32)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+for ns in (1, 2, 1, 2):
+    run_halves(10, ns)
+    t = run_halves(150, ns)
+    print('64 scenes as two 32-scene halves on %d stream(s): %.3f ms per 64 scenes, %.0f scene-steps/s' % (ns, t * 1e3, 64 * 21 / t))
+for nfl in (3, 4):
+    ms = [build() for _ in range(nfl)]
+    ss = [torch.cuda.Stream() for _ in range(nfl)]
+    def run_n(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for i in range(n):
+                k = i % nfl
+                with torch.cuda.stream(ss[k]):
+                    ms[k](*batches[k & 1], n_predict=12)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    run_n(20)
+    t = run_n(240)
+    print('%d batches in flight: %.3f ms per forward, %.0f scene-steps/s' % (nfl, t * 1e3, 64 * 21 / t))
