@@ -239,3 +239,44 @@ def test_stored_duplicate_fixture_is_single_threaded(ref):
         pool.hidden_dim_encoding.weight.copy_(torch.tensor(z['Wh']))
         pool.hidden_dim_encoding.bias.copy_(torch.tensor(z['bh']))
         assert np.array_equal(pool.social(torch.tensor(z['hidden']), o1.clone(), o2.clone()).numpy(), z['grid_social'])
+
+
+def test_scatter_backward_rule_on_random_crowds(ref):
+    """The rule of tnp_pool_pair_cells_autograd (helpers.pair_cells_autograd_numpy) against the reference's autograd on NEW
+    random crowds every run: dense scenes with duplicates, absent tracks, padded slots, a genuine neighbour forced into the
+    corner cell (0, 0) with out-of-range slots behind it, constant 0 and != 0 -- per-pair gradients of the scattered values,
+    exactly (every gradient is a copy of an upstream entry or zero)."""
+    rng = np.random.RandomState()
+    masked = 0
+    for case in range(12):
+        B, N = int(rng.randint(1, 4)), int(rng.randint(3, 20))
+        n = int(rng.choice([4, 8, 16]))
+        cs = float(rng.choice([0.6, 1.0]))
+        const = float(rng.choice([0.0, 0.0, 0.5]))
+        ext = n * cs * 0.6
+        obs2 = ((rng.rand(B, N, 2) * 2 - 1) * ext).astype(np.float32)
+        obs2[:, 1] = obs2[:, 0] - np.float32(n * cs / 2 - 0.25 * cs)        # corner cell of ego 0
+        obs2[rng.rand(B, N) < 0.15] = np.nan
+        obs2[:, 0] = np.nan_to_num(obs2[:, 0], nan=0.3)
+        if rng.rand() < 0.5:
+            obs2[-1, N - 1:] = np.nan
+        C = 3
+        pool = ref.GridBasedPooling(type_='occupancy', hidden_dim=16, cell_side=cs, n=n, out_dim=8, constant=const)
+        pool.pooling_dim = C
+        vals = torch.tensor(rng.randn(B, N, N - 1, C).astype(np.float32), requires_grad=True)
+        g = pool.occupancy(torch.tensor(obs2.copy()), vals * 1.0, past_obs=torch.tensor(obs2.copy()))
+        w = torch.tensor(rng.randn(*g.shape).astype(np.float32))
+        (g * w).sum().backward()
+        want = vals.grad.numpy()
+        got = np.zeros_like(want)
+        for b in range(B):
+            cells, _ = helpers.pair_cells_autograd_numpy(obs2[b], n, cs, const)
+            raw, _ = helpers.pair_cells_autograd_numpy(obs2[b], n, cs, 1.0)
+            masked += int(((raw >= 0) & (cells < 0)).sum())
+            for i in range(N):
+                for j in range(N):
+                    if j != i and cells[i, j] >= 0:
+                        c = cells[i, j]
+                        got[b, i, j - (j > i)] = w[b * N + i, :, c // n, c % n].numpy()
+        np.testing.assert_array_equal(got, want, err_msg='case %d: B=%d N=%d n=%d cs=%g constant=%g' % (case, B, N, n, cs, const))
+    print('in-range pairs without gradient (clobbered cell 0):', masked)
