@@ -226,12 +226,14 @@ class StreamMark(object):
     re-laid-out weight copies, the scene index tables -- be used by forward passes on several streams."""
 
     def __init__(self):
+        # the CURRENT device's current stream: the one _lib.stream_ptr() hands to every native launch
+        self.device = None
         self.stream = torch.cuda.current_stream()
         self.event = torch.cuda.Event()
         self.event.record(self.stream)
 
     def join(self):
-        cur = torch.cuda.current_stream()
+        cur = torch.cuda.current_stream(self.device)
         if cur != self.stream:
             cur.wait_event(self.event)
 

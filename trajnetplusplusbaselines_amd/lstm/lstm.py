@@ -304,7 +304,7 @@ class LSTM(torch.nn.Module):
         # the recurrent state and scratch buffers
         if not isinstance(self._ws, dict):
             self._ws = {}
-        sk = torch.cuda.current_stream(dev).cuda_stream
+        sk = torch.cuda.current_stream().cuda_stream          # what _lib.stream_ptr() launches on
         ws = self._ws.get(sk)
         if ws is None or ws.numel() < need or ws.device != dev:
             ws = self._ws[sk] = torch.empty(need, dtype=torch.uint8, device=dev)
