@@ -307,6 +307,8 @@ class LSTM(torch.nn.Module):
         sk = torch.cuda.current_stream().cuda_stream          # what _lib.stream_ptr() launches on
         ws = self._ws.get(sk)
         if ws is None or ws.numel() < need or ws.device != dev:
+            if len(self._ws) >= 8:                # streams come and go: keep the most recently created workspaces only
+                self._ws.pop(next(iter(self._ws)))
             ws = self._ws[sk] = torch.empty(need, dtype=torch.uint8, device=dev)
         return ws, need
 
@@ -477,6 +479,11 @@ class LSTMPredictor(object):
     def __init__(self, model):
         self.model = model
 
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop('_streams', None)          # predict_batches' HIP streams are not part of the pickle
+        return state
+
     def save(self, state, filename):
         with open(filename, 'wb') as f:
             torch.save(self, f)
@@ -568,7 +575,11 @@ class LSTMPredictor(object):
         self.model.eval()
         normalize = bool(getattr(args, 'normalize_scene', False))
         dev = next(self.model.parameters()).device
-        streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(in_flight)))]
+        n_streams = max(1, int(in_flight))
+        pool = self.__dict__.setdefault('_streams', [])        # reused across calls (each stream owns a workspace of the model)
+        while len(pool) < n_streams:
+            pool.append(torch.cuda.Stream(device=dev))
+        streams = pool[:n_streams]
         start = torch.cuda.Event()
         start.record(torch.cuda.current_stream(dev))
         pending = []
