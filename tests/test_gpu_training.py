@@ -651,3 +651,42 @@ def test_full_size_training_curve_matches_reference():
                 assert np.abs(s['samples'] - z['curve_final_' + k + '@samples']).max() < 5e-4, k
                 assert np.abs(s['rowsum'] - z['curve_final_' + k + '@rowsum']).max() < 5e-4 * np.sqrt(got.size / got.shape[0]) * 4, k
         print('losses', losses, 'reference', z['curve_losses'].tolist())
+
+
+@pytest.mark.parametrize('kind', ['occupancy', 'social3_front', 'social_const', 'directional_goals', 'lstm_layer'])
+def test_gradient_variants_match_reference_autograd(kind):
+    """Training-path options the earlier gradient fixtures did not exercise, on a DENSE ragged crowd (duplicates, clobbered
+    corner cells): occupancy grid, social three_layer with front=True, social with constant = 0.5 (the clobbered cell (0, 0)
+    then holds 0.5 and DOES pass gradient to the neighbours standing in it), directional with goals, embedding_arch =
+    'lstm_layer' -- against the reference's autograd (tests/golden/grad_variants.npz, oracle/gen_golden_r4.py; weights =
+    default init under the stored seed, per-tensor sums checked)."""
+    from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling, PredictionLoss
+    z = np.load(os.path.join(helpers.GOLDEN, 'grad_variants.npz'))
+    cfgs = {
+        'occupancy': (dict(type_='occupancy', n=8, out_dim=32, embedding_arch='one_layer'), False),
+        'social3_front': (dict(type_='social', n=8, out_dim=64, embedding_arch='three_layer', layer_dims=[64, 48], latent_dim=8, front=True), False),
+        'social_const': (dict(type_='social', n=8, out_dim=64, embedding_arch='two_layer', layer_dims=[128], latent_dim=8, constant=0.5), False),
+        'directional_goals': (dict(type_='directional', n=12, out_dim=64), True),
+        'lstm_layer': (dict(type_='directional', n=12, out_dim=64, embedding_arch='lstm_layer'), False),
+    }
+    pool_kw, goal = cfgs[kind]
+    pre = kind + '_'
+    torch.manual_seed(int(z[pre + 'seed']))
+    model = LSTM(pool=GridBasedPooling(hidden_dim=128, cell_side=0.6, **pool_kw), goal_flag=goal)
+    for k, v in model.state_dict().items():
+        assert abs(v.double().sum().item() - float(z[pre + 'wsum_' + k])) < 1e-9, 'seeded weight differs: ' + k
+    model = model.cuda().train()
+    xy, split, goals = torch.tensor(z[pre + 'xy']), torch.tensor(z[pre + 'split']), torch.tensor(z[pre + 'goals'])
+    targets = (xy[9:21] - xy[8:20]).cuda()
+    rel, pred = model(xy[:9].clone(), goals, split, xy[9:20].clone())
+    loss = PredictionLoss()(rel[-12:], targets, split) * 5 + 0.1 * torch.nan_to_num(pred[-12:, split[:-1].cuda()]).pow(2).mean()
+    np.testing.assert_allclose(float(loss.detach()), float(z[pre + 'loss']), rtol=1e-4, atol=2e-5)
+    loss.backward()
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if (pre + 'nograd_' + name) in z.files:
+            assert p.grad is None, name + ': the reference leaves this gradient None'
+            continue
+        assert p.grad is not None, name
+        worst = max(worst, helpers.assert_matches_stored(z, pre + 'grad_' + name, p.grad.cpu().numpy(), 1e-4, kind))
+    print(kind, 'worst relative gradient error %.2e' % worst)
