@@ -1,5 +1,5 @@
-"""RCCL itself (backend 'nccl' on ROCm), one process per GPU: skipped on boxes with fewer than two GPUs -- the first
-multi-GPU box that runs `pytest -m gpu` executes the in-backward gradient all-reduce (parallel.GradReducer), the flat
+"""RCCL itself (backend 'nccl' on ROCm), one process per GPU.  The two-rank tests are skipped on boxes with fewer than two
+GPUs (a one-rank 'nccl' group runs c10d's RCCL code path on any box) -- the first multi-GPU box that runs `pytest -m gpu` executes the in-backward gradient all-reduce (parallel.GradReducer), the flat
 buckets and the sharded train_batch over xGMI.  The same logic runs on gloo in tests/test_parallel_gloo.py (CPU)."""
 import os
 import socket
@@ -95,6 +95,31 @@ def test_two_rank_rccl_training_matches_reference_curve(mode):
         train_batch(model, opt, PredictionLoss(), xy, torch.zeros(xy.shape[1], 2), split, 9, 12)
     for k, v in model.state_dict().items():
         assert np.abs(v.cpu().numpy() - ret['sd'][k]).max() < 5e-4, k
+
+
+@pytest.mark.parametrize('mode', ['overlap', 'buckets', 'flat'])
+def test_one_rank_rccl_backend_runs_the_reducers(mode):
+    """What a ONE-GPU box can execute of the RCCL path: a one-rank 'nccl' process group.  c10d's ProcessGroupNCCL -- its side
+    streams, the asynchronous work handles GradReducer waits on inside the backward pass, the flat buckets -- runs for real
+    (gloo is synchronous on the host, so tests/test_parallel_gloo.py cannot catch a missing stream dependency); only the
+    xGMI transfers are missing.  Four optimisation steps follow the REFERENCE's loss trajectory (train_curve.npz) and end
+    with the weights of a run without any process group."""
+    import torch.multiprocessing as mp
+    mgr = mp.get_context('spawn').Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(1, _free_port(), mode, ret), nprocs=1, join=True)
+    _, z = _build_model()
+    np.testing.assert_allclose(ret['losses'], z['losses'][:4], rtol=5e-5)
+    from trajnetplusplusbaselines_amd.lstm import PredictionLoss
+    from trajnetplusplusbaselines_amd.lstm.train_step import train_batch
+    model, _ = _build_model()
+    model = model.cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    for it in range(4):
+        xy, split = torch.tensor(z['b%d_xy' % (it % 2)]), torch.tensor(z['b%d_split' % (it % 2)])
+        train_batch(model, opt, PredictionLoss(), xy, torch.zeros(xy.shape[1], 2), split, 9, 12)
+    for k, v in model.state_dict().items():
+        assert np.abs(v.cpu().numpy() - ret['sd'][k]).max() < 1e-6, k
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs')
