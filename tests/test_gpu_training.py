@@ -623,6 +623,45 @@ def test_full_size_gradients_match_reference_autograd(tag):
     print(tag, 'worst relative gradient error %.2e' % worst)
 
 
+@pytest.mark.parametrize('tag', ['social', 'directional'])
+def test_gradients_with_scenes_larger_than_a_wavefront_match_reference_autograd(tag):
+    """Scenes of 97..117 agents (tests/golden/big_scene_grads.npz: synth.ragged_crowd(4, 70, 120, seed=31), dense -- dozens of
+    neighbours per cell, clobbered corner cells, entering / leaving tracks), more slots per scene than a wavefront has lanes:
+    the multi-pass vote / hit-list / pair kernels of the backward sweep, through the headline Social-LSTM (sparse first layer,
+    N1 == 1024 kernels) and the config-3 D-LSTM.  Trainer loss against the reference's autograd: loss 2e-5, primaries 5e-5,
+    every gradient within 1e-4 of its largest magnitude."""
+    from trajnetplusplusbaselines_amd import synth
+    from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling, PredictionLoss
+    z = np.load(os.path.join(helpers.GOLDEN, 'big_scene_grads.npz'))
+    if tag == 'social':
+        model, _ = helpers.real_model()
+    else:
+        torch.manual_seed(int(z[tag + '_seed']))
+        model = LSTM(pool=GridBasedPooling(type_='directional', hidden_dim=128, cell_side=0.6, n=12, out_dim=256, embedding_arch='one_layer'))
+    for k, v in model.state_dict().items():
+        assert abs(v.double().sum().item() - float(z[tag + '_wsum_' + k])) < 1e-9, 'seeded weight differs from the reference run: ' + k
+    model = model.cuda().train()
+    xy, split = synth.ragged_crowd(4, 70, 120, seed=int(z['crowd_seed']))
+    M = xy.shape[1]
+    assert M == int(z['tracks']) and int(split.diff().max()) > 64
+    targets = (xy[9:21] - xy[8:20]).cuda()
+    rel, pred = model(xy[:9].clone(), torch.zeros(M, 2), split, xy[9:20].clone())
+    loss = PredictionLoss()(rel[-12:], targets, split) * (split.numel() - 1)
+    np.testing.assert_allclose(float(loss), float(z[tag + '_loss']), rtol=2e-5)
+    prim = split[:-1].cuda()
+    helpers.assert_close_nan(rel.detach()[:, prim].cpu().numpy(), z[tag + '_rel_prim'], 5e-5, 'rel (primaries)')
+    helpers.assert_close_nan(pred.detach()[:, prim].cpu().numpy(), z[tag + '_pred_prim'], 5e-5, 'pred (primaries)')
+    loss.backward()
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if (tag + '_nograd_' + name) in z.files:
+            assert p.grad is None, name + ': the reference leaves this gradient None'
+            continue
+        assert p.grad is not None, name
+        worst = max(worst, helpers.assert_matches_stored(z, tag + '_grad_' + name, p.grad.cpu().numpy(), 1e-4, tag))
+    print(tag, 'worst relative gradient error %.2e' % worst)
+
+
 def test_full_size_training_curve_matches_reference():
     """Four optimisation steps of the headline model (train_step.train_batch == Trainer.train_batch; Adam lr 1e-3, weight_decay
     1e-4 as lstm/trainer.py:497), alternating the 64 x 32 synthetic batch and the hotel scenes: the reference's loss trajectory
