@@ -69,11 +69,15 @@ class OracleModel(object):
     """Holds fp32 copies of the weights and the ctypes struct that points at them."""
 
     def __init__(self, state_dict, pool_type=None, n=4, cell_side=2.0, constant=0.0, front=False,
-                 pool_size=1, blur_size=1, goal_flag=False, embedding_dim=64, hidden_dim=128, pool_to_input=True):
+                 pool_size=1, blur_size=1, goal_flag=False, embedding_dim=None, hidden_dim=None, pool_to_input=True):
         sd = {k: _c32(v.detach().cpu().numpy() if hasattr(v, 'detach') else v) for k, v in state_dict.items()}
         self._keep = sd
         m = _Model()
-        m.E, m.H = embedding_dim, hidden_dim
+        # the state sizes are those of the weights (lstm/lstm.py:63-85: InputEmbedding(2, E, 4.0) holds E - 2 rows, the cells'
+        # weight_hh is [4H, H]); the keyword arguments are kept for callers that state them and must agree
+        m.E = sd['input_embedding.input_embeddings.0.weight'].shape[0] + 2
+        m.H = sd['encoder.weight_hh'].shape[1]
+        assert embedding_dim in (None, m.E) and hidden_dim in (None, m.H), (embedding_dim, m.E, hidden_dim, m.H)
         m.goal_flag = int(goal_flag)
         m.goal_dim = sd['goal_embedding.input_embeddings.0.weight'].shape[0] + 2
         m.pool_type = POOL_TYPES[pool_type]

@@ -12,7 +12,7 @@ from tests import helpers
 pytestmark = pytest.mark.gpu
 
 
-def make_model(kind, goal_flag, rng):
+def make_model(kind, goal_flag, rng, hidden_dim=128, embedding_dim=64):
     from trajnetplusplusbaselines_amd import lstm as L
     torch.manual_seed(int(rng.randint(1 << 30)))
     pool_to_input = True
@@ -21,11 +21,11 @@ def make_model(kind, goal_flag, rng):
     elif kind in ('occupancy', 'directional', 'social'):
         n = int(rng.choice([4, 8, 12, 16]))
         arch = str(rng.choice(['one_layer', 'two_layer']))
-        pool = L.GridBasedPooling(type_=kind, hidden_dim=128, cell_side=float(rng.choice([0.4, 0.6, 1.0])), n=n,
+        pool = L.GridBasedPooling(type_=kind, hidden_dim=hidden_dim, cell_side=float(rng.choice([0.4, 0.6, 1.0])), n=n,
                                   out_dim=int(rng.choice([32, 64, 128])), embedding_arch=arch,
                                   layer_dims=[int(rng.choice([64, 256]))], latent_dim=int(rng.choice([8, 16])),
                                   front=bool(rng.rand() < 0.2))
-        if pool.out_dim == 128 and rng.rand() < 0.5:
+        if pool.out_dim == hidden_dim and rng.rand() < 0.5:
             pool_to_input = False
     else:
         pool = {'nn': lambda: L.NearestNeighborMLP(n=4, out_dim=32),
@@ -33,7 +33,8 @@ def make_model(kind, goal_flag, rng):
                 'attentionmlp': lambda: L.AttentionMLPPooling(hidden_dim=128, out_dim=32),
                 'nn_lstm': lambda: L.NearestNeighborLSTM(n=4, hidden_dim=64, out_dim=32),
                 'traj_pool': lambda: L.TrajectronPooling(hidden_dim=64, out_dim=32)}[kind]()
-    model = L.LSTM(pool=pool, goal_flag=goal_flag, pool_to_input=pool_to_input).cuda().eval()
+    model = L.LSTM(embedding_dim=embedding_dim, hidden_dim=hidden_dim, pool=pool, goal_flag=goal_flag,
+                   pool_to_input=pool_to_input).cuda().eval()
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     kw = {}
     if kind in ('occupancy', 'directional', 'social'):
@@ -93,3 +94,24 @@ def test_random_batches_match_oracle(seed):
         what = '%s goal=%d sizes=%s %s' % (kind, goal_flag, np.diff(split).tolist(), mode)
         helpers.assert_close_nan(rel.cpu().numpy(), rel_o, 1e-4, 'rel ' + what)
         helpers.assert_close_nan(pred.cpu().numpy(), pred_o, 1e-4, 'pred ' + what)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_batches_with_other_state_sizes_match_oracle(seed):
+    """The trainer's --hidden-dim / --coordinate-embedding-dim (lstm/trainer.py:411-415) away from their defaults: hidden_dim
+    64 / 96 / 256, embedding_dim 32 / 64 / 128, vanilla and every grid type, random ragged batches as above."""
+    rng = np.random.RandomState(5000 + seed)
+    kind = ['vanilla', 'occupancy', 'directional', 'social'][seed % 4]
+    hidden_dim = int(rng.choice([64, 96, 256]))
+    embedding_dim = int(rng.choice([32, 64, 128]))
+    goal_flag = bool(rng.rand() < 0.3)
+    model, om = make_model(kind, goal_flag, rng, hidden_dim=hidden_dim, embedding_dim=embedding_dim)
+    xy, split = random_batch(rng)
+    M = xy.shape[1]
+    goals = rng.uniform(-5, 5, size=(M, 2)).astype(np.float32)
+    xt, gt, st = torch.tensor(xy), torch.tensor(goals), torch.tensor(split)
+    rel, pred = model(xt[:9], gt, st, n_predict=12)
+    rel_o, pred_o = om.forward(xy[:9], goals, split, n_predict=12)
+    what = '%s H=%d E=%d goal=%d sizes=%s' % (kind, hidden_dim, embedding_dim, goal_flag, np.diff(split).tolist())
+    helpers.assert_close_nan(rel.cpu().numpy(), rel_o, 1e-4, 'rel ' + what)
+    helpers.assert_close_nan(pred.cpu().numpy(), pred_o, 1e-4, 'pred ' + what)

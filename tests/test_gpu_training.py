@@ -729,3 +729,40 @@ def test_gradient_variants_match_reference_autograd(kind):
         assert p.grad is not None, name
         worst = max(worst, helpers.assert_matches_stored(z, pre + 'grad_' + name, p.grad.cpu().numpy(), 1e-4, kind))
     print(kind, 'worst relative gradient error %.2e' % worst)
+
+
+@pytest.mark.parametrize('kind', ['social_h64_e32', 'directional_h256_e128', 'vanilla_h96_e64', 'occupancy_h32_e16'])
+def test_gradients_with_other_state_sizes_match_reference_autograd(kind):
+    """--hidden-dim / --coordinate-embedding-dim away from 128 / 64 (lstm/trainer.py:411-415) on the training path: hidden_dim
+    32 / 64 / 96 / 256, embedding_dim 16 / 32 / 64 / 128 against the reference's autograd (tests/golden/grad_other_dims.npz,
+    oracle/gen_golden_r4.py; default init under the stored seed, per-tensor sums checked)."""
+    from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling, PredictionLoss
+    z = np.load(os.path.join(helpers.GOLDEN, 'grad_other_dims.npz'))
+    cfgs = {
+        'social_h64_e32': (64, 32, dict(type_='social', n=8, out_dim=32, embedding_arch='two_layer', layer_dims=[64], latent_dim=8)),
+        'directional_h256_e128': (256, 128, dict(type_='directional', n=12, out_dim=64)),
+        'vanilla_h96_e64': (96, 64, None),
+        'occupancy_h32_e16': (32, 16, dict(type_='occupancy', n=8, out_dim=32, embedding_arch='one_layer')),
+    }
+    H, E, pool_kw = cfgs[kind]
+    pre = kind + '_'
+    torch.manual_seed(int(z[pre + 'seed']))
+    pool = GridBasedPooling(hidden_dim=H, cell_side=0.6, **pool_kw) if pool_kw else None
+    model = LSTM(embedding_dim=E, hidden_dim=H, pool=pool)
+    for k, v in model.state_dict().items():
+        assert abs(v.double().sum().item() - float(z[pre + 'wsum_' + k])) < 1e-9, 'seeded weight differs: ' + k
+    model = model.cuda().train()
+    xy, split = torch.tensor(z[pre + 'xy']), torch.tensor(z[pre + 'split'])
+    targets = (xy[9:21] - xy[8:20]).cuda()
+    rel, pred = model(xy[:9].clone(), torch.zeros(xy.shape[1], 2), split, xy[9:20].clone())
+    loss = PredictionLoss()(rel[-12:], targets, split) * 5 + 0.1 * torch.nan_to_num(pred[-12:, split[:-1].cuda()]).pow(2).mean()
+    np.testing.assert_allclose(float(loss.detach()), float(z[pre + 'loss']), rtol=1e-4, atol=2e-5)
+    loss.backward()
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if (pre + 'nograd_' + name) in z.files:
+            assert p.grad is None, name + ': the reference leaves this gradient None'
+            continue
+        assert p.grad is not None, name
+        worst = max(worst, helpers.assert_matches_stored(z, pre + 'grad_' + name, p.grad.cpu().numpy(), 1e-4, kind))
+    print(kind, 'worst relative gradient error %.2e' % worst)

@@ -108,6 +108,35 @@ def test_random_ragged_batches(ref, kind):
     print('%s: worst |oracle - reference| over 44 forwards = %.2e' % (kind, worst))
 
 
+def test_state_sizes_other_than_the_defaults(ref):
+    """--hidden-dim / --coordinate-embedding-dim away from 128 / 64 (lstm/trainer.py:411-415): the oracle takes the state
+    sizes from the weights; vanilla and every grid type at hidden_dim 64 / 96 / 256 and embedding_dim 32 / 64 / 128."""
+    rng = np.random.RandomState(77)
+    worst = 0.0
+    for it in range(12):
+        kind = [None, 'occupancy', 'directional', 'social'][it % 4]
+        H, E = int(rng.choice([64, 96, 256])), int(rng.choice([32, 64, 128]))
+        torch.manual_seed(int(rng.randint(1 << 30)))
+        pool, kw = None, {}
+        if kind is not None:
+            n, cs = int(rng.choice([4, 8, 12])), float(rng.choice([0.4, 0.6]))
+            pool = ref.GridBasedPooling(type_=kind, hidden_dim=H, cell_side=cs, n=n, out_dim=int(rng.choice([32, 64])),
+                                        embedding_arch=str(rng.choice(['one_layer', 'two_layer'])), layer_dims=[64], latent_dim=8)
+            kw = dict(n=n, cell_side=cs)
+        model = ref.LSTM(embedding_dim=E, hidden_dim=H, pool=pool).eval()
+        om = oracle.OracleModel({k: v.detach().numpy() for k, v in model.state_dict().items()}, pool_type=kind, **kw)
+        xy, split = _ragged_batch(rng, max_scenes=4)
+        goals = np.zeros((xy.shape[1], 2), dtype=np.float32)
+        for mode in ('n_predict', 'truth'):
+            rel_r, pred_r = _run_ref(model, xy, goals, split, mode)
+            rel_o, pred_o = _run_oracle(om, xy, goals, split, mode)
+            what = '%s H=%d E=%d %s' % (kind, H, E, mode)
+            helpers.assert_close_nan(rel_o, rel_r, 2e-5, 'rel ' + what)
+            helpers.assert_close_nan(pred_o, pred_r, 2e-5, 'pred ' + what)
+            worst = max(worst, float(np.nanmax(np.abs(pred_o - pred_r))))
+    print('other state sizes: worst |oracle - reference| = %.2e' % worst)
+
+
 def _nongrid_model(ref, kind, rng):
     from trajnetbaselines.lstm import non_gridbased_pooling as ngp
     torch.manual_seed(int(rng.randint(1 << 30)))
