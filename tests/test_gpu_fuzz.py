@@ -115,3 +115,31 @@ def test_random_batches_with_other_state_sizes_match_oracle(seed):
     what = '%s H=%d E=%d goal=%d sizes=%s' % (kind, hidden_dim, embedding_dim, goal_flag, np.diff(split).tolist())
     helpers.assert_close_nan(rel.cpu().numpy(), rel_o, 1e-4, 'rel ' + what)
     helpers.assert_close_nan(pred.cpu().numpy(), pred_o, 1e-4, 'pred ' + what)
+
+
+@pytest.mark.parametrize('seed', range(14))
+def test_random_batches_with_other_sequence_lengths_match_oracle(seed):
+    """--obs_length / --pred_length away from 9 / 12 (lstm/trainer.py:389-392): 2..12 observed and 1..16 predicted frames, both
+    decoder modes, every interaction module in turn."""
+    rng = np.random.RandomState(7000 + seed)
+    T_obs, T_pred = [(2, 1), (2, 6), (3, 16), (5, 4), (8, 8), (12, 2), (9, 1)][seed % 7]
+    kind = KINDS[(seed * 2 + 1) % len(KINDS)]
+    goal_flag = bool(rng.rand() < 0.3)
+    model, om = make_model(kind, goal_flag, rng)
+    xy, split = random_batch(rng)
+    xy = np.concatenate([xy, xy[-7:] + (xy[-1:] - xy[-8:-7])], axis=0)                # 28 frames
+    M = xy.shape[1]
+    goals = rng.uniform(-5, 5, size=(M, 2)).astype(np.float32)
+    xt, gt, st = torch.tensor(xy), torch.tensor(goals), torch.tensor(split)
+    what = '%s %d+%d goal=%d sizes=%s' % (kind, T_obs, T_pred, goal_flag, np.diff(split).tolist())
+    rel, pred = model(xt[:T_obs], gt, st, n_predict=T_pred)
+    rel_o, pred_o = om.forward(xy[:T_obs], goals, split, n_predict=T_pred)
+    assert rel.shape[0] == T_obs + T_pred - 2
+    helpers.assert_close_nan(rel.cpu().numpy(), rel_o, 1e-4, 'rel free ' + what)
+    helpers.assert_close_nan(pred.cpu().numpy(), pred_o, 1e-4, 'pred free ' + what)
+    if T_pred > 1:
+        truth = xy[T_obs:T_obs + T_pred - 1]
+        rel, pred = model(xt[:T_obs], gt, st, prediction_truth=torch.tensor(truth))
+        rel_o, pred_o = om.forward(xy[:T_obs], goals, split, prediction_truth=truth)
+        helpers.assert_close_nan(rel.cpu().numpy(), rel_o, 1e-4, 'rel truth ' + what)
+        helpers.assert_close_nan(pred.cpu().numpy(), pred_o, 1e-4, 'pred truth ' + what)

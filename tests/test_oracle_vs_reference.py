@@ -137,6 +137,34 @@ def test_state_sizes_other_than_the_defaults(ref):
     print('other state sizes: worst |oracle - reference| = %.2e' % worst)
 
 
+def test_sequence_lengths_other_than_9_plus_12(ref):
+    """--obs_length / --pred_length away from 9 / 12 (lstm/trainer.py:389-392): 2..12 observed frames, 1..16 predicted ones,
+    both decoder modes (n_predict = len(prediction_truth) + 1, lstm/lstm.py:199-201)."""
+    rng = np.random.RandomState(91)
+    worst = 0.0
+    for it, (T_obs, T_pred) in enumerate([(2, 1), (2, 6), (3, 16), (5, 4), (8, 8), (12, 2), (9, 1)]):
+        kind = ['social', 'directional', 'occupancy'][it % 3]
+        model, om, cfg = _ref_model(ref, kind, rng)
+        xy, split = _ragged_batch(rng, max_scenes=4)
+        xy = np.concatenate([xy, xy[-7:] + (xy[-1:] - xy[-8:-7])], axis=0)            # 28 frames
+        goals = rng.uniform(-5, 5, size=(xy.shape[1], 2)).astype(np.float32)
+        xt, gt, st = torch.tensor(xy), torch.tensor(goals), torch.tensor(split)
+        with torch.no_grad():
+            rel_r, pred_r = model(xt[:T_obs].clone(), gt, st, n_predict=T_pred)
+        rel_o, pred_o = om.forward(xy[:T_obs], goals, split, n_predict=T_pred)
+        helpers.assert_close_nan(rel_o, rel_r.numpy(), 2e-5, 'rel free %d+%d' % (T_obs, T_pred))
+        helpers.assert_close_nan(pred_o, pred_r.numpy(), 2e-5, 'pred free %d+%d' % (T_obs, T_pred))
+        worst = max(worst, float(np.nanmax(np.abs(pred_o - pred_r.numpy()))))
+        if T_pred > 1:
+            truth = xy[T_obs:T_obs + T_pred - 1]
+            with torch.no_grad():
+                rel_r, pred_r = model(xt[:T_obs].clone(), gt, st, prediction_truth=torch.tensor(truth).clone())
+            rel_o, pred_o = om.forward(xy[:T_obs], goals, split, prediction_truth=truth)
+            helpers.assert_close_nan(rel_o, rel_r.numpy(), 2e-5, 'rel truth %d+%d' % (T_obs, T_pred))
+            helpers.assert_close_nan(pred_o, pred_r.numpy(), 2e-5, 'pred truth %d+%d' % (T_obs, T_pred))
+    print('other sequence lengths: worst |oracle - reference| = %.2e' % worst)
+
+
 def _nongrid_model(ref, kind, rng):
     from trajnetbaselines.lstm import non_gridbased_pooling as ngp
     torch.manual_seed(int(rng.randint(1 << 30)))
