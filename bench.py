@@ -784,6 +784,7 @@ def main():
             torch.cuda.synchronize()
             ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
             _lib.check(L.tnp_profile_read(ctypes.byref(ms), ctypes.byref(n)), 'tnp_profile_read')
+            dispatch_timed = int(L.tnp_profile_dispatch_timed())
             L.tnp_profile_end()
             K0 = cfg['n'] * cfg['n'] * model.pool.pooling_dim
             N0 = model.pool.embedding_layers()[0].weight.shape[0]
@@ -825,10 +826,15 @@ def main():
                             launches=n.value, avg_launch_us=avg_s * 1e6, flops_per_launch=flops,
                             dense_equivalent_tflops=dense_flops / avg_s / 1e12,
                             share_of_step=ms.value * 1e-3 / elapsed,
-                            event_pair_empty_us=empty_us,
-                            event_note='avg_launch_us is the span between two HIP events around each launch; two events with nothing '
-                                       'between them already read event_pair_empty_us on this stream (about half of that sits inside a '
-                                       'bracketed launch), which is why the rocprofv3 mean of the same kernel under profiles/ is ~3 us lower')
+                            event_pair_empty_us=empty_us, dispatch_timed_launches=dispatch_timed,
+                            event_note=('avg_launch_us: the two HIP events of every launch travel IN its dispatch (hipExtLaunchKernelGGL '
+                                        'start / stop events = begin / end timestamps of the kernel\'s own AQL packet, the quantity the '
+                                        'committed rocprofv3 kernel trace reports).  Two hipEventRecord calls around a launch read '
+                                        'event_pair_empty_us with NOTHING between them on this stream; rounds 1-3 bracketed the launch that '
+                                        'way and read ~3 us more than rocprofv3.') if dispatch_timed == n.value else
+                                       ('avg_launch_us is the span between two HIP events recorded around each launch; two events with '
+                                        'nothing between them already read event_pair_empty_us on this stream (about half of that sits '
+                                        'inside a bracketed launch), which is why the rocprofv3 mean under profiles/ is ~3 us lower'))
                 if hits is not None:
                     # the (A-1)-cell bound is an upper bound of the work; this is the work that was actually there
                     mean_hits = float(np.mean(hits))

@@ -15,12 +15,19 @@ extern "C" {
 /* -------------------------------------------------------------------------------------------
  * Kernel timing hook: when enabled, every launch of the chosen kernel class (`which`: 0 = first
  * pooling-embedding layer -- the sparse kernel or the dense GEMM --, 1 = all GEMM launches) is
- * bracketed by hipEvents recorded on the stream the kernel is launched on; tnp_profile_read
+ * timed by a pair of hipEvents on the stream the kernel is launched on; tnp_profile_read
  * synchronises those events and returns the summed milliseconds and the launch count since
  * tnp_profile_begin (at most 32768 launches are recorded, later ones are not timed).
+ * The sparse first layer's register-accumulator kernel -- the dominant kernel of the step --
+ * carries the two events IN ITS DISPATCH (hipExtLaunchKernelGGL start / stop events: the begin
+ * and end timestamps of the kernel's own AQL packet, the quantity rocprofv3's kernel trace
+ * reports); every other launch is bracketed by two hipEventRecord calls, whose markers add
+ * about 3 us to the span.  tnp_profile_dispatch_timed: how many of the launches returned by the
+ * last tnp_profile_read were timed by their dispatch.
  * ----------------------------------------------------------------------------------------- */
 TNP_API int tnp_profile_begin(int which);
 TNP_API int tnp_profile_read(double *total_ms, int *launches);
+TNP_API int tnp_profile_dispatch_timed(void);
 TNP_API int tnp_profile_end(void);
 
 #ifdef __cplusplus

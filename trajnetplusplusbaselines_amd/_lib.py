@@ -102,6 +102,7 @@ def lib():
                                 ctypes.c_double, _fp]
     L.tnp_profile_begin.argtypes = [ctypes.c_int]
     L.tnp_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    L.tnp_profile_dispatch_timed.argtypes = []
     L.tnp_constant_velocity.argtypes = [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp]
     L.tnp_pool_embed_sparse_workspace_bytes.restype = ctypes.c_size_t
     L.tnp_pool_embed_sparse_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]

@@ -27,6 +27,7 @@
 // All three share the hit discovery (winner per (ego, cell), "last writer in ascending j wins", cell-0 clobber) and the
 // packed-FMA hit; blocks b, b+8, ... share an XCD and a column block, whose weight slice stays in that XCD's L2.
 #include "tnp_internal.h"
+#include <hip/hip_ext.h>
 
 // Timing ablations and shader-clock stamps exist only in builds of tools/experiments/*.hip, which define
 // TNP_EXPERIMENT_HOOKS before including this file; the library compiles none of it.
@@ -977,6 +978,9 @@ size_t sparse_partial_bytes(int M, int N1, int ncell) {
 }
 
 bool sparse_fuses_grid(int ncell, int n_max) { return ncell <= TL_MAXCELL_LDS && n_max <= 32767; }
+bool sparse_uses_regacc(int M, int ldv, int C, int ncell) {
+    return M > 0 && (size_t)M * ldv * sizeof(float) < ((size_t)1 << 32) && regacc_supported(C, ncell);
+}
 
 int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, const int32_t *row_base,
                              const float *Wp, const float *bias, int M, int ncell, int C, int N1, int relu,
@@ -1000,12 +1004,15 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
         const bool quad = Wq != nullptr && fg != nullptr && N1 % 64 == 0 && C % 4 == 0 &&
                           (size_t)ncell * N1 * C * 4 < ((size_t)1 << 31);   // 32-bit byte offsets of the cells' weight blocks
         if (quad) a.Wp = Wq;
+        hipEvent_t pe0 = nullptr, pe1 = nullptr;
+        const bool pev = take_dispatch_events(&pe0, &pe1);   // profiling: events of the dispatch itself (tnp_internal.h)
 #define RA_LAUNCH(CC, FGB, QB) { static bool set = false; if (!set) { hipFuncAttributes fa; \
         TNP_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(pool_embed_regacc_kernel<CC, FGB, QB>))); \
         if (fa.localSizeBytes != 0) TNP_FAIL(-3, "pool_embed_regacc_kernel: accumulators left the register file (%zu bytes of scratch)", (size_t)fa.localSizeBytes); \
         TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
         pool_embed_regacc_kernel<CC, FGB, QB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        hipLaunchKernelGGL((pool_embed_regacc_kernel<CC, FGB, QB>), dim3(rblocks), dim3(64 * RA_NQ * RA_NCS), rsmem, s, a); }
+        if (pev) hipExtLaunchKernelGGL((pool_embed_regacc_kernel<CC, FGB, QB>), dim3(rblocks), dim3(64 * RA_NQ * RA_NCS), rsmem, s, pe0, pe1, 0, a); \
+        else hipLaunchKernelGGL((pool_embed_regacc_kernel<CC, FGB, QB>), dim3(rblocks), dim3(64 * RA_NQ * RA_NCS), rsmem, s, a); }
 #define RA_SWITCH(CC) { if (quad) RA_LAUNCH(CC, true, true) else if (fg) RA_LAUNCH(CC, true, false) else RA_LAUNCH(CC, false, false) }
         if (C == 4) RA_SWITCH(4) else if (C == 8) RA_SWITCH(8) else RA_SWITCH(16)
         TNP_HIP(hipGetLastError());

@@ -80,6 +80,7 @@ struct SparseGridFuse {
     const float *obs2; const int32_t *row_end; const int32_t *row_padded; int G; float cell, half_x, half_y; int16_t *winners_out;
 };
 bool sparse_fuses_grid(int ncell, int n_max);
+bool sparse_uses_regacc(int M, int ldv, int C, int ncell);   // launch_pool_embed_sparse will run pool_embed_regacc_kernel
 int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, const int32_t *row_base,
                              const float *Wp, const float *bias, int M, int ncell, int C, int N1, int relu,
                              float *out, int ldo, float *partial, hipStream_t s, const SparseGridFuse *fg = nullptr,
@@ -132,5 +133,11 @@ __device__ __forceinline__ float primary_loss_value(int mode, float n0, float n1
 enum { PROF_GEMM1 = 0, PROF_ALL_GEMM = 1 };
 void prof_before(int cls, hipStream_t s);
 void prof_after(int cls, hipStream_t s);
+// Events carried by the DISPATCH itself (hipExtLaunchKernelGGL start / stop events = the begin / end timestamps of the kernel's
+// AQL packet, what rocprofv3's kernel trace reports) instead of two hipEventRecord calls around it, whose own markers add ~3 us
+// to a bracketed launch.  prof_dispatch_events reserves the next event pair when profiling of `cls` is on; a launcher that
+// supports it takes the pair with take_dispatch_events() and clears it.
+bool prof_dispatch_events(int cls);
+bool take_dispatch_events(hipEvent_t *start, hipEvent_t *stop);
 
 }  // namespace tnp
