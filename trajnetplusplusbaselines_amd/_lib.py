@@ -234,6 +234,8 @@ class StreamMark(object):
         self.event.record(self.stream)
 
     def join(self):
+        if torch.cuda.is_current_stream_capturing():
+            return          # hipGraph capture (LSTM._forward_graphed): the capture begins after a device synchronisation
         cur = torch.cuda.current_stream(self.device)
         if cur != self.stream:
             cur.wait_event(self.event)

@@ -58,6 +58,43 @@ bool take_dispatch_events(hipEvent_t *start, hipEvent_t *stop) {
     return true;
 }
 
+// ---- fills and copies as KERNELS ------------------------------------------------------------------
+// The sequence driver is captured into hipGraphs (lstm/lstm.py: _forward_graphed).  With ROCm 7.2 a hipMemsetAsync captured
+// as a memset node clears its whole range on the first replay only -- later replays leave more than half of the bytes as they
+// were (tools/diag/graph_memset_probe.py: every size from 64 B to 1 MB) -- so the driver does not use memset / memcpy nodes.
+__global__ void __launch_bounds__(256) fill_u32_kernel(uint32_t *p, uint32_t v, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+__global__ void __launch_bounds__(256) fill_u8_kernel(uint8_t *p, uint8_t v, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+__global__ void __launch_bounds__(256) copy_u32_kernel(uint32_t *dst, const uint32_t *src, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+static unsigned fill_blocks(size_t n) { const size_t b = (n + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
+// bytes: a multiple of 4 on a 4-byte aligned address, or any count for a byte value
+static int fill_bytes(void *p, int byte, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return 0;
+    if (bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 3) == 0) {
+        const uint32_t v = 0x01010101u * (uint32_t)(byte & 0xff);
+        hipLaunchKernelGGL(fill_u32_kernel, dim3(fill_blocks(bytes / 4)), dim3(256), 0, s, reinterpret_cast<uint32_t *>(p), v, bytes / 4);
+    } else {
+        hipLaunchKernelGGL(fill_u8_kernel, dim3(fill_blocks(bytes)), dim3(256), 0, s, reinterpret_cast<uint8_t *>(p), (uint8_t)byte, bytes);
+    }
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+static int copy_floats(float *dst, const float *src, size_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(copy_u32_kernel, dim3(fill_blocks(n)), dim3(256), 0, s, reinterpret_cast<uint32_t *>(dst),
+                       reinterpret_cast<const uint32_t *>(src), n);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---- per-track prepare kernel -----------------------------------------------------------------
 struct PrepArgs {
     int M, H, E, goal_flag, goal_dim, C, I;  // I = row stride of X
@@ -628,7 +665,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
     memset(&g, 0, sizeof(g));
     if (w.to_hidden) {   // hplus = h_in + pooled (rows of absent tracks are never used: their state is copied through)
         const long tot4 = (long)M * H / 4;
-        if (w.pvec_save) TNP_HIP(hipMemcpyAsync(w.pvec_save, w.hplus, (size_t)M * H * 4, hipMemcpyDeviceToDevice, s));
+        if (w.pvec_save) { int rcc = copy_floats(w.pvec_save, w.hplus, (size_t)M * H, s); if (rcc) return rcc; }
         hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((tot4 + 255) / 256)), dim3(256), 0, s, w.hplus, h_in, tot4);
         TNP_HIP(hipGetLastError());
     }
@@ -730,20 +767,20 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
     float *hcur = sv ? sv->h_all : w.h[0];
     const size_t flag_bytes = ((size_t)(M + 31) / 32 + 16) * sizeof(unsigned);
     if (!sv && w.c > w.h[0]) {      // lstm.py:207-210; h[0], h[1], c, the chain counters lie one after the other: one fill
-        TNP_HIP(hipMemsetAsync(hcur, 0, (size_t)(reinterpret_cast<char *>(w.chain_flags) + flag_bytes - reinterpret_cast<char *>(w.h[0])), s));
+        rc = fill_bytes(hcur, 0, (size_t)(reinterpret_cast<char *>(w.chain_flags) + flag_bytes - reinterpret_cast<char *>(w.h[0])), s); if (rc) return rc;
     } else {
-        TNP_HIP(hipMemsetAsync(hcur, 0, MH * 4, s));
-        TNP_HIP(hipMemsetAsync(sv ? sv->c_all : w.c, 0, MH * 4, s));
-        TNP_HIP(hipMemsetAsync(w.chain_flags, 0, flag_bytes, s));
+        rc = fill_bytes(hcur, 0, MH * 4, s); if (rc) return rc;
+        rc = fill_bytes(sv ? sv->c_all : w.c, 0, MH * 4, s); if (rc) return rc;
+        rc = fill_bytes(w.chain_flags, 0, flag_bytes, s); if (rc) return rc;
     }
     if (w.ph[0]) {  // pool.reset() (lstm/lstm.py:213-216): zero interaction-encoder state, all tracks "present"
-        TNP_HIP(hipMemsetAsync((sv && stateful) ? sv->ph_all : w.ph[0], 0, (size_t)M * md->dims[0] * 4, s));
-        TNP_HIP(hipMemsetAsync((sv && stateful) ? sv->pc_all : w.pc, 0, (size_t)M * md->dims[0] * 4, s));
-        TNP_HIP(hipMemsetAsync(w.ones, 1, (size_t)M, s));
+        rc = fill_bytes((sv && stateful) ? sv->ph_all : w.ph[0], 0, (size_t)M * md->dims[0] * 4, s); if (rc) return rc;
+        rc = fill_bytes((sv && stateful) ? sv->pc_all : w.pc, 0, (size_t)M * md->dims[0] * 4, s); if (rc) return rc;
+        rc = fill_bytes(w.ones, 1, (size_t)M, s); if (rc) return rc;
     }
     int npos = 0, nnorm = 0, cur = 0;
     if (T_obs == 2) {  // lstm.py:222-223
-        TNP_HIP(hipMemcpyAsync(pred, observed + F, F * 4, hipMemcpyDeviceToDevice, s));
+        rc = copy_floats(pred, observed + F, F, s); if (rc) return rc;
         npos = 1;
     }
     const int n_steps = (T_obs - 1) + T_dec;
@@ -820,7 +857,7 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
             float *noisy = w.h[cur ^ 1];
             if (sv) {   // h_all[st] becomes the decoder's input state; the clean encoder state is kept beside it
                 if (!sv->h_clean) TNP_FAIL(-1, "tnp_lstm_forward_train: noise interface without h_clean");
-                TNP_HIP(hipMemcpyAsync(sv->h_clean, hcur, MH * 4, hipMemcpyDeviceToDevice, s));
+                { int rcc = copy_floats(sv->h_clean, hcur, MH, s); if (rcc) return rcc; }
                 clean = sv->h_clean;
                 noisy = hcur;
             }
@@ -859,7 +896,7 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
             hcur = hnext;
         }
     }
-    if (ex && ex->h_final) TNP_HIP(hipMemcpyAsync(ex->h_final, hcur, MH * 4, hipMemcpyDeviceToDevice, s));
+    if (ex && ex->h_final) { rc = copy_floats(ex->h_final, hcur, MH, s); if (rc) return rc; }
     return 0;
 }
 
@@ -915,7 +952,7 @@ static int lstm_step_impl(const tnp_lstm_model *md, int decoder, const float *h_
         if (sv->winners && w.sparse) { w.winners = sv->winners; w.save_winners = 1; }
     }
     if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s, w.row_end, w.row_padded, scene_slots, n_max); if (rc) return rc; }
-    TNP_HIP(hipMemsetAsync(w.chain_flags, 0, ((size_t)(M + 31) / 32 + 16) * sizeof(unsigned), s));   // chained launch: fresh counters
+    { int rcc = fill_bytes(w.chain_flags, 0, ((size_t)(M + 31) / 32 + 16) * sizeof(unsigned), s); if (rcc) return rcc; }   // chained launch: fresh counters
     PrepArgs p;
     fill_prep_common(p, md, w, M);
     p.h = h_in; p.goals = goals;

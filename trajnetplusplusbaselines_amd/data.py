@@ -29,6 +29,14 @@ def paths_to_xy(paths):
     return xy
 
 
+def xy_to_paths(xy, frame_step=10, first_pedestrian=100):
+    """Inverse of ``paths_to_xy``: float [T, N, 2] (NaN = absent, track 0 = the primary, present in every frame) -> list of
+    lists of TrackRow.  For tests and for callers that hold scenes as arrays but talk to the predictors' path interface."""
+    xy = np.asarray(xy)
+    return [[TrackRow(frame_step * t, first_pedestrian + p, float(xy[t, p, 0]), float(xy[t, p, 1]))
+             for t in range(xy.shape[0]) if not np.isnan(xy[t, p, 0])] for p in range(xy.shape[1])]
+
+
 def rotate_path(xy, theta):
     """Rotate every [.., 2] point by `theta` (row-vector convention of reference lstm/utils.py:24-30)."""
     ct, st = np.cos(theta), np.sin(theta)

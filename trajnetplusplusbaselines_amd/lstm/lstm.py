@@ -6,6 +6,7 @@ sites keep working; the recurrent step runs in hand-written HIP (csrc/lstm_seq.h
 [M,H] state instead of the reference's Python lists of per-track tensors.  There is no CPU fallback.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -66,13 +67,17 @@ class LSTM(torch.nn.Module):
         self._grad_reduce_fn = None   # data-parallel training: parallel.GradReducer, see lstm/train_step.py
         self._cell_major = None  # (key, tensor): cell-major copy of pool.embedding[0].weight
         self._quad_major = None  # (key, tensor): its quad-major copy (register-accumulator sparse kernel)
+        #: inference forwards replayed as hipGraphs (see _forward_graphed): True = every no-grad forward, False = never,
+        #: None = only where a caller asks for it (LSTMPredictor does)
+        self.graph_replay = None
+        self._graphs = None      # {key: _GraphedForward}
 
     #: subclasses that only run the encoder (the S-GAN discriminator) construct neither decoder nor Hidden2Normal, so that
     #: they draw their parameters from the RNG in the reference's order (same seed => same weights)
     _ENCODER_ONLY = False
 
     # device-side caches (workspace, re-laid-out weight copies): rebuilt lazily, never pickled / deep-copied
-    _CACHES = ('_ws', '_cell_major', '_quad_major', '_dummy_head', '_grad_reduce_fn', '_desc_cache', '_plist_cache')
+    _CACHES = ('_ws', '_cell_major', '_quad_major', '_dummy_head', '_grad_reduce_fn', '_desc_cache', '_plist_cache', '_graphs')
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -344,8 +349,11 @@ class LSTM(torch.nn.Module):
         return (h_out, c_out), normal
 
     # ---- whole sequence (reference lstm/lstm.py:170-264) ----------------------------------------------
-    def forward(self, observed, goals, batch_split, prediction_truth=None, n_predict=None, pad_to=None):
+    def forward(self, observed, goals, batch_split, prediction_truth=None, n_predict=None, pad_to=None, graph=None):
         """observed [T_obs,M,2], goals [M,2], batch_split [B+1] -> (rel_pred_scene [S,M,5], pred_scene [S,M,2]).
+
+        ``graph`` (extension): replay this inference forward as a hipGraph when the same call shape comes back (see
+        ``_forward_graphed``); None = what ``self.graph_replay`` says.
 
         ``pad_to`` (extension, keyword only in spirit) names the number of slots the reference would have padded the
         scenes to (lstm/lstm.py:29: the padded, absent slots clobber cell (0, 0) of shorter scenes' grids and enter
@@ -384,8 +392,56 @@ class LSTM(torch.nn.Module):
             # under torch.compile the whole sequence is ONE dispatcher op (ops.py: trajnet::lstm_sequence) -- no graph break
             return torch.ops.trajnet.lstm_sequence(observed, goals, torch.as_tensor(batch_split), prediction_truth, T_dec,
                                                    int(pad_to or 0), self._op_handle, list(self.parameters()))
+        use_graph = self.graph_replay if self.graph_replay is not None else bool(graph)
+        if use_graph and not torch.is_grad_enabled() and _GRAPHS_ALLOWED:
+            return self._forward_graphed(observed, goals, batch_split, prediction_truth, T_dec, pad_to)
         rel_pred, pred, _ = self._run_sequence(observed, goals, batch_split, prediction_truth, T_dec, pad_to=pad_to)
         return rel_pred, pred
+
+    # ---- inference forward as a hipGraph ----------------------------------------------------------------
+    _GRAPH_AFTER = 2          # calls of one shape that run eagerly before it is captured
+    _GRAPH_MAX = 24           # captured shapes kept (least recently used goes first) ...
+    _GRAPH_MAX_BYTES = 4 << 30   # ... and the bytes of their private workspaces / static buffers
+
+    def _forward_graphed(self, observed, goals, batch_split, truth, T_dec, pad_to):
+        """One inference forward = 4 launches x (T_obs - 1 + T_dec) steps enqueued by ``tnp_lstm_forward``: ~80 launches, 0.6-1.1 ms
+        of host time, which is ALL of the wall time of a small batch (1 scene x 4 agents: 0.76 ms per forward, of which the
+        kernels are 0.3 ms) and caps several batches in flight at the host's launch rate.  The sequence driver never
+        synchronises or allocates, so it is captured once per call shape -- (model weights' addresses and configuration,
+        scene structure, sequence lengths, decoder mode, stream) -- into a hipGraph over static input / output buffers and a
+        private workspace; later calls of that shape copy their inputs in, replay the graph (one host call) and clone the
+        outputs.  A shape is captured on its third call (one-off shapes stay eager); the kernels, their order and their
+        arguments are those of the eager path, so the outputs are bit-identical (tests/test_gpu_graph.py)."""
+        m, keep, dev = self._descriptor()
+        idx = _lib.SceneIndex.get(batch_split, dev, pad_to)
+        T_obs, M = observed.size(0), observed.size(1)
+        if idx.M != M:
+            raise ValueError('batch_split covers %d tracks, observed has %d' % (idx.M, M))
+        goals_t = goals if (goals is not None and self.goal_flag) else None
+        # (the caller's stream is part of the key: forwards on different streams -- batches in flight -- must not share buffers)
+        key = (bytes(m), idx, T_obs, T_dec, truth is not None, goals_t is not None, torch.cuda.current_stream().cuda_stream)
+        if not isinstance(self._graphs, dict):
+            self._graphs = {}
+        e = self._graphs.get(key)
+        if not isinstance(e, _GraphedForward):
+            seen = int(e or 0) + 1
+            if seen <= self._GRAPH_AFTER or M == 0:
+                self._graphs[key] = seen
+                if len(self._graphs) > 8 * self._GRAPH_MAX:       # shapes that never came back
+                    for k in [k for k, v in self._graphs.items() if not isinstance(v, _GraphedForward)][:4 * self._GRAPH_MAX]:
+                        del self._graphs[k]
+                rel_pred, pred, _ = self._run_sequence(observed, goals_t, batch_split, truth, T_dec, pad_to=pad_to)
+                return rel_pred, pred
+            e = _GraphedForward(self, keep, _lib.f32c(observed, dev), _lib.f32c(goals_t, dev) if goals_t is not None else None,
+                                batch_split, _lib.f32c(truth, dev) if truth is not None else None, T_dec, pad_to)
+            self._graphs.pop(key, None)
+            self._graphs[key] = e
+            live = [(k, v) for k, v in self._graphs.items() if isinstance(v, _GraphedForward)]
+            while len(live) > self._GRAPH_MAX or (len(live) > 1 and sum(v.nbytes for _, v in live) > self._GRAPH_MAX_BYTES):
+                del self._graphs[live.pop(0)[0]]
+        else:
+            self._graphs[key] = self._graphs.pop(key)             # most recently used last
+        return e(observed, goals_t, truth)
 
     def forward_with_loss(self, observed, goals, batch_split, targets, criterion, prediction_truth=None, n_predict=None,
                           pad_to=None):
@@ -419,7 +475,7 @@ class LSTM(torch.nn.Module):
         return rel_pred, pred, (out if keep else out[0])
 
     def _run_sequence(self, observed, goals, batch_split, truth, T_dec, w_ctx=None, b_ctx=None, noise=None,
-                      want_h_final=False, pad_to=None, fused_loss=None, h_scale=None):
+                      want_h_final=False, pad_to=None, fused_loss=None, h_scale=None, private_ws=None):
         """tnp_lstm_forward(_ex): T_obs-1 encoder steps + T_dec decoder steps; optional S-GAN hooks.
         ``fused_loss`` = (targets [T_loss, M, 2], mode, background_rate): the per-primary loss values of the last T_loss
         outputs are evaluated inside the sequence (returned in place of h_final as [T_loss, M] rows)."""
@@ -435,7 +491,14 @@ class LSTM(torch.nn.Module):
         npos = n_steps + (1 if T_obs == 2 else 0)
         rel_pred = torch.empty(n_steps, M, 5, dtype=torch.float32, device=dev)
         pred = torch.empty(npos, M, 2, dtype=torch.float32, device=dev)
-        ws, need = self._workspace(m, M, idx.B, dev)
+        if private_ws is not None:       # hipGraph capture: the workspace belongs to the graph (private_ws: a list that receives it)
+            need = _lib.lib().tnp_lstm_workspace_bytes(ctypes.byref(m), M, idx.B)
+            if need == 0:
+                _lib.check(-1, 'tnp_lstm_workspace_bytes')
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            private_ws.append(ws)
+        else:
+            ws, need = self._workspace(m, M, idx.B, dev)
         ex = _lib.LstmExtras()
         h_final = None
         if noise is not None:
@@ -473,8 +536,60 @@ class LSTM(torch.nn.Module):
         return rel_pred, pred, h_final
 
 
+#: kill switch for the hipGraph replay of inference forwards (TNP_NO_GRAPHS=1)
+_GRAPHS_ALLOWED = os.environ.get('TNP_NO_GRAPHS', '0') in ('', '0')
+
+
+class _GraphedForward(object):
+    """One captured inference forward of one call shape: static inputs, the outputs and the workspace the captured launches
+    point into, and the instantiated hipGraph (LSTM._forward_graphed).
+
+    The graph is captured AND replayed on a stream of its own; the caller's stream is joined by events on both sides.  Not
+    a matter of taste: with ROCm 7.2 / torch 2.10 a replay on the DEFAULT (null) stream is not ordered with the copies in
+    front of it -- from the third replay on, a vanilla LSTM (the shortest kernels) returned outputs that belonged to no
+    input (tools/diag/graph_race_probe.py: wrong on the default stream, right on any other stream or with a device
+    synchronisation anywhere in the call)."""
+
+    def __init__(self, model, keep, observed, goals, batch_split, truth, T_dec, pad_to):
+        self.keep = keep                     # the weight tensors the captured kernel arguments point into
+        self.obs = observed.clone()
+        self.goals = goals.clone() if goals is not None else None
+        self.truth = truth.clone() if truth is not None else None
+        self.stream = torch.cuda.Stream(device=observed.device)
+        ws = []
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):   # (synchronises the device first; private memory pool)
+            self.rel, self.pred, _ = model._run_sequence(self.obs, self.goals, batch_split, self.truth, T_dec, pad_to=pad_to,
+                                                         private_ws=ws)
+        self.ws = ws[0]
+        self.nbytes = sum(t.numel() * t.element_size() for t in (self.obs, self.goals, self.truth, self.rel, self.pred, self.ws)
+                          if t is not None)
+        self.replays = 0
+
+    def __call__(self, observed, goals, truth):
+        cur = torch.cuda.current_stream(self.obs.device)
+        self.stream.wait_stream(cur)                             # the caller's inputs, and the previous call's clones
+        with torch.cuda.stream(self.stream):
+            self.obs.copy_(observed, non_blocking=True)
+            if self.goals is not None:
+                self.goals.copy_(goals, non_blocking=True)
+            if self.truth is not None:
+                self.truth.copy_(truth, non_blocking=True)
+            self.graph.replay()
+            rel, pred = self.rel.clone(), self.pred.clone()
+        cur.wait_stream(self.stream)
+        rel.record_stream(cur)
+        pred.record_stream(cur)
+        self.replays += 1
+        return rel, pred
+
+
 class LSTMPredictor(object):
     """Reference lstm/lstm.py:266-313: pickle-compatible wrapper used by the evaluator."""
+
+    #: replay repeated call shapes as hipGraphs (LSTM._forward_graphed): the evaluator calls the predictor once per scene,
+    #: which is launch-bound (0.76 ms per call for a 4-agent scene, 0.3 ms of it kernels)
+    graph_replay = True
 
     def __init__(self, model):
         self.model = model
@@ -483,6 +598,9 @@ class LSTMPredictor(object):
         state = self.__dict__.copy()
         state.pop('_streams', None)          # predict_batches' HIP streams are not part of the pickle
         return state
+
+    def _graph_kw(self):
+        return {'graph': True} if (self.graph_replay and isinstance(self.model, LSTM)) else {}
 
     def save(self, state, filename):
         with open(filename, 'wb') as f:
@@ -511,7 +629,7 @@ class LSTMPredictor(object):
             multimodal_outputs = {}
             for num_p in range(modes):
                 _, output_scenes = self.model(xy[start_length:obs_length], scene_goal, batch_split,
-                                              n_predict=n_predict)
+                                              n_predict=n_predict, **self._graph_kw())
                 output_scenes = output_scenes.cpu().numpy()
                 if normalize:
                     output_scenes = trajdata.inverse_scene(output_scenes, rotation, center)
@@ -549,7 +667,8 @@ class LSTMPredictor(object):
             obs = torch.tensor(xy, dtype=torch.float32)
             goal = torch.tensor(np.concatenate(goals, axis=0), dtype=torch.float32)
             batch_split = torch.tensor(split, dtype=torch.int64)
-            outputs = [self.model(obs, goal, batch_split, n_predict=n_predict, pad_to='scene')[1] for _ in range(modes)]
+            outputs = [self.model(obs, goal, batch_split, n_predict=n_predict, pad_to='scene', **self._graph_kw())[1]
+                       for _ in range(modes)]
         return self._unpack(outputs, split, frames, normalize, n_predict)
 
     @staticmethod
@@ -605,7 +724,8 @@ class LSTMPredictor(object):
                 obs = torch.tensor(xy, dtype=torch.float32)
                 goal = torch.tensor(np.concatenate(goals, axis=0), dtype=torch.float32)
                 batch_split = torch.tensor(split, dtype=torch.int64)
-                outputs = [self.model(obs, goal, batch_split, n_predict=n_predict, pad_to='scene')[1] for _ in range(modes)]
+                outputs = [self.model(obs, goal, batch_split, n_predict=n_predict, pad_to='scene', **self._graph_kw())[1]
+                           for _ in range(modes)]
             pending.append((outputs, split, frames))
         for st in streams:
             st.synchronize()
