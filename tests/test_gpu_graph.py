@@ -1,5 +1,5 @@
-"""Inference forwards replayed as hipGraphs (LSTM._forward_graphed): a call shape that comes back is captured once -- the
-sequence driver's ~80 launches over static buffers -- and replayed with one host call.  Same kernels, same order, same
+"""Inference forwards replayed as hipGraphs (LSTM._forward_graphed, opt-in): a call shape that comes back is captured once --
+the sequence driver's ~80 launches over static buffers -- and replayed with one host call.  Same kernels, same order, same
 arguments as the eager path: every output must be BIT-identical to it."""
 import numpy as np
 import pytest
@@ -90,7 +90,8 @@ def test_predictor_per_scene_calls_replay_and_match():
     scenes = scenes + scenes + scenes                                   # every agent count comes back
     model = _model('social')
     fast, slow = LSTMPredictor(model), LSTMPredictor(model)
-    slow.graph_replay = False
+    fast.graph_replay = True
+    assert slow.graph_replay is False                                   # opt-in: see LSTMPredictor.graph_replay
     for xy in scenes:
         paths = data.xy_to_paths(xy)
         a = fast(paths, np.zeros((xy.shape[1], 2)), n_predict=12, obs_length=9)
@@ -106,13 +107,13 @@ def test_batches_in_flight_replay_on_their_own_streams():
     from trajnetplusplusbaselines_amd.lstm import LSTMPredictor
     model = _model('social')
     pred = LSTMPredictor(model)
+    pred.graph_replay = True
     batches = []
     for seed in range(2):
         xy, split = synth.linear_crowd(6, 20, seed=40 + seed)
         batches.append([(data.xy_to_paths(xy[:, split[s]:split[s + 1]].numpy()), None) for s in range(6)])
     many = batches * 5
     ref = LSTMPredictor(model)
-    ref.graph_replay = False
     want = [ref.predict_batch(b) for b in batches]
     got = pred.predict_batches(many, in_flight=2)
     for i, res in enumerate(got):

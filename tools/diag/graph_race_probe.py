@@ -1,7 +1,8 @@
-"""hipGraph replay on the default stream (ROCm 7.2 / torch 2.10): a vanilla LSTM forward (the shortest kernels) replayed on the
-null stream returns, from the third replay on, outputs that belong to no input; on any other stream, or with a device
-synchronisation anywhere in the call, every replay is right.  `product` = _GraphedForward as shipped (its own stream);
-`bare_*` = copy in / replay / clone directly on the caller's stream.  usage (gpurun): python tools/diag/graph_race_probe.py"""
+"""hipGraph replays of a vanilla LSTM forward (the shortest kernels), copy in / replay / clone on the default stream, on a side
+stream and through _GraphedForward as shipped.  History: while the sequence driver still used hipMemsetAsync (a memset NODE
+in the captured graph) the default-stream variant returned, from the third replay on, outputs that belonged to no input, and a
+device synchronisation anywhere in the call -- or a side stream -- hid it; tools/diag/graph_memset_probe.py shows the cause
+(memset nodes lose bytes on replay), and with kernel fills every variant is right.  usage (gpurun): python tools/diag/graph_race_probe.py"""
 import sys
 
 import numpy as np

@@ -32,3 +32,33 @@ for scenes, agents in ((1, 4), (1, 32), (8, 32), (64, 32)):
             torch.cuda.synchronize()
         t_lat = (time.perf_counter() - t1) / 100
     print('%3d scenes x %2d agents: host enqueue %.3f ms / forward, back-to-back %.3f ms, one at a time %.3f ms' % (scenes, agents, t_host * 1e3, t_all * 1e3, t_lat * 1e3))
+    with torch.no_grad():                                            # the same as hipGraph replays (LSTM._forward_graphed)
+        for _ in range(20):
+            model(obs, goals, split, n_predict=12, graph=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            model(obs, goals, split, n_predict=12, graph=True)
+        t_host = (time.perf_counter() - t0) / 200
+        torch.cuda.synchronize()
+        t_all = (time.perf_counter() - t0) / 200
+        t1 = time.perf_counter()
+        for _ in range(100):
+            model(obs, goals, split, n_predict=12, graph=True)
+            torch.cuda.synchronize()
+        t_lat = (time.perf_counter() - t1) / 100
+        # several batches in flight, each on its own stream with its own graph
+        streams = [torch.cuda.Stream() for _ in range(4)]
+        for nfl in (2, 4):
+            for i in range(4 * nfl):
+                with torch.cuda.stream(streams[i % nfl]):
+                    model(obs, goals, split, n_predict=12, graph=True)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for i in range(200):
+                with torch.cuda.stream(streams[i % nfl]):
+                    model(obs, goals, split, n_predict=12, graph=True)
+            torch.cuda.synchronize()
+            t_all_n = (time.perf_counter() - t2) / 200
+            print('      %d in flight, replayed: %.3f ms per forward' % (nfl, t_all_n * 1e3))
+    print('      replayed as a hipGraph: host %.3f ms / forward, back-to-back %.3f ms, one at a time %.3f ms' % (t_host * 1e3, t_all * 1e3, t_lat * 1e3))

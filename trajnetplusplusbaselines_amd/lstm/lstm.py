@@ -404,14 +404,19 @@ class LSTM(torch.nn.Module):
     _GRAPH_MAX_BYTES = 4 << 30   # ... and the bytes of their private workspaces / static buffers
 
     def _forward_graphed(self, observed, goals, batch_split, truth, T_dec, pad_to):
-        """One inference forward = 4 launches x (T_obs - 1 + T_dec) steps enqueued by ``tnp_lstm_forward``: ~80 launches, 0.6-1.1 ms
-        of host time, which is ALL of the wall time of a small batch (1 scene x 4 agents: 0.76 ms per forward, of which the
-        kernels are 0.3 ms) and caps several batches in flight at the host's launch rate.  The sequence driver never
-        synchronises or allocates, so it is captured once per call shape -- (model weights' addresses and configuration,
-        scene structure, sequence lengths, decoder mode, stream) -- into a hipGraph over static input / output buffers and a
-        private workspace; later calls of that shape copy their inputs in, replay the graph (one host call) and clone the
-        outputs.  A shape is captured on its third call (one-off shapes stay eager); the kernels, their order and their
-        arguments are those of the eager path, so the outputs are bit-identical (tests/test_gpu_graph.py)."""
+        """One inference forward = 4 launches x (T_obs - 1 + T_dec) steps enqueued by ``tnp_lstm_forward``: ~80 launches, ~0.64 ms of
+        host time.  The sequence driver never synchronises or allocates, so it can be captured once per call shape -- (model
+        weights' addresses and configuration, scene structure, sequence lengths, decoder mode, stream) -- into a hipGraph over
+        static input / output buffers and a private workspace; later calls of that shape copy their inputs in, replay the graph
+        (0.11 ms of host time) and clone the outputs.  A shape is captured on its third call (one-off shapes stay eager); the
+        kernels, their order and their arguments are those of the eager path, so the outputs are bit-identical
+        (tests/test_gpu_graph.py).
+
+        OPT-IN (``graph=True`` / ``self.graph_replay``), because on MI355X with ROCm 7.2 the replayed kernel nodes run slower on
+        the device than the same launches enqueued one by one (tools/diag/small_batch_latency.py: 64 x 32 agents 1.45 ms per
+        forward replayed against 1.31 ms; one 4-agent scene 0.88 against 0.76 ms): what the replay buys is host time, which pays
+        when several SMALL batches are in flight on their own streams (8 x 32 agents: 0.72 ms per forward with two graphs in
+        flight against 1.26 ms eager; 1 x 32: 0.64 against 1.04 ms) or when the host has other work to do."""
         m, keep, dev = self._descriptor()
         idx = _lib.SceneIndex.get(batch_split, dev, pad_to)
         T_obs, M = observed.size(0), observed.size(1)
@@ -544,11 +549,12 @@ class _GraphedForward(object):
     """One captured inference forward of one call shape: static inputs, the outputs and the workspace the captured launches
     point into, and the instantiated hipGraph (LSTM._forward_graphed).
 
-    The graph is captured AND replayed on a stream of its own; the caller's stream is joined by events on both sides.  Not
-    a matter of taste: with ROCm 7.2 / torch 2.10 a replay on the DEFAULT (null) stream is not ordered with the copies in
-    front of it -- from the third replay on, a vanilla LSTM (the shortest kernels) returned outputs that belonged to no
-    input (tools/diag/graph_race_probe.py: wrong on the default stream, right on any other stream or with a device
-    synchronisation anywhere in the call)."""
+    The graph is captured AND replayed on a stream of its own; the caller's stream is joined by events on both sides (a
+    replay then never depends on which stream -- the default one included -- the caller happens to be on).  The captured
+    sequence holds kernel nodes only: with ROCm 7.2 / torch 2.10 a hipMemsetAsync captured as a memset node clears its whole
+    range on the first replay and less than half of it afterwards (tools/diag/graph_memset_probe.py; first seen as a vanilla
+    LSTM whose third replay returned outputs that belonged to no input, tools/diag/graph_race_probe.py), which is why
+    csrc/lstm_seq.hip fills and copies with kernels of its own."""
 
     def __init__(self, model, keep, observed, goals, batch_split, truth, T_dec, pad_to):
         self.keep = keep                     # the weight tensors the captured kernel arguments point into
@@ -587,9 +593,11 @@ class _GraphedForward(object):
 class LSTMPredictor(object):
     """Reference lstm/lstm.py:266-313: pickle-compatible wrapper used by the evaluator."""
 
-    #: replay repeated call shapes as hipGraphs (LSTM._forward_graphed): the evaluator calls the predictor once per scene,
-    #: which is launch-bound (0.76 ms per call for a 4-agent scene, 0.3 ms of it kernels)
-    graph_replay = True
+    #: replay repeated call shapes as hipGraphs (LSTM._forward_graphed).  OFF by default: measured on MI355X / ROCm 7.2 a replay
+    #: frees the host (0.11 ms instead of 0.64 ms of launch work per forward) but the graph's kernel nodes run SLOWER on the
+    #: device than the same launches enqueued one by one (+1.7 us per node at 64 x 32, ~11 us per node for the tiny kernels of a
+    #: 4-agent scene: 0.91 ms per call against 0.82 ms), so it pays only with several small batches in flight (DESIGN.md 9)
+    graph_replay = False
 
     def __init__(self, model):
         self.model = model
