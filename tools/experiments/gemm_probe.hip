@@ -59,7 +59,7 @@ int main() {
             const int nb = d.tiles_m * d.tiles_n, nw = WM * WN * WK;
             long long *dbg; CK(hipMalloc(&dbg, (size_t)nb * nw * 64)); CK(hipMemset(dbg, 0, (size_t)nb * nw * 64));
             d.gates_out = reinterpret_cast<float *>(dbg);
-            auto k = gemm_nt_pipe<WM, WN, WK, AN, BK, EPI_BIAS, false, 1>;
+            auto k = gemm_nt_pipe<WM, WN, WK, AN, BK, EPI_BIAS, false, 1, false, 1>;   // the product's interleaved schedule
             const size_t smem = (size_t)3 * WK * (32 * WM + 32 * WN * AN) * (BK + 4) * 4;
             CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(nb), dim3(64 * nw), smem, 0, d);
@@ -131,6 +131,29 @@ int main() {
         g.prio = 1;
         run("pipe<1,1,4,4,16> prio", [](GemmArgs g, hipStream_t s) { return launch_pipe<1, 1, 4, 4, 16, EPI_LSTM>(g, s); });
         g.prio = 0;
+        {   // phase stamps of the PRODUCT gates kernel (gate split: four waves own one gate block each over the whole K)
+            constexpr int WM = 1, WN = 4, WK = 1, AN = 1, BK = 32;
+            GemmArgs d = g; d.tiles_m = M / 32; d.tiles_n = H / 32;
+            const int nb = d.tiles_m * d.tiles_n, nw = WM * WN * WK;
+            long long *dbg; CK(hipMalloc(&dbg, (size_t)nb * nw * 64)); CK(hipMemset(dbg, 0, (size_t)nb * nw * 64));
+            d.C = reinterpret_cast<float *>(dbg);
+            auto k = gemm_nt_pipe<WM, WN, WK, AN, BK, EPI_LSTM, true, 1, false, 1>;
+            const size_t smem = (size_t)3 * WK * (32 * WM + 32 * WN * AN) * (BK + 4) * 4;
+            CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(nb), dim3(64 * nw), smem, 0, d);
+            CK(hipDeviceSynchronize());
+            std::vector<long long> h((size_t)nb * nw * 8); CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+            const char *names[] = {"address setup + first loads issued", "first tile in LDS (load latency)", "main loop", "gate exchange + LSTM epilogue"};
+            const int from[] = {0, 1, 2, 3}, to[] = {1, 2, 3, 5};
+            for (int ph = 0; ph < 4; ++ph) {
+                double sum = 0, mx = 0; long cnt = 0;
+                for (size_t w = 0; w < (size_t)nb * nw; ++w) { const long long a0 = h[w * 8 + from[ph]], a1 = h[w * 8 + to[ph]]; if (a1 && a0) { sum += a1 - a0; mx = fmax(mx, (double)(a1 - a0)); ++cnt; } }
+                printf("   product gates <1,4,1,1,32> phase %-38s mean %7.0f max %7.0f clocks (%ld waves)\n", names[ph], cnt ? sum / cnt : 0, mx, cnt);
+            }
+            long long lo = 1ll << 62, hi = 0; double res = 0;
+            for (int b = 0; b < nb; ++b) { long long l = 1ll << 62, hh = 0; for (int v = 0; v < nw; ++v) for (int q = 0; q < 6; ++q) { const long long t = h[((size_t)b * nw + v) * 8 + q]; if (t) { l = std::min(l, t); hh = std::max(hh, t); } } res += hh - l; lo = std::min(lo, l); hi = std::max(hi, hh); }
+            printf("   product gates: workgroup residency mean %.0f clocks; first start to last end %lld clocks\n", res / nb, hi - lo);
+        }
         {
             constexpr int WM = 1, WN = 1, WK = 4, AN = 4, BK = 16;
             GemmArgs d = g; d.tiles_m = M / 32; d.tiles_n = H / 32;
