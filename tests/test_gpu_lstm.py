@@ -453,3 +453,27 @@ def test_predict_batches_equals_predict_batch():
         assert len(res) == len(want)
         for r, w in zip(res, want):
             assert np.array_equal(r[0][0], w[0][0]) and np.array_equal(np.nan_to_num(r[0][1]), np.nan_to_num(w[0][1]))
+
+
+def test_profile_hook_times_the_sparse_layer_by_its_dispatch():
+    """include/trajnet_hip_profile.h: with the hook on, every launch of the sparse first layer carries its two HIP events in
+    the dispatch (tnp_profile_dispatch_timed == launches) and the mean lies in the range of a kernel of that size."""
+    import ctypes
+    from trajnetplusplusbaselines_amd import _lib
+    model = _config2_model().cuda()
+    xy, split = synth.linear_crowd(64, 32, seed=3)
+    L = _lib.lib()
+    with torch.no_grad():
+        model(xy[:9], torch.zeros(xy.shape[1], 2), split, n_predict=12)
+        _lib.check(L.tnp_profile_begin(0), 'tnp_profile_begin')
+        try:
+            for _ in range(3):
+                model(xy[:9], torch.zeros(xy.shape[1], 2), split, n_predict=12)
+            torch.cuda.synchronize()
+            ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+            _lib.check(L.tnp_profile_read(ctypes.byref(ms), ctypes.byref(n)), 'tnp_profile_read')
+            timed = int(L.tnp_profile_dispatch_timed())
+        finally:
+            L.tnp_profile_end()
+    assert n.value == 3 * 19 and timed == n.value
+    assert 5e-3 < ms.value / n.value < 0.5, ms.value / n.value        # ~0.033 ms per launch

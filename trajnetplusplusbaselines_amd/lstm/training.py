@@ -560,7 +560,11 @@ class SequenceFn(torch.autograd.Function):
         # first-layer bias gradient of the sparse backward: column sums of dy_all[0] per block of 32 tracks, left by the
         # data-gradient GEMM that produces it (an ATen sum over the [S M, N1] operand afterwards read 159 MB again: 38 us)
         bias0_partial = None
-        if sparse_bwd and len(lay_names) >= 2 and dy_all[0].shape[2] % 32 == 0 and not os.environ.get('TNP_NO_BIAS0_FUSE'):
+        # (only where launch_linear's automatic choice for that GEMM is the 64 x 64-tile kernel anyway -- its rule, csrc/
+        # gemm_f32_mfma.hip: ceil(M / 128) * ceil(N / 64) >= 192 -- so that dy_all[0] and everything downstream stay bit-identical
+        # to the unfused path; below that the operand is small and the ATen sum costs a few microseconds)
+        if sparse_bwd and len(lay_names) >= 2 and dy_all[0].shape[2] % 32 == 0 and not os.environ.get('TNP_NO_BIAS0_FUSE') \
+                and ((M + 127) // 128) * ((dy_all[0].shape[2] + 63) // 64) >= 192:
             bias0_partial = torch.empty(S, (M + 31) // 32, dy_all[0].shape[2], device=dev)
             sw.bias0_partial = bias0_partial.data_ptr()
         sw.dh, sw.dc = dh.data_ptr(), dc.data_ptr()
