@@ -393,10 +393,6 @@ typedef struct tnp_bwd_sweep {
     const int32_t *cellwin_all;      /* directional_in: [S,M,n_max] winner table of tnp_pool_pair_cells_autograd, or NULL */
     int32_t *hm_wslot_all;           /* TNP_POOL_HIDDENMLP, optional out: [S,M,ms+mv] winning rows (position gradients), or NULL */
     float *at_posrec_all;            /* TNP_POOL_ATTNMLP, optional out: [S,M,n_max,4] per-pair position-gradient records, or NULL */
-    float *bias0_partial;            /* grid MLP of two or more layers, optional out: [S, ceil(M/32), dims[1]] column sums of
-                                      * dy_all[0] per block of 32 tracks, written by the data-gradient GEMM that produces
-                                      * dy_all[0]; their sum over [S, blocks] is the first layer's bias gradient (the reference's
-                                      * autograd through Linear, lstm/gridbased_pooling.py:308-335) -- or NULL */
 } tnp_bwd_sweep;
 /* sizeof() of the structs of this header as the library was compiled (which: 0 tnp_lstm_model, 1 tnp_lstm_extras,
  * 2 tnp_step_saves, 3 tnp_train_saves, 4 tnp_bwd_sweep; 0 for any other value) -- lets a binding check its mirrors */

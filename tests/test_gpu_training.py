@@ -767,32 +767,3 @@ def test_gradients_with_other_state_sizes_match_reference_autograd(kind):
         worst = max(worst, helpers.assert_matches_stored(z, pre + 'grad_' + name, p.grad.cpu().numpy(), 1e-4, kind))
     print(kind, 'worst relative gradient error %.2e' % worst)
 
-
-def test_fused_first_layer_bias_gradient_equals_the_column_sum():
-    """tnp_bwd_sweep.bias0_partial: the first layer's bias gradient of the sparse backward comes from per-block column sums the
-    data-gradient GEMM leaves behind; without them (TNP_NO_BIAS0_FUSE=1) it is an ATen sum over dy_all[0].  Same rows, another
-    summation tree: equal within fp32 rounding of a 38 912-term sum; every other gradient bit-identical."""
-    from trajnetplusplusbaselines_amd import synth
-    from trajnetplusplusbaselines_amd.lstm import PredictionLoss
-    xy, split = synth.ragged_crowd(56, 24, 44, seed=12)            # large enough for the fused path; a partial last block
-    M = xy.shape[1]
-    assert M % 32 != 0 and ((M + 127) // 128) * 16 >= 192
-    grads = {}
-    for fused in (True, False):
-        if not fused:
-            os.environ['TNP_NO_BIAS0_FUSE'] = '1'
-        try:
-            model, _ = helpers.real_model('cuda')
-            model.train()
-            rel, pred = model(xy[:9].clone(), torch.zeros(M, 2), split, xy[9:20].clone())
-            loss = PredictionLoss()(rel[-12:], (xy[9:21] - xy[8:20]).cuda(), split) * (split.numel() - 1)
-            loss.backward()
-            grads[fused] = {n: p.grad.cpu().numpy() for n, p in model.named_parameters() if p.grad is not None}
-        finally:
-            os.environ.pop('TNP_NO_BIAS0_FUSE', None)
-    for n in grads[True]:
-        a, b = grads[True][n], grads[False][n]
-        if n == 'pool.embedding.0.bias':
-            assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max()), n
-        else:
-            assert np.array_equal(a, b), n

@@ -225,7 +225,6 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[AN], i
                     mk[r] = g.mask_act[(size_t)row * g.ld_mask + col];
                 }
             }
-            float csum = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
@@ -234,13 +233,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[AN], i
                     if (g.relu) v = v > 0.0f ? v : 0.0f;
                     if (g.mask_act) v = mk[r] > 0.0f ? v : 0.0f;
                     g.C[(size_t)row * g.ldc + col] = v;
-                    csum += v;
                 }
-            }
-            if (g.colsum) {   // the two half-waves hold the two halves of the column's 32 rows (rows + 4): one add, lanes 0..31 store
-                csum += __shfl_xor(csum, 32);
-                const int rb32 = rbase - 4 * (lane >> 5);             // first row of this wave's block
-                if (lane < 32 && rb32 < g.M) g.colsum[(size_t)(rb32 >> 5) * g.ld_colsum + col] = csum;
             }
             if (g.nseg > 0 && sout) {
 #pragma unroll
@@ -1031,10 +1024,6 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
     const long big_tiles = (long)((g.M + 127) / 128) * ((g.N + 63) / 64);
     // tile selection measured on MI355X (profiles/round1_b_variant_sweep.jsonl): 64x64 tiles when they fill the chip, else
     // the pipelined 32x64 split-K 2 kernel; `variant` pins one of the two (12 / 24), anything else is an error
-    if (g.colsum) {   // per-32-row-block column sums: only the kernels whose waves own whole blocks over the whole K
-        TNP_TRY_FAST(2, 2, 1, 1, 32, EPI_BIAS);
-        return launch_general<4, 2, 1, 1, 32, EPI_BIAS>(g, s);
-    }
     if (variant == 0) {
         variant = (big_tiles >= 192) ? 12 : 24;
         // 32x64 tiles that need a second round of workgroups while 32x128 tiles fit in one (the backward data-gradient GEMM,

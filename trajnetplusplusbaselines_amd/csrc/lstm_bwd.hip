@@ -1432,9 +1432,6 @@ extern "C" TNP_API int tnp_lstm_backward_sweep(const tnp_bwd_sweep *a, int s_hi,
                 g.A1 = a->dy_all[l] + r * n_out; g.lda1 = n_out; g.K1 = n_out; g.B1 = a->layT[l]; g.ldb1 = n_out;
                 g.M = M; g.N = n_in; g.C = a->dy_all[l - 1] + r * n_in; g.ldc = n_in;
                 g.mask_act = sv->act_all[l - 1] + r * n_in; g.ld_mask = n_in;
-                if (l == 1 && a->bias0_partial) {   // first-layer bias gradient: per-block column sums of dy_all[0] (tnp_bwd_sweep)
-                    g.colsum = a->bias0_partial + (size_t)st * ((M + 31) / 32) * n_in; g.ld_colsum = n_in;
-                }
                 TNP_RC(tnp::launch_linear(g, 0, s));
             }
             const int N1 = md->dims[1];

@@ -45,10 +45,6 @@ struct GemmArgs {
     // (lstm_bwd.hip: what a relu_mask3 launch did after it)
     struct EpiSeg { int col0, n; const float *act; int ld_act; float *out; int ld_out; };
     EpiSeg seg[3]; int nseg;
-    // EPI_BIAS, optional: column sums of the stored values per block of 32 rows, colsum[(row / 32) * ld_colsum + col] -- the
-    // bias gradient of the layer below rides on the data-gradient GEMM that produces dy (the caller adds the blocks up: a
-    // fixed order, no atomics).  launch_linear then keeps to the kernels whose waves own whole 32-row blocks (no split-K).
-    float *colsum; int ld_colsum;
 };
 
 // generic dense layer (variant selects the tile configuration)

@@ -17,7 +17,6 @@ detached exactly as in the reference (lstm/lstm.py:240-250), hidden states poole
 (lstm/lstm.py:26), so BPTT couples the agents of a scene through the social encoding.
 """
 import ctypes
-import os
 
 import torch
 
@@ -107,8 +106,7 @@ class BwdSweep(ctypes.Structure):
                 ('at_A_all', ctypes.c_void_p), ('stateful', ctypes.c_int32), ('st_pwT', ctypes.c_void_p),
                 ('st_h2pT', ctypes.c_void_p), ('st_zeros', ctypes.c_void_p), ('st_dG_all', ctypes.c_void_p),
                 ('st_dfeat_all', ctypes.c_void_p), ('st_dph', ctypes.c_void_p), ('st_dpc', ctypes.c_void_p),
-                ('cellwin_all', ctypes.c_void_p), ('hm_wslot_all', ctypes.c_void_p), ('at_posrec_all', ctypes.c_void_p),
-                ('bias0_partial', ctypes.c_void_p)]
+                ('cellwin_all', ctypes.c_void_p), ('hm_wslot_all', ctypes.c_void_p), ('at_posrec_all', ctypes.c_void_p)]
 
 
 def _attention_param_grads(pool, P, grads, wgrad, dout_all, bufs, denc_all, h_prev_all, rows, L, dev, sp):
@@ -557,16 +555,6 @@ class SequenceFn(torch.autograd.Function):
         sw.dnn_all = dnn_all.data_ptr() if nn_pool else None
         sw.dvel_pool_all = dvel_pool_all.data_ptr() if directional_in else None
         sw.grid_all = grid_all.data_ptr() if grid_all is not None else None
-        # first-layer bias gradient of the sparse backward: column sums of dy_all[0] per block of 32 tracks, left by the
-        # data-gradient GEMM that produces it (an ATen sum over the [S M, N1] operand afterwards read 159 MB again: 38 us)
-        bias0_partial = None
-        # (only where launch_linear's automatic choice for that GEMM is the 64 x 64-tile kernel anyway -- its rule, csrc/
-        # gemm_f32_mfma.hip: ceil(M / 128) * ceil(N / 64) >= 192 -- so that dy_all[0] and everything downstream stay bit-identical
-        # to the unfused path; below that the operand is small and the ATen sum costs a few microseconds)
-        if sparse_bwd and len(lay_names) >= 2 and dy_all[0].shape[2] % 32 == 0 and not os.environ.get('TNP_NO_BIAS0_FUSE') \
-                and ((M + 127) // 128) * ((dy_all[0].shape[2] + 63) // 64) >= 192:
-            bias0_partial = torch.empty(S, (M + 31) // 32, dy_all[0].shape[2], device=dev)
-            sw.bias0_partial = bias0_partial.data_ptr()
         sw.dh, sw.dc = dh.data_ptr(), dc.data_ptr()
         need = L.tnp_lstm_backward_scratch_bytes(ctypes.byref(sw))
         scratch = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -708,7 +696,7 @@ class SequenceFn(torch.autograd.Function):
                 _lib.check(L.tnp_transpose_grouped(table, C, sp()), 'tnp_transpose_grouped')
                 grads[name + '.weight'] = gw
                 publish(grads[name + '.weight'])
-                grads[name + '.bias'] = (bias0_partial if bias0_partial is not None else dy_all[0]).reshape(-1, N1).sum(0)
+                grads[name + '.bias'] = dy_all[0].reshape(-1, N1).sum(0)
                 publish(grads[name + '.bias'])
                 return
             wgrad(name + '.weight', dy_all[li], grid_all if li == 0 else act_all[li - 1], name + '.bias')
