@@ -404,8 +404,8 @@ class LSTM(torch.nn.Module):
     _GRAPH_MAX_BYTES = 4 << 30   # ... and the bytes of their private workspaces / static buffers
 
     def _forward_graphed(self, observed, goals, batch_split, truth, T_dec, pad_to):
-        """One inference forward = 4 launches x (T_obs - 1 + T_dec) steps enqueued by ``tnp_lstm_forward``: ~80 launches, ~0.64 ms of
-        host time.  The sequence driver never synchronises or allocates, so it can be captured once per call shape -- (model
+        """One inference forward = 4 launches x (T_obs - 1 + T_dec) steps enqueued by ``tnp_lstm_forward``: ~80 launches, ~0.35 ms of
+        host time (0.25 ms inside the native call).  The sequence driver never synchronises or allocates, so it can be captured once per call shape -- (model
         weights' addresses and configuration, scene structure, sequence lengths, decoder mode, stream) -- into a hipGraph over
         static input / output buffers and a private workspace; later calls of that shape copy their inputs in, replay the graph
         (0.11 ms of host time) and clone the outputs.  A shape is captured on its third call (one-off shapes stay eager); the
@@ -594,7 +594,7 @@ class LSTMPredictor(object):
     """Reference lstm/lstm.py:266-313: pickle-compatible wrapper used by the evaluator."""
 
     #: replay repeated call shapes as hipGraphs (LSTM._forward_graphed).  OFF by default: measured on MI355X / ROCm 7.2 a replay
-    #: frees the host (0.11 ms instead of 0.64 ms of launch work per forward) but the graph's kernel nodes run SLOWER on the
+    #: frees the host (0.11 ms instead of ~0.35 ms per forward) but the graph's kernel nodes run SLOWER on the
     #: device than the same launches enqueued one by one (+1.7 us per node at 64 x 32, ~11 us per node for the tiny kernels of a
     #: 4-agent scene: 0.91 ms per call against 0.82 ms), so it pays only with several small batches in flight (DESIGN.md 9)
     graph_replay = False
