@@ -1,6 +1,8 @@
 """Inference forwards replayed as hipGraphs (LSTM._forward_graphed, opt-in): a call shape that comes back is captured once --
 the sequence driver's ~80 launches over static buffers -- and replayed with one host call.  Same kernels, same order, same
 arguments as the eager path: every output must be BIT-identical to it."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -84,7 +86,7 @@ def test_predictor_per_scene_calls_replay_and_match():
     agents share a graph; predictions equal those of a predictor with graph_replay = False."""
     from trajnetplusplusbaselines_amd import data
     from trajnetplusplusbaselines_amd.lstm import LSTMPredictor
-    z = np.load(helpers.os.path.join(helpers.GOLDEN, 'real_eval.npz'))
+    z = np.load(os.path.join(helpers.GOLDEN, 'real_eval.npz'))
     xy_all, split = z['f0_xy'], z['f0_split']
     scenes = [xy_all[:, split[s]:split[s + 1]] for s in range(len(split) - 1)]
     scenes = scenes + scenes + scenes                                   # every agent count comes back
