@@ -35,39 +35,45 @@ def _sf_b(r, speeds, dirs, delta_t):
         return 0.5 * np.sqrt((n1 + n2) ** 2 - (delta_t * speeds)[None, :] ** 2)
 
 
+def sf_step(pos, vel, goal, speed0, tau=0.5, v0=2.1, sigma=0.3, delta_t=0.05):
+    """One explicit-Euler step of one scene: pos, vel, goal [n, 2], speed0 [n] (initial speeds, the cap is 1.3 x) ->
+    (pos, vel) after the step.  ``sf_rollout`` and the driving stub of ``oracle/classical_stubs.py`` both run this."""
+    n = pos.shape[0]
+    cosphi = np.cos(np.deg2rad(100.0))
+    eps = 1e-3
+    e = goal - pos
+    e = e / np.linalg.norm(e, axis=1, keepdims=True)
+    force = (speed0[:, None] * e - vel) / tau
+    if n > 1:
+        r = pos[:, None, :] - pos[None, :, :]
+        sp = np.linalg.norm(vel, axis=1)
+        pot = lambda rr: v0 * np.exp(-_sf_b(rr, sp, e, delta_t) / sigma)
+        v = pot(r)
+        grad = np.stack([(pot(r + np.array([eps, 0.0])) - v) / eps, (pot(r + np.array([0.0, eps])) - v) / eps], axis=-1)
+        f = -grad                                               # force on a from b
+        seen = np.einsum('ak,abk->ab', e, -f) > np.linalg.norm(f, axis=-1) * cosphi
+        w = np.where(seen, 1.0, 0.5)
+        np.fill_diagonal(w, 0.0)
+        f[np.arange(n), np.arange(n)] = 0.0
+        force = force + (w[..., None] * f).sum(axis=1)
+    wv = vel + delta_t * force
+    ws = np.linalg.norm(wv, axis=1)
+    vel = wv * np.minimum(1.0, 1.3 * speed0 / ws)[:, None]
+    return pos + vel * delta_t, vel
+
+
 def sf_rollout(state0, scene_start, n_steps=96, sample_every=8, tau=0.5, v0=2.1, sigma=0.3, delta_t=0.05):
     """state0 [M, 6] = x, y, vx, vy, goal_x, goal_y -> positions after steps 1, 1 + sample_every, ... [n_out, M, 2]
     (the wrapper keeps every 8th of the post-step states starting with the first, classical/socialforce.py:95)."""
     state0 = np.asarray(state0, dtype=np.float64)
     M = state0.shape[0]
     out = np.empty(((n_steps + sample_every - 1) // sample_every, M, 2))
-    cosphi = np.cos(np.deg2rad(100.0))
-    eps = 1e-3
     for lo, hi in zip(scene_start[:-1], scene_start[1:]):
         pos, vel, goal = state0[lo:hi, 0:2].copy(), state0[lo:hi, 2:4].copy(), state0[lo:hi, 4:6]
-        n = hi - lo
         speed0 = np.linalg.norm(vel, axis=1)
         k = 0
         for step in range(n_steps):
-            e = goal - pos
-            e = e / np.linalg.norm(e, axis=1, keepdims=True)
-            force = (speed0[:, None] * e - vel) / tau
-            if n > 1:
-                r = pos[:, None, :] - pos[None, :, :]
-                sp = np.linalg.norm(vel, axis=1)
-                pot = lambda rr: v0 * np.exp(-_sf_b(rr, sp, e, delta_t) / sigma)
-                v = pot(r)
-                grad = np.stack([(pot(r + np.array([eps, 0.0])) - v) / eps, (pot(r + np.array([0.0, eps])) - v) / eps], axis=-1)
-                f = -grad                                               # force on a from b
-                seen = np.einsum('ak,abk->ab', e, -f) > np.linalg.norm(f, axis=-1) * cosphi
-                w = np.where(seen, 1.0, 0.5)
-                np.fill_diagonal(w, 0.0)
-                f[np.arange(n), np.arange(n)] = 0.0
-                force = force + (w[..., None] * f).sum(axis=1)
-            wv = vel + delta_t * force
-            ws = np.linalg.norm(wv, axis=1)
-            vel = wv * np.minimum(1.0, 1.3 * speed0 / ws)[:, None]
-            pos = pos + vel * delta_t
+            pos, vel = sf_step(pos, vel, goal, speed0, tau, v0, sigma, delta_t)
             if step % sample_every == 0:
                 out[k, lo:hi] = pos
                 k += 1
@@ -101,34 +107,53 @@ def _kf_smooth(obs, Q, R, m0, P0):
     return xs, Ps, G
 
 
+def kalman_em(obs, n_iter=10, transition_var=1e-5, observation_var=0.05 ** 2):
+    """EM over transition covariance, observation covariance, initial mean and initial covariance (pykalman's default
+    ``em_vars``) for one track obs [T, 2]; initial mean (x0, 0, y0, 0), initial covariance I (classical/kalman.py:32-49).
+    -> Q, R, m0, P0"""
+    T = obs.shape[0]
+    Q, R = transition_var * np.eye(4), observation_var * np.eye(2)
+    m0, P0 = np.array([obs[0, 0], 0.0, obs[0, 1], 0.0]), np.eye(4)
+    for _ in range(n_iter):
+        xs, Ps, G = _kf_smooth(obs, Q, R, m0, P0)
+        err = obs - xs @ _C.T
+        R = (np.einsum('ti,tj->ij', err, err) + (_C @ Ps @ _C.T).sum(axis=0)) / T
+        if T > 1:
+            d = xs[1:] - xs[:-1] @ _A.T
+            pair = Ps[1:] @ np.transpose(G, (0, 2, 1))            # Cov(x_{t+1}, x_t | all observations)
+            Q = (np.einsum('ti,tj->ij', d, d) + (_A @ Ps[:-1] @ _A.T).sum(axis=0) + Ps[1:].sum(axis=0)
+                 - (pair @ _A.T).sum(axis=0) - (_A @ np.transpose(pair, (0, 2, 1))).sum(axis=0)) / (T - 1)
+        m0, P0 = xs[0], Ps[0]
+    return Q, R, m0, P0
+
+
+def kalman_sample(x0, Q, R, z):
+    """One sampled continuation: z [n_steps, 6] standard normal draws (4 state + 2 observation components per step);
+    step 0 is x0 itself (no transition noise), every step emits C x + observation noise.  -> (states, observations)"""
+    LQ, LR = _chol_psd(Q), _chol_psd(R)
+    n_steps = z.shape[0]
+    xs, ys = np.zeros((n_steps, 4)), np.zeros((n_steps, 2))
+    x = np.asarray(x0, dtype=np.float64).copy()
+    for t in range(n_steps):
+        if t > 0:
+            x = _A @ x + LQ @ z[t, :4]
+        xs[t] = x
+        ys[t] = _C @ x + LR @ z[t, 4:6]
+    return xs, ys
+
+
 def kalman_predict(obs, z, n_iter=10, transition_var=1e-5, observation_var=0.05 ** 2):
     """obs [n, T, 2], z [n, n_samples, n_steps, 6] standard normal draws (4 state + 2 observation components per step)
     -> mean sampled observations [n, n_steps, 2]; step 0 is the last smoothed state itself (no transition noise)."""
     obs, z = np.asarray(obs, dtype=np.float64), np.asarray(z, dtype=np.float64)
-    n, T = obs.shape[:2]
+    n = obs.shape[0]
     n_samples, n_steps = z.shape[1], z.shape[2]
     out = np.zeros((n, n_steps, 2))
     for i in range(n):
-        Q, R = transition_var * np.eye(4), observation_var * np.eye(2)
-        m0, P0 = np.array([obs[i, 0, 0], 0.0, obs[i, 0, 1], 0.0]), np.eye(4)
-        for _ in range(n_iter):
-            xs, Ps, G = _kf_smooth(obs[i], Q, R, m0, P0)
-            err = obs[i] - xs @ _C.T
-            R = (np.einsum('ti,tj->ij', err, err) + (_C @ Ps @ _C.T).sum(axis=0)) / T
-            if T > 1:
-                d = xs[1:] - xs[:-1] @ _A.T
-                pair = Ps[1:] @ np.transpose(G, (0, 2, 1))            # Cov(x_{t+1}, x_t | all observations)
-                Q = (np.einsum('ti,tj->ij', d, d) + (_A @ Ps[:-1] @ _A.T).sum(axis=0) + Ps[1:].sum(axis=0)
-                     - (pair @ _A.T).sum(axis=0) - (_A @ np.transpose(pair, (0, 2, 1))).sum(axis=0)) / (T - 1)
-            m0, P0 = xs[0], Ps[0]
+        Q, R, m0, P0 = kalman_em(obs[i], n_iter, transition_var, observation_var)
         xs, _, _ = _kf_smooth(obs[i], Q, R, m0, P0)
-        LQ, LR = _chol_psd(Q), _chol_psd(R)
         for s in range(n_samples):
-            x = xs[-1].copy()
-            for t in range(n_steps):
-                if t > 0:
-                    x = _A @ x + LQ @ z[i, s, t, :4]
-                out[i, t] += _C @ x + LR @ z[i, s, t, 4:6]
+            out[i] += kalman_sample(xs[-1], Q, R, z[i, s])[1]
         out[i] /= n_samples
     return out
 

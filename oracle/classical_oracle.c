@@ -119,3 +119,57 @@ ORC_API void orc_kalman_predict(const double *obs, int n_tracks, int T, int n_it
         kf_sample_mean(&md, x_last, n_steps, n_samples, z + (size_t)i * n_samples * n_steps * 6, out + (size_t)i * n_steps * 2);
     }
 }
+
+/* ---- single-step entry points for the driving stubs of oracle/classical_stubs.py (backend "core"): the reference's
+ * wrappers call step() / doStep() / em() / sample() themselves, one call at a time (classical/socialforce.py:91,
+ * classical/orca.py:102, classical/kalman.py:47-55) ---- */
+
+/* one socialforce.Simulator.step(): st [n][7] updated in place, isp [n] = initial speeds */
+ORC_API void orc_sf_step(double *st, const double *isp, int ns, double v0, double sigma, double delta_t) {
+    sf_params p;
+    p.delta_t = delta_t; p.v0 = v0; p.sigma = sigma; p.cosphi = cos(200.0 / 2.0 / 180.0 * M_PI); p.out_of_view = 0.5;
+    sf_agent_terms *terms = (sf_agent_terms *)malloc(sizeof(sf_agent_terms) * (size_t)ns + sizeof(double) * (size_t)ns * 2);
+    double *nv = (double *)(terms + ns);
+    for (int a = 0; a < ns; ++a) sf_terms(st + a * 7, &p, &terms[a]);
+    for (int a = 0; a < ns; ++a) sf_agent_step_terms(a, ns, st, terms, isp[a], 1.3 * isp[a], &p, &nv[2 * a], &nv[2 * a + 1]);
+    for (int a = 0; a < ns; ++a) {
+        st[a * 7 + 0] += nv[2 * a] * delta_t; st[a * 7 + 1] += nv[2 * a + 1] * delta_t;
+        st[a * 7 + 2] = nv[2 * a]; st[a * 7 + 3] = nv[2 * a + 1];
+    }
+    free(terms);
+}
+
+/* one rvo2 doStep(): pos / vel [n][2] updated in place from the preferred velocities prf [n][2] */
+ORC_API void orc_orca_step(float *pos, float *vel, const float *prf, const float *max_speed, int ns, float time_step,
+                           float neighbor_dist, int max_neighbors, float time_horizon, float radius) {
+    orca_params p;
+    p.time_step = time_step; p.neighbor_dist = neighbor_dist; p.time_horizon = time_horizon; p.radius = radius;
+    p.max_neighbors = max_neighbors;
+    float *nvl = (float *)malloc(sizeof(float) * (size_t)ns * 2);
+    for (int a = 0; a < ns; ++a)
+        orca_agent_new_velocity(a, ns, pos, vel, prf[2 * a], prf[2 * a + 1], max_speed[a], &p, &nvl[2 * a], &nvl[2 * a + 1], NULL);
+    for (int a = 0; a < ns; ++a) {
+        vel[2 * a] = nvl[2 * a]; vel[2 * a + 1] = nvl[2 * a + 1];
+        pos[2 * a] += vel[2 * a] * time_step; pos[2 * a + 1] += vel[2 * a + 1] * time_step;
+    }
+    free(nvl);
+}
+
+/* KalmanFilter.em(X) followed by smooth(X)[-1]: model [46] = Q(16) R(4) m0(4) P0(16) + 6 spare, x_last [4] */
+ORC_API void orc_kalman_em(const double *obs, int T, int n_iter, double q0, double r0, double *model, double *x_last) {
+    kf_model md;
+    for (int k = 0; k < 16; ++k) { md.Q[k] = (k % 5 == 0) ? q0 : 0.0; md.P0[k] = (k % 5 == 0) ? 1.0 : 0.0; }
+    md.R[0] = r0; md.R[1] = 0.0; md.R[2] = 0.0; md.R[3] = r0;
+    md.m0[0] = obs[0]; md.m0[1] = 0.0; md.m0[2] = obs[1]; md.m0[3] = 0.0;
+    kf_em_smooth(obs, T, n_iter, &md, x_last);
+    for (int k = 0; k < 16; ++k) { model[k] = md.Q[k]; model[24 + k] = md.P0[k]; }
+    for (int k = 0; k < 4; ++k) { model[16 + k] = md.R[k]; model[20 + k] = md.m0[k]; }
+}
+
+/* one KalmanFilter.sample(n_steps, initial_state=x0): observations [n_steps][2] from draws z [n_steps][6] */
+ORC_API void orc_kalman_sample(const double *model, const double *x0, int n_steps, const double *z, double *out) {
+    kf_model md;
+    for (int k = 0; k < 16; ++k) { md.Q[k] = model[k]; md.P0[k] = model[24 + k]; }
+    for (int k = 0; k < 4; ++k) { md.R[k] = model[16 + k]; md.m0[k] = model[20 + k]; }
+    kf_sample_mean(&md, x0, n_steps, 1, z, out);
+}

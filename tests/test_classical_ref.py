@@ -1,0 +1,237 @@
+"""Classical predictors against the REFERENCE'S OWN wrapper code (VERDICT r4 "missing 1").
+
+``tests/golden/classical_ref.npz`` was written by ``oracle/gen_golden_r5.py``: the unmodified reference
+``classical/{socialforce,orca,kalman,constant_velocity}.py:predict`` run on 62 scenes (56 real DATA_BLOCK scenes of all
+seven training files + 6 edited ones: stationary primary, neighbours with 1 / 2 / 3 past frames, primary alone) on top of
+driving stubs for the three absent third-party simulators (``oracle/classical_stubs.py``).  Everything the wrappers decide
+is therefore the reference's: agent selection, stride-3 velocity, extrapolated goal, ``dest_type`` variants,
+max_speed = 1.3 x speed, social force's 96 steps / states 0, 8, .., 88, ORCA's 97 steps sampled at count 8..96 and its
+preferred-velocity rule, Kalman's initial mean / 13 samples / mean of 5, neighbour ordering, ``predict_all``.
+The simulator arithmetic behind the stubs is ours, in two forms, both stored:
+  * ``*_primary`` / ``*_neigh``           -- stub arithmetic = oracle/classical_numpy.py (independent numpy restatement);
+  * ``*_core_primary`` / ``*_core_neigh`` -- stub arithmetic = csrc/classical_core.h on the host, one simulator call at a
+                                             time (orc_sf_step / orc_orca_step / orc_kalman_em / orc_kalman_sample).
+Row status: WRAPPER PINNED to the reference, third-party arithmetic unpinned.
+
+CPU tests: the product's host-side wrapper logic (classical/_common.py) == what the reference handed to the simulators,
+and the oracle's batched host execution from those states == the reference-driven outputs (cadence, sampling, ordering).
+GPU tests: the public ``classical.*.predict`` on the HIP path == the fixture (social force 1e-9, ORCA float32 bit-exact,
+Kalman 1e-9 against the core-backed run; looser, stated bounds against the numpy-backed run)."""
+import ast
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from trajnetplusplusbaselines_amd import data as trajdata
+from trajnetplusplusbaselines_amd.classical import _common
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'classical_ref.npz')
+
+
+@pytest.fixture(scope='module')
+def ref():
+    return np.load(GOLDEN)
+
+
+def case_paths(g, i):
+    rows, lens = g['c%d_rows' % i], g['c%d_lens' % i]
+    paths, k = [], 0
+    for n in lens:
+        paths.append([trajdata.TrackRow(int(r[0]), int(r[1]), float(r[2]), float(r[3])) for r in rows[k:k + n]])
+        k += n
+    return paths
+
+
+def case_kwargs(g, i, which):
+    kw = ast.literal_eval(str(g['c%d_%s_kw' % (i, which)]))
+    if which == 'orca' and kw.get('dest_type') == 'true':
+        kw['dest_dict'] = {int(r[0]): [float(r[1]), float(r[2])] for r in g['c%d_dest_dict' % i]}
+    return kw
+
+
+def cases(g):
+    return range(int(g['n_cases']))
+
+
+def test_fixture_covers_the_wrapper_branches(ref):
+    kinds = [str(k) for k in ref['kinds']]
+    assert len(kinds) >= 50 and {'real', 'stationary_primary', 'late_entries', 'primary_only'} <= set(kinds)
+    assert len(set(str(f) for f in ref['files'])) == 7
+    short = absent = 0
+    dest = set()
+    for i in cases(ref):
+        paths = case_paths(ref, i)
+        start = paths[0][8].frame
+        for p in paths:
+            past = [r for r in p if r.frame <= start]
+            if not past or past[-1].frame != start:
+                absent += 1
+            elif len(past) < 4:
+                short += 1
+        dest.add(case_kwargs(ref, i, 'sf').get('dest_type', 'interp'))
+        dest.add(case_kwargs(ref, i, 'orca').get('dest_type', 'interp'))
+    assert absent > 100 and short > 40 and dest == {'interp', 'pred_end', 'vel', 'true'}
+    assert {int(ref['c%d_predict_all' % i]) for i in cases(ref)} == {0, 1}
+
+
+def test_scene_init_equals_what_the_reference_hands_to_the_simulators(ref):
+    """classical/socialforce.py:15-55 (initial_state rows) and classical/orca.py:14-57 (addAgent arguments): float64,
+    bit for bit."""
+    for i in cases(ref):
+        paths = case_paths(ref, i)
+        kw = case_kwargs(ref, i, 'sf')
+        rows = _common.scene_init(paths, 9, 12, kw.get('dest_dict'), kw.get('dest_type', 'interp'))
+        st = np.array([[r[0], r[1], r[2], r[3], r[5], r[6]] for r in rows]).reshape(-1, 6)
+        assert np.array_equal(st, ref['c%d_sf_initial_state' % i]), i
+        kw = case_kwargs(ref, i, 'orca')
+        rows = _common.scene_init(paths, 9, 12, kw.get('dest_dict'), kw.get('dest_type', 'interp'), allow_vel_dest=False)
+        ag = np.array([[r[0], r[1], 1.3 * r[4], r[2], r[3]] for r in rows]).reshape(-1, 5)
+        assert np.array_equal(ag, ref['c%d_orca_agents' % i]), i
+        # rvo2.PyRVOSimulator(1 / fps, nDist, 10, nReact, 5, radius, 1.5) (classical/orca.py:91)
+        p = kw.get('orca_params', [1.5, 1.5, 0.4])
+        assert np.array_equal(ref['c%d_orca_sim_args' % i], [1 / 20, p[0], 10, p[1], 5, p[2], 1.5])
+    with pytest.raises(NotImplementedError):       # ORCA has no 'vel' destination (classical/orca.py:41-50)
+        _common.scene_init(case_paths(ref, 0), 9, 12, None, 'vel', allow_vel_dest=False)
+
+
+def _pack(prim, neigh):
+    return np.concatenate([prim[:, None], neigh.reshape(12, -1, 2)], axis=1) if np.size(neigh) else prim[:, None]
+
+
+def test_social_force_cadence_host_execution(ref):
+    """96 steps, post-step states 0, 8, .., 88 (classical/socialforce.py:91-95): the oracle's batched host rollout from the
+    recorded initial states == the reference-driven step-by-step run."""
+    for i in cases(ref):
+        st = ref['c%d_sf_initial_state' % i]
+        tau, v0, sigma = ref['c%d_sf_params' % i]
+        with np.errstate(all='ignore'):
+            got = oracle.sf_rollout(st, [0, len(st)], tau=tau, v0=v0, sigma=sigma)
+        all_ = int(ref['c%d_predict_all' % i])
+        want = _pack(ref['c%d_sf_core_primary' % i], ref['c%d_sf_core_neigh' % i])
+        got = got if all_ else got[:, :1]
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12, equal_nan=True, err_msg=str(i))
+        want = _pack(ref['c%d_sf_primary' % i], ref['c%d_sf_neigh' % i])
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9, equal_nan=True, err_msg=str(i))
+
+
+def test_orca_cadence_and_preferred_velocity_rule_host_execution(ref):
+    """97 doStep calls, positions at count 8, 16, .., 96, preferred velocity from the float64 goal vector capped to the
+    initial speed and zero within 0.05 m (classical/orca.py:99-119): the oracle's batched host rollout == the
+    reference-driven run, float32 bit for bit."""
+    for i in cases(ref):
+        ag = ref['c%d_orca_agents' % i]
+        paths = case_paths(ref, i)
+        kw = case_kwargs(ref, i, 'orca')
+        rows = _common.scene_init(paths, 9, 12, kw.get('dest_dict'), kw.get('dest_type', 'interp'), allow_vel_dest=False)
+        goals = np.array([[r[5], r[6]] for r in rows])
+        speed = np.array([r[4] for r in rows])
+        p = kw.get('orca_params', [1.5, 1.5, 0.4])
+        got = oracle.orca_rollout(ag[:, 0:2], ag[:, 3:5], goals, speed, ag[:, 2], [0, len(ag)], neighbor_dist=p[0],
+                                  time_horizon=p[1], radius=p[2])
+        # the first setAgentPrefVelocity calls the reference made after step 1: (step, agent, vx, vy) in agent order
+        calls = ref['c%d_orca_core_pref_calls' % i]
+        assert np.array_equal(calls[:len(ag), 0], np.ones(len(ag))) and np.array_equal(calls[:len(ag), 1], np.arange(len(ag)))
+        got = got if int(ref['c%d_predict_all' % i]) else got[:, :1]
+        want = _pack(ref['c%d_orca_core_primary' % i], ref['c%d_orca_core_neigh' % i])
+        assert np.array_equal(got.astype(np.float64), want), i
+        wantn = _pack(ref['c%d_orca_primary' % i], ref['c%d_orca_neigh' % i])
+        assert np.abs(got - wantn).max() < 5e-4, i
+
+
+def _kalman_tracks(paths, predict_all):
+    start = paths[0][8].frame
+    tracks = []
+    for p in (paths if predict_all else paths[:1]):
+        past = [r for r in p if r.frame <= start]
+        if past and past[-1].frame == start and len(past) >= 2:
+            tracks.append(np.array([(r.x, r.y) for r in past]))
+    return tracks
+
+
+def test_kalman_sampling_rule_host_execution(ref):
+    """13 samples from the last smoothed state, the first dropped, mean of 5 (classical/kalman.py:50-62)."""
+    worst = 0.0
+    for i in cases(ref):
+        tracks = _kalman_tracks(case_paths(ref, i), int(ref['c%d_predict_all' % i]))
+        z = ref['c%d_kalman_noise' % i]
+        assert [len(t) for t in tracks] == list(ref['c%d_kalman_obs_lens' % i]) and len(z) == len(tracks)
+        got = np.stack([oracle.kalman_predict(t[None], z[k:k + 1])[0, 1:] for k, t in enumerate(tracks)], axis=1)
+        want = _pack(ref['c%d_kalman_core_primary' % i], ref['c%d_kalman_core_neigh' % i])
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12, err_msg=str(i))
+        wantn = _pack(ref['c%d_kalman_primary' % i], ref['c%d_kalman_neigh' % i])
+        worst = max(worst, np.abs(got - wantn).max())
+    assert worst < 1e-4       # EM on 2- and 3-sample tracks is ill-conditioned: the two restatements part at 1e-5 there
+
+
+def test_constant_velocity_host(ref):
+    for i in cases(ref):
+        # the reference extrapolates from the last two rows of whatever paths it is given (classical/constant_velocity.py:8-12)
+        xy = trajdata.paths_to_xy(case_paths(ref, i))
+        got = oracle.constant_velocity(xy, 12)
+        want = _pack(ref['c%d_cv_primary' % i], ref['c%d_cv_neigh' % i].reshape(12, -1, 2))
+        assert np.array_equal(got, want, equal_nan=True), i
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _check(res, g, pre, atol, exact=False):
+    prim, neigh = res[0]
+    wp, wn = g[pre + 'primary'], g[pre + 'neigh']
+    assert np.shape(prim) == wp.shape, (pre, np.shape(prim), wp.shape)
+    if wn.size == 0:
+        assert np.size(neigh) == 0, pre
+    else:
+        assert np.shape(neigh) == wn.shape, (pre, np.shape(neigh), wn.shape)
+    got = _pack(np.asarray(prim, dtype=np.float64), np.asarray(neigh, dtype=np.float64))
+    want = _pack(wp, wn)
+    if exact:
+        assert np.array_equal(got, want, equal_nan=True), pre
+    else:
+        np.testing.assert_allclose(got, want, rtol=0, atol=atol, equal_nan=True, err_msg=pre)
+    return float(np.nanmax(np.abs(got - want))) if np.isfinite(got - want).any() else 0.0
+
+
+@pytest.mark.gpu
+def test_gpu_social_force_predict_equals_reference_wrapper(ref):
+    from trajnetplusplusbaselines_amd.classical import socialforce
+    worst = 0.0
+    for i in cases(ref):
+        res = socialforce.predict(case_paths(ref, i), predict_all=bool(ref['c%d_predict_all' % i]), **case_kwargs(ref, i, 'sf'))
+        _check(res, ref, 'c%d_sf_core_' % i, 1e-9)
+        worst = max(worst, _check(res, ref, 'c%d_sf_' % i, 1e-8))
+    print('social force predict() vs reference wrapper over numpy arithmetic: max |d| %.2e' % worst)
+
+
+@pytest.mark.gpu
+def test_gpu_orca_predict_equals_reference_wrapper_bit_exact(ref):
+    from trajnetplusplusbaselines_amd.classical import orca
+    worst = 0.0
+    for i in cases(ref):
+        res = orca.predict(case_paths(ref, i), predict_all=bool(ref['c%d_predict_all' % i]), **case_kwargs(ref, i, 'orca'))
+        _check(res, ref, 'c%d_orca_core_' % i, 0.0, exact=True)          # float32 positions, bit for bit
+        worst = max(worst, _check(res, ref, 'c%d_orca_' % i, 5e-4))
+    print('ORCA predict() vs reference wrapper over numpy arithmetic: max |d| %.2e' % worst)
+
+
+@pytest.mark.gpu
+def test_gpu_kalman_predict_equals_reference_wrapper(ref):
+    from trajnetplusplusbaselines_amd.classical import kalman
+    worst = 0.0
+    for i in cases(ref):
+        np.random.seed(int(ref['c%d_kalman_seed' % i]))           # the global stream, as the reference consumes it
+        res = kalman.predict(case_paths(ref, i), predict_all=bool(ref['c%d_predict_all' % i]))
+        _check(res, ref, 'c%d_kalman_core_' % i, 1e-9)
+        worst = max(worst, _check(res, ref, 'c%d_kalman_' % i, 1e-4))
+        res2 = kalman.predict(case_paths(ref, i), predict_all=bool(ref['c%d_predict_all' % i]),
+                              rng=np.random.RandomState(int(ref['c%d_kalman_seed' % i])))
+        assert np.array_equal(res2[0][0], res[0][0])
+    print('Kalman predict() vs reference wrapper over numpy arithmetic: max |d| %.2e' % worst)
+
+
+@pytest.mark.gpu
+def test_gpu_constant_velocity_predict_equals_reference(ref):
+    from trajnetplusplusbaselines_amd.classical import constant_velocity
+    for i in cases(ref):
+        res = constant_velocity.predict(case_paths(ref, i))
+        _check(res, ref, 'c%d_cv_' % i, 0.0, exact=True)

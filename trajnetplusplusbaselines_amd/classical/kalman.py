@@ -24,7 +24,11 @@ def predict_batch(obs, n_predict=12, n_samples=5, noise=None, rng=None, n_iter=1
     return out.cpu().numpy()[:, 1:]       # first sample corresponds to the last state (classical/kalman.py:52-62)
 
 
-def predict(paths, predict_all=True, n_predict=12, obs_length=9):
+def predict(paths, predict_all=True, n_predict=12, obs_length=9, rng=None):
+    """``rng`` (not in the reference's signature): a ``numpy.random.RandomState``; default = numpy's global one, which
+    is what pykalman's ``sample(random_state=None)`` draws from.  The draws are taken track by track in the order of
+    ``paths``, 5 samples x (n_predict + 1) steps x 6 components each -- the order in which the reference's loop
+    (classical/kalman.py:22-60) consumes them -- so a seeded run is reproducible against a seeded reference run."""
     primary = paths[0]
     start_frame = primary[obs_length - 1].frame
     if not predict_all:
@@ -36,6 +40,7 @@ def predict(paths, predict_all=True, n_predict=12, obs_length=9):
             continue
         tracks.append(past_path)
         index.append(i)
+    noise = (rng or np.random).standard_normal((len(tracks), 5, n_predict + 1, 6))
     # tracks may have different lengths: one launch per length
     results = {}
     by_len = {}
@@ -43,7 +48,7 @@ def predict(paths, predict_all=True, n_predict=12, obs_length=9):
         by_len.setdefault(len(tr), []).append(k)
     for length, ks in by_len.items():
         obs = np.array([[(r.x, r.y) for r in tracks[k]] for k in ks], dtype=np.float64)
-        pred = predict_batch(obs, n_predict)
+        pred = predict_batch(obs, n_predict, noise=noise[ks])
         for k, p in zip(ks, pred):
             results[index[k]] = p
     primary_track = results.get(0)
