@@ -67,7 +67,21 @@ def _worker(rank, world, port, ret):
         assert red2.flush() is None
         for h in hs:
             h.wait()
+        # a caller that only knows "call, then wait" (never flush()): the handle of a coalesced gradient sends the message
+        red3 = parallel.GradReducer(coalesce_below=64)
+        u1, u2 = torch.full((4,), float(rank + 1)), torch.full((3,), 5.0 * (rank + 1))
+        h1, h2 = red3(u1), red3(u2)
+        h1.wait()
+        h2.wait()
+        # a pass that raised before flush() leaves tensors behind: begin() drops them, they do not join the next message
+        stale = torch.full((2,), 100.0)
+        red3(stale)
+        red3.begin()
+        u3 = torch.full((2,), 7.0 * (rank + 1))
+        red3(u3)
+        red3.flush().wait()
         if rank == 0:
+            ret['lazy'] = (u1.tolist(), u2.tolist(), stale.tolist(), u3.tolist(), red3.messages)
             ret['full'] = full.numpy()
             ret['ranges'] = rng
             ret['tmax'] = t
@@ -103,6 +117,7 @@ def test_two_rank_scene_sharding_matches_single_process():
     assert np.all(ret['g1'] == 3.0) and np.all(ret['g2'] == 30.0)
     assert ret['n_msgs'] == 2 and ret['p3_none']
     assert ret['reducer'] == ([3.0] * 6, [30.0] * 6, 2, 48)
+    assert ret['lazy'] == ([3.0] * 4, [15.0] * 3, [100.0] * 2, [21.0] * 2, 2)
     assert ret['coalesced'] == ([3.0] * 5, [6.0] * 6, [9.0] * 40, 2, (5 + 6 + 40) * 4)      # two messages for three tensors
 
 

@@ -342,6 +342,7 @@ class SceneIndex(object):
             if len(cls._cache) > 64:
                 cls._cache.clear()
             idx = cls(host, device, pad_to)
+            idx.key = key                 # content key: what hipGraph captures of a call shape are filed under
             cls._cache[key] = idx
         if idx._mark is not None:
             idx._mark.join()           # a cached index built on another stream: wait for its tables

@@ -76,6 +76,18 @@ class LSTM(torch.nn.Module):
     #: they draw their parameters from the RNG in the reference's order (same seed => same weights)
     _ENCODER_ONLY = False
 
+    # class-level defaults of everything __init__ sets besides parameters: whole-object pickles are the checkpoint format
+    # (LSTMPredictor.save) and __setstate__ restores __dict__ verbatim, so a module pickled by an older revision must still
+    # find the attributes that later revisions read
+    kernel_variant = 0
+    sparse_embedding = True
+    graph_replay = None
+    _graphs = None
+    _ws = None
+    _grad_reduce_fn = None
+    _cell_major = None
+    _quad_major = None
+
     # device-side caches (workspace, re-laid-out weight copies): rebuilt lazily, never pickled / deep-copied
     _CACHES = ('_ws', '_cell_major', '_quad_major', '_dummy_head', '_grad_reduce_fn', '_desc_cache', '_plist_cache', '_graphs')
 
@@ -424,7 +436,10 @@ class LSTM(torch.nn.Module):
             raise ValueError('batch_split covers %d tracks, observed has %d' % (idx.M, M))
         goals_t = goals if (goals is not None and self.goal_flag) else None
         # (the caller's stream is part of the key: forwards on different streams -- batches in flight -- must not share buffers)
-        key = (bytes(m), idx, T_obs, T_dec, truth is not None, goals_t is not None, torch.cuda.current_stream().cuda_stream)
+        # ... and the scene structure enters by CONTENT (SceneIndex.key), not by object identity: clearing SceneIndex._cache
+        # must not orphan captured graphs (they would pin their private pools until evicted)
+        key = (bytes(m), getattr(idx, 'key', idx), T_obs, T_dec, truth is not None, goals_t is not None,
+               torch.cuda.current_stream().cuda_stream)
         if not isinstance(self._graphs, dict):
             self._graphs = {}
         e = self._graphs.get(key)
@@ -608,7 +623,9 @@ class LSTMPredictor(object):
         return state
 
     def _graph_kw(self):
-        return {'graph': True} if (self.graph_replay and isinstance(self.model, LSTM)) else {}
+        # only the plain LSTM.forward takes ``graph``: LSTMGenerator / LSTMDiscriminator / the VAE's cells subclass LSTM but
+        # override forward() without it
+        return {'graph': True} if (self.graph_replay and type(self.model).forward is LSTM.forward) else {}
 
     def save(self, state, filename):
         with open(filename, 'wb') as f:

@@ -623,6 +623,8 @@ class SequenceFn(torch.autograd.Function):
         # collectives overlap the remaining weight-gradient GEMMs; the compute stream waits for them before the gradients
         # are handed to autograd.
         reduce_fn = ctx.reduce_fn
+        if hasattr(reduce_fn, 'begin'):
+            reduce_fn.begin()          # nothing a failed earlier pass left behind travels with this step's message
         pending = []
 
         pending_tensors = []

@@ -229,12 +229,19 @@ class GradReducer(object):
         self.messages = 0
         self.bytes = 0
         self._small = []
+        self._flushed = None          # handle of the last coalesced message until someone has waited for it
+
+    def begin(self):
+        """Start of a backward pass: drop gradients a previous pass collected but never sent (it raised before ``flush()``);
+        they must not travel with this step's message."""
+        self._small = []
+        self._flushed = None
 
     def __call__(self, tensor):
         self.bytes += tensor.numel() * tensor.element_size()
         if tensor.numel() * tensor.element_size() < self.coalesce_below and tensor.dtype == torch.float32:
             self._small.append(tensor)
-            return _Done()
+            return _Done(self, tensor)
         self.messages += 1
         return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -246,13 +253,25 @@ class GradReducer(object):
         tensors, self._small = self._small, []
         flat = torch.cat([t.reshape(-1) for t in tensors])
         self.messages += 1
-        return _FlatWork(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, tensors)
+        self._flushed = _FlatWork(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, tensors)
+        return self._flushed
 
 
 class _Done(object):
-    """handle of a gradient that travels with the coalesced message (GradReducer.flush)"""
+    """Handle of a gradient that travels with the coalesced message (GradReducer.flush).  The call-then-wait contract of a
+    plain ``reduce_fn`` still holds: waiting on it before anyone called ``flush()`` sends the coalesced message now, and the
+    wait covers that message -- a caller that never heard of ``flush()`` cannot end up with an unreduced gradient."""
+
+    def __init__(self, reducer, tensor):
+        self.reducer, self.tensor = reducer, tensor
 
     def wait(self):
+        r = self.reducer
+        if any(t is self.tensor for t in r._small):
+            r.flush()
+        w = r._flushed
+        if w is not None and any(t is self.tensor for t in w.tensors):
+            w.wait()
         return True
 
 
@@ -261,7 +280,10 @@ class _FlatWork(object):
         self.work, self.flat, self.tensors = work, flat, tensors
 
     def wait(self):
+        if self.work is None:          # already waited for (a _Done handle and the backward's own flush handle may both wait)
+            return True
         self.work.wait()
+        self.work = None
         off = 0
         for t in self.tensors:
             t.copy_(self.flat[off:off + t.numel()].view_as(t))
