@@ -162,6 +162,179 @@ def classical():
     print('classical_ref.npz  %d cases' % len(cases))
 
 
+def pool_grad():
+    """Autograd through the STAND-ALONE reference ``GridBasedPooling.forward(hidden_state, obs1, obs2)``
+    (lstm/gridbased_pooling.py:94-110), called outside LSTM.forward: gradients of sum(out * R) (R a fixed random matrix)
+    with respect to hidden_state, the pool's parameters and -- directional -- obs1 / obs2.  Crowds with absent (NaN) agents,
+    several neighbours per cell and out-of-range neighbours (cell (0,0) clobbers).  single-threaded.
+    tests/golden/pool_grad.npz"""
+    import torch
+    ref = ref_import.import_reference()
+    torch.set_num_threads(1)
+    out = {}
+    rng = np.random.RandomState(17)
+    cases = [('social', dict(type_='social', hidden_dim=32, cell_side=0.6, n=6, out_dim=16, embedding_arch='two_layer',
+                             layer_dims=[64], latent_dim=8), 3, 7),
+             ('social_one', dict(type_='social', hidden_dim=32, cell_side=0.5, n=4, out_dim=24, embedding_arch='one_layer',
+                                 latent_dim=16), 2, 12),
+             ('directional', dict(type_='directional', hidden_dim=32, cell_side=0.6, n=6, out_dim=16,
+                                  embedding_arch='one_layer'), 3, 7),
+             ('directional_const', dict(type_='directional', hidden_dim=32, cell_side=0.5, n=4, out_dim=8, constant=1,
+                                        embedding_arch='two_layer', layer_dims=[32]), 2, 9),
+             ('occupancy', dict(type_='occupancy', hidden_dim=32, cell_side=0.6, n=6, out_dim=16, embedding_arch='one_layer'), 2, 5)]
+    for name, kw, B, N in cases:
+        torch.manual_seed(11)
+        pool = ref.GridBasedPooling(**kw)
+        H = kw['hidden_dim']
+        obs2 = rng.randn(B, N, 2) * 0.7
+        obs1 = obs2 - rng.randn(B, N, 2) * 0.15
+        obs2[0, 2] = np.nan; obs1[0, 2] = np.nan          # an absent agent
+        obs2[B - 1, 1] = [40.0, 40.0]                      # out of range for everybody
+        obs2[0, 4] = obs2[0, 3] + 0.01                     # two neighbours in one cell for most egos
+        hid = rng.randn(B, N, H)
+        hid[0, 2] = np.nan
+        o1 = torch.tensor(obs1, dtype=torch.float32, requires_grad=name.startswith('directional'))
+        o2 = torch.tensor(obs2, dtype=torch.float32, requires_grad=name.startswith('directional'))
+        h = torch.tensor(hid, dtype=torch.float32, requires_grad=True)
+        R = torch.tensor(rng.randn(B * N, kw['out_dim']), dtype=torch.float32)
+        # (the reference writes -500 into absent rows of obs IN PLACE, :249: a leaf that requires grad cannot be passed)
+        y = pool(h, o1 * 1.0 if o1.requires_grad else o1, o2 * 1.0 if o2.requires_grad else o2)
+        (y * R).sum().backward()
+        pre = name + '_'
+        out[pre + 'kw'] = np.asarray(repr(kw))
+        out[pre + 'obs1'], out[pre + 'obs2'], out[pre + 'hidden'], out[pre + 'R'] = obs1.astype(np.float32), obs2.astype(np.float32), hid.astype(np.float32), R.numpy()
+        out[pre + 'out'] = y.detach().numpy()
+        for k, v in pool.state_dict().items():
+            out[pre + 'w_' + k] = v.numpy().copy()
+        for k, p_ in pool.named_parameters():
+            out[pre + 'g_' + k] = p_.grad.numpy().copy() if p_.grad is not None else np.zeros(0, dtype=np.float32)
+        if h.grad is not None:
+            out[pre + 'g_hidden'] = torch.nan_to_num(h.grad).numpy().copy()
+        if o2.grad is not None:
+            out[pre + 'g_obs1'], out[pre + 'g_obs2'] = torch.nan_to_num(o1.grad).numpy().copy(), torch.nan_to_num(o2.grad).numpy().copy()
+        print(name, 'out', tuple(y.shape), 'grads:', sorted(k for k in out if k.startswith(pre + 'g_')))
+    np.savez_compressed(os.path.join(OUT, 'pool_grad.npz'), **out)
+    print('pool_grad.npz')
+
+
+def ref_pickle():
+    """A checkpoint written by the REFERENCE's ``LSTMPredictor.save`` (lstm/lstm.py:270-277: ``torch.save(self)`` + ``.state``)
+    for a small Social-LSTM, and the reference predictor's own ``__call__`` on three real scenes.
+    tests/golden/ref_predictor.pkl (+ .state), tests/golden/ref_predictor_cases.npz"""
+    import types
+    import torch
+    ref = ref_import.import_reference()
+    import trajnetbaselines.lstm.lstm as ref_lstm
+    from oracle import classical_stubs
+    from trajnetplusplusbaselines_amd import data
+    sys.modules['trajnetplusplustools'].Reader = classical_stubs._Reader
+    ref_lstm.trajnetplusplustools = sys.modules['trajnetplusplustools']
+    torch.set_num_threads(1)
+    torch.manual_seed(5)
+    pool = ref.GridBasedPooling(type_='social', hidden_dim=64, cell_side=0.6, n=6, out_dim=32, embedding_arch='two_layer',
+                                layer_dims=[64], latent_dim=8)
+    model = ref.LSTM(embedding_dim=32, hidden_dim=64, pool=pool)
+    predictor = ref_lstm.LSTMPredictor(model)
+    state = {'epoch': 3, 'state_dict': model.state_dict(), 'optimizer': None, 'scheduler': None}
+    path = os.path.join(OUT, 'ref_predictor.pkl')
+    predictor.save(state, path)
+    root = os.path.join(ref_import.REFERENCE_ROOT, 'DATA_BLOCK', 'trajdata', 'train')
+    scenes = data.read_ndjson_scenes(os.path.join(root, 'biwi_hotel.ndjson'))
+    out = {}
+    out['normalize'] = np.array([0, 1, 0], dtype=np.int64)
+    for k, si in enumerate((3, 40, 111)):
+        args = types.SimpleNamespace(normalize_scene=bool(out['normalize'][k]))
+        paths = scenes[si][1]
+        xy = data.paths_to_xy(paths)
+        res = predictor(paths, np.zeros((xy.shape[1], 2)), n_predict=12, obs_length=9, args=args)
+        out['s%d_rows' % k], out['s%d_lens' % k] = _rows(paths)
+        out['s%d_primary' % k], out['s%d_neigh' % k] = res[0][0], res[0][1]
+    np.savez_compressed(os.path.join(OUT, 'ref_predictor_cases.npz'), **out)
+    print('ref_predictor.pkl %d bytes' % os.path.getsize(path))
+
+
+def writer():
+    """The reference's ``write_predictions`` (evaluator/write_utils.py:42-81) and ``preprocess_test`` (:34-40), unmodified, on a
+    small real test file with given predictions (two modes; one scene with the primary alone).  ``trajnetplusplustools`` is
+    absent: TrackRow / SceneRow / writers.trajnet are stubbed with the package's published record layout (coordinates rounded
+    to two decimals) -- what IS pinned is the reference's row order, frame arithmetic, ids and SceneRow fields.
+    tests/golden/writer_case.ndjson (input: 8 scenes of DATA_BLOCK/trajdata/train/biwi_hotel.ndjson re-serialised),
+    writer_case_expected.ndjson, writer_case_preds.npz"""
+    import importlib.util
+    import json
+    import types
+    from collections import namedtuple
+    from trajnetplusplusbaselines_amd import data
+    tools = types.ModuleType('trajnetplusplustools')
+    tools.TrackRow = namedtuple('Row', ['frame', 'pedestrian', 'x', 'y', 'prediction_number', 'scene_id'])
+    tools.TrackRow.__new__.__defaults__ = (None, None, None, None, None, None)
+    tools.SceneRow = namedtuple('Row', ['scene', 'pedestrian', 'start', 'end', 'fps', 'tag'])
+    tools.SceneRow.__new__.__defaults__ = (None, None, None, None, None, None)
+
+    def trajnet(row):
+        if isinstance(row, tools.TrackRow):
+            x, y = round(row.x, 2), round(row.y, 2)
+            if row.prediction_number is None:
+                return json.dumps({'track': {'f': row.frame, 'p': row.pedestrian, 'x': x, 'y': y}})
+            return json.dumps({'track': {'f': row.frame, 'p': row.pedestrian, 'x': x, 'y': y,
+                                         'prediction_number': row.prediction_number, 'scene_id': row.scene_id}})
+        return json.dumps({'scene': {'id': row.scene, 'p': row.pedestrian, 's': row.start, 'e': row.end, 'fps': row.fps, 'tag': row.tag}})
+    tools.writers = types.ModuleType('trajnetplusplustools.writers')
+    tools.writers.trajnet = trajnet
+    saved = sys.modules.get('trajnetplusplustools')
+    sys.modules['trajnetplusplustools'] = tools
+    spec = importlib.util.spec_from_file_location('_ref_write_utils', os.path.join(ref_import.REFERENCE_ROOT, 'evaluator', 'write_utils.py'))
+    wu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wu)
+    if saved is not None:
+        sys.modules['trajnetplusplustools'] = saved
+    src = os.path.join(ref_import.REFERENCE_ROOT, 'DATA_BLOCK', 'trajdata', 'train', 'biwi_hotel.ndjson')
+    all_scenes = data.read_ndjson_scenes(src)
+    pick = [all_scenes[i] for i in (0, 7, 19, 33, 58, 90, 120, 150)]
+    # the input file of the test: the picked scenes' rows re-serialised (scene rows first, then every track row once)
+    inp = os.path.join(OUT, 'writer_case.ndjson')
+    seen = set()
+    with open(inp, 'w') as f:
+        for sid, paths in pick:
+            f.write(json.dumps({'scene': {'id': sid, 'p': paths[0][0].pedestrian, 's': paths[0][0].frame, 'e': paths[0][-1].frame,
+                                          'fps': 2.5, 'tag': [0, []]}}) + '\n')
+        for sid, paths in pick:
+            for p in paths:
+                for r in p:
+                    if (r.frame, r.pedestrian) not in seen:
+                        seen.add((r.frame, r.pedestrian))
+                        f.write(json.dumps({'track': {'f': r.frame, 'p': r.pedestrian, 'x': r.x, 'y': r.y}}) + '\n')
+    scenes = data.read_ndjson_scenes(inp)
+    rng = np.random.RandomState(2)
+    pred_list, ref_scenes, store = [], [], {}
+    for k, (sid, paths) in enumerate(scenes):
+        paths = [[tools.TrackRow(r.frame, r.pedestrian, r.x, r.y) for r in p] for p in paths]
+        paths = wu.preprocess_test(paths, 9)
+        if k == 5:
+            paths = paths[:1]
+        preds = {}
+        for m in range(2):
+            prim = np.array([paths[0][-1].x, paths[0][-1].y]) + np.cumsum(rng.randn(12, 2) * 0.3, axis=0)
+            neigh = rng.randn(12, len(paths) - 1, 2) * 3 if len(paths) > 1 else []
+            preds[m] = [prim.astype(np.float32), np.asarray(neigh, dtype=np.float32) if len(paths) > 1 else []]
+            store['s%d_m%d_prim' % (k, m)] = preds[m][0]
+            store['s%d_m%d_neigh' % (k, m)] = np.asarray(preds[m][1], dtype=np.float32)
+        store['s%d_ids' % k] = np.array([p[0].pedestrian for p in paths], dtype=np.int64)
+        pred_list.append(preds)
+        ref_scenes.append(('biwi_hotel', sid, paths))
+    exp = os.path.join(OUT, 'writer_case_expected.ndjson')
+    if os.path.exists(exp):
+        os.remove(exp)
+    args = types.SimpleNamespace(obs_length=9, pred_length=12, path=OUT + '/')
+    # write_predictions opens args.path + '{model_name}/{dataset_name}'
+    os.makedirs(os.path.join(OUT, '_w'), exist_ok=True)
+    wu.write_predictions(pred_list, ref_scenes, '_w', 'out.ndjson', args)
+    os.replace(os.path.join(OUT, '_w', 'out.ndjson'), exp)
+    os.rmdir(os.path.join(OUT, '_w'))
+    np.savez_compressed(os.path.join(OUT, 'writer_case_preds.npz'), **store)
+    print('writer_case: %d scenes, %d lines expected' % (len(scenes), sum(1 for _ in open(exp))))
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['classical']
     for w in what:

@@ -129,3 +129,17 @@ def test_train_batch_reduces_the_loss():
     losses = [train_batch(model, opt, PredictionLoss(), xy, torch.zeros(xy.shape[1], 2), split, alpha_kld=0.7) for _ in range(6)]
     np.testing.assert_allclose(losses[0], float(Z['directional_reconstr']), rtol=3e-5)
     assert np.isfinite(losses).all() and min(losses[3:]) < losses[0]
+
+
+def test_stateful_interaction_modules_are_refused_loudly():
+    """the reference carries NearestNeighborLSTM / TrajectronPooling's own LSTM state through obs_encoder ->
+    pred_encoder -> every decoder mode (vae/vae.py:229-301); the sequence driver starts every run from a zero state, so the
+    mirror refuses instead of computing something else."""
+    from trajnetplusplusbaselines_amd import synth
+    from trajnetplusplusbaselines_amd.lstm.non_gridbased_pooling import NearestNeighborLSTM
+    from trajnetplusplusbaselines_amd.vae import VAE
+    pool = NearestNeighborLSTM(n=4, hidden_dim=128, out_dim=32)
+    model = VAE(pool=pool).cuda().eval()
+    xy, split = synth.linear_crowd(2, 5, seed=1)
+    with pytest.raises(NotImplementedError, match='stateful'):
+        model(xy[:9].cuda(), torch.zeros(xy.shape[1], 2).cuda(), split, n_predict=12)

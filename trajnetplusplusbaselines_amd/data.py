@@ -191,3 +191,94 @@ class SceneBatcher(object):
             gx, gy = goals[:, 0], goals[:, 1]
             goals = torch.stack([gx * ct - gy * st, gx * st + gy * ct], dim=-1)
         return xy, goals, split
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Evaluator feed: test file -> batched predictions -> prediction file in the reference's layout
+# ---------------------------------------------------------------------------------------------------------------------
+def trajnet_format(row):
+    """One ndjson line for a TrackRow / SceneRow.  Stands in for ``trajnetplusplustools.writers.trajnet`` (not vendored,
+    SURVEY.md 8c): coordinates rounded to two decimals, prediction rows carry ``prediction_number`` and ``scene_id`` --
+    the record layout of the data files ``read_ndjson_scenes`` parses."""
+    import json
+    if isinstance(row, SceneRow):
+        return json.dumps({'scene': {'id': row.scene, 'p': row.pedestrian, 's': row.start, 'e': row.end, 'fps': row.fps,
+                                     'tag': row.tag}})
+    x, y = round(float(row.x), 2), round(float(row.y), 2)
+    if row.prediction_number is None:
+        return json.dumps({'track': {'f': row.frame, 'p': row.pedestrian, 'x': x, 'y': y}})
+    return json.dumps({'track': {'f': row.frame, 'p': row.pedestrian, 'x': x, 'y': y,
+                                 'prediction_number': row.prediction_number, 'scene_id': row.scene_id}})
+
+
+def preprocess_test(scene, obs_len):
+    """Drop tracks that only appear after the observation period and the rows after it (reference
+    evaluator/write_utils.py:34-40; test files hold overlapping scenes)."""
+    last_obs_frame = [r.frame for r in scene[0]][:obs_len][-1]
+    return [[row for row in ped if row.frame <= last_obs_frame] for ped in scene if ped[0].frame <= last_obs_frame]
+
+
+def write_predictions(pred_list, scenes, filename, obs_length=9, pred_length=12, mode='a'):
+    """Append the predictions of ``scenes`` = [(scene_id, paths)] to ``filename`` exactly as the reference's
+    ``write_predictions`` lays them out (evaluator/write_utils.py:42-81): per scene one SceneRow (primary id, first frame,
+    first frame + (obs + pred - 1) frame steps, fps 2.5, tag 0), then per mode the primary's ``pred_length`` rows followed
+    by every neighbour's rows, neighbours in the order of ``paths[1:]`` (which must be the paths the prediction was made
+    from, i.e. after ``preprocess_test``); frames continue the primary's frame step."""
+    seq_length = obs_length + pred_length
+    with open(filename, mode) as f:
+        for predictions, (scene_id, paths) in zip(pred_list, scenes):
+            observed_path = paths[0]
+            frame_diff = observed_path[1].frame - observed_path[0].frame
+            first_frame = observed_path[obs_length - 1].frame + frame_diff
+            ped_id = observed_path[0].pedestrian
+            neigh_ids = [p[0].pedestrian for p in paths[1:]]
+            f.write(trajnet_format(SceneRow(scene_id, ped_id, observed_path[0].frame,
+                                            observed_path[0].frame + (seq_length - 1) * frame_diff, 2.5, 0)))
+            f.write('\n')
+            for m in range(len(predictions)):
+                prediction, neigh_predictions = predictions[m]
+                for i in range(len(prediction)):
+                    f.write(trajnet_format(TrackRow(first_frame + i * frame_diff, ped_id, float(prediction[i, 0]),
+                                                    float(prediction[i, 1]), m, scene_id)))
+                    f.write('\n')
+                if len(neigh_predictions):
+                    for n in range(neigh_predictions.shape[1]):
+                        neigh = neigh_predictions[:, n]
+                        for j in range(len(neigh)):
+                            f.write(trajnet_format(TrackRow(first_frame + j * frame_diff, neigh_ids[n], float(neigh[j, 0]),
+                                                            float(neigh[j, 1]), m, scene_id)))
+                            f.write('\n')
+
+
+def predict_dataset(ndjson_in, predictor, out_path, batch_scenes=64, obs_length=9, pred_length=12, modes=1, goals=None,
+                    in_flight=1, args=None, limit=None):
+    """The evaluator's prediction loop for one test file (reference lstm/trajnet_evaluator.py:29-65 ``get_predictions`` +
+    evaluator/write_utils.py): read the scenes, ``preprocess_test`` each, predict them ``batch_scenes`` at a time through
+    ``predictor.predict_batch`` (ONE ``LSTM.forward`` per batch instead of one call per scene on 12 joblib workers;
+    ``in_flight`` > 1 keeps that many batches on the GPU at once, ``predict_batches``) and write the prediction file in
+    the reference's layout.  ``goals``: {pedestrian id: (x, y)} (the reference's goal pickle, write_utils.py:21-26) or None
+    = zeros.  ``predictor`` is anything with ``predict_batch(scenes, n_predict=, modes=, obs_length=, args=)`` -- the
+    ``LSTMPredictor`` / ``SGANPredictor`` mirrors -- or a per-scene callable ``predictor(paths, scene_goal, ...)`` (the
+    classical predictors).  Returns the number of scenes written."""
+    import os
+    scenes = read_ndjson_scenes(ndjson_in, limit=limit)
+    scenes = [(sid, preprocess_test(paths, obs_length)) for sid, paths in scenes]
+    scene_goals = [np.array([goals[p[0].pedestrian] for p in paths], dtype=np.float64) if goals is not None
+                   else np.zeros((len(paths), 2)) for _, paths in scenes]
+    d = os.path.dirname(os.path.abspath(out_path))
+    if not os.path.isdir(d):
+        os.makedirs(d)
+    open(out_path, 'w').close()
+    chunks = [list(range(lo, min(lo + batch_scenes, len(scenes)))) for lo in range(0, len(scenes), batch_scenes)]
+    batches = [[(scenes[i][1], scene_goals[i]) for i in ids] for ids in chunks]
+    if hasattr(predictor, 'predict_batches') and in_flight > 1:
+        results = predictor.predict_batches(batches, n_predict=pred_length, modes=modes, obs_length=obs_length, args=args,
+                                            in_flight=in_flight)
+    elif hasattr(predictor, 'predict_batch'):
+        results = [predictor.predict_batch(b, n_predict=pred_length, modes=modes, obs_length=obs_length, args=args)
+                   for b in batches]
+    else:
+        results = [[predictor(paths, goal, n_predict=pred_length, obs_length=obs_length) for paths, goal in b] for b in batches]
+    for ids, preds in zip(chunks, results):
+        write_predictions(preds, [scenes[i] for i in ids], out_path, obs_length, pred_length, mode='a')
+    return len(scenes)

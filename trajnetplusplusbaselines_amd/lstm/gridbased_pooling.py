@@ -8,6 +8,61 @@ import torch
 from .. import _lib
 
 
+class _GridScatter(torch.autograd.Function):
+    """Autograd through the STAND-ALONE grid build (reference ``pool(hidden_state, obs1, obs2)`` is differentiable,
+    lstm/gridbased_pooling.py:94-110, 227-305): ``occ[arange, oi] = other_values`` hands every in-range neighbour the gradient of
+    its cell (overwritten duplicates included), and the grid leaves ``occupancy()`` through ``lp_pool2d(x, 1, 1)`` whose
+    derivative at 0 is 0 (:304).  The tables are ``tnp_pool_pair_cells_autograd``'s -- the ones the training path of
+    ``LSTM.forward`` uses -- and the reductions ``tnp_social_scatter_backward`` / ``tnp_directional_scatter_backward``.
+    Cell indices are not differentiable (the reference's ``.long()``, :273)."""
+
+    @staticmethod
+    def forward(ctx, pool, type_id, obs1, obs2, values):
+        grid, _ = pool._winner_grid(obs1, obs2, type_id, values=values)
+        ctx.pool, ctx.type_id, ctx.shape = pool, type_id, (obs2.size(0), obs2.size(1))
+        ctx.save_for_backward(obs1, obs2)
+        return grid
+
+    @staticmethod
+    def backward(ctx, d_grid):
+        pool, (B, N) = ctx.pool, ctx.shape
+        obs1, obs2 = ctx.saved_tensors
+        dev = d_grid.device
+        G, cell, half_x, half_y = pool._geometry()
+        M, ncell = B * N, G * G
+        L = _lib.lib()
+        o1 = _lib.f32c(obs1 if obs1 is not None else obs2, dev).reshape(M, 2)
+        o2 = _lib.f32c(obs2, dev).reshape(M, 2)
+        row_base = (torch.arange(M, dtype=torch.int32, device=dev) // N) * N
+        row_count = torch.full((M,), N, dtype=torch.int32, device=dev)
+        raw = torch.empty(M, N, dtype=torch.int32, device=dev)
+        cells = torch.empty(M, N, dtype=torch.int32, device=dev)
+        directional = ctx.type_id == _lib.POOL_DIRECTIONAL
+        winner = torch.empty(M, N, dtype=torch.int32, device=dev) if directional else None
+        _lib.check(L.tnp_pool_pair_cells_autograd(_lib.ptr(o2), _lib.ptr(row_base), _lib.ptr(row_count), None, N, M, N, G, cell,
+                                                  half_x, half_y, float(pool.constant), _lib.ptr(raw), _lib.ptr(cells),
+                                                  _lib.ptr(winner), _lib.stream_ptr()), 'tnp_pool_pair_cells_autograd')
+        dg = _lib.f32c(d_grid, dev)
+        d_obs1 = d_obs2 = d_values = None
+        if directional:
+            dvel = torch.empty(M, 2, dtype=torch.float32, device=dev)
+            _lib.check(L.tnp_directional_scatter_backward(_lib.ptr(dg), dg.stride(0), _lib.ptr(cells), _lib.ptr(winner),
+                                                          _lib.ptr(row_base), _lib.ptr(row_count), _lib.ptr(o1), _lib.ptr(o2), M, N,
+                                                          ncell, _lib.ptr(dvel), _lib.stream_ptr()), 'tnp_directional_scatter_backward')
+            dvel = dvel.reshape(B, N, 2)
+            if ctx.needs_input_grad[3]:
+                d_obs2 = dvel
+            if ctx.needs_input_grad[2]:
+                d_obs1 = -dvel
+        elif ctx.needs_input_grad[4]:
+            C = dg.size(1) // ncell
+            d_values = torch.empty(M, C, dtype=torch.float32, device=dev)
+            _lib.check(L.tnp_social_scatter_backward(_lib.ptr(dg), dg.stride(0), _lib.ptr(cells), _lib.ptr(row_base),
+                                                     _lib.ptr(row_count), M, N, C, ncell, _lib.ptr(d_values), _lib.stream_ptr()),
+                       'tnp_social_scatter_backward')
+        return None, None, d_obs1, d_obs2, d_values
+
+
 class GridBasedPooling(torch.nn.Module):
     def __init__(self, cell_side=2.0, n=4, hidden_dim=128, out_dim=None,
                  type_='occupancy', pool_size=1, blur_size=1, front=False,
@@ -179,7 +234,10 @@ class GridBasedPooling(torch.nn.Module):
         B, N = obs2.size(0), obs2.size(1)
         if N == 1:
             return self.occupancy(obs2, None, past_obs=obs1)
-        grid, _ = self._winner_grid(obs1, obs2, _lib.POOL_DIRECTIONAL)
+        if torch.is_grad_enabled() and (obs2.requires_grad or (obs1 is not None and obs1.requires_grad)):
+            grid = _GridScatter.apply(self, _lib.POOL_DIRECTIONAL, obs1, obs2, None)     # velocities carry gradient
+        else:
+            grid, _ = self._winner_grid(obs1, obs2, _lib.POOL_DIRECTIONAL)
         return self._finish(grid, B * N, 2)
 
     def social(self, hidden_state, obs1, obs2):
@@ -189,8 +247,15 @@ class GridBasedPooling(torch.nn.Module):
         lin = self.hidden_dim_encoding
         _lib.require_device(lin.weight, 'GridBasedPooling parameters')
         h = torch.nan_to_num(_lib.f32c(hidden_state, lin.weight.device).reshape(B * N, -1))  # reference :166
-        enc = _lib.linear_forward(h, lin.weight.detach(), lin.bias.detach())
-        grid, _ = self._winner_grid(obs1, obs2, _lib.POOL_SOCIAL, values=enc)
+        if torch.is_grad_enabled() and (h.requires_grad or lin.weight.requires_grad):
+            # stand-alone call under autograd (outside LSTM.forward, whose sequence op has its own backward sweep): the same
+            # kernels, wrapped so that gradients reach hidden_state and hidden_dim_encoding (reference :165-170)
+            from .. import ops  # noqa: F401  (registers trajnet::linear with its autograd rule)
+            enc = torch.ops.trajnet.linear(h, lin.weight, lin.bias, False)
+            grid = _GridScatter.apply(self, _lib.POOL_SOCIAL, obs1, obs2, enc)
+        else:
+            enc = _lib.linear_forward(h, lin.weight.detach(), lin.bias.detach())
+            grid, _ = self._winner_grid(obs1, obs2, _lib.POOL_SOCIAL, values=enc)
         return self._finish(grid, B * N, self.pooling_dim)
 
     def forward(self, hidden_state, obs1, obs2):
@@ -204,7 +269,13 @@ class GridBasedPooling(torch.nn.Module):
             grid = self.social(hidden_state, obs1, obs2)
         grid = grid.reshape(batch_size * num_tracks, -1)
         x = grid
-        for lin in self.embedding_layers():
+        layers = self.embedding_layers()
+        if torch.is_grad_enabled() and (x.requires_grad or any(l.weight.requires_grad for l in layers)):
+            from .. import ops  # noqa: F401
+            for lin in layers:     # trajnet::linear = the same MFMA GEMM + its data / weight gradient kernels
+                x = torch.ops.trajnet.linear(x, lin.weight, lin.bias, True)
+            return x
+        for lin in layers:
             x = _lib.linear_forward(x, lin.weight.detach(), lin.bias.detach(), relu=True)
         return x
 

@@ -605,6 +605,28 @@ class _GraphedForward(object):
         return rel, pred
 
 
+def _reference_pickle_module():
+    """A ``pickle``-like module for ``torch.load`` whose Unpickler maps the reference's class paths
+    (``trajnetbaselines.lstm.lstm.LSTM``, ``...gridbased_pooling.GridBasedPooling``, ``...sgan.sgan.SGAN``, ...) to this
+    package's mirrors; everything else resolves as usual."""
+    import pickle
+    import types
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module == 'trajnetbaselines' or module.startswith('trajnetbaselines.'):
+                module = __name__.split('.')[0] + module[len('trajnetbaselines'):]
+            return super(Unpickler, self).find_class(module, name)
+
+    mod = types.ModuleType('trajnet_reference_pickle')
+    mod.Unpickler = Unpickler
+    mod.load = lambda f, **kw: Unpickler(f, **kw).load()
+    mod.loads = lambda b, **kw: Unpickler(__import__('io').BytesIO(b), **kw).load()
+    for k in ('dump', 'dumps', 'Pickler', 'PickleError', 'PicklingError', 'UnpicklingError', 'HIGHEST_PROTOCOL', 'DEFAULT_PROTOCOL'):
+        setattr(mod, k, getattr(pickle, k))
+    return mod
+
+
 class LSTMPredictor(object):
     """Reference lstm/lstm.py:266-313: pickle-compatible wrapper used by the evaluator."""
 
@@ -635,8 +657,12 @@ class LSTMPredictor(object):
 
     @staticmethod
     def load(filename):
+        """Reference lstm/lstm.py:279-282.  A whole-object pickle written by the REFERENCE (``trajnetbaselines.lstm.lstm.
+        LSTMPredictor`` holding ``trajnetbaselines.lstm.*`` modules) loads too: class paths under ``trajnetbaselines.`` resolve to
+        the mirrors of this package (same attribute names, same state_dict keys), so existing ``.pkl`` checkpoints are a
+        drop-in (tests/test_predictor_pickle.py)."""
         with open(filename, 'rb') as f:
-            return torch.load(f, weights_only=False)
+            return torch.load(f, weights_only=False, pickle_module=_reference_pickle_module())
 
     def __call__(self, paths, scene_goal, n_predict=12, modes=1, predict_all=True, obs_length=9, start_length=0,
                  args=None):

@@ -142,6 +142,15 @@ class VAE(torch.nn.Module):
         if not self.desire:
             raise NotImplementedError('VAE.desire = False (latent prior from vae_encoder_x) is not wired to a trainer option in '
                                       'the reference either (vae/vae.py:81 fixes it to True)')
+        from ..lstm.non_gridbased_pooling import _StatefulInteractionEncoder
+        if isinstance(self.pool, _StatefulInteractionEncoder):
+            # NearestNeighborLSTM / TrajectronPooling keep an LSTM state of their own.  The reference resets it ONCE per forward
+            # (vae/vae.py:229-231) and carries it through the observation encoder, the prediction encoder and then every decoder
+            # mode in turn; the sequence driver here starts each of those runs from a zero interaction-encoder state, which
+            # would silently compute something else.  Not supported rather than different.
+            raise NotImplementedError('VAE with a stateful interaction module (%s): the reference threads pool_lstm\'s state '
+                                      'through obs_encoder -> pred_encoder -> every decoder mode; use a scene-local module '
+                                      '(grid pooling, nn, hiddenstatemlp, attentionmlp)' % type(self.pool).__name__)
         obs_run, pred_run = self._runners()
         dev = self.obs_encoder.weight_ih.device
         if dev.type != 'cuda':
