@@ -337,3 +337,41 @@ def test_scatter_backward_rule_on_random_crowds(ref):
                         got[b, i, j - (j > i)] = w[b * N + i, :, c // n, c % n].numpy()
         np.testing.assert_array_equal(got, want, err_msg='case %d: B=%d N=%d n=%d cs=%g constant=%g' % (case, B, N, n, cs, const))
     print('in-range pairs without gradient (clobbered cell 0):', masked)
+
+
+def test_default_thread_reference_delta_at_config2(ref):
+    """What a user who compares against the reference AS SHIPPED (torch's default intra-op threads) will see:
+    parity is defined against the single-threaded reference because its ``index_put_`` with duplicate indices
+    (lstm/gridbased_pooling.py:290-293) keeps a thread-dependent writer.  Reference vs reference, 1 thread against the
+    container's default thread count, at BASELINE config 2 (the bench crowd) and on a crowd four times as dense (many shared
+    cells): max |dADE| / |dFDE| over the primaries is REPORTED for both and asserted <= 1e-4 m at config 2 (north_star's
+    tolerance), so INTEGRATION.md can state the bound."""
+    from trajnetplusplusbaselines_amd import synth
+    default_threads = int(os.environ.get('TNP_REF_DEFAULT_THREADS', os.cpu_count() or 8))
+    torch.manual_seed(0)
+    pool = ref.GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=16, out_dim=256,
+                                embedding_arch='two_layer', layer_dims=[1024], latent_dim=16)
+    model = ref.LSTM(pool=pool).eval()
+    report = {}
+    for name, (xy, split) in (('config 2 (64 x 32, 8 m box)', synth.linear_crowd(64, 32, seed=100)),
+                              ('dense (16 x 48, positions / 2)', synth.linear_crowd(16, 48, seed=7))):
+        xy, split = xy.numpy().copy(), split.numpy()
+        if name.startswith('dense'):
+            xy *= 0.5
+        goals = np.zeros((xy.shape[1], 2), dtype=np.float32)
+        _, pred_1 = _run_ref(model, xy, goals, split, 'n_predict')
+        torch.set_num_threads(default_threads)
+        try:
+            _, pred_n = _run_ref(model, xy, goals, split, 'n_predict')
+        finally:
+            torch.set_num_threads(1)
+        prim = split[:-1]
+        ade_1, fde_1 = helpers.ade_fde(pred_1[-12:, prim], xy[9:, prim])
+        ade_n, fde_n = helpers.ade_fde(pred_n[-12:, prim], xy[9:, prim])
+        d_ade, d_fde = float(np.abs(ade_1 - ade_n).max()), float(np.abs(fde_1 - fde_n).max())
+        d_pos = float(np.nanmax(np.abs(pred_1 - pred_n)))
+        report[name] = (d_ade, d_fde, d_pos)
+        print('%s: reference with %d threads vs 1 thread: max |dADE| %.2e m, max |dFDE| %.2e m, max |d position| (all tracks) %.2e m'
+              % (name, default_threads, d_ade, d_fde, d_pos))
+    d_ade, d_fde, _ = report['config 2 (64 x 32, 8 m box)']
+    assert d_ade <= 1e-4 and d_fde <= 1e-4
