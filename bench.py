@@ -464,6 +464,140 @@ def classical_leg(device, scenes=4096, agents=128):
                 finite=bool(torch.isfinite(out_sf).all() and torch.isfinite(out_orca).all() and torch.isfinite(out_k).all()))
 
 
+def operating_point_legs(device, steps=200):
+    """The reference's REAL operating point (VERDICT r4 "missing 3"), reported beside the headline -- never as `value`:
+
+    trainer_default   scripts/interaction/social.sh trains the headline model at the trainer's default batch_size = 8
+                      (lstm/trainer.py:30,125) on ragged scenes with a NEW batch_split every step.  Here: the headline model, 8
+                      scenes per step drawn fresh from a pool of 256 ragged scenes (8..72 agents, ~20 % NaN entries: SURVEY 8d
+                      regime ii) through data.SceneBatcher with the rotation augmentation, `steps` optimisation steps, nothing
+                      cached across steps that a trainer would not have (scene tables are rebuilt for every new split).
+    per_scene_predict LSTMPredictor.__call__ on single scenes (the evaluator's call, lstm/lstm.py:285-313): host paths in,
+                      numpy predictions out, one blocking call per scene; and the same scenes through predict_batch, 64 at a
+                      time (data.predict_dataset's default)."""
+    import random as _random
+    from oracle import oracle as _oracle
+    from trajnetplusplusbaselines_amd import _lib, data as trajdata
+    from trajnetplusplusbaselines_amd.lstm import LSTMPredictor, PredictionLoss
+    from trajnetplusplusbaselines_amd.lstm.train_step import train_batch
+    cfg = CONFIGS['social']
+    out = {}
+    # ---- trainer_default ----
+    model = build_model(cfg, device, seed=1)
+    optimizer = make_adam(model.parameters())
+    criterion = PredictionLoss()
+    xy, split = synth.ragged_crowd(256, 8, 72, seed=2024, nan_frac=0.2)
+    xy_np, split_np = xy.numpy(), split.numpy()
+    scenes = [xy_np[:, split_np[i]:split_np[i + 1]] for i in range(len(split_np) - 1)]
+    batcher = trajdata.SceneBatcher(scenes, device=device, drop_distant_r=None)
+    rng = _random.Random(7)
+    order = [[rng.randrange(len(scenes)) for _ in range(8)] for _ in range(steps + 10)]
+
+    def one(ids):
+        bxy, bgoals, bsplit = batcher.batch(ids, augment=True)
+        return train_batch(model, optimizer, criterion, bxy, bgoals, bsplit, 9, 12, batch_size=8)
+
+    for ids in order[:10]:
+        one(ids)
+    torch.cuda.synchronize()
+
+    def timed_loop():
+        _lib.SceneIndex._cache.clear()
+        t0 = time.perf_counter()
+        n_tracks = 0
+        for ids in order[10:]:
+            one(ids)
+            n_tracks += int(sum(batcher.sizes[ids]))
+        th = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        return th, time.perf_counter() - t0, n_tracks
+
+    t_host, t_all, tracks = timed_loop()
+    # the same loop with Python's cyclic collector kept off torch's long-lived objects (gc.freeze(): one line in a trainer):
+    # a full collection walks every module object torch created at import, and the step's many small host objects trigger it
+    import gc
+    gc.collect()
+    gc.freeze()
+    try:
+        t_host_f, t_all_f, _ = timed_loop()
+    finally:
+        gc.unfreeze()
+    # device time of a step in isolation: events around a step with the queue drained in front of it
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
+    for (a, b), ids in zip(ev, order[10:50]):
+        torch.cuda.synchronize()
+        a.record()
+        one(ids)
+        b.record()
+    torch.cuda.synchronize()
+    gpu_ms = sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2]
+    out['trainer_default'] = dict(
+        workload='Social-LSTM n=16 two_layer 1024 (the headline model), batch_size 8, ragged scenes of 8..72 agents with ~20 %% '
+                 'NaN entries, a new batch_split and rotation every step (data.SceneBatcher), %d optimisation steps '
+                 '(forward, NLL loss, backward, Adam)' % steps,
+        ms_per_step=t_all / steps * 1e3, host_enqueue_ms_per_step=t_host / steps * 1e3, gpu_ms_per_step_isolated=gpu_ms,
+        ms_per_step_gc_frozen=t_all_f / steps * 1e3, host_enqueue_ms_per_step_gc_frozen=t_host_f / steps * 1e3,
+        tracks_per_step=tracks / steps, scene_steps_per_s=8 * 21 * steps / t_all, steps=steps,
+        note='ms_per_step: wall clock of the pipelined loop; host_enqueue: until the loop has queued its last step (the host '
+             'only blocks on queue back-pressure); gpu isolated: median HIP-event time of one step started on an idle queue '
+             '(host enqueue included where the device waits for it); gc_frozen: the same loop after gc.freeze() -- Python\'s '
+             'cyclic collector otherwise walks torch\'s import-time objects every few steps (INTEGRATION.md)')
+    del model, optimizer
+    # ---- per_scene_predict ----
+    model = build_model(cfg, device, seed=1).eval()
+    predictor = LSTMPredictor(model)
+    n_sc = 128
+    paths_list = [trajdata.xy_to_paths(sc) for sc in scenes[:n_sc]]
+    goals_list = [np.zeros((sc.shape[1], 2)) for sc in scenes[:n_sc]]
+    for paths, g in zip(paths_list[:8], goals_list[:8]):
+        predictor(paths, g, n_predict=12)
+    _lib.SceneIndex._cache.clear()
+    t0 = time.perf_counter()
+    for paths, g in zip(paths_list, goals_list):
+        predictor(paths, g, n_predict=12)
+    t_call = (time.perf_counter() - t0) / n_sc
+    # device part of one call: the model forward alone on resident tensors, events on an idle queue
+    dev_ms = []
+    for sc in scenes[:32]:
+        obs = torch.tensor(sc[:9], dtype=torch.float32, device=device)
+        gl = torch.zeros(sc.shape[1], 2, device=device)
+        sp = torch.tensor([0, sc.shape[1]])
+        with torch.no_grad():
+            model(obs, gl, sp, n_predict=12)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            model(obs, gl, sp, n_predict=12)
+            b.record()
+            torch.cuda.synchronize()
+        dev_ms.append(a.elapsed_time(b))
+    t0 = time.perf_counter()
+    for lo in range(0, n_sc, 64):
+        predictor.predict_batch(list(zip(paths_list[lo:lo + 64], goals_list[lo:lo + 64])), n_predict=12)
+    t_batch = (time.perf_counter() - t0) / n_sc
+    # CPU beside it: the oracle's C port of the same forward on the same single scenes (bounded sample)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    om = _oracle.OracleModel(sd, pool_type='social', n=cfg['n'], cell_side=0.6)
+    t0 = time.perf_counter()
+    n_cpu = 0
+    for sc in scenes[:n_sc]:
+        om.forward(sc[:9].astype(np.float32), None, np.array([0, sc.shape[1]]), n_predict=12)
+        n_cpu += 1
+        if time.perf_counter() - t0 > 8.0:
+            break
+    t_cpu = (time.perf_counter() - t0) / n_cpu
+    out['per_scene_predict'] = dict(
+        workload='LSTMPredictor.__call__ (the evaluator\'s per-scene call) on %d single scenes of 8..72 agents: host paths in, '
+                 'numpy predictions out, one blocking call per scene' % n_sc,
+        ms_per_call=t_call * 1e3, device_ms_per_forward=sorted(dev_ms)[len(dev_ms) // 2], scenes_per_s=1.0 / t_call,
+        predict_batch_64_ms_per_scene=t_batch * 1e3, predict_batch_scenes_per_s=1.0 / t_batch,
+        cpu_port_ms_per_scene=t_cpu * 1e3, cpu_port_note='oracle/trajnet_oracle.c forward of the same scenes on the host (kind "port"); the '
+                                                         'Python reference needs 6.4 ms for a 1 x 4 VANILLA forward (BASELINE.md section 2) '
+                                                         'and ~2 s for the 64 x 32 social batch',
+        mean_agents=float(np.mean([sc.shape[1] for sc in scenes[:n_sc]])))
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: run this script under `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>` (what the contract's command line does) and
@@ -498,6 +632,8 @@ def main():
     ap.add_argument('--global-scenes', type=int, default=0, help='STRONG scaling: one fixed batch of this many scenes (BASELINE '
                     'config 3: --config directional --global-scenes 256) sharded over the ranks with parallel.shard_batch')
     ap.add_argument('--no-strong', action='store_true', help='skip the config-3 strong-scaling leg of the default run')
+    ap.add_argument('--no-op-point', action='store_true', help='skip the trainer_default / per_scene_predict legs (batch_size 8 '
+                    'training on fresh ragged batches, the evaluator\'s per-scene predictor call)')
     ap.add_argument('--no-sustain', action='store_true', help='skip the sustained-throughput leg (>= 2 s of back-to-back forwards)')
     args = ap.parse_args()
 
@@ -770,6 +906,12 @@ def main():
                 classical5 = classical_leg(device)
             except Exception as exc:
                 classical5 = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:300]))
+    op_point = None
+    if world == 1 and strong3 is not None and not args.no_op_point:
+        try:
+            op_point = operating_point_legs(device)
+        except Exception as exc:
+            op_point = dict(error='%s: %s' % (type(exc).__name__, str(exc)[:300]))
 
     with torch.set_grad_enabled(args.train):
         # ---- roofline leg: same region again with HIP events around every launch of the dominant kernel ----
@@ -920,6 +1062,8 @@ def main():
             'strong_scaling_config3': strong3,
             'strong_scaling_config4_sgan': strong4,
             'classical_config5': classical5,
+            'trainer_default': (op_point or {}).get('trainer_default', op_point),
+            'per_scene_predict': (op_point or {}).get('per_scene_predict', op_point),
         }
         if world == 1 and not args.no_cpu_baseline and not is_sgan:
             out['cpu_baseline'] = cpu_baseline(cfg, xy, split)

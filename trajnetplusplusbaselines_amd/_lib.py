@@ -8,6 +8,7 @@ import ctypes
 import numbers
 import os
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -292,8 +293,12 @@ class SceneIndex(object):
         self.starts = split.to(torch.int32).to(device)
         # first row / size of every row's scene (training backward): built on the host, one copy, no device-side sync later
         # (the host copies stay: stacked_rows() builds the whole-sweep tables from them without reading the device back)
-        self._row_base_host = torch.repeat_interleave(split[:-1], sizes).to(torch.int32)
-        self._row_count_host = torch.repeat_interleave(sizes, sizes).to(torch.int32)
+        # (numpy, not torch.repeat_interleave: torch's CPU kernel is an at::parallel_for -- on a 256-core host its thread
+        # pool costs 0.7 ms per call warm and 7 ms cold for these ~300-element tables, every step of a trainer whose
+        # batch_split changes; tools/diag/host_micro.py)
+        sizes_np = sizes.numpy()
+        self._row_base_host = torch.from_numpy(np.repeat(split[:-1].numpy(), sizes_np).astype(np.int32))
+        self._row_count_host = torch.from_numpy(np.repeat(sizes_np, sizes_np).astype(np.int32))
         self.row_base = self._row_base_host.to(device)
         self.row_count = self._row_count_host.to(device)
         self.primary = torch.empty(max(self.M, 1), dtype=torch.uint8, device=device)
@@ -313,7 +318,7 @@ class SceneIndex(object):
             off = (torch.arange(S, dtype=torch.int32) * self.M)[:, None]
             tabs = [(off + self._row_base_host[None]).reshape(-1), self._row_count_host.repeat(S)]
             if self._slots_host is not None:
-                tabs.append(torch.repeat_interleave(self._slots_host, self._sizes_host).to(torch.int32).repeat(S))
+                tabs.append(torch.from_numpy(np.repeat(self._slots_host.numpy(), self._sizes_host.numpy()).astype(np.int32)).repeat(S))
             if dev.type == 'cuda':
                 tabs = [t.pin_memory().to(dev, non_blocking=True) for t in tabs]
             else:

@@ -179,13 +179,14 @@ class SceneBatcher(object):
         import random
         import torch
         ids = list(ids)
-        cols = torch.cat([torch.arange(self.starts[i], self.starts[i + 1], device=self.device) for i in ids])
+        cols = torch.from_numpy(np.concatenate([np.arange(self.starts[i], self.starts[i + 1]) for i in ids])).to(self.device)
         xy, goals = self.xy[:, cols], self.goals[cols]
         split = torch.tensor(np.concatenate([[0], np.cumsum(self.sizes[ids])]), dtype=torch.int64)
         if augment:
-            theta = torch.tensor([random.random() * 2.0 * math.pi for _ in ids], dtype=torch.float64)
-            per_track = torch.repeat_interleave(theta, torch.tensor(self.sizes[ids])).to(self.device)
-            ct, st = torch.cos(per_track).float(), torch.sin(per_track).float()
+            theta = np.array([random.random() * 2.0 * math.pi for _ in ids], dtype=np.float64)
+            per_track = np.repeat(theta, self.sizes[ids])             # (numpy: torch's CPU repeat_interleave wakes a thread pool)
+            cs = torch.from_numpy(np.stack([np.cos(per_track), np.sin(per_track)]).astype(np.float32)).to(self.device)
+            ct, st = cs[0], cs[1]
             x, y = xy[..., 0], xy[..., 1]
             xy = torch.stack([x * ct - y * st, x * st + y * ct], dim=-1)   # row vector times [[ct, st], [-st, ct]]
             gx, gy = goals[:, 0], goals[:, 1]
