@@ -1,0 +1,34 @@
+"""Small-batch workloads for rocprofv3 --kernel-trace --stats: `predict` = single-scene forwards (the evaluator's call,
+~36 agents), `train` = batch_size-8 optimisation steps on fresh ragged batches (bench.py's trainer_default)."""
+import os, random, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import bench
+from trajnetplusplusbaselines_amd import synth, data as trajdata
+from trajnetplusplusbaselines_amd.lstm import PredictionLoss
+from trajnetplusplusbaselines_amd.lstm.train_step import train_batch
+
+mode = sys.argv[1] if len(sys.argv) > 1 else 'predict'
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+device = torch.device('cuda', 0)
+model = bench.build_model(bench.CONFIGS['social'], device, seed=1)
+xy, split = synth.ragged_crowd(256, 8, 72, seed=2024, nan_frac=0.2)
+xy_np, split_np = xy.numpy(), split.numpy()
+scenes = [xy_np[:, split_np[i]:split_np[i + 1]] for i in range(len(split_np) - 1)]
+if mode == 'predict':
+    model.eval()
+    with torch.no_grad():
+        for sc in scenes[:n]:
+            obs = torch.tensor(sc[:9], dtype=torch.float32, device=device)
+            model(obs, torch.zeros(sc.shape[1], 2, device=device), torch.tensor([0, sc.shape[1]]), n_predict=12)
+else:
+    optimizer = bench.make_adam(model.parameters())
+    batcher = trajdata.SceneBatcher(scenes, device=device, drop_distant_r=None)
+    rng = random.Random(7)
+    for _ in range(n):
+        ids = [rng.randrange(len(scenes)) for _ in range(8)]
+        bxy, bgoals, bsplit = batcher.batch(ids, augment=True)
+        train_batch(model, optimizer, PredictionLoss(), bxy, bgoals, bsplit, 9, 12, batch_size=8)
+torch.cuda.synchronize()

@@ -1030,6 +1030,16 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
         // N = 448: 448 against 256 workgroups on 256 CUs): 22.8 -> 18.0 us (tools/experiments/run_r3v.sh)
         const long b64 = (long)((g.M + 31) / 32) * ((g.N + 63) / 64), b128 = (long)((g.M + 31) / 32) * ((g.N + 127) / 128);
         if (variant == 24 && b64 > compute_units() && b128 <= compute_units() && fast_ok(g, 1, 32)) variant = 25;
+        // SMALL batches with a long contraction (one scene, a batch_size-8 training batch: the second embedding layer,
+        // K = 1024): a handful of workgroups on an empty chip wait for their own K loop, so 32 x 32 tiles with the K range
+        // split over eight (four) waves of the workgroup finish sooner -- 15.0 -> 9.5 us for M <= 1024, N = 256, K = 1024
+        // (tools/diag/small_gemm_probe.py, profiles/round5_small_gemm_probe.txt); no gain for K = 256, a loss once the
+        // 32 x 32 tiles need a second round of workgroups
+        const long b32 = (long)((g.M + 31) / 32) * ((g.N + 31) / 32);
+        if (variant == 24 && g.K2 <= 0 && g.K1 >= 512 && b32 <= compute_units()) {
+            if (fast_ok(g, 8, 16)) variant = 29;
+            else if (fast_ok(g, 4, 16)) variant = 27;
+        }
     }
     switch (variant) {
         case 12: TNP_TRY_FAST(2, 2, 1, 1, 32, EPI_BIAS); break;  // 64x64, 4 waves
@@ -1041,9 +1051,11 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
             break;
         case 25: TNP_TRY_PIPE(1, 4, 1, 1, 32, EPI_BIAS); break;  // pipelined: 32x128, four waves over the whole K
         case 26: TNP_TRY_PIPE(1, 2, 2, 2, 32, EPI_BIAS); break;  // pipelined: 32x128, split-K 2, two blocks per wave
-        case 27: TNP_TRY_PIPE(1, 1, 4, 1, 16, EPI_BIAS); break;  // probe: 32x32, split-K 4, 61 KB: two INDEPENDENT workgroups per CU
+        case 27: TNP_TRY_PIPE(1, 1, 4, 1, 16, EPI_BIAS); break;  // 32x32, split-K 4, 61 KB (two workgroups per CU): small batches when K % 128 != 0
         case 28: TNP_TRY_PIPE(1, 1, 4, 1, 32, EPI_BIAS); break;  // probe: 32x32, split-K 4, K tile 32 (110 KB: one per CU)
-        default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d (0 = automatic, 12, 24, 25, 26, 27, 28)", variant);
+        case 29: TNP_TRY_PIPE(1, 1, 8, 1, 16, EPI_BIAS); break;  // 32x32, split-K 8 (eight waves, 120 KB): small batches, long K
+        case 30: TNP_TRY_PIPE(1, 2, 4, 1, 16, EPI_BIAS); break;  // probe: 32x64, split-K 4 (eight waves)
+        default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d (0 = automatic, 12, 24 .. 30)", variant);
     }
     // shape not eligible for the fast path: masked general kernel
     if (big_tiles >= 192) return launch_general<4, 2, 1, 1, 32, EPI_BIAS>(g, s);
