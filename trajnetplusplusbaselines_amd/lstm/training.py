@@ -17,10 +17,26 @@ detached exactly as in the reference (lstm/lstm.py:240-250), hidden states poole
 (lstm/lstm.py:26), so BPTT couples the agents of a scene through the social encoding.
 """
 import ctypes
+import os
 
 import torch
 
 from .. import _lib
+
+#: the sparse first-layer weight gradient on a side stream beside the grouped weight-gradient launch.  OFF by default: measured
+#: SLOWER on MI355X (3.74 against 3.565 ms per optimisation step at config 2, three alternating runs each,
+#: tools/diag/ab_train_side_stream.sh / profiles/round5_train_side_stream.txt) -- the two matrix-pipe kernels stream 160 MB operands
+#: each and evict each other from the L2s; TNP_BWD_SIDE_STREAM=1 turns it on
+_SIDE_STREAM = os.environ.get('TNP_BWD_SIDE_STREAM', '0') not in ('0', '')
+_side_streams = {}
+
+
+def _side_stream(dev):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=dev)
+    return st
 
 
 def _lin(x, w, b=None, relu=False, out=None):
@@ -702,8 +718,24 @@ class SequenceFn(torch.autograd.Function):
                 publish(grads[name + '.bias'])
                 return
             wgrad(name + '.weight', dy_all[li], grid_all if li == 0 else act_all[li - 1], name + '.bias')
+        side_done = None
         if lay_names:
-            layer_wgrad(0, lay_names[0])     # first: the largest gradient (16.8 MB at config 2) gets the longest overlap
+            # first: the largest gradient (16.8 MB at config 2) gets the longest overlap with the collectives.  The sparse form
+            # (hit lists -> per-cell contraction -> re-layout -> bias column sums: ~330 us of kernels at config 2) shares no
+            # operand it WRITES with the grouped weight-gradient launch below (~400 us), so it CAN run on a side stream beside it
+            # (opt-in, see _SIDE_STREAM: measured slower).
+            side = _side_stream(dev) if (sparse_bwd and _SIDE_STREAM and dev.type == 'cuda') else None
+            if side is not None:
+                main = torch.cuda.current_stream(dev)
+                fork = torch.cuda.Event()
+                fork.record(main)
+                side.wait_event(fork)                 # everything the sweep left behind is complete for the side stream
+                with torch.cuda.stream(side):
+                    layer_wgrad(0, lay_names[0])
+                    side_done = torch.cuda.Event()
+                    side_done.record(side)
+            else:
+                layer_wgrad(0, lay_names[0])
         h_out_all, h_prev_all = h_all[1:], h_all[:-1]
         if hook_at is not None:     # the last encoder step's output is the hidden state BEFORE the noise was added / the scaling
             h_out_all = h_out_all.clone()
@@ -782,6 +814,11 @@ class SequenceFn(torch.autograd.Function):
                     pending.append(w)
             for w in pending:
                 w.wait()                  # the compute stream waits for RCCL's stream; no host synchronisation
+        if side_done is not None:
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(side_done)                # join: the first layer's gradients are final for whatever comes next
+            for n in (lay_names[0] + '.weight', lay_names[0] + '.bias'):
+                grads[n].record_stream(main)          # allocated on the side stream, consumed (optimizer, all-reduce) on this one
         for dst_name, src_name in hh_clones:
             grads[dst_name] = grads[src_name].clone()
         # parameters the forward never touches get no gradient (None, as autograd does for the reference), so that
