@@ -269,20 +269,21 @@ def test_config4_full_size_sgan_forward_properties():
 
 
 def test_gates_kernel_variants_agree():
-    """The LSTM-gates GEMM has three tilings (tnp_lstm_model.variant bits 8-15: 5 = 128-track tiles, 20 = split-K 4 per
-    workgroup, 21 = one gate block per wave; 0 picks 21 here): same forward within fp32 summation order."""
+    """The LSTM-gates GEMM has four tilings (tnp_lstm_model.variant bits 8-15: 5 = 128-track tiles, 20 = split-K 4 per
+    workgroup, 21 = one gate block per wave, 22 = 21 with the K range over two wave quartets; 0 picks 22 here): same forward
+    within fp32 summation order."""
     model = _config2_model(seed=4).cuda().eval()
     xy, split = synth.ragged_crowd(12, 5, 30, seed=21)
     goals = torch.zeros(xy.shape[1], 2)
     outs = {}
     with torch.no_grad():
-        for v in (0, 5, 20, 21):
+        for v in (0, 5, 20, 21, 22):
             model.kernel_variant = v << 8
             outs[v] = model(xy[:9], goals, split, n_predict=12)[1]
     model.kernel_variant = 0
-    assert torch.equal(torch.nan_to_num(outs[0]), torch.nan_to_num(outs[21]))
-    for v in (5, 20):
-        assert (torch.nan_to_num(outs[v]) - torch.nan_to_num(outs[21])).abs().max().item() < 2e-5
+    assert torch.equal(torch.nan_to_num(outs[0]), torch.nan_to_num(outs[22]))
+    for v in (5, 20, 21):
+        assert (torch.nan_to_num(outs[v]) - torch.nan_to_num(outs[22])).abs().max().item() < 2e-5
 
 
 def _counted_flip_check(got, want, what, tol=2e-5, flip_frac=0.01, flip_tol=5e-3):
@@ -375,10 +376,12 @@ def test_config2_full_size_neighbours_counted_flip_rule():
     print('config 2 full size: rows beyond 2e-5 of 2048 (positions, normals):', f)
 
 
-def test_chained_second_layer_and_gates_launch_is_bit_identical():
+def test_chained_second_layer_and_gates_launch_agrees_with_the_two_launches():
     """The experimental chained launch (TNP_CHAIN=1: last embedding layer + LSTM gates in one kernel, consumers waiting on
-    per-row-tile arrival counters, csrc/gemm_f32_mfma.hip) against the two launches: bit-identical outputs on a ragged
-    config-2 crowd, both decoder modes.  The switch is read once per process, so the chained run is a child process."""
+    per-row-tile arrival counters, csrc/gemm_f32_mfma.hip) against the two launches on a ragged config-2 crowd, both decoder
+    modes.  The chained kernel keeps the four-wave tiles it was written with; since round 5 the stand-alone launches run the
+    eight-wave tiles (another summation order), so the outputs agree to fp32 rounding, no longer bit for bit.  The switch is read
+    once per process, so the chained run is a child process."""
     import subprocess
     import sys
     import tempfile
@@ -407,7 +410,7 @@ np.savez(sys.argv[1], a=a.cpu().numpy(), b=b.cpu().numpy())
             z = np.load(path)
             outs[tag] = (z['a'], z['b'])
     for x, y in zip(outs['separate'], outs['chain']):
-        assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(np.nan_to_num(x), np.nan_to_num(y))
+        assert np.array_equal(np.isnan(x), np.isnan(y)) and np.abs(np.nan_to_num(x) - np.nan_to_num(y)).max() < 2e-5
 
 
 def test_two_batches_in_flight_on_two_streams_equal_sequential_runs():

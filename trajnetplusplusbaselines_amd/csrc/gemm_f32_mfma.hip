@@ -18,6 +18,7 @@
 //   gets a contiguous chunk of a panel-ordered tile list (4 tile-rows x many tile-columns share A rows / W rows).
 // * EPI_LSTM fuses torch.nn.LSTMCell's pointwise part (reference lstm/lstm.py:154): the 128 tile columns are
 //   the i,f,g,o gates of 32 hidden units, so one lane holds all four gates of its (track, unit) pairs.
+#include <cstdlib>
 #include "tnp_internal.h"
 
 #include <stdlib.h>
@@ -621,7 +622,9 @@ __device__ __forceinline__ void gemm_nt_pipe_body(const GemmArgs &g, const int b
     constexpr int WRITE_AT = NK8 / 2 - 1;
     // LSTM epilogue: either a wave owns all four gate blocks of its 32 units (WN == 1, AN == 4; K split over the waves), or
     // "gate split": four waves own one gate block each over the whole K (WN == 4, AN == 1, WK == 1) and swap tiles through LDS
-    constexpr bool GSPLIT = EPI == EPI_LSTM && WM == 1 && WN == 4 && AN == 1 && WK == 1;
+    // Round 5: the gate split also comes with the K range over two wave quartets (WK == 2: eight waves, two per SIMD -- a
+    // wave's LDS / global waits are covered by its SIMD partner's MFMAs); the quartets' partial tiles meet in the LDS swap
+    constexpr bool GSPLIT = EPI == EPI_LSTM && WM == 1 && WN == 4 && AN == 1 && (WK == 1 || WK == 2);
     static_assert(EPI != EPI_LSTM || (WN == 1 && AN == 4) || GSPLIT, "LSTM epilogue: 4 gate blocks per wave or gate split");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][WK][GROUP_FLOATS]
@@ -732,13 +735,13 @@ __device__ __forceinline__ void gemm_nt_pipe_body(const GemmArgs &g, const int b
     LstmPrefetch lpf;
     float ebias[AN];
     if constexpr ((EPI == EPI_LSTM && WK > 1) || GSPLIT) {
-        constexpr int RN = GSPLIT ? 4 : 16 / WK;
+        constexpr int RN = GSPLIT ? 4 / WK : 16 / WK;
         const int unit = tn * 32 + (lane & 31), uc = unit < g.H ? unit : g.H - 1;
 #pragma unroll
         for (int an = 0; an < 4; ++an) lpf.bias[an] = g.bias1[an * g.H + uc] + g.bias2[an * g.H + uc];
 #pragma unroll
         for (int rr = 0; rr < RN; ++rr) {
-            const int r = (GSPLIT ? wn : kg) * RN + rr;
+            const int r = (GSPLIT ? kg * 4 + wn : kg) * RN + rr;
             const int row = min(m0 + wm * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2), g.M - 1);
             lpf.c[rr] = g.c_in[(size_t)row * g.H + uc];
             lpf.present[rr] = g.mask[row];
@@ -818,22 +821,28 @@ __device__ __forceinline__ void gemm_nt_pipe_body(const GemmArgs &g, const int b
     GP_T(3);
 
     if constexpr (GSPLIT) {
-        // wave `wn` holds the pre-activations of gate `wn` for the tile's 32 tracks x 32 units; the tiles are swapped through
-        // LDS and wave w runs the cell update of accumulator registers 4 w .. 4 w + 3 (8 tracks x 32 units)
+        // wave (kg, wn) holds the pre-activations of gate `wn` for the tile's 32 tracks x 32 units over K group kg; the tiles
+        // are swapped through LDS and wave w = 4 kg + wn runs the cell update of accumulator registers RN w .. RN w + RN - 1
+        // (8 tracks x 32 units with one K group, 4 x 32 with two; the K groups' partials are added group 0 + group 1)
+        constexpr int RN = 4 / WK;
         __syncthreads();  // everybody is done with the tile ring before it is reused
         float *red = smem;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(wn * 16 + r) * 64 + lane] = acc[0][r];
+        for (int r = 0; r < 16; ++r) red[((kg * 4 + wn) * 16 + r) * 64 + lane] = acc[0][r];
         __syncthreads();
         const int unit = tn * 32 + (lane & 31);
         if (unit < g.H) {
             const int rbase = m0 + 4 * (lane >> 5);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int r = wn * 4 + rr;
+            for (int rr = 0; rr < RN; ++rr) {
+                const int r = (kg * 4 + wn) * RN + rr;
                 float pre[4];
 #pragma unroll
-                for (int gt = 0; gt < 4; ++gt) pre[gt] = red[(gt * 16 + r) * 64 + lane] + lpf.bias[gt];
+                for (int gt = 0; gt < 4; ++gt) {
+                    float v = red[(gt * 16 + r) * 64 + lane];
+                    if constexpr (WK == 2) v += red[((4 + gt) * 16 + r) * 64 + lane];
+                    pre[gt] = v + lpf.bias[gt];
+                }
                 lstm_cell_store_pf(g, rbase + (r & 3) + 8 * (r >> 2), unit, pre[0], pre[1], pre[2], pre[3], lpf.c[rr], lpf.present[rr]);
             }
         }
@@ -1040,6 +1049,11 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
             if (fast_ok(g, 8, 16)) variant = 29;
             else if (fast_ok(g, 4, 16)) variant = 27;
         }
+        // Round 5: long contractions on the 32 x 64 tile with the K range over FOUR wave pairs (eight waves = two per SIMD:
+        // a wave's LDS / global waits are covered by its partner's MFMAs) instead of two -- the second embedding layer at
+        // config 2 15.4 -> 14.9 us, the gates' data gradient (K = 512) 25.6 -> 24.3 us (profiles/round5_small_gemm_probe.txt);
+        // 1.031 -> 1.046 M scene-steps/s on the headline (profiles/round5_eight_wave_gemms.txt)
+        if (variant == 24 && g.K2 <= 0 && g.K1 >= 512 && fast_ok(g, 4, 16)) variant = 30;
     }
     switch (variant) {
         case 12: TNP_TRY_FAST(2, 2, 1, 1, 32, EPI_BIAS); break;  // 64x64, 4 waves
@@ -1054,7 +1068,7 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
         case 27: TNP_TRY_PIPE(1, 1, 4, 1, 16, EPI_BIAS); break;  // 32x32, split-K 4, 61 KB (two workgroups per CU): small batches when K % 128 != 0
         case 28: TNP_TRY_PIPE(1, 1, 4, 1, 32, EPI_BIAS); break;  // probe: 32x32, split-K 4, K tile 32 (110 KB: one per CU)
         case 29: TNP_TRY_PIPE(1, 1, 8, 1, 16, EPI_BIAS); break;  // 32x32, split-K 8 (eight waves, 120 KB): small batches, long K
-        case 30: TNP_TRY_PIPE(1, 2, 4, 1, 16, EPI_BIAS); break;  // probe: 32x64, split-K 4 (eight waves)
+        case 30: TNP_TRY_PIPE(1, 2, 4, 1, 16, EPI_BIAS); break;  // 32x64, split-K 4 (eight waves): long K at one workgroup per CU
         default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d (0 = automatic, 12, 24 .. 30)", variant);
     }
     // shape not eligible for the fast path: masked general kernel
@@ -1131,12 +1145,15 @@ int launch_lstm_gates(const GemmArgs &g_in, int variant, hipStream_t s) {
     // measured on MI355X (profiles/round1_b_variant_sweep.jsonl, tools/experiments/gemm_probe.hip): big batches the 128-track
     // kernel, else "gate split" (four waves own one gate block each over the whole K and swap tiles through LDS: no split-K
     // reduction, half the staged chunks per thread; 17.9 -> 16.1 us at config 2) when K1, K2 are multiples of 32
-    if (variant == 0) variant = (g.M >= 4096) ? 5 : (fast_ok(g, 1, 32) ? 21 : 20);
+    // round 5: the gate split with the K range over two wave quartets (22: eight waves, two per SIMD) where K1 + K2 is a
+    // multiple of 64 -- 1.046 -> 1.068 M scene-steps/s on the headline (profiles/round5_eight_wave_gemms.txt)
+    if (variant == 0) variant = (g.M >= 4096) ? 5 : (fast_ok(g, 2, 32) ? 22 : (fast_ok(g, 1, 32) ? 21 : 20));
     switch (variant) {
         case 5: TNP_TRY_FAST(4, 1, 2, 4, 16, EPI_LSTM); break;   // 128 tracks x 32 units, 8 waves
         case 20: TNP_TRY_PIPE(1, 1, 4, 4, 16, EPI_LSTM); break;  // pipelined: 32 tracks x 32 units, split-K 4
         case 21: TNP_TRY_PIPE(1, 4, 1, 1, 32, EPI_LSTM); TNP_TRY_PIPE(1, 1, 4, 4, 16, EPI_LSTM); break;   // gate split
-        default: TNP_FAIL(-1, "lstm gates: unknown variant %d (0 = automatic, 5, 20, 21)", variant);
+        case 22: TNP_TRY_PIPE(1, 4, 2, 1, 32, EPI_LSTM); TNP_TRY_PIPE(1, 4, 1, 1, 32, EPI_LSTM); TNP_TRY_PIPE(1, 1, 4, 4, 16, EPI_LSTM); break;   // gate split x K split 2 (eight waves)
+        default: TNP_FAIL(-1, "lstm gates: unknown variant %d (0 = automatic, 5, 20, 21, 22)", variant);
     }
     if (g.M >= 4096) return launch_general<2, 1, 2, 4, 32, EPI_LSTM>(g, s);
     return launch_general<1, 1, 4, 4, 16, EPI_LSTM>(g, s);
