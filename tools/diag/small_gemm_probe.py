@@ -21,15 +21,15 @@ def timeit(f, n=300):
     return a.elapsed_time(b) / n * 1e3
 
 
-for (N, K, what) in ((256, 1024, 'second embedding layer'), (1024, 256, 'its data gradient'), (448 + 128, 512, 'gates data gradient')):
+for (N, K, what) in ((448, 512, 'gates data gradient'), (256, 1024, 'second embedding layer')):
     W = torch.randn(N, K, device='cuda')
     bias = torch.randn(N, device='cuda')
-    for M in (36, 310, 640, 1024, 2048):
+    for M in (310, 2048, 4096):
         x = torch.randn(M, K, device='cuda')
         out = torch.empty(M, N, device='cuda')
         ref = None
         row = []
-        for v in (0, 24, 27, 28, 29, 30):
+        for v in (0, 24, 25, 30, 31):
             try:
                 us = timeit(lambda: _lib.linear_forward(x, W, bias, relu=True, variant=v, out=out))
                 if ref is None:

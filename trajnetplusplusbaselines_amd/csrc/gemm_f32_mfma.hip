@@ -1054,6 +1054,9 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
         // config 2 15.4 -> 14.9 us, the gates' data gradient (K = 512) 25.6 -> 24.3 us (profiles/round5_small_gemm_probe.txt);
         // 1.031 -> 1.046 M scene-steps/s on the headline (profiles/round5_eight_wave_gemms.txt)
         if (variant == 24 && g.K2 <= 0 && g.K1 >= 512 && fast_ok(g, 4, 16)) variant = 30;
+        // ... and the 32 x 128 tile likewise with the K range over two wave quartets (the gates' data gradient in training,
+        // [2048, 512] x [448, 512]^T: 14.8 -> 13.9 us)
+        if (variant == 25 && g.K2 <= 0 && g.K1 >= 512 && fast_ok(g, 2, 32)) variant = 31;
     }
     switch (variant) {
         case 12: TNP_TRY_FAST(2, 2, 1, 1, 32, EPI_BIAS); break;  // 64x64, 4 waves
@@ -1068,8 +1071,9 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
         case 27: TNP_TRY_PIPE(1, 1, 4, 1, 16, EPI_BIAS); break;  // 32x32, split-K 4, 61 KB (two workgroups per CU): small batches when K % 128 != 0
         case 28: TNP_TRY_PIPE(1, 1, 4, 1, 32, EPI_BIAS); break;  // probe: 32x32, split-K 4, K tile 32 (110 KB: one per CU)
         case 29: TNP_TRY_PIPE(1, 1, 8, 1, 16, EPI_BIAS); break;  // 32x32, split-K 8 (eight waves, 120 KB): small batches, long K
+        case 31: TNP_TRY_PIPE(1, 4, 2, 1, 32, EPI_BIAS); break;  // 32x128, K range over two wave quartets (eight waves)
         case 30: TNP_TRY_PIPE(1, 2, 4, 1, 16, EPI_BIAS); break;  // 32x64, split-K 4 (eight waves): long K at one workgroup per CU
-        default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d (0 = automatic, 12, 24 .. 30)", variant);
+        default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d (0 = automatic, 12, 24 .. 31)", variant);
     }
     // shape not eligible for the fast path: masked general kernel
     if (big_tiles >= 192) return launch_general<4, 2, 1, 1, 32, EPI_BIAS>(g, s);
