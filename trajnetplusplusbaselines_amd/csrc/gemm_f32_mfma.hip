@@ -1031,12 +1031,12 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
     GemmArgs g = g_in;
     check_vec(g);
     const long big_tiles = (long)((g.M + 127) / 128) * ((g.N + 63) / 64);
-    // tile selection measured on MI355X (profiles/round1_b_variant_sweep.jsonl): 64x64 tiles when they fill the chip, else
+    // tile selection measured on MI355X (profiles/archive/round1_b_variant_sweep.jsonl): 64x64 tiles when they fill the chip, else
     // the pipelined 32x64 split-K 2 kernel; `variant` pins one of the two (12 / 24), anything else is an error
     if (variant == 0) {
         variant = (big_tiles >= 192) ? 12 : 24;
         // 32x64 tiles that need a second round of workgroups while 32x128 tiles fit in one (the backward data-gradient GEMM,
-        // N = 448: 448 against 256 workgroups on 256 CUs): 22.8 -> 18.0 us (tools/experiments/run_r3v.sh)
+        // N = 448: 448 against 256 workgroups on 256 CUs): 22.8 -> 18.0 us (round 3 sweep run_r3v, git history)
         const long b64 = (long)((g.M + 31) / 32) * ((g.N + 63) / 64), b128 = (long)((g.M + 31) / 32) * ((g.N + 127) / 128);
         if (variant == 24 && b64 > compute_units() && b128 <= compute_units() && fast_ok(g, 1, 32)) variant = 25;
         // SMALL batches with a long contraction (one scene, a batch_size-8 training batch: the second embedding layer,
@@ -1110,7 +1110,7 @@ static int launch_chain_impl(GemmArgs &gp, GemmArgs &gc, const ChainCtl &cc, hip
 
 // 0 = launched; 1 = this pair of shapes is not eligible (the caller launches the two kernels on their own); < 0 error
 int launch_chain_l2_gates(const GemmArgs &gp_in, const GemmArgs &gc_in, unsigned *flags, unsigned epoch, hipStream_t s) {
-    // EXPERIMENTAL, off by default (measured slower than the two launches: DESIGN.md section 9): TNP_CHAIN=1 turns it on,
+    // EXPERIMENTAL, off by default (measured slower than the two launches: docs/history.md section 9): TNP_CHAIN=1 turns it on,
     // TNP_CHAIN_BK=32 selects the 32-wide producer K tile (83 KB of LDS: one workgroup per CU, no co-residency),
     // TNP_CHAIN_NOWAIT=1 drops the consumer's wait (wrong results; timing of pure co-residency)
     static const bool enabled = getenv("TNP_CHAIN") != nullptr && getenv("TNP_CHAIN")[0] == '1';
@@ -1146,7 +1146,7 @@ int launch_lstm_gates(const GemmArgs &g_in, int variant, hipStream_t s) {
     gates_h_first(g);
     check_vec(g);
     if (g.H % 32 != 0) TNP_FAIL(-1, "LSTM hidden_dim must be a multiple of 32 (got %d)", g.H);
-    // measured on MI355X (profiles/round1_b_variant_sweep.jsonl, tools/experiments/gemm_probe.hip): big batches the 128-track
+    // measured on MI355X (profiles/archive/round1_b_variant_sweep.jsonl, tools/experiments/gemm_probe.hip): big batches the 128-track
     // kernel, else "gate split" (four waves own one gate block each over the whole K and swap tiles through LDS: no split-K
     // reduction, half the staged chunks per thread; 17.9 -> 16.1 us at config 2) when K1, K2 are multiples of 32
     // round 5: the gate split with the K range over two wave quartets (22: eight waves, two per SIMD) where K1 + K2 is a

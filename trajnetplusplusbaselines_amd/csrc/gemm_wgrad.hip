@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_group_kernel(const WgradGrou
 static void wgrad_plan(int Mo, int No, int K, int &regions, int &SK, int &kchunk) {
     regions = ((Mo + 127) / 128) * ((No + 127) / 128);
     int want = (512 + regions - 1) / regions;      // ~2 workgroups per CU; in the grouped launch 256 - 512 measure the same
-                                                   // (365 us), 768 / 1024 / 2048: 384 / 389 / 410 us (tools/experiments/run_r3w.sh)
+                                                   // (365 us), 768 / 1024 / 2048: 384 / 389 / 410 us (round 3 sweep run_r3w, git history)
     if (want > 128) want = 128;
     const int maxsk = (K + 255) / 256;
     if (want > maxsk) want = maxsk;
@@ -316,7 +316,7 @@ extern "C" TNP_API int tnp_wgrad_grouped(const tnp_wgrad_problem *problems, int 
         // block order of the contraction launch: problems by the estimated duration of one of their workgroups, longest
         // first (rows of K per split; x 3 for blocks that take the edge loop, which has no operand prefetch).  With the
         // queue order the five tiny contractions came last and their 50-us edge-loop workgroups ran on an empty chip
-        // (1.2 of 2 waves per SIMD resident on average, profiles/round3_q_pmc_train.md).  Plans, partial buffers and the
+        // (1.2 of 2 waves per SIMD resident on average, profiles/archive/round3_q_pmc_train.md).  Plans, partial buffers and the
         // reduce launch are untouched: results do not depend on the order.
         {
             long cost[WG_MAX_PROBLEMS];

@@ -985,7 +985,7 @@ __global__ void __launch_bounds__(256) sparse_wgrad_mfma_kernel(const float *__r
     // Every load is unconditional: past the end of the list the entry index is 0 and the operands come from a row of
     // zeros (g_swg_zeros, a zero-initialised device global), chosen by ADDRESS.  A `valid ? load : 0` select is turned back
     // into a branch around the load by the compiler, and a load under a branch is waited for at the join: round 2's kernel
-    // did that and took 286 us, this one 235 (profiles/round3_p_sparse_wgrad_sweep.md).
+    // did that and took 286 us, this one 235 (profiles/archive/round3_p_sparse_wgrad_sweep.md).
     auto entry = [&](int b) -> int2 { const int k = 4 * b + g; return L[(b < nb && k < cnt) ? k : 0]; };
     auto valid = [&](int b) -> bool { return b < nb && 4 * b + g < cnt; };
     // (as element offsets from the operand bases, so that every lane forms its address with the same arithmetic)

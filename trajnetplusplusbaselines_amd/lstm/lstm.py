@@ -633,7 +633,7 @@ class LSTMPredictor(object):
     #: replay repeated call shapes as hipGraphs (LSTM._forward_graphed).  OFF by default: measured on MI355X / ROCm 7.2 a replay
     #: frees the host (0.11 ms instead of ~0.35 ms per forward) but the graph's kernel nodes run SLOWER on the
     #: device than the same launches enqueued one by one (+1.7 us per node at 64 x 32, ~11 us per node for the tiny kernels of a
-    #: 4-agent scene: 0.91 ms per call against 0.82 ms), so it pays only with several small batches in flight
+    #: 4-agent scene: 0.91 ms per call against 0.82 ms), so it pays only with several small batches in flight (docs/history.md section 9)
     graph_replay = False
 
     def __init__(self, model):
