@@ -235,3 +235,31 @@ def test_gpu_constant_velocity_predict_equals_reference(ref):
     for i in cases(ref):
         res = constant_velocity.predict(case_paths(ref, i))
         _check(res, ref, 'c%d_cv_' % i, 0.0, exact=True)
+
+
+@pytest.mark.gpu
+def test_gpu_predict_scenes_equals_per_scene_predict_bit_for_bit(ref, tmp_path):
+    """The evaluator feed of config 5: all scenes of a batch in one launch (``classical.*.predict_scenes``) against one
+    ``predict`` call per scene -- what the reference's classical evaluator does (classical/trajnet_evaluator.py:14-27)."""
+    from trajnetplusplusbaselines_amd.classical import socialforce, orca, kalman, constant_velocity
+    scenes = [case_paths(ref, i) for i in cases(ref)]
+    with np.errstate(all='ignore'):
+        for mod in (socialforce, orca, constant_velocity):
+            for predict_all in (True, False):
+                kw = {} if mod is constant_velocity else {'predict_all': predict_all}
+                got = mod.predict_scenes(scenes, **kw)
+                for paths, g in zip(scenes, got):
+                    w = mod.predict(paths, **kw)
+                    assert np.array_equal(g[0][0], w[0][0], equal_nan=True), mod.__name__
+                    assert np.array_equal(np.asarray(g[0][1], dtype=np.float64), np.asarray(w[0][1], dtype=np.float64), equal_nan=True), mod.__name__
+    got = kalman.predict_scenes(scenes, rng=np.random.RandomState(4))
+    rng = np.random.RandomState(4)
+    for paths, g in zip(scenes, got):
+        w = kalman.predict(paths, rng=rng)              # the same stream, consumed scene by scene
+        assert np.array_equal(g[0][0], w[0][0]) and np.array_equal(np.asarray(g[0][1]), np.asarray(w[0][1]))
+    # ... and through the dataset loop: module -> predict_scenes, function -> one call per scene; same file
+    inp = os.path.join(os.path.dirname(GOLDEN), 'writer_case.ndjson')
+    a, b = str(tmp_path / 'a.ndjson'), str(tmp_path / 'b.ndjson')
+    assert trajdata.predict_dataset(inp, orca, a, batch_scenes=3) == 8
+    assert trajdata.predict_dataset(inp, orca.predict, b) == 8
+    assert open(a).read() == open(b).read()

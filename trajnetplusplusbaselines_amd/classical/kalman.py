@@ -24,13 +24,8 @@ def predict_batch(obs, n_predict=12, n_samples=5, noise=None, rng=None, n_iter=1
     return out.cpu().numpy()[:, 1:]       # first sample corresponds to the last state (classical/kalman.py:52-62)
 
 
-def predict(paths, predict_all=True, n_predict=12, obs_length=9, rng=None):
-    """``rng`` (not in the reference's signature): a ``numpy.random.RandomState``; default = numpy's global one, which
-    is what pykalman's ``sample(random_state=None)`` draws from.  The draws are taken track by track in the order of
-    ``paths``, 5 samples x (n_predict + 1) steps x 6 components each -- the order in which the reference's loop
-    (classical/kalman.py:22-60) consumes them -- so a seeded run is reproducible against a seeded reference run."""
-    primary = paths[0]
-    start_frame = primary[obs_length - 1].frame
+def _scene_tracks(paths, predict_all, obs_length):
+    start_frame = paths[0][obs_length - 1].frame
     if not predict_all:
         paths = paths[0:1]
     tracks, index = [], []
@@ -40,9 +35,12 @@ def predict(paths, predict_all=True, n_predict=12, obs_length=9, rng=None):
             continue
         tracks.append(past_path)
         index.append(i)
-    noise = (rng or np.random).standard_normal((len(tracks), 5, n_predict + 1, 6))
-    # tracks may have different lengths: one launch per length
-    results = {}
+    return tracks, index
+
+
+def _predict_tracks(tracks, noise, n_predict):
+    """tracks of any lengths, noise [n_tracks, 5, n_predict + 1, 6] -> list of [n_predict, 2]: one launch per track length"""
+    results = [None] * len(tracks)
     by_len = {}
     for k, tr in enumerate(tracks):
         by_len.setdefault(len(tr), []).append(k)
@@ -50,8 +48,39 @@ def predict(paths, predict_all=True, n_predict=12, obs_length=9, rng=None):
         obs = np.array([[(r.x, r.y) for r in tracks[k]] for k in ks], dtype=np.float64)
         pred = predict_batch(obs, n_predict, noise=noise[ks])
         for k, p in zip(ks, pred):
-            results[index[k]] = p
-    primary_track = results.get(0)
-    neighbours = [results[i] for i in sorted(results) if i != 0]
+            results[k] = p
+    return results
+
+
+def _pack(results, index):
+    by_path = dict(zip(index, results))
+    primary_track = by_path.get(0)
+    neighbours = [by_path[i] for i in sorted(by_path) if i != 0]
     neighbours_tracks = np.array(neighbours).transpose(1, 0, 2) if len(neighbours) else []
     return {0: (primary_track, neighbours_tracks)}
+
+
+def predict(paths, predict_all=True, n_predict=12, obs_length=9, rng=None):
+    """``rng`` (not in the reference's signature): a ``numpy.random.RandomState``; default = numpy's global one, which
+    is what pykalman's ``sample(random_state=None)`` draws from.  The draws are taken track by track in the order of
+    ``paths``, 5 samples x (n_predict + 1) steps x 6 components each -- the order in which the reference's loop
+    (classical/kalman.py:22-60) consumes them -- so a seeded run is reproducible against a seeded reference run."""
+    tracks, index = _scene_tracks(paths, predict_all, obs_length)
+    noise = (rng or np.random).standard_normal((len(tracks), 5, n_predict + 1, 6))
+    return _pack(_predict_tracks(tracks, noise, n_predict), index)
+
+
+def predict_scenes(scenes, n_predict=12, modes=1, obs_length=9, start_length=0, args=None, predict_all=True, rng=None):
+    """``predict`` for many scenes: the tracks of ALL scenes go to the GPU together (one launch per track length); the normal
+    draws are taken scene by scene, track by track -- the stream a loop of per-scene ``predict`` calls would consume -- so every
+    result equals the per-scene call under the same seed bit for bit.  ``scenes``: list of ``paths`` or ``(paths, scene_goal)``."""
+    paths_list = [sc[0] if isinstance(sc, tuple) else sc for sc in scenes]
+    per_scene = [_scene_tracks(p, predict_all, obs_length) for p in paths_list]
+    counts = [len(t) for t, _ in per_scene]
+    noise = (rng or np.random).standard_normal((sum(counts), 5, n_predict + 1, 6))
+    flat = _predict_tracks([tr for t, _ in per_scene for tr in t], noise, n_predict)
+    out, lo = [], 0
+    for (t, index), n in zip(per_scene, counts):
+        out.append(_pack(flat[lo:lo + n], index))
+        lo += n
+    return out

@@ -45,3 +45,24 @@ def predict(input_paths, dest_dict=None, dest_type='interp', orca_params=[1.5, 1
     primary_track = states[:, 0, 0:2]
     neighbours_tracks = states[:, 1:, 0:2] if predict_all else []
     return {0: (primary_track, neighbours_tracks)}
+
+
+def predict_scenes(scenes, n_predict=12, modes=1, obs_length=9, start_length=0, args=None, dest_dict=None, dest_type='interp',
+                  orca_params=(1.5, 1.5, 0.4), predict_all=True):
+    """``predict`` for many scenes in one launch; every result equals the per-scene call bit for bit (see
+    ``socialforce.predict_scenes``)."""
+    paths_list = [sc[0] if isinstance(sc, tuple) else sc for sc in scenes]
+    rows = [scene_init(p, obs_length, n_predict, dest_dict, dest_type, allow_vel_dest=False) for p in paths_list]
+    live = [k for k, r in enumerate(rows) if len(r)]
+    results = [{0: (np.zeros((n_predict, 0)), [])} for _ in paths_list]
+    if live:
+        flat = [r for k in live for r in rows[k]]
+        sizes = [len(rows[k]) for k in live]
+        out = rollout_batch(np.array([[r[0], r[1]] for r in flat]), np.array([[r[2], r[3]] for r in flat]),
+                            np.array([r[4] for r in flat]), np.array([[r[5], r[6]] for r in flat]), sizes, orca_params, n_predict)
+        lo = 0
+        for k, n in zip(live, sizes):
+            o = out[:, lo:lo + n]
+            results[k] = {0: (o[:, 0, 0:2], o[:, 1:, 0:2] if predict_all else [])}
+            lo += n
+    return results

@@ -35,3 +35,28 @@ def predict(input_paths, dest_dict=None, dest_type='interp', sf_params=[0.5, 2.1
     primary_track = out[:, 0, 0:2]
     neighbours_tracks = out[:, 1:, 0:2] if predict_all else []
     return {0: (primary_track, neighbours_tracks)}
+
+
+def predict_scenes(scenes, n_predict=12, modes=1, obs_length=9, start_length=0, args=None, dest_dict=None, dest_type='interp',
+                  sf_params=(0.5, 2.1, 0.3), predict_all=True):
+    """``predict`` for MANY scenes in one launch (the evaluator feed of BASELINE config 5; the reference's classical
+    evaluator predicts one scene per call on 12 joblib workers, classical/trajnet_evaluator.py:14-27, 86-92).  ``scenes``: a list
+    of ``paths`` or of ``(paths, scene_goal)`` pairs (the goal is unused, as in the reference's call).  Scenes never interact, so
+    every result equals ``predict(paths, ...)`` of that scene bit for bit (tests/test_classical_ref.py)."""
+    paths_list = [sc[0] if isinstance(sc, tuple) else sc for sc in scenes]
+    rows = [scene_init(p, obs_length, n_predict, dest_dict, dest_type) for p in paths_list]
+    live = [k for k, r in enumerate(rows) if len(r)]
+    results = [None] * len(paths_list)
+    if live:
+        states = np.array([[r[0], r[1], r[2], r[3], r[5], r[6]] for k in live for r in rows[k]])
+        sizes = [len(rows[k]) for k in live]
+        out = rollout_batch(states, sizes, sf_params, n_predict)
+        lo = 0
+        for k, n in zip(live, sizes):
+            o = out[:, lo:lo + n]
+            results[k] = {0: (o[:, 0, 0:2], o[:, 1:, 0:2] if predict_all else [])}
+            lo += n
+    for k, r in enumerate(results):
+        if r is None:       # nobody present at the last observed frame: the wrapper's stationary branch
+            results[k] = predict(paths_list[k], dest_dict, dest_type, list(sf_params), predict_all, n_predict, obs_length)
+    return results

@@ -252,7 +252,7 @@ def write_predictions(pred_list, scenes, filename, obs_length=9, pred_length=12,
 
 
 def predict_dataset(ndjson_in, predictor, out_path, batch_scenes=64, obs_length=9, pred_length=12, modes=1, goals=None,
-                    in_flight=2, args=None, limit=None):
+                    in_flight=2, args=None, limit=None, predict_kwargs=None):
     """The evaluator's prediction loop for one test file (reference lstm/trajnet_evaluator.py:29-65 ``get_predictions`` +
     evaluator/write_utils.py): read the scenes, ``preprocess_test`` each, predict them ``batch_scenes`` at a time through
     ``predictor.predict_batch`` (ONE ``LSTM.forward`` per batch instead of one call per scene on 12 joblib workers;
@@ -261,7 +261,10 @@ def predict_dataset(ndjson_in, predictor, out_path, batch_scenes=64, obs_length=
     the reference's layout.  ``goals``: {pedestrian id: (x, y)} (the reference's goal pickle, write_utils.py:21-26) or None
     = zeros.  ``predictor`` is anything with ``predict_batch(scenes, n_predict=, modes=, obs_length=, args=)`` -- the
     ``LSTMPredictor`` / ``SGANPredictor`` mirrors -- or a per-scene callable ``predictor(paths, scene_goal, ...)`` (the
-    classical predictors).  Returns the number of scenes written."""
+    classical predictors).  A classical MODULE (``classical.socialforce`` / ``orca`` / ``kalman`` / ``constant_velocity``) is
+    predicted through its ``predict_scenes`` (all scenes of a batch in one launch), a classical ``predict`` FUNCTION one scene per
+    call as the reference's classical evaluator does (classical/trajnet_evaluator.py:14-27: no goal argument);
+    ``predict_kwargs`` are handed on (``sf_params=``, ``orca_params=``, ...).  Returns the number of scenes written."""
     import os
     scenes = read_ndjson_scenes(ndjson_in, limit=limit)
     scenes = [(sid, preprocess_test(paths, obs_length)) for sid, paths in scenes]
@@ -273,14 +276,20 @@ def predict_dataset(ndjson_in, predictor, out_path, batch_scenes=64, obs_length=
     open(out_path, 'w').close()
     chunks = [list(range(lo, min(lo + batch_scenes, len(scenes)))) for lo in range(0, len(scenes), batch_scenes)]
     batches = [[(scenes[i][1], scene_goals[i]) for i in ids] for ids in chunks]
-    if hasattr(predictor, 'predict_batches') and in_flight > 1:
+    kw = dict(predict_kwargs or {})
+    if hasattr(predictor, 'predict_scenes'):
+        results = [predictor.predict_scenes(b, n_predict=pred_length, obs_length=obs_length, **kw) for b in batches]
+    elif hasattr(predictor, 'predict_batches') and in_flight > 1:
         results = predictor.predict_batches(batches, n_predict=pred_length, modes=modes, obs_length=obs_length, args=args,
                                             in_flight=in_flight)
     elif hasattr(predictor, 'predict_batch'):
         results = [predictor.predict_batch(b, n_predict=pred_length, modes=modes, obs_length=obs_length, args=args)
                    for b in batches]
-    else:
-        results = [[predictor(paths, goal, n_predict=pred_length, obs_length=obs_length) for paths, goal in b] for b in batches]
+    elif hasattr(predictor, 'model'):          # a Predictor object without a batched form: the evaluator's per-scene call
+        results = [[predictor(paths, goal, n_predict=pred_length, obs_length=obs_length, modes=modes, args=args, **kw)
+                    for paths, goal in b] for b in batches]
+    else:                                      # a classical predict function
+        results = [[predictor(paths, n_predict=pred_length, obs_length=obs_length, **kw) for paths, goal in b] for b in batches]
     for ids, preds in zip(chunks, results):
         write_predictions(preds, [scenes[i] for i in ids], out_path, obs_length, pred_length, mode='a')
     return len(scenes)
