@@ -1035,6 +1035,11 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
     // the pipelined 32x64 split-K 2 kernel; `variant` pins one of the two (12 / 24), anything else is an error
     if (variant == 0) {
         variant = (big_tiles >= 192) ? 12 : 24;
+        // 64 x 64 tiles, at most four rounds of workgroups: the PIPELINED form (three-stage LDS ring, interleaved schedule) of the
+        // same tile -- the layer-2 data gradient of training, [2048, 256] x [1024, 256]^T: 15.8 -> 13.2 us; at 16 k rows the plain
+        // double-buffered kernel is ahead again (83.5 vs 88.2 us), tools/diag/small_gemm_probe.py
+        if (variant == 12 && g.K2 <= 0 && fast_ok(g, 1, 32) &&
+            (long)((g.M + 63) / 64) * ((g.N + 63) / 64) <= 4L * compute_units()) variant = 33;
         // 32x64 tiles that need a second round of workgroups while 32x128 tiles fit in one (the backward data-gradient GEMM,
         // N = 448: 448 against 256 workgroups on 256 CUs): 22.8 -> 18.0 us (round 3 sweep run_r3v, git history)
         const long b64 = (long)((g.M + 31) / 32) * ((g.N + 63) / 64), b128 = (long)((g.M + 31) / 32) * ((g.N + 127) / 128);
@@ -1071,9 +1076,11 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
         case 27: TNP_TRY_PIPE(1, 1, 4, 1, 16, EPI_BIAS); break;  // 32x32, split-K 4, 61 KB (two workgroups per CU): small batches when K % 128 != 0
         case 28: TNP_TRY_PIPE(1, 1, 4, 1, 32, EPI_BIAS); break;  // probe: 32x32, split-K 4, K tile 32 (110 KB: one per CU)
         case 29: TNP_TRY_PIPE(1, 1, 8, 1, 16, EPI_BIAS); break;  // 32x32, split-K 8 (eight waves, 120 KB): small batches, long K
+        case 32: TNP_TRY_PIPE(2, 2, 2, 1, 16, EPI_BIAS); break;  // probe: 64x64, K range over two wave quartets (eight waves)
+        case 33: TNP_TRY_PIPE(2, 2, 1, 1, 32, EPI_BIAS); break;  // 64x64 pipelined, four waves: up to four rounds of workgroups
         case 31: TNP_TRY_PIPE(1, 4, 2, 1, 32, EPI_BIAS); break;  // 32x128, K range over two wave quartets (eight waves)
         case 30: TNP_TRY_PIPE(1, 2, 4, 1, 16, EPI_BIAS); break;  // 32x64, split-K 4 (eight waves): long K at one workgroup per CU
-        default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d (0 = automatic, 12, 24 .. 31)", variant);
+        default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d (0 = automatic, 12, 24 .. 33)", variant);
     }
     // shape not eligible for the fast path: masked general kernel
     if (big_tiles >= 192) return launch_general<4, 2, 1, 1, 32, EPI_BIAS>(g, s);
