@@ -8,8 +8,8 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp; R=
 OUT=gpurun_out/${TAG}_sweep_scenes.md
 echo "# scenes sweep (variant $VAR): bench.py --scenes S, 32 agents per scene, inference forward, 1 x MI355X" > $OUT
 for S in 64 128 256 512; do
-  python bench.py --scenes $S --steps 30 --warmup 5 --variant $VAR --no-cpu-baseline --no-traffic --no-train --no-sustain --no-strong 2>/dev/null | tail -1 > gpurun_out/${TAG}_sweep_$S.json
-  (cd /tmp && TNP_BENCH_PRIME_S=0.3 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_s$S -o bench -- python $R/bench.py --scenes $S --steps 30 --warmup 3 --variant $VAR --no-cpu-baseline --no-traffic --no-train --no-roofline --no-strong > $R/gpurun_out/rocprof_s$S.log 2>&1)
+  python bench.py --scenes $S --steps 30 --warmup 5 --variant $VAR --no-cpu-baseline --no-traffic --no-train --no-sustain --no-strong --no-op-point 2>/dev/null | tail -1 > gpurun_out/${TAG}_sweep_$S.json
+  (cd /tmp && TNP_BENCH_PRIME_S=0.3 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_s$S -o bench -- python $R/bench.py --scenes $S --steps 30 --warmup 3 --variant $VAR --no-cpu-baseline --no-traffic --no-train --no-roofline --no-strong --no-op-point > $R/gpurun_out/rocprof_s$S.log 2>&1)
   echo >> $OUT; echo "## $S scenes ($((S*32)) tracks)" >> $OUT
   python - gpurun_out/${TAG}_sweep_$S.json >> $OUT <<'P'
 import json, sys

@@ -1156,9 +1156,16 @@ int launch_lstm_gates(const GemmArgs &g_in, int variant, hipStream_t s) {
     // measured on MI355X (profiles/archive/round1_b_variant_sweep.jsonl, tools/experiments/gemm_probe.hip): big batches the 128-track
     // kernel, else "gate split" (four waves own one gate block each over the whole K and swap tiles through LDS: no split-K
     // reduction, half the staged chunks per thread; 17.9 -> 16.1 us at config 2) when K1, K2 are multiples of 32
-    // round 5: the gate split with the K range over two wave quartets (22: eight waves, two per SIMD) where K1 + K2 is a
-    // multiple of 64 -- 1.046 -> 1.068 M scene-steps/s on the headline (profiles/round5_eight_wave_gemms.txt)
-    if (variant == 0) variant = (g.M >= 4096) ? 5 : (fast_ok(g, 2, 32) ? 22 : (fast_ok(g, 1, 32) ? 21 : 20));
+    // round 5 (tools/diag/gates_variant_sweep.py, profiles/round5_gates_variant_sweep.txt): one round of workgroups (M <= 2048 at
+    // H = 128) -> the gate split with the K range over two wave quartets (22: eight waves, two per SIMD; 1.046 -> 1.068 M
+    // scene-steps/s on the headline); several rounds -> the four-wave gate split (21: two workgroups co-resident per CU; at
+    // 4096 tracks 2.13 ms per forward against 2.47 with the 128-track tiles); from 8192 tracks the 128-track kernel (5)
+    if (variant == 0) {
+        const long wgs = (long)((g.M + 31) / 32) * ((g.H + 31) / 32);
+        if (g.M >= 8192) variant = 5;
+        else if (wgs <= compute_units() && fast_ok(g, 2, 32)) variant = 22;
+        else variant = fast_ok(g, 1, 32) ? 21 : 20;
+    }
     switch (variant) {
         case 5: TNP_TRY_FAST(4, 1, 2, 4, 16, EPI_LSTM); break;   // 128 tracks x 32 units, 8 waves
         case 20: TNP_TRY_PIPE(1, 1, 4, 4, 16, EPI_LSTM); break;  // pipelined: 32 tracks x 32 units, split-K 4
