@@ -226,6 +226,21 @@ def write_predictions(pred_list, scenes, filename, obs_length=9, pred_length=12,
     by every neighbour's rows, neighbours in the order of ``paths[1:]`` (which must be the paths the prediction was made
     from, i.e. after ``preprocess_test``); frames continue the primary's frame step."""
     seq_length = obs_length + pred_length
+
+    def rows(frame0, frame_diff, ped, xy, m, scene_id):
+        # the lines trajnet_format(TrackRow(...)) produces for one track, without a dict + json.dumps per row (the writer was 3/4
+        # of the host time of predict_dataset).  json.dumps writes float.__repr__ for a float; xy [pred_length, 2] -> Python floats
+        # of the float32 values, as the reference's .item() gives them.  Anything unusual (NaN / infinite coordinates, non-integer
+        # frames or ids) takes the general path.
+        arr = np.asarray(xy)
+        pts = arr.tolist()
+        if all(type(v) is int for v in (frame0, frame_diff, ped, m, scene_id)) and np.isfinite(arr).all():
+            head = '{"track": {"f": %d, "p": ' + str(ped) + ', "x": %s, "y": %s, "prediction_number": ' + str(m) + \
+                   ', "scene_id": ' + str(scene_id) + '}}\n'
+            return ''.join([head % (frame0 + i * frame_diff, repr(round(x, 2)), repr(round(y, 2))) for i, (x, y) in enumerate(pts)])
+        return ''.join(trajnet_format(TrackRow(frame0 + i * frame_diff, ped, x, y, m, scene_id)) + '\n' for i, (x, y) in enumerate(pts))
+
+    import json
     with open(filename, mode) as f:
         for predictions, (scene_id, paths) in zip(pred_list, scenes):
             observed_path = paths[0]
@@ -238,17 +253,10 @@ def write_predictions(pred_list, scenes, filename, obs_length=9, pred_length=12,
             f.write('\n')
             for m in range(len(predictions)):
                 prediction, neigh_predictions = predictions[m]
-                for i in range(len(prediction)):
-                    f.write(trajnet_format(TrackRow(first_frame + i * frame_diff, ped_id, float(prediction[i, 0]),
-                                                    float(prediction[i, 1]), m, scene_id)))
-                    f.write('\n')
+                f.write(rows(first_frame, frame_diff, ped_id, prediction, m, scene_id))
                 if len(neigh_predictions):
                     for n in range(neigh_predictions.shape[1]):
-                        neigh = neigh_predictions[:, n]
-                        for j in range(len(neigh)):
-                            f.write(trajnet_format(TrackRow(first_frame + j * frame_diff, neigh_ids[n], float(neigh[j, 0]),
-                                                            float(neigh[j, 1]), m, scene_id)))
-                            f.write('\n')
+                        f.write(rows(first_frame, frame_diff, neigh_ids[n], neigh_predictions[:, n], m, scene_id))
 
 
 def predict_dataset(ndjson_in, predictor, out_path, batch_scenes=64, obs_length=9, pred_length=12, modes=1, goals=None,
