@@ -1116,11 +1116,16 @@ static int launch_chain_impl(GemmArgs &gp, GemmArgs &gc, const ChainCtl &cc, hip
 }
 
 // 0 = launched; 1 = this pair of shapes is not eligible (the caller launches the two kernels on their own); < 0 error
+bool chain_l2_gates_enabled() {
+    static const bool enabled = getenv("TNP_CHAIN") != nullptr && getenv("TNP_CHAIN")[0] == '1';
+    return enabled;
+}
+
 int launch_chain_l2_gates(const GemmArgs &gp_in, const GemmArgs &gc_in, unsigned *flags, unsigned epoch, hipStream_t s) {
     // EXPERIMENTAL, off by default (measured slower than the two launches: docs/history.md section 9): TNP_CHAIN=1 turns it on,
     // TNP_CHAIN_BK=32 selects the 32-wide producer K tile (83 KB of LDS: one workgroup per CU, no co-residency),
     // TNP_CHAIN_NOWAIT=1 drops the consumer's wait (wrong results; timing of pure co-residency)
-    static const bool enabled = getenv("TNP_CHAIN") != nullptr && getenv("TNP_CHAIN")[0] == '1';
+    const bool enabled = chain_l2_gates_enabled();
     static const bool bk32 = getenv("TNP_CHAIN_BK") != nullptr && atoi(getenv("TNP_CHAIN_BK")) == 32;
     static const bool nowait = getenv("TNP_CHAIN_NOWAIT") != nullptr;
     if (!enabled || !flags) return 1;

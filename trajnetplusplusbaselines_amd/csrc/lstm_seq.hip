@@ -51,6 +51,12 @@ bool prof_dispatch_events(int cls) {
     ++g_prof_n; ++g_prof_disp_n;
     return true;
 }
+bool prof_dispatch_release() {
+    if (!g_disp_ev[0]) return false;
+    g_disp_ev[0] = g_disp_ev[1] = nullptr;
+    --g_prof_n; --g_prof_disp_n;
+    return true;
+}
 bool take_dispatch_events(hipEvent_t *start, hipEvent_t *stop) {
     if (!g_disp_ev[0]) return false;
     *start = g_disp_ev[0]; *stop = g_disp_ev[1];
@@ -628,6 +634,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
                                           md->n * md->n, md->C, md->dims[1], 1, dst, ldo, w.partial, s,
                                           fused_grid ? &fg : nullptr, md->Wp0_quad_major);
             if (!disp) prof_after(PROF_GEMM1, s);
+            else prof_dispatch_release();        // (no-op when the register-accumulator launch took the pair)
             if (rc) return rc;
             src = dst; lds = ldo; l0 = 1;
         }
@@ -645,7 +652,7 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
             const int cls = (l == 0) ? PROF_GEMM1 : PROF_ALL_GEMM;
             // the last layer feeds the LSTM input directly: chained with the gates GEMM in one launch when the shapes allow
             // it (gemm_f32_mfma.hip: launch_chain_l2_gates -- experimental, enabled by TNP_CHAIN=1, measured slower; variant bit 18 forbids it)
-            if (last && !w.to_hidden && ((md->variant >> 18) & 1) == 0 && ((md->variant >> 8) & 0xff) == 0 &&
+            if (last && chain_l2_gates_enabled() && !w.to_hidden && ((md->variant >> 18) & 1) == 0 && ((md->variant >> 8) & 0xff) == 0 &&
                 (l > 0 || (md->variant & 0xff) == 0)) {
                 GemmArgs gg;
                 fill_gates_args(gg, md, decoder, w, h_in, h_out, c_in, c_out, M);

@@ -55,6 +55,7 @@ int launch_lstm_gates(const GemmArgs &g, int variant, hipStream_t s);
 // flags = [ceil(M/32) + 1] unsigned zeroed at the start of the forward pass, epoch = 1, 2, ... per step.  Returns 1 when the
 // pair of shapes is not eligible (the caller then launches the two kernels on their own).
 int launch_chain_l2_gates(const GemmArgs &producer, const GemmArgs &gates, unsigned *flags, unsigned epoch, hipStream_t s);
+bool chain_l2_gates_enabled();   // TNP_CHAIN=1 (read once per process)
 
 // ---- grid pooling ---------------------------------------------------------------------------
 struct GridArgs {
@@ -138,6 +139,9 @@ void prof_after(int cls, hipStream_t s);
 // to a bracketed launch.  prof_dispatch_events reserves the next event pair when profiling of `cls` is on; a launcher that
 // supports it takes the pair with take_dispatch_events() and clears it.
 bool prof_dispatch_events(int cls);
+// a reserved pair that no launcher took (the launch went down a kernel path without dispatch events): give the slot back, so that
+// tnp_profile_read never meets unrecorded events and the next launch does not inherit a stale pair.  Returns true if it did.
+bool prof_dispatch_release();
 bool take_dispatch_events(hipEvent_t *start, hipEvent_t *stop);
 
 }  // namespace tnp
