@@ -214,8 +214,15 @@ def require_device(t, what):
 
 
 def f32c(t, device=None):
-    """fp32, contiguous, on `device` (H2D copy if the caller handed a host tensor)."""
+    """fp32, contiguous, on `device` (H2D copy if the caller handed a host tensor: converted on the host first, then ONE
+    asynchronous copy from pinned memory -- a pageable .to(device) blocks the host until the stream has drained, which keeps a
+    loop over batches from ever running ahead of the GPU)."""
     if device is not None and t.device != device:
+        if t.device.type == 'cpu' and torch.device(device).type == 'cuda':
+            t = t.detach()
+            if t.dtype != torch.float32:
+                t = t.float()
+            return t.contiguous().pin_memory().to(device, non_blocking=True)
         t = t.to(device)
     if t.dtype != torch.float32:
         t = t.float()
@@ -288,10 +295,8 @@ class SceneIndex(object):
                 raise ValueError('pad_to is smaller than a scene: padded slot counts must be >= the track counts')
             self.n_max = int(slots.max()) if self.B > 0 else 0
             if not isinstance(pad_to, int):
-                self.slots = slots.to(torch.int32).to(device)
                 self._slots_host = slots.to(torch.int64)
-        self.starts = split.to(torch.int32).to(device)
-        # first row / size of every row's scene (training backward): built on the host, one copy, no device-side sync later
+        # first row / size of every row's scene (training backward): built on the host, no device-side sync later
         # (the host copies stay: stacked_rows() builds the whole-sweep tables from them without reading the device back)
         # (numpy, not torch.repeat_interleave: torch's CPU kernel is an at::parallel_for -- on a 256-core host its thread
         # pool costs 0.7 ms per call warm and 7 ms cold for these ~300-element tables, every step of a trainer whose
@@ -299,8 +304,23 @@ class SceneIndex(object):
         sizes_np = sizes.numpy()
         self._row_base_host = torch.from_numpy(np.repeat(split[:-1].numpy(), sizes_np).astype(np.int32))
         self._row_count_host = torch.from_numpy(np.repeat(sizes_np, sizes_np).astype(np.int32))
-        self.row_base = self._row_base_host.to(device)
-        self.row_count = self._row_count_host.to(device)
+        # ALL tables travel in ONE asynchronous copy from pinned memory: a pageable .to(device) is a blocking hipMemcpy that
+        # first waits for everything queued on the stream -- with a new batch_split every step (the reference trainer) the host
+        # could never run ahead of the GPU, which then idled between steps while the next batch was being prepared
+        parts = [split.to(torch.int32), self._row_base_host, self._row_count_host]
+        if self._slots_host is not None:
+            parts.append(self._slots_host.to(torch.int32))
+        flat = torch.cat(parts)
+        if torch.device(device).type == 'cuda':
+            flat = flat.pin_memory().to(device, non_blocking=True)
+        else:
+            flat = flat.to(device)
+        o = 0
+        self.starts = flat[o:o + self.B + 1]; o += self.B + 1
+        self.row_base = flat[o:o + self.M]; o += self.M
+        self.row_count = flat[o:o + self.M]; o += self.M
+        if self._slots_host is not None:
+            self.slots = flat[o:o + self.B]
         self.primary = torch.empty(max(self.M, 1), dtype=torch.uint8, device=device)
         check(lib().tnp_mark_primaries(ptr(self.starts), self.B, self.M, ptr(self.primary), stream_ptr()),
               'tnp_mark_primaries')

@@ -174,18 +174,24 @@ class SceneBatcher(object):
     def __len__(self):
         return len(self.sizes)
 
+    def _h2d(self, t):
+        # pinned + asynchronous: a pageable copy blocks the host until the stream has drained (see _lib.SceneIndex)
+        if self.device.type == 'cuda':
+            return t.pin_memory().to(self.device, non_blocking=True)
+        return t.to(self.device)
+
     def batch(self, ids, augment=False):
         import math
         import random
         import torch
         ids = list(ids)
-        cols = torch.from_numpy(np.concatenate([np.arange(self.starts[i], self.starts[i + 1]) for i in ids])).to(self.device)
+        cols = self._h2d(torch.from_numpy(np.concatenate([np.arange(self.starts[i], self.starts[i + 1]) for i in ids])))
         xy, goals = self.xy[:, cols], self.goals[cols]
         split = torch.tensor(np.concatenate([[0], np.cumsum(self.sizes[ids])]), dtype=torch.int64)
         if augment:
             theta = np.array([random.random() * 2.0 * math.pi for _ in ids], dtype=np.float64)
             per_track = np.repeat(theta, self.sizes[ids])             # (numpy: torch's CPU repeat_interleave wakes a thread pool)
-            cs = torch.from_numpy(np.stack([np.cos(per_track), np.sin(per_track)]).astype(np.float32)).to(self.device)
+            cs = self._h2d(torch.from_numpy(np.stack([np.cos(per_track), np.sin(per_track)]).astype(np.float32)))
             ct, st = cs[0], cs[1]
             x, y = xy[..., 0], xy[..., 1]
             xy = torch.stack([x * ct - y * st, x * st + y * ct], dim=-1)   # row vector times [[ct, st], [-st, ct]]
