@@ -271,7 +271,7 @@ def predict_dataset(ndjson_in, predictor, out_path, batch_scenes=64, obs_length=
     evaluator/write_utils.py): read the scenes, ``preprocess_test`` each, predict them ``batch_scenes`` at a time through
     ``predictor.predict_batch`` (ONE ``LSTM.forward`` per batch instead of one call per scene on 12 joblib workers;
     ``in_flight`` batches on the GPU at once through ``predict_batches`` -- two by default: +20 % scenes per second on MI355X,
-    results bit-identical to one at a time) and write the prediction file in
+    results identical to one batch at a time) and write the prediction file in
     the reference's layout.  ``goals``: {pedestrian id: (x, y)} (the reference's goal pickle, write_utils.py:21-26) or None
     = zeros.  ``predictor`` is anything with ``predict_batch(scenes, n_predict=, modes=, obs_length=, args=)`` -- the
     ``LSTMPredictor`` / ``SGANPredictor`` mirrors -- or a per-scene callable ``predictor(paths, scene_goal, ...)`` (the

@@ -371,7 +371,7 @@ class LSTM(torch.nn.Module):
         scenes to (lstm/lstm.py:29: the padded, absent slots clobber cell (0, 0) of shorter scenes' grids and enter
         AttentionMLPPooling's softmax).  None = the largest scene of this call, i.e. exactly what the reference does
         with this batch; an int = the largest scene of the WHOLE batch when this call holds a shard of it (results then
-        equal the unsharded batch bit for bit); 'scene' = every scene unpadded, i.e. what one reference call per scene
+        equal the unsharded batch bit for bit while both select the same GEMM tiles, to fp32 summation order otherwise); 'scene' = every scene unpadded, i.e. what one reference call per scene
         gives (the evaluator); or per-scene slot counts.  See ``_lib.SceneIndex``."""
         assert ((prediction_truth is None) + (n_predict is None)) == 1
         if prediction_truth is not None and isinstance(prediction_truth, (list, tuple)):
