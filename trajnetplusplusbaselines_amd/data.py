@@ -16,16 +16,28 @@ SceneRow.__new__.__defaults__ = (None, None, None, None, None, None)
 
 def paths_to_xy(paths):
     """list (primary first) of lists of rows with .frame .pedestrian .x .y -> float64 [T, N, 2], NaN = absent.
-    Frames are the primary's frames (sorted); tracks keep the order of `paths`."""
-    frames = sorted(set(r.frame for r in paths[0]))
-    frame_to_index = {f: i for i, f in enumerate(frames)}
+    Frames are the primary's frames (sorted); tracks keep the order of `paths`; of two rows of a track in one frame the later
+    one stays.  (All rows of the scene are transposed with ``zip`` and placed with ONE numpy assignment: the per-row Python
+    loop was the host cost of ``predict_batch``.)"""
+    frames = np.array(sorted(set(r.frame for r in paths[0])))
     xy = np.full((len(frames), len(paths), 2), np.nan)
-    for ped_index, path in enumerate(paths):
-        for row in path:
-            i = frame_to_index.get(row.frame)
-            if i is None:
-                continue
-            xy[i, ped_index] = [row.x, row.y]
+    rows = [r for path in paths for r in path]
+    if not rows:
+        return xy
+    if isinstance(rows[0], tuple):                        # TrackRow (a namedtuple): frame, pedestrian, x, y, ...
+        cols = tuple(zip(*rows))
+        f, x, y = np.array(cols[0]), np.array(cols[2], dtype=np.float64), np.array(cols[3], dtype=np.float64)
+    else:                                                 # any object with the four attributes
+        f = np.array([r.frame for r in rows])
+        x, y = np.array([r.x for r in rows], dtype=np.float64), np.array([r.y for r in rows], dtype=np.float64)
+    ped = np.repeat(np.arange(len(paths)), [len(path) for path in paths])
+    i = np.searchsorted(frames, f)
+    i = np.minimum(i, len(frames) - 1)
+    ok = frames[i] == f
+    if not ok.all():
+        i, ped, x, y = i[ok], ped[ok], x[ok], y[ok]
+    xy[i, ped, 0] = x          # (duplicate (frame, track) pairs: numpy keeps the last assignment, as the row loop did)
+    xy[i, ped, 1] = y
     return xy
 
 
