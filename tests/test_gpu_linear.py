@@ -14,10 +14,12 @@ SHAPES = [
     (2048, 256, 1024), (512, 1024, 4096),
     (2048, 448, 512),                  # 32x64 tiles need a second round of workgroups: automatic selection takes 32x128
     (2048, 256, 288), (300, 100, 96),  # K a multiple of 96, not of 64: split-K 3 of the pipelined kernel
+    # round 5: shapes that select the eight-wave / small-batch tiles, with ragged edges in M and N
+    (36, 256, 1024), (310, 250, 1024), (1000, 40, 512), (1, 33, 640), (2048, 448, 1024), (2050, 70, 512), (2048, 1024, 256),
 ]
 
 
-@pytest.mark.parametrize('variant', [0, 12, 24, 25, 26])   # automatic selection and the tile shapes it picks from; shapes
+@pytest.mark.parametrize('variant', [0, 12, 24, 25, 26, 27, 29, 30, 31, 33])   # automatic selection and the tile shapes it picks from; shapes
 # the fast kernels cannot take (K not a multiple of the K step / of 4) fall through to the masked general kernel
 @pytest.mark.parametrize('M,N,K', SHAPES)
 def test_linear_matches_oracle(M, N, K, variant):
