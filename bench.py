@@ -499,6 +499,10 @@ def classical_leg(device, scenes=4096, agents=128):
                 finite=bool(torch.isfinite(out_sf).all() and torch.isfinite(out_orca).all() and torch.isfinite(out_k).all()))
 
 
+# the Python reference at its real operating point, measured in the build container (8 vCPUs) by tools/ref_operating_point.py
+REF_TRAINER_DEFAULT_MS, REF_PER_SCENE_MS = 1249.1, 86.4
+
+
 def operating_point_legs(device, steps=200):
     """The reference's REAL operating point (VERDICT r4 "missing 3"), reported beside the headline -- never as `value`:
 
@@ -575,6 +579,10 @@ def operating_point_legs(device, steps=200):
         ms_per_step=t_all / steps * 1e3, host_enqueue_ms_per_step=t_host / steps * 1e3, gpu_ms_per_step_isolated=gpu_ms,
         ms_per_step_gc_frozen=t_all_f / steps * 1e3, host_enqueue_ms_per_step_gc_frozen=t_host_f / steps * 1e3,
         tracks_per_step=tracks / steps, scene_steps_per_s=8 * 21 * steps / t_all, steps=steps,
+        reference_python_ms_per_step=REF_TRAINER_DEFAULT_MS,
+        reference_note='the Python reference on the same crowd and batch size (forward + loss + backward + Adam as Trainer.train_batch), '
+                       '8 vCPUs of the build container: tools/ref_operating_point.py -> profiles/round5_reference_operating_point.txt '
+                       '(it cannot run on the GPU box)',
         note='ms_per_step: wall clock of the pipelined loop; host_enqueue: until the loop has queued its last step (the host '
              'only blocks on queue back-pressure); gpu isolated: median HIP-event time of one step started on an idle queue '
              '(host enqueue included where the device waits for it); gc_frozen: the same loop after gc.freeze() -- Python\'s '
@@ -628,7 +636,7 @@ def operating_point_legs(device, steps=200):
                  'numpy predictions out, one blocking call per scene' % n_sc,
         ms_per_call=t_call * 1e3, device_ms_per_forward=sorted(dev_ms)[len(dev_ms) // 2], scenes_per_s=1.0 / t_call,
         predict_batch_64_ms_per_scene=t_batch * 1e3, predict_batch_scenes_per_s=1.0 / t_batch,
-        cpu_port_ms_per_scene=t_cpu * 1e3, cpu_port_note='oracle/trajnet_oracle.c forward of the same scenes on the host (kind "port"); the '
+        cpu_port_ms_per_scene=t_cpu * 1e3, reference_python_ms_per_scene=REF_PER_SCENE_MS, cpu_port_note='oracle/trajnet_oracle.c forward of the same scenes on the host (kind "port"); the '
                                                          'Python reference needs 6.4 ms for a 1 x 4 VANILLA forward (BASELINE.md section 2) '
                                                          'and ~2 s for the 64 x 32 social batch',
         mean_agents=float(np.mean([sc.shape[1] for sc in scenes[:n_sc]])))

@@ -51,4 +51,5 @@ for ids in order[60:120]:
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(28)
+st.sort_stats('tottime').print_stats(14)
+st.sort_stats('cumtime').print_stats(30)
