@@ -1,0 +1,41 @@
+"""End-to-end throughput of data.predict_dataset (file in -> prediction file out) on a synthetic test file of ragged scenes,
+headline model: scenes per second including reading, host preprocessing, prediction (batched, two batches in flight) and writing."""
+import json, os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import bench
+from trajnetplusplusbaselines_amd import synth, data
+from trajnetplusplusbaselines_amd.lstm import LSTMPredictor
+
+n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+xy, split = synth.ragged_crowd(n_scenes, 8, 72, seed=77, nan_frac=0.2)
+xy, split = xy.numpy(), split.numpy()
+tmp = tempfile.mkdtemp()
+src, dst = os.path.join(tmp, 'test.ndjson'), os.path.join(tmp, 'pred.ndjson')
+with open(src, 'w') as f:
+    ped = 0
+    rows = []
+    for s in range(n_scenes):
+        sc = xy[:, split[s]:split[s + 1]]
+        f0 = 1000 * s
+        f.write(json.dumps({'scene': {'id': s, 'p': ped, 's': f0, 'e': f0 + 200, 'fps': 2.5, 'tag': 0}}) + '\n')
+        for a in range(sc.shape[1]):
+            for t in range(21):
+                if not np.isnan(sc[t, a, 0]):
+                    rows.append({'track': {'f': f0 + 10 * t, 'p': ped + a, 'x': round(float(sc[t, a, 0]), 2), 'y': round(float(sc[t, a, 1]), 2)}})
+        ped += sc.shape[1]
+    for r in rows:
+        f.write(json.dumps(r) + '\n')
+model = bench.build_model(bench.CONFIGS['social'], torch.device('cuda', 0), seed=1).eval()
+p = LSTMPredictor(model)
+data.predict_dataset(src, p, dst, batch_scenes=64, limit=128)            # warm-up
+for inflight in (1, 2):
+    t0 = time.perf_counter()
+    n = data.predict_dataset(src, p, dst, batch_scenes=64, in_flight=inflight)
+    dt = time.perf_counter() - t0
+    print('predict_dataset, %d scenes (%.1f agents per scene), batch_scenes 64, in_flight %d: %.2f s = %.0f scenes/s (%.3f ms per scene), output %d lines'
+          % (n, (split[-1]) / n_scenes, inflight, dt, n / dt, dt / n * 1e3, sum(1 for _ in open(dst))))
+t0 = time.perf_counter(); sc = data.read_ndjson_scenes(src); t1 = time.perf_counter()
+print('of which reading + parsing the test file: %.2f s' % (t1 - t0))
