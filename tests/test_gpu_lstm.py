@@ -480,3 +480,19 @@ def test_profile_hook_times_the_sparse_layer_by_its_dispatch():
             L.tnp_profile_end()
     assert n.value == 3 * 19 and timed == n.value
     assert 5e-3 < ms.value / n.value < 0.5, ms.value / n.value        # ~0.033 ms per launch
+
+
+@pytest.mark.parametrize('scenes,agents', [(1, 36), (8, 40), (31, 33), (64, 32)])
+def test_round5_tiles_are_bitwise_repeatable(scenes, agents):
+    """The eight-wave / small-batch GEMM tiles of round 5 (K range over several wave groups of a workgroup, partial tiles meeting in
+    an LDS swap) across the batch sizes that select them: sixty forwards of the same input, every output equal to the first bit for
+    bit (NaN pattern included) -- a missing barrier around the swap would show up as an occasional wrong row."""
+    model = _config2_model(seed=6).cuda().eval()
+    xy, split = synth.ragged_crowd(scenes, max(2, agents - 8), agents, seed=3 + scenes)
+    obs, goals = xy[:9].cuda(), torch.zeros(xy.shape[1], 2).cuda()
+    with torch.no_grad():
+        first_rel, first = model(obs, goals, split, n_predict=12)
+        for _ in range(60):
+            rel, pred = model(obs, goals, split, n_predict=12)
+            assert torch.equal(torch.nan_to_num(pred, nan=-7.0), torch.nan_to_num(first, nan=-7.0))
+            assert torch.equal(torch.nan_to_num(rel, nan=-7.0), torch.nan_to_num(first_rel, nan=-7.0))

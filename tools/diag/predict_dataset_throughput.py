@@ -39,3 +39,9 @@ for inflight in (1, 2):
           % (n, (split[-1]) / n_scenes, inflight, dt, n / dt, dt / n * 1e3, sum(1 for _ in open(dst))))
 t0 = time.perf_counter(); sc = data.read_ndjson_scenes(src); t1 = time.perf_counter()
 print('of which reading + parsing the test file: %.2f s' % (t1 - t0))
+if len(sys.argv) > 2:
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    data.predict_dataset(src, p, dst, batch_scenes=64, in_flight=1)
+    pr.disable()
+    pstats.Stats(pr).sort_stats('tottime').print_stats(14)

@@ -286,12 +286,13 @@ def write_predictions(pred_list, scenes, filename, obs_length=9, pred_length=12,
 
 
 def predict_dataset(ndjson_in, predictor, out_path, batch_scenes=64, obs_length=9, pred_length=12, modes=1, goals=None,
-                    in_flight=2, args=None, limit=None, predict_kwargs=None):
+                    in_flight=1, args=None, limit=None, predict_kwargs=None):
     """The evaluator's prediction loop for one test file (reference lstm/trajnet_evaluator.py:29-65 ``get_predictions`` +
     evaluator/write_utils.py): read the scenes, ``preprocess_test`` each, predict them ``batch_scenes`` at a time through
     ``predictor.predict_batch`` (ONE ``LSTM.forward`` per batch instead of one call per scene on 12 joblib workers;
-    ``in_flight`` batches on the GPU at once through ``predict_batches`` -- two by default: +20 % scenes per second on MI355X,
-    results identical to one batch at a time) and write the prediction file in
+    ``in_flight`` > 1 keeps that many batches on the GPU at once through ``predict_batches``: +20 % on the GPU side, but the
+    loop is bound by reading and writing the files -- 350-410 scenes/s end to end at 40 agents per scene against 6 300 scenes/s of
+    prediction alone, tools/diag/predict_dataset_throughput.py -- so the default is one) and write the prediction file in
     the reference's layout.  ``goals``: {pedestrian id: (x, y)} (the reference's goal pickle, write_utils.py:21-26) or None
     = zeros.  ``predictor`` is anything with ``predict_batch(scenes, n_predict=, modes=, obs_length=, args=)`` -- the
     ``LSTMPredictor`` / ``SGANPredictor`` mirrors -- or a per-scene callable ``predictor(paths, scene_goal, ...)`` (the

@@ -673,8 +673,8 @@ class LSTMPredictor(object):
             normalize = bool(getattr(args, 'normalize_scene', False))
             if normalize:
                 xy, rotation, center, scene_goal = trajdata.center_scene(xy, obs_length, goals=scene_goal)
-            xy = torch.tensor(np.asarray(xy), dtype=torch.float32)
-            scene_goal = torch.tensor(np.asarray(scene_goal), dtype=torch.float32)
+            xy = torch.from_numpy(np.ascontiguousarray(xy, dtype=np.float32))
+            scene_goal = torch.from_numpy(np.ascontiguousarray(scene_goal, dtype=np.float32))
             batch_split = torch.tensor(batch_split, dtype=torch.int64)
 
             multimodal_outputs = {}
@@ -715,8 +715,8 @@ class LSTMPredictor(object):
             return []
         xy, split = trajdata.batch_scenes(xys)
         with torch.no_grad():
-            obs = torch.tensor(xy, dtype=torch.float32)
-            goal = torch.tensor(np.concatenate(goals, axis=0), dtype=torch.float32)
+            obs = torch.from_numpy(np.ascontiguousarray(xy, dtype=np.float32))   # (numpy converts: torch.tensor() of a float64 array wakes the CPU thread pool, ~5 ms on a 256-core host)
+            goal = torch.from_numpy(np.ascontiguousarray(np.concatenate(goals, axis=0), dtype=np.float32))
             batch_split = torch.tensor(split, dtype=torch.int64)
             outputs = [self.model(obs, goal, batch_split, n_predict=n_predict, pad_to='scene', **self._graph_kw())[1]
                        for _ in range(modes)]
@@ -772,8 +772,8 @@ class LSTMPredictor(object):
             st = streams[bi % len(streams)]
             st.wait_event(start)                                   # whatever the caller had queued before this call
             with torch.no_grad(), torch.cuda.stream(st):
-                obs = torch.tensor(xy, dtype=torch.float32)
-                goal = torch.tensor(np.concatenate(goals, axis=0), dtype=torch.float32)
+                obs = torch.from_numpy(np.ascontiguousarray(xy, dtype=np.float32))   # (numpy converts: torch.tensor() of a float64 array wakes the CPU thread pool, ~5 ms on a 256-core host)
+                goal = torch.from_numpy(np.ascontiguousarray(np.concatenate(goals, axis=0), dtype=np.float32))
                 batch_split = torch.tensor(split, dtype=torch.int64)
                 outputs = [self.model(obs, goal, batch_split, n_predict=n_predict, pad_to='scene', **self._graph_kw())[1]
                            for _ in range(modes)]
