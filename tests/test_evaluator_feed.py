@@ -125,3 +125,32 @@ def test_predict_dataset_with_the_lstm_predictor_on_device(tmp_path):
             want = res[0][1][:, n].astype(np.float64)
             assert np.array_equal(np.isnan(got), np.isnan(want))
             assert np.array_equal(got[~np.isnan(got)], np.round(want[~np.isnan(want)], 2))
+
+
+def test_paths_to_xy_equals_the_row_loop_definition():
+    """``paths_to_xy`` places all rows of a scene with one numpy assignment; its definition is the reference tool's row loop
+    (frames of the primary, NaN for absent, the later of two rows of a track in one frame stays, rows outside the primary's frames
+    are dropped)."""
+    def rows_loop(paths):
+        frames = sorted(set(r.frame for r in paths[0]))
+        index = {f: i for i, f in enumerate(frames)}
+        xy = np.full((len(frames), len(paths), 2), np.nan)
+        for p, path in enumerate(paths):
+            for r in path:
+                if r.frame in index:
+                    xy[index[r.frame], p] = [r.x, r.y]
+        return xy
+
+    for sid, paths in trajdata.read_ndjson_scenes(INP):
+        assert np.array_equal(trajdata.paths_to_xy(paths), rows_loop(paths), equal_nan=True)
+        cut = trajdata.preprocess_test(paths, 9)
+        assert np.array_equal(trajdata.paths_to_xy(cut), rows_loop(cut), equal_nan=True)
+    T = trajdata.TrackRow
+    odd = [[T(10 * t, 1, float(t), 0.0) for t in range(5)], [T(10 * t, 2, 1.0 * k, 2.0) for k, t in enumerate((0, 1, 1, 7, 3))], []]
+    assert np.array_equal(trajdata.paths_to_xy(odd), rows_loop(odd), equal_nan=True)
+
+    class Row(object):
+        def __init__(self, f, p, x, y):
+            self.frame, self.pedestrian, self.x, self.y = f, p, x, y
+    objs = [[Row(10 * t, 1, float(t), 0.5) for t in range(4)], [Row(10 * t, 2, 2.0, float(t)) for t in (1, 2, 9)]]
+    assert np.array_equal(trajdata.paths_to_xy(objs), rows_loop(objs), equal_nan=True)
