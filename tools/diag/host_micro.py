@@ -44,3 +44,21 @@ print('pin_memory() of 300 ints                %8.1f us' % t(lambda: cpu.pin_mem
 print('small H2D pinned non_blocking           %8.1f us' % t(lambda: pin.to('cuda', non_blocking=True)))
 print('torch.tensor(list of 9) int64           %8.1f us' % t(lambda: torch.tensor([0, 1, 2, 3, 4, 5, 6, 7, 8], dtype=torch.int64)))
 torch.cuda.synchronize()
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from trajnetplusplusbaselines_amd import _lib
+dev = torch.device('cuda', 0)
+for n in (40, 300, 2000):
+    h = torch.randn(9, n, 2)
+    print('f32c host [9,%d,2] -> device (pinned async)   %8.1f us' % (n, t(lambda: _lib.f32c(h, dev))))
+    print('  .to(device) pageable                       %8.1f us' % t(lambda: h.to(dev)))
+    print('  pin_memory() alone                         %8.1f us' % t(lambda: h.pin_memory()))
+sizes_list = [torch.randn(9, k, 2) for k in range(8, 72)]
+import itertools
+it = itertools.cycle(sizes_list)
+print('f32c, sizes cycling 8..72 agents               %8.1f us' % t(lambda: _lib.f32c(next(it), dev), n=400))
+it = itertools.cycle(sizes_list)
+def call_sync():
+    x = _lib.f32c(next(it), dev); torch.cuda.synchronize()
+print('f32c + synchronize, sizes cycling              %8.1f us' % t(call_sync, n=400))
+torch.cuda.synchronize()

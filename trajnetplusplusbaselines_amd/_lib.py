@@ -7,6 +7,7 @@ torch.distributed.  Every entry point enqueues on ``torch.cuda.current_stream()`
 import ctypes
 import numbers
 import os
+import threading
 
 import numpy as np
 import torch
@@ -213,6 +214,44 @@ def require_device(t, what):
                            % (what, t.device))
 
 
+class _Staging(threading.local):
+    """A small ring of REUSED pinned host buffers per thread for asynchronous host-to-device copies.  ``tensor.pin_memory()``
+    asks torch's caching host allocator for a block per call; with ever-new sizes (one scene per call, a new batch_split per
+    step) that is a hipHostMalloc of about a millisecond for every size class it has not seen -- the evaluator's per-scene call
+    went from 1.2 to 2.4 ms.  Thirty-two slots (a host that runs a step or two ahead of the GPU never waits for one) of at least 64 KB, grown to the next power of two on demand; a slot is reused only after
+    the event recorded behind its last copy has completed."""
+
+    def __init__(self):
+        self.slots, self.events, self.k = [None] * 32, [None] * 32, 0
+
+
+_staging = _Staging()
+
+
+def h2d_async(t, device):
+    """contiguous host tensor -> device tensor through a reused pinned buffer, without blocking the host"""
+    t = t.contiguous()
+    nbytes = t.numel() * t.element_size()
+    if nbytes == 0 or torch.device(device).type != 'cuda':
+        return t.to(device)
+    s = _staging
+    k = s.k
+    s.k = (k + 1) % len(s.slots)
+    if s.events[k] is not None:
+        s.events[k].synchronize()
+    buf = s.slots[k]
+    if buf is None or buf.numel() < nbytes:
+        buf = s.slots[k] = torch.empty(max(1 << 16, 1 << (nbytes - 1).bit_length()), dtype=torch.uint8, pin_memory=True)
+    view = buf[:nbytes].view(t.dtype).view(t.shape)
+    view.copy_(t)
+    with torch.cuda.device(device):
+        out = view.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+    s.events[k] = ev
+    return out
+
+
 def f32c(t, device=None):
     """fp32, contiguous, on `device` (H2D copy if the caller handed a host tensor: converted on the host first, then ONE
     asynchronous copy from pinned memory -- a pageable .to(device) blocks the host until the stream has drained, which keeps a
@@ -222,7 +261,7 @@ def f32c(t, device=None):
             t = t.detach()
             if t.dtype != torch.float32:
                 t = t.float()
-            return t.contiguous().pin_memory().to(device, non_blocking=True)
+            return h2d_async(t, device)
         t = t.to(device)
     if t.dtype != torch.float32:
         t = t.float()
@@ -311,10 +350,7 @@ class SceneIndex(object):
         if self._slots_host is not None:
             parts.append(self._slots_host.to(torch.int32))
         flat = torch.cat(parts)
-        if torch.device(device).type == 'cuda':
-            flat = flat.pin_memory().to(device, non_blocking=True)
-        else:
-            flat = flat.to(device)
+        flat = h2d_async(flat, device)
         o = 0
         self.starts = flat[o:o + self.B + 1]; o += self.B + 1
         self.row_base = flat[o:o + self.M]; o += self.M
@@ -340,7 +376,7 @@ class SceneIndex(object):
             if self._slots_host is not None:
                 tabs.append(torch.from_numpy(np.repeat(self._slots_host.numpy(), self._sizes_host.numpy()).astype(np.int32)).repeat(S))
             if dev.type == 'cuda':
-                tabs = [t.pin_memory().to(dev, non_blocking=True) for t in tabs]
+                tabs = [h2d_async(t, dev) for t in tabs]
             else:
                 tabs = [t.to(dev) for t in tabs]
             if len(tabs) == 2:

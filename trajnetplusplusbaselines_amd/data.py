@@ -196,9 +196,8 @@ class SceneBatcher(object):
 
     def _h2d(self, t):
         # pinned + asynchronous: a pageable copy blocks the host until the stream has drained (see _lib.SceneIndex)
-        if self.device.type == 'cuda':
-            return t.pin_memory().to(self.device, non_blocking=True)
-        return t.to(self.device)
+        from . import _lib
+        return _lib.h2d_async(t, self.device)
 
     def batch(self, ids, augment=False):
         import math
