@@ -594,13 +594,15 @@ def operating_point_legs(device, steps=200):
     n_sc = 128
     paths_list = [trajdata.xy_to_paths(sc) for sc in scenes[:n_sc]]
     goals_list = [np.zeros((sc.shape[1], 2)) for sc in scenes[:n_sc]]
-    for paths, g in zip(paths_list[:8], goals_list[:8]):
-        predictor(paths, g, n_predict=12)
-    _lib.SceneIndex._cache.clear()
-    t0 = time.perf_counter()
-    for paths, g in zip(paths_list, goals_list):
-        predictor(paths, g, n_predict=12)
-    t_call = (time.perf_counter() - t0) / n_sc
+    import gc
+    gc.collect()                      # the training leg's garbage is not the evaluator's
+    t_call = None
+    for _ in range(2):                # first pass: the device allocator meets the scenes' sizes; reported: the second
+        _lib.SceneIndex._cache.clear()
+        t0 = time.perf_counter()
+        for paths, g in zip(paths_list, goals_list):
+            predictor(paths, g, n_predict=12)
+        t_call = (time.perf_counter() - t0) / n_sc
     # device part of one call: the model forward alone on resident tensors, events on an idle queue
     dev_ms = []
     for sc in scenes[:32]:

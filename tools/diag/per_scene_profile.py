@@ -24,8 +24,9 @@ for rep in range(2):
     for a, g in zip(paths, goals):
         p(a, g, n_predict=12)
     print('pass %d: %.3f ms per call' % (rep, (time.perf_counter() - t0) / len(paths) * 1e3))
+_lib.SceneIndex._cache.clear()
 pr = cProfile.Profile(); pr.enable()
 for a, g in zip(paths, goals):
     p(a, g, n_predict=12)
 pr.disable()
-pstats.Stats(pr).sort_stats('tottime').print_stats(12)
+pstats.Stats(pr).sort_stats('tottime').print_stats(16)
