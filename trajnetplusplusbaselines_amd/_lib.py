@@ -226,6 +226,8 @@ class _Staging(threading.local):
 
 
 _staging = _Staging()
+#: largest copy that goes through the ring: its pinned footprint is bounded by 32 slots x 4 MB = 128 MB per thread
+_STAGING_MAX_SLOT = 4 << 20
 
 
 def h2d_async(t, device):
@@ -234,6 +236,11 @@ def h2d_async(t, device):
     nbytes = t.numel() * t.element_size()
     if nbytes == 0 or torch.device(device).type != 'cuda':
         return t.to(device)
+    if nbytes > _STAGING_MAX_SLOT:
+        # big one-off inputs (a 4096 x 128 classical batch is 88 MB) must not grow the ring: 32 slots of 128 MB each would pin
+        # 4 GB per thread for good.  torch's caching host allocator recycles the block once the copy has completed.
+        with torch.cuda.device(device):
+            return t.pin_memory().to(device, non_blocking=True)
     s = _staging
     k = s.k
     s.k = (k + 1) % len(s.slots)
@@ -257,7 +264,8 @@ def f32c(t, device=None):
     asynchronous copy from pinned memory -- a pageable .to(device) blocks the host until the stream has drained, which keeps a
     loop over batches from ever running ahead of the GPU)."""
     if device is not None and t.device != device:
-        if t.device.type == 'cpu' and torch.device(device).type == 'cuda':
+        if t.device.type == 'cpu' and torch.device(device).type == 'cuda' and not (t.requires_grad and torch.is_grad_enabled()):
+            # (a host tensor that requires grad keeps its autograd edge: the differentiable .to(device) below)
             t = t.detach()
             if t.dtype != torch.float32:
                 t = t.float()

@@ -64,7 +64,11 @@ def predict(paths, predict_all=True, n_predict=12, obs_length=9, rng=None):
     """``rng`` (not in the reference's signature): a ``numpy.random.RandomState``; default = numpy's global one, which
     is what pykalman's ``sample(random_state=None)`` draws from.  The draws are taken track by track in the order of
     ``paths``, 5 samples x (n_predict + 1) steps x 6 components each -- the order in which the reference's loop
-    (classical/kalman.py:22-60) consumes them -- so a seeded run is reproducible against a seeded reference run."""
+    (classical/kalman.py:22-60) asks for samples.  A seeded run is reproducible against ``oracle/classical_stubs.py`` (the
+    driving stubs of tests/test_classical_ref.py), NOT against the real pykalman: ``KalmanFilter.sample(initial_state=...)``
+    draws no transition noise at t = 0 and transforms its normals with ``rng.multivariate_normal`` (SVD), not with the
+    Cholesky factors used here, so the two random streams part at the first step.  The predictive MEAN (what the reference
+    returns is a mean of 5 noisy samples around it) is the comparable quantity."""
     tracks, index = _scene_tracks(paths, predict_all, obs_length)
     noise = (rng or np.random).standard_normal((len(tracks), 5, n_predict + 1, 6))
     return _pack(_predict_tracks(tracks, noise, n_predict), index)

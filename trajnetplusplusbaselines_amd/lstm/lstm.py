@@ -573,6 +573,9 @@ class _GraphedForward(object):
 
     def __init__(self, model, keep, observed, goals, batch_split, truth, T_dec, pad_to):
         self.keep = keep                     # the weight tensors the captured kernel arguments point into
+        # ... and the scene-index tables (starts / primary / slots): the graph is keyed by their CONTENT, so nothing else keeps
+        # this object alive once SceneIndex._cache is cleared -- the captured kernels would then read freed memory
+        self.idx = _lib.SceneIndex.get(batch_split, observed.device, pad_to)
         self.obs = observed.clone()
         self.goals = goals.clone() if goals is not None else None
         self.truth = truth.clone() if truth is not None else None
