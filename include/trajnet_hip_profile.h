@@ -30,6 +30,21 @@ TNP_API int tnp_profile_read(double *total_ms, int *launches);
 TNP_API int tnp_profile_dispatch_timed(void);
 TNP_API int tnp_profile_end(void);
 
+/* -------------------------------------------------------------------------------------------
+ * Tile-selection knobs (tests and tools/diag/small_step_probe.py pin a tile to show that results do not
+ * depend on it; a caller never needs them).  Process-wide, not thread-safe against running launches.
+ *   "sparse_tile"     value = (egos_per_tile << 8) | column_sets: tile of the sparse first embedding layer
+ *                     (64|2, 32|2, 32|1, 16|1, 8|1, 4|1); 0 = automatic (the largest tile that gives about
+ *                     one workgroup per CU).  Every tile gives the same result bit for bit.
+ *   "sparse_min_wg"   workgroups a tile must reach before the next smaller one is tried (0 = one per CU)
+ *   "skinny_max_rows" / "skinny_gates_max_rows"
+ *                     tracks up to which the 16-track register-operand GEMMs (csrc/gemm_skinny.hip) run the
+ *                     step's dense layers / LSTM gates (defaults 160 / 512; 0 = never)
+ * Initial values: environment TNP_SPARSE_TILE="te,ncs", TNP_SPARSE_MIN_WG, TNP_SKINNY_MAX_M (both),
+ * TNP_SKINNY_GATES_MAX_M.
+ * ----------------------------------------------------------------------------------------- */
+TNP_API int tnp_tuning_set(const char *key, long value);
+
 #ifdef __cplusplus
 }
 #endif

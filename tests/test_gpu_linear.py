@@ -38,6 +38,44 @@ def test_linear_matches_oracle(M, N, K, variant):
         assert err <= tol, (err, tol)
 
 
+SKINNY_SHAPES = [(1, 5, 16), (4, 256, 1024), (36, 256, 1024), (37, 250, 1024), (310, 1024, 256), (100, 576, 512), (17, 33, 288),
+                 (512, 256, 1024), (50, 70, 2048), (20, 16, 48)]
+
+
+@pytest.mark.parametrize('variant', [40, 41, 42, 43, 44, 45])
+@pytest.mark.parametrize('M,N,K', SKINNY_SHAPES)
+def test_skinny_linear_matches_oracle(M, N, K, variant):
+    """Round 6, csrc/gemm_skinny.hip: 16-track tiles, operands straight into registers, K over the waves of a workgroup (what the
+    step's dense layers run on up to 512 tracks): ragged M / N, K in chunks of 16, every (column tiles, K split) form."""
+    rng = np.random.RandomState(M + 7 * N + 13 * K)
+    x = rng.randn(M, K).astype(np.float32)
+    x[rng.rand(M, K) < 0.5] = 0.0
+    w = (rng.randn(N, K) / np.sqrt(K)).astype(np.float32)
+    b = rng.randn(N).astype(np.float32)
+    xd, wd, bd = torch.tensor(x).cuda(), torch.tensor(w).cuda(), torch.tensor(b).cuda()
+    for relu in (False, True):
+        want = oracle.linear(x, w, b, relu=relu)
+        out = torch.full((M + 1, N + 3), -7.0, device='cuda')
+        _lib.linear_forward(xd, wd, bd, relu=relu, variant=variant, out=out[:M, :N])
+        got = out.cpu().numpy()
+        assert np.all(got[M:] == -7.0) and np.all(got[:, N:] == -7.0)             # nothing written past the ragged edges
+        tol = 2e-6 * np.sqrt(K) * max(1.0, float(np.abs(want).max()))
+        err = float(np.abs(got[:M, :N] - want).max())
+        assert err <= tol, (err, tol)
+    # a row's sum does not depend on how many rows the call holds (batch invariance inside the regime)
+    if M > 1:
+        one = _lib.linear_forward(xd[M // 2:M // 2 + 1].contiguous(), wd, bd, relu=True, variant=variant)
+        assert torch.equal(one[0], out[M // 2, :N])
+
+
+def test_skinny_linear_refuses_unaligned_k():
+    x, w = torch.randn(8, 40, device='cuda'), torch.randn(8, 40, device='cuda')
+    with pytest.raises(RuntimeError, match='chunks of 16'):
+        _lib.linear_forward(x, w, None, variant=40)
+    got = _lib.linear_forward(x, w, None)                                          # automatic: falls to the 32-track kernels
+    assert (got - x @ w.t()).abs().max().item() < 1e-4
+
+
 def test_linear_transpose_detecting():
     """A = I with an asymmetric W: catches swapped rows / columns in the accumulator mapping."""
     K = 64

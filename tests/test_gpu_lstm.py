@@ -269,21 +269,26 @@ def test_config4_full_size_sgan_forward_properties():
 
 
 def test_gates_kernel_variants_agree():
-    """The LSTM-gates GEMM has four tilings (tnp_lstm_model.variant bits 8-15: 5 = 128-track tiles, 20 = split-K 4 per
-    workgroup, 21 = one gate block per wave, 22 = 21 with the K range over two wave quartets; 0 picks 22 here): same forward
-    within fp32 summation order."""
+    """The LSTM-gates GEMM has four 32-track tilings (tnp_lstm_model.variant bits 8-15: 5 = 128-track tiles, 20 = split-K 4 per
+    workgroup, 21 = one gate block per wave, 22 = 21 with the K range over two wave quartets) and, round 6, the 16-track
+    register-operand tiles of csrc/gemm_skinny.hip (30 .. 34; 0 picks 34 up to 512 tracks): same forward within fp32
+    summation order; the automatic choice is one of them, bit for bit."""
     model = _config2_model(seed=4).cuda().eval()
     xy, split = synth.ragged_crowd(12, 5, 30, seed=21)
+    assert xy.shape[1] <= 512
     goals = torch.zeros(xy.shape[1], 2)
     outs = {}
     with torch.no_grad():
-        for v in (0, 5, 20, 21, 22):
+        for v in (0, 5, 20, 21, 22, 30, 31, 32, 33, 34):
             model.kernel_variant = v << 8
             outs[v] = model(xy[:9], goals, split, n_predict=12)[1]
     model.kernel_variant = 0
-    assert torch.equal(torch.nan_to_num(outs[0]), torch.nan_to_num(outs[22]))
-    for v in (5, 20, 21):
+    assert torch.equal(torch.nan_to_num(outs[0]), torch.nan_to_num(outs[34]))
+    for v in (5, 20, 21, 30, 31, 32, 33, 34):
         assert (torch.nan_to_num(outs[v]) - torch.nan_to_num(outs[22])).abs().max().item() < 2e-5
+    # the K split of a 16-track tile does not depend on how many column groups share the workgroup
+    assert torch.equal(torch.nan_to_num(outs[30]), torch.nan_to_num(outs[31])) and torch.equal(torch.nan_to_num(outs[32]), torch.nan_to_num(outs[33]))
+    assert torch.equal(torch.nan_to_num(outs[30]), torch.nan_to_num(outs[34]))
 
 
 def _counted_flip_check(got, want, what, tol=2e-5, flip_frac=0.01, flip_tol=5e-3):

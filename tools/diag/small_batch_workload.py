@@ -23,7 +23,7 @@ if mode == 'predict':
         for sc in scenes[:n]:
             obs = torch.tensor(sc[:9], dtype=torch.float32, device=device)
             model(obs, torch.zeros(sc.shape[1], 2, device=device), torch.tensor([0, sc.shape[1]]), n_predict=12)
-else:
+elif mode == "train":
     optimizer = bench.make_adam(model.parameters())
     batcher = trajdata.SceneBatcher(scenes, device=device, drop_distant_r=None)
     rng = random.Random(7)
@@ -32,3 +32,42 @@ else:
         bxy, bgoals, bsplit = batcher.batch(ids, augment=True)
         train_batch(model, optimizer, PredictionLoss(), bxy, bgoals, bsplit, 9, 12, batch_size=8)
 torch.cuda.synchronize()
+if mode == 'train_hostprofile':
+    # where the HOST spends a batch_size-8 optimisation step (the loop is host-enqueue bound)
+    import cProfile, pstats, time
+    optimizer = bench.make_adam(model.parameters())
+    batcher = trajdata.SceneBatcher(scenes, device=device, drop_distant_r=None)
+    rng = random.Random(7)
+    crit = PredictionLoss()
+    def one():
+        ids = [rng.randrange(len(scenes)) for _ in range(8)]
+        bxy, bgoals, bsplit = batcher.batch(ids, augment=True)
+        train_batch(model, optimizer, crit, bxy, bgoals, bsplit, 9, 12, batch_size=8)
+    for _ in range(80):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one()
+    th = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    print('%.3f ms host enqueue, %.3f ms per step' % (th / n * 1e3, (time.perf_counter() - t0) / n * 1e3))
+    torch.autograd.set_multithreading_enabled(False)      # backward on THIS thread: cProfile sees inside it
+    for _ in range(20):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one()
+    th = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    print('single-threaded autograd: %.3f ms host enqueue, %.3f ms per step' % (th / n * 1e3, (time.perf_counter() - t0) / n * 1e3))
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(n):
+        one()
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats('cumulative').print_stats(60)
+    st.sort_stats('tottime').print_stats(35)

@@ -105,6 +105,7 @@ def lib():
     L.tnp_profile_begin.argtypes = [ctypes.c_int]
     L.tnp_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     L.tnp_profile_dispatch_timed.argtypes = []
+    L.tnp_tuning_set.argtypes = [ctypes.c_char_p, ctypes.c_long]
     L.tnp_constant_velocity.argtypes = [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp]
     L.tnp_pool_embed_sparse_workspace_bytes.restype = ctypes.c_size_t
     L.tnp_pool_embed_sparse_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -191,14 +192,26 @@ def lib():
     return L
 
 
+def tuning_set(key, value):
+    """Tile-selection knob of the native library (include/trajnet_hip_profile.h: tests and probes only)."""
+    check(lib().tnp_tuning_set(key.encode(), int(value)), 'tnp_tuning_set')
+
+
 def check(rc, what):
     if rc != 0:
         msg = lib().tnp_last_error().decode('utf-8', 'replace')
         raise RuntimeError('%s failed (%d): %s' % (what, rc, msg))
 
 
+def raw_stream():
+    """The CURRENT device's current HIP stream as an integer.  (``torch.cuda.current_stream().cuda_stream`` builds a Stream
+    object through five layers of device-index helpers: 9 us a call, 32 calls per optimisation step = 0.28 ms of a
+    batch_size-8 step's 2.3 ms of host time -- tools/diag/small_batch_workload.py train_hostprofile.)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(raw_stream())
 
 
 def ptr(t):
@@ -285,10 +298,13 @@ class StreamMark(object):
         # the CURRENT device's current stream: the one _lib.stream_ptr() hands to every native launch
         self.device = None
         self.stream = torch.cuda.current_stream()
+        self.raw = self.stream.cuda_stream
         self.event = torch.cuda.Event()
         self.event.record(self.stream)
 
     def join(self):
+        if raw_stream() == self.raw:
+            return          # the common case: same stream, ordered anyway
         if torch.cuda.is_current_stream_capturing():
             return          # hipGraph capture (LSTM._forward_graphed): the capture begins after a device synchronisation
         cur = torch.cuda.current_stream(self.device)

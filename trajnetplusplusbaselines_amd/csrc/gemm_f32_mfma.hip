@@ -20,6 +20,7 @@
 //   the i,f,g,o gates of 32 hidden units, so one lane holds all four gates of its (track, unit) pairs.
 #include <cstdlib>
 #include "tnp_internal.h"
+#include "lstm_cell.h"
 
 #include <stdlib.h>
 #include <utility>
@@ -73,65 +74,6 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
     const int rows = min(PM, tiles_m - p * PM);
     tm = p * PM + within % rows;
     tn = within / rows;
-}
-
-// LSTMCell activations on the hardware transcendental units: sigmoid(x) = rcp(1 + exp(-x)) with v_exp_f32 / v_rcp_f32
-// (1 ulp each), tanh(x) = 2 sigmoid(2x) - 1 (absolute error ~1e-7).  libm's expf / tanhf and an IEEE divide are 20 precise
-// transcendentals per lane = 6 k of the gates kernel's 32 k cycles; with these the step is 1 us shorter (1.6 % of the forward)
-// and the distance to the oracle does not move: max |pred - oracle| at config 2 full size 2.9e-6 against 2.4e-6 (summation
-// order dominates both; tests/parity_margin.py), all parity tests unchanged.  -DTNP_PRECISE_GATES restores libm.
-#ifndef TNP_PRECISE_GATES
-__device__ __forceinline__ float sigmoidf_acc(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_acc(float x) { return fmaf(2.0f, sigmoidf_acc(2.0f * x), -1.0f); }
-#else
-__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float tanhf_acc(float x) { return tanhf(x); }
-#endif
-
-// One (track, unit) of torch.nn.LSTMCell from the four gate pre-activations (bias included).
-__device__ __forceinline__ void lstm_cell_store(const GemmArgs &g, int row, int unit, float pi, float pf, float pg,
-                                                float po) {
-    if (row >= g.M) return;
-    const size_t o = (size_t)row * g.H + unit;
-    if (g.mask[row]) {
-        const float ig = sigmoidf_acc(pi);
-        const float fg = sigmoidf_acc(pf);
-        const float gg = tanhf_acc(pg);
-        const float og = sigmoidf_acc(po);
-        const float cn = fg * g.c_in[o] + ig * gg;
-        g.c_out[o] = cn;
-        g.h_out[o] = og * tanhf_acc(cn);
-        if (g.gates_out) {
-            float *go = g.gates_out + (size_t)row * 4 * g.H + unit;
-            go[0] = ig; go[g.H] = fg; go[2 * g.H] = gg; go[3 * g.H] = og;
-        }
-    } else {  // absent track: state frozen (reference lstm/lstm.py:118-124,158-166)
-        g.c_out[o] = g.c_in[o];
-        g.h_out[o] = g.h_in[o];
-    }
-}
-
-// same, with c_in / mask of the (row, unit) fetched by the caller before its main loop
-__device__ __forceinline__ void lstm_cell_store_pf(const GemmArgs &g, int row, int unit, float pi, float pf, float pg,
-                                                   float po, float c_prev, int present) {
-    if (row >= g.M) return;
-    const size_t o = (size_t)row * g.H + unit;
-    if (present) {
-        const float ig = sigmoidf_acc(pi);
-        const float fg = sigmoidf_acc(pf);
-        const float gg = tanhf_acc(pg);
-        const float og = sigmoidf_acc(po);
-        const float cn = fg * c_prev + ig * gg;
-        g.c_out[o] = cn;
-        g.h_out[o] = og * tanhf_acc(cn);
-        if (g.gates_out) {
-            float *go = g.gates_out + (size_t)row * 4 * g.H + unit;
-            go[0] = ig; go[g.H] = fg; go[2 * g.H] = gg; go[3 * g.H] = og;
-        }
-    } else {
-        g.c_out[o] = c_prev;
-        g.h_out[o] = g.h_in[o];
-    }
 }
 
 // Split-K reduction fused with the LSTM epilogue, spread over ALL WK k-group waves: wave kg owns accumulator
@@ -1027,12 +969,26 @@ static int compute_units() {
     return n;
 }
 
+// Rows up to which the 16-track kernels of gemm_skinny.hip take the step's dense layers (Tuning::skinny_max_rows, 160) and
+// which of them.  Device time per launch (rocprofv3, tools/diag/gemm_device_times.py -> profiles/round6_gemm_device_times.txt):
+// second embedding layer [M,1024]x[256,1024]^T at 36 tracks 6.8 us (v40) against 9.1 (v29), its data gradient 5.1 (v45)
+// against 5.7, the gates' data gradient 5.1 against 6.8; from ~200 tracks on the 32 x 32 tiles with K over eight waves are
+// ahead again (310 tracks: 8.8 against 10.3).  One column tile per workgroup (variants 40 / 45) is the best form throughout.
+static int skinny_max_rows() { return tuning().skinny_max_rows; }
+static int skinny_linear_variant(const GemmArgs &g) { return g.K1 + g.K2 >= 1024 ? 40 : 45; }
+
 int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
     GemmArgs g = g_in;
     check_vec(g);
     const long big_tiles = (long)((g.M + 127) / 128) * ((g.N + 63) / 64);
     // tile selection measured on MI355X (profiles/archive/round1_b_variant_sweep.jsonl): 64x64 tiles when they fill the chip, else
     // the pipelined 32x64 split-K 2 kernel; `variant` pins one of the two (12 / 24), anything else is an error
+    if (variant >= 40 && variant <= 45) return launch_skinny_linear(g, variant, s);
+    if (variant == 0 && g.M <= skinny_max_rows() && skinny_ok(g)) {
+        // SMALL batches (one scene, a batch_size-8 training batch): 16-track tiles with the operands straight in registers
+        // (gemm_skinny.hip; tools/diag/small_step_probe.py, profiles/round6_small_step_probe.txt)
+        return launch_skinny_linear(g, skinny_linear_variant(g), s);
+    }
     if (variant == 0) {
         variant = (big_tiles >= 192) ? 12 : 24;
         // 64 x 64 tiles, at most four rounds of workgroups: the PIPELINED form (three-stage LDS ring, interleaved schedule) of the
@@ -1165,6 +1121,10 @@ int launch_lstm_gates(const GemmArgs &g_in, int variant, hipStream_t s) {
     // H = 128) -> the gate split with the K range over two wave quartets (22: eight waves, two per SIMD; 1.046 -> 1.068 M
     // scene-steps/s on the headline); several rounds -> the four-wave gate split (21: two workgroups co-resident per CU; at
     // 4096 tracks 2.13 ms per forward against 2.47 with the 128-track tiles); from 8192 tracks the 128-track kernel (5)
+    if (variant >= 30 && variant <= 34) return launch_skinny_gates(g, variant, s);
+    // up to 512 tracks the 16-track gates kernel (16 tracks x 4 units per workgroup, K over four waves: variant 34) -- one
+    // 36-agent scene 8.0 us against 14.2, a batch_size-8 training batch (310 tracks) 11.2 against 14.7 (profiles/round6_small_*)
+    if (variant == 0 && g.M <= tuning().skinny_gates_max_rows && g.H % 4 == 0 && skinny_ok(g)) return launch_skinny_gates(g, 34, s);
     if (variant == 0) {
         const long wgs = (long)((g.M + 31) / 32) * ((g.H + 31) / 32);
         if (g.M >= 8192) variant = 5;

@@ -16,8 +16,23 @@
 
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
+#include <string>
 
 namespace tnp {
+
+Tuning &tuning() {
+    static Tuning t = [] {
+        Tuning v = {0, 0, 0, 160, 512};
+        const char *e = getenv("TNP_SPARSE_TILE");
+        if (e && sscanf(e, "%d,%d", &v.sparse_te, &v.sparse_ncs) != 2) v.sparse_te = v.sparse_ncs = 0;
+        if ((e = getenv("TNP_SPARSE_MIN_WG")) != nullptr) v.sparse_min_wg = atol(e);
+        if ((e = getenv("TNP_SKINNY_MAX_M")) != nullptr) v.skinny_max_rows = v.skinny_gates_max_rows = atoi(e);
+        if ((e = getenv("TNP_SKINNY_GATES_MAX_M")) != nullptr) v.skinny_gates_max_rows = atoi(e);
+        return v;
+    }();
+    return t;
+}
 
 static thread_local char g_err[512] = "";
 void set_error(const char *fmt, ...) {
@@ -1007,6 +1022,17 @@ extern "C" TNP_API int tnp_linear_forward(const float *A, int lda, const float *
     int rc = launch_linear(g, variant, (hipStream_t)stream);
     prof_after(PROF_GEMM1, (hipStream_t)stream);
     return rc;
+}
+
+extern "C" TNP_API int tnp_tuning_set(const char *key, long value) {
+    tnp::Tuning &t = tnp::tuning();
+    const std::string k = key ? key : "";
+    if (k == "sparse_tile") { t.sparse_te = (int)(value >> 8); t.sparse_ncs = (int)(value & 0xff); }
+    else if (k == "sparse_min_wg") t.sparse_min_wg = value;
+    else if (k == "skinny_max_rows") t.skinny_max_rows = (int)value;
+    else if (k == "skinny_gates_max_rows") t.skinny_gates_max_rows = (int)value;
+    else TNP_FAIL(-1, "tnp_tuning_set: unknown key '%s' (sparse_tile, sparse_min_wg, skinny_max_rows, skinny_gates_max_rows)", k.c_str());
+    return 0;
 }
 
 extern "C" TNP_API int tnp_profile_begin(int which) {

@@ -28,14 +28,17 @@
 // packed-FMA hit; blocks b, b+8, ... share an XCD and a column block, whose weight slice stays in that XCD's L2.
 #include "tnp_internal.h"
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 
 // Timing ablations and shader-clock stamps exist only in builds of tools/experiments/*.hip, which define
 // TNP_EXPERIMENT_HOOKS before including this file; the library compiles none of it.
 #ifdef TNP_EXPERIMENT_HOOKS
 #define TNP_ABL_TPARAM , int ABL = 0
+#define TNP_ABL_ARG , 0
 #define TNP_ABL(bits) ((ABL & (bits)) != 0)
 #else
 #define TNP_ABL_TPARAM
+#define TNP_ABL_ARG
 #define TNP_ABL(bits) false
 #endif
 
@@ -592,27 +595,36 @@ __global__ void __launch_bounds__(64 * NQ * (OB / 64)) pool_embed_cellsplit_kern
 constexpr int RA_TE = 64, RA_OB = 128, RA_NQ = 8, RA_NCS = RA_OB / 64, RA_RED = 32;
 typedef float ra_f32x32 __attribute__((ext_vector_type(32)));
 
-constexpr int RA_KS = RA_TE + 1;   // row stride of the transposed key table (odd: conflict-free both ways)
-static size_t ra_smem_bytes(int ncell) {
-    const size_t keys = (((size_t)ncell * RA_KS * 4 + 15) & ~(size_t)15) + (size_t)ncell * 4 + 6 * RA_TE * 4;
-    const size_t red = (size_t)RA_NQ * RA_RED * RA_OB * 4;
+// (row stride of the transposed key table = TE + 1: odd, conflict-free both ways)
+static size_t ra_smem_bytes(int ncell, int te = RA_TE, int ncs = RA_NCS) {
+    const size_t keys = (((size_t)ncell * (te + 1) * 4 + 15) & ~(size_t)15) + (size_t)ncell * 4 + 6 * te * 4;
+    const size_t red = (size_t)RA_NQ * (te < RA_RED ? te : RA_RED) * (64 * ncs) * 4;
     return keys > red ? keys : red;
 }
 
 // QW: weights in the quad-major layout W''[c][o / 64][ch / 4][o % 64][ch % 4] (one scalar base per cell and column block,
 // one 16-byte load per lane and channel quad); else the cell-major W'[c][ch][o].
-template <int C, bool FG, bool QW TNP_ABL_TPARAM>
-__global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(const SparseArgs a) {
-    constexpr int TE = RA_TE, OB = RA_OB, NQ = RA_NQ, NCS = RA_NCS, NTH = 64 * NQ * NCS, NW = NTH / 64;
+//
+// SMALL batches (round 6): TE (egos per tile: 4 .. 64) and NCS (column sets: OB = 64 NCS) are template parameters.  At 2048
+// tracks the 64 x 128 tile gives exactly one round of 256 workgroups; one scene (36 tracks) on that tile is 8 workgroups,
+// each streaming 2 MB of weights through ONE CU's L1 (64 B / clk: 13 us) with 248 CUs idle.  A smaller tile has fewer hits
+// per wave AND fewer occupied cells, i.e. less weight traffic per workgroup, and needs no partial sums (the cell split across
+// workgroups of the fallback kernel would).  NQ = 8 and the cell -> group map stay, so an ego's sum has the same order on
+// every tile: the result does not depend on the tile size, bit for bit.
+template <int C, bool FG, bool QW TNP_ABL_TPARAM, int TE = RA_TE, int NCS = RA_NCS>
+__global__ void __launch_bounds__(64 * RA_NQ * NCS) pool_embed_regacc_kernel(const SparseArgs a) {
+    constexpr int OB = 64 * NCS, NQ = RA_NQ, NTH = 64 * NQ * NCS, NW = NTH / 64;
+    constexpr int RED = TE < RA_RED ? TE : RA_RED;                                    // egos per epilogue round
+    static_assert(TE == 4 || TE == 8 || TE == 16 || TE == 32 || TE == 64, "ego tile");
     extern __shared__ __attribute__((aligned(16))) float rsm[];
     // keys [ncell][KS]: key of (cell, ego) = 2 * neighbour + in_range, -1 = empty -- written by LDS integer max ("last writer
     // in ascending j wins"), read by the cell loop as one row per cell (lane <-> ego)
-    constexpr int KS = RA_KS;
+    constexpr int KS = TE + 1;
     int *keyT = reinterpret_cast<int *>(rsm);
     int *socc = keyT + (((size_t)a.ncell * KS + 3) & ~(size_t)3);                   // [ncell] cell may have a hit in the tile
     int *sg = socc + a.ncell;                                                       // lo / ns / ki / pad [TE] each, then x / y
     float *sp = reinterpret_cast<float *>(sg + 4 * TE);
-    float *red = rsm;                                                               // epilogue: [NQ][RA_RED][OB]
+    float *red = rsm;                                                               // epilogue: [NQ][RED][OB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cs = wave % NCS, q = wave / NCS;
@@ -689,7 +701,8 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
         __syncthreads();
         RA_T(1);
         const float fG = (float)a.G;
-        constexpr int EU = TE / NW;
+        constexpr int EU = TE >= NW ? TE / NW : 1;                  // egos per wave (tiles smaller than the wave count: waves >= TE sit out)
+        static_assert(TE < NW || TE % NW == 0, "egos per wave");
         // branch-free votes: every lane computes its (ego, neighbour) pair, invalid ones are masked at the atomic only.  A
         // cell other than 0 that receives an in-range vote ends up with an in-range winner; cell 0 may still be clobbered
         // (then the cell loop finds no hit there: harmless).
@@ -704,7 +717,7 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
                 if (inr) socc[cellid] = 1;
             }
         };
-        if constexpr (!TNP_ABL(32)) {
+        if (!TNP_ABL(32) && (TE >= NW || wave < TE)) {
             const int e0 = wave * EU;
             int lo[EU], ns[EU], ki[EU], pad[EU];
             float px[EU], py[EU];
@@ -722,7 +735,7 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
                 // two egos per pass: lanes 0-31 vote for ego e0 + 2 p, lanes 32-63 for ego e0 + 2 p + 1 (half the vector work
                 // of the one-ego-per-pass form below for scenes that fill half a wave; the votes themselves are the same)
                 const int hi = lane >> 5, j = lane & 31;
-                float2 pq[EU / 2];
+                float2 pq[EU >= 2 ? EU / 2 : 1];
 #pragma unroll
                 for (int p = 0; p < EU / 2; ++p) {
                     const int lo_ = hi ? lo[2 * p + 1] : lo[2 * p], ns_ = hi ? ns[2 * p + 1] : ns[2 * p];
@@ -775,18 +788,21 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
         __syncthreads();
     }
     int rb;
-    if constexpr (FG) rb = sg[lane];
-    else rb = a.row_base[min(row0 + lane, a.M - 1)];
+    if constexpr (FG) rb = sg[TE == 64 ? lane : (lane & (TE - 1))];
+    else rb = a.row_base[min(row0 + (TE == 64 ? lane : (lane & (TE - 1))), a.M - 1)];
     asm volatile("" : "+v"(rb));
     RA_T(3);
 
-    const int col2 = 2 * lane;                                                      // this lane's column pair in the epilogue
+    const int col2 = 2 * (tid & (OB / 2 - 1));                                      // this thread's column pair in the epilogue
     float2 bias2 = {0.0f, 0.0f};                                                    // fetched here: after the cell loop its latency would be exposed
     if (a.bias && ob * OB + col2 + 1 < a.N1) bias2 = *reinterpret_cast<const float2 *>(a.bias + ob * OB + col2);
     asm volatile("" : "+v"(bias2));                                                 // landed before the loop (see rb above)
-    ra_f32x32 accA, accB;                                                           // egos 0..31 / 32..63 of the tile, this lane's column
+    // egos 0..31 / 32..63 of the tile, this lane's column (tiles of <= 32 egos: accA alone, TE entries)
+    constexpr int AE = TE < 32 ? TE : 32;
+    typedef float ra_acc __attribute__((ext_vector_type(AE)));
+    ra_acc accA, accB;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) { accA[i] = 0.0f; accB[i] = 0.0f; }
+    for (int i = 0; i < AE; ++i) { accA[i] = 0.0f; accB[i] = 0.0f; }
 
     const unsigned vo = ocu * 4u;
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -855,7 +871,7 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
         return p.x + p.y;
     };
     // the hits of one half of the tile (32 egos, bits of `m`) against the accumulator vector of that half
-    auto half = [&](const WS &w, ra_f32x32 &acc, unsigned m, unsigned off, int lane0) {
+    auto half = [&](const WS &w, ra_acc &acc, unsigned m, unsigned off, int lane0) {
         // (pops as s_ff1 + s_bitset0 and a hit counter for the loop test: `m &= m - 1` twice plus `m & (m - 1)` are seven
         // scalar instructions per pair of hits, this is six less one)
         int left = __popc(m);
@@ -880,13 +896,14 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
         }
     };
     auto process = [&](WS &w, int kq) {                                              // kq = keyT[cell][lane]: lane <-> ego of the tile
+        if constexpr (TE < 64) kq = lane < TE ? kq : -1;                             // (lanes past the tile read the next cell's row)
         const int wv = (kq >= 0 && (kq & 1)) ? (kq >> 1) : -1;
         const unsigned long long mask = __ballot(wv >= 0);
         wait_w(w);
         if constexpr (TNP_ABL(2)) { if (mask == 1234567ull) accA[0] += wch(w, 0) + wch(w, C - 1); return; }
         const unsigned off = __umul24((unsigned)(rb + wv), (unsigned)(a.ldv * 4));
         half(w, accA, (unsigned)mask, off, 0);
-        half(w, accB, (unsigned)(mask >> 32), off, 32);
+        if constexpr (TE == 64) half(w, accB, (unsigned)(mask >> 32), off, 32);
     };
     // cells of this wave's group with a hit in the tile; group q takes cell NQ k + ((q - k) mod NQ) of every block k of NQ cells
     const int nk = (a.ncell + NQ - 1) / NQ;                                          // <= 64: ncell <= 512
@@ -928,30 +945,46 @@ __global__ void __launch_bounds__(64 * RA_NQ * RA_NCS) pool_embed_regacc_kernel(
     // ---- the 8 cell groups' partial sums, 32 egos per round: every wave leaves its partials in LDS, then wave w sums the
     //      copies of egos w and w + 16 of the round in fixed order (group 0 + 1 + ... + 7), bias + activation, coalesced rows
     if constexpr (TNP_ABL(128)) { if (accA[3] + accB[5] == 1.234e30f) a.out[tid] = 0.0f; return; }
+    // (thread t takes the column pairs t, t + NTH, ... of the round's RED x OB / 2: ego (t + NTH h) / (OB / 2), the same pair every time)
+    constexpr int ITEMS = RED * (OB / 2);
 #pragma unroll
-    for (int r = 0; r < TE / RA_RED; ++r) {
+    for (int r = 0; r < TE / RED; ++r) {
         __syncthreads();                                                            // prologue data / previous round no longer read
 #pragma unroll
-        for (int e = 0; e < RA_RED; ++e)
-            red[(q * RA_RED + e) * OB + cs * 64 + lane] = r == 0 ? accA[e] : accB[e];
+        for (int e = 0; e < RED; ++e)
+            red[(q * RED + e) * OB + cs * 64 + lane] = r == 0 ? accA[e] : accB[e];
         __syncthreads();
 #pragma unroll
-        for (int h = 0; h < RA_RED / NW; ++h) {
-            const int e = wave + NW * h;
+        for (int h = 0; h < (ITEMS + NTH - 1) / NTH; ++h) {
+            const int e = (tid + NTH * h) / (OB / 2);
+            if (ITEMS % NTH != 0 && e >= RED) break;
             float2 v = *reinterpret_cast<const float2 *>(red + (size_t)e * OB + col2);
 #pragma unroll
             for (int qq = 1; qq < NQ; ++qq) {
-                const float2 t = *reinterpret_cast<const float2 *>(red + ((size_t)qq * RA_RED + e) * OB + col2);
+                const float2 t = *reinterpret_cast<const float2 *>(red + ((size_t)qq * RED + e) * OB + col2);
                 v.x += t.x; v.y += t.y;
             }
             v.x += bias2.x; v.y += bias2.y;
             if (a.relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); }
-            const int row = row0 + RA_RED * r + e;
+            const int row = row0 + RED * r + e;
             if (row < a.M && ob * OB + col2 + 1 < a.N1) *reinterpret_cast<float2 *>(a.out + (size_t)row * a.ldo + ob * OB + col2) = v;
         }
     }
     RA_T(5);
 #undef RA_T
+}
+
+// workgroups a smaller tile must reach before the next smaller one is tried: about half a round (a workgroup of the smaller
+// tile streams fewer weights, but all of them together stream more)
+static long sparse_tile_min_workgroups() {
+    if (tuning().sparse_min_wg > 0) return tuning().sparse_min_wg;
+    static long cus = 0;
+    if (cus == 0) {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+        cus = cu;
+    }
+    return cus;
 }
 
 bool regacc_supported(int C, int ncell) { return (C == 4 || C == 8 || C == 16) && ncell <= 64 * RA_NQ && ra_smem_bytes(ncell) <= (size_t)160 * 1024; }
@@ -999,21 +1032,40 @@ int launch_pool_embed_sparse(const int16_t *winners, const float *enc, int ldv, 
             a.obs2 = fg->obs2; a.row_end = fg->row_end; a.row_padded = fg->row_padded; a.G = fg->G;
             a.cell = fg->cell; a.half_x = fg->half_x; a.half_y = fg->half_y; a.winners_out = fg->winners_out;
         }
-        const size_t rsmem = ra_smem_bytes(ncell);
-        const int rblocks = a.ego_tiles * a.out_blocks;
         const bool quad = Wq != nullptr && fg != nullptr && N1 % 64 == 0 && C % 4 == 0 &&
                           (size_t)ncell * N1 * C * 4 < ((size_t)1 << 31);   // 32-bit byte offsets of the cells' weight blocks
         if (quad) a.Wp = Wq;
+        // Tile: 64 egos x 128 columns when that fills the chip (2048 tracks x 1024 columns = 256 workgroups), else the largest
+        // tile that still gives about one workgroup per CU (quad-major weights only) -- see the note in front of the kernel.
+        // Tuning::sparse_te / sparse_ncs (TNP_SPARSE_TILE="te,ncs", tnp_tuning_set) pin one: tests, tools/diag/small_step_probe.py.
+        int te = RA_TE, ncs = RA_NCS;
+        if (quad) {
+            static const int tiles[][2] = {{64, 2}, {32, 2}, {32, 1}, {16, 1}, {8, 1}, {4, 1}};
+            const int pin_te = tuning().sparse_te, pin_ncs = tuning().sparse_ncs;
+            const long want = sparse_tile_min_workgroups();
+            for (const auto &t : tiles) {
+                te = t[0]; ncs = t[1];
+                if (pin_te > 0 ? (te == pin_te && ncs == pin_ncs) : ((long)((M + te - 1) / te) * ((N1 + 64 * ncs - 1) / (64 * ncs)) >= want)) break;
+            }
+            if (pin_te > 0 && !(te == pin_te && ncs == pin_ncs)) TNP_FAIL(-1, "TNP_SPARSE_TILE=%d,%d is not a tile of the sparse first layer", pin_te, pin_ncs);
+        }
+        a.ego_tiles = (M + te - 1) / te; a.out_blocks = (N1 + 64 * ncs - 1) / (64 * ncs);
+        const size_t rsmem = ra_smem_bytes(ncell, te, ncs) + 256;   // (+ 256: lanes past a small tile read behind the last key row)
+        const int rblocks = a.ego_tiles * a.out_blocks;
         hipEvent_t pe0 = nullptr, pe1 = nullptr;
         const bool pev = take_dispatch_events(&pe0, &pe1);   // profiling: events of the dispatch itself (tnp_internal.h)
-#define RA_LAUNCH(CC, FGB, QB) { static bool set = false; if (!set) { hipFuncAttributes fa; \
-        TNP_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(pool_embed_regacc_kernel<CC, FGB, QB>))); \
+#define RA_LAUNCH(CC, FGB, QB, TEE, NCC) { static bool set = false; auto kern = pool_embed_regacc_kernel<CC, FGB, QB TNP_ABL_ARG, TEE, NCC>; \
+        if (!set) { hipFuncAttributes fa; \
+        TNP_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern))); \
         if (fa.localSizeBytes != 0) TNP_FAIL(-3, "pool_embed_regacc_kernel: accumulators left the register file (%zu bytes of scratch)", (size_t)fa.localSizeBytes); \
-        TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>( \
-        pool_embed_regacc_kernel<CC, FGB, QB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
-        if (pev) hipExtLaunchKernelGGL((pool_embed_regacc_kernel<CC, FGB, QB>), dim3(rblocks), dim3(64 * RA_NQ * RA_NCS), rsmem, s, pe0, pe1, 0, a); \
-        else hipLaunchKernelGGL((pool_embed_regacc_kernel<CC, FGB, QB>), dim3(rblocks), dim3(64 * RA_NQ * RA_NCS), rsmem, s, a); }
-#define RA_SWITCH(CC) { if (quad) RA_LAUNCH(CC, true, true) else if (fg) RA_LAUNCH(CC, true, false) else RA_LAUNCH(CC, false, false) }
+        TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } \
+        if (pev) hipExtLaunchKernelGGL(kern, dim3(rblocks), dim3(64 * RA_NQ * NCC), rsmem, s, pe0, pe1, 0, a); \
+        else hipLaunchKernelGGL(kern, dim3(rblocks), dim3(64 * RA_NQ * NCC), rsmem, s, a); }
+#define RA_SWITCH(CC) { if (quad) { \
+            if (te == 64) RA_LAUNCH(CC, true, true, 64, 2) else if (te == 32 && ncs == 2) RA_LAUNCH(CC, true, true, 32, 2) \
+            else if (te == 32) RA_LAUNCH(CC, true, true, 32, 1) else if (te == 16) RA_LAUNCH(CC, true, true, 16, 1) \
+            else if (te == 8) RA_LAUNCH(CC, true, true, 8, 1) else RA_LAUNCH(CC, true, true, 4, 1) } \
+        else if (fg) RA_LAUNCH(CC, true, false, 64, 2) else RA_LAUNCH(CC, false, false, 64, 2) }
         if (C == 4) RA_SWITCH(4) else if (C == 8) RA_SWITCH(8) else RA_SWITCH(16)
         TNP_HIP(hipGetLastError());
         return 0;

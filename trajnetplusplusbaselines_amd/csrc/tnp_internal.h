@@ -16,6 +16,15 @@ void set_error(const char *fmt, ...);
 #define TNP_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     ::tnp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return -2; } } while (0)
 
+// ---- tile-selection knobs (tnp_tuning_set; initial values from the environment, read once) ------------------------------
+struct Tuning {
+    int sparse_te, sparse_ncs;   // pinned tile of the sparse first layer (0 = automatic)          TNP_SPARSE_TILE="te,ncs"
+    long sparse_min_wg;          // workgroups a tile must reach before a smaller one is tried (0 = one per CU)   TNP_SPARSE_MIN_WG
+    int skinny_max_rows;         // rows up to which gemm_skinny.hip takes the dense layers                        TNP_SKINNY_MAX_M
+    int skinny_gates_max_rows;   // ... and the LSTM gates                                                          TNP_SKINNY_GATES_MAX_M
+};
+Tuning &tuning();
+
 // ---- GEMM on the matrix cores ---------------------------------------------------------------
 enum { EPI_BIAS = 0, EPI_LSTM = 1 };
 
@@ -51,6 +60,10 @@ struct GemmArgs {
 int launch_linear(const GemmArgs &g, int variant, hipStream_t s);
 // fused LSTM gates GEMM + cell update
 int launch_lstm_gates(const GemmArgs &g, int variant, hipStream_t s);
+// small batches (gemm_skinny.hip): 16-track tiles, operands straight into registers; variants 40 .. 45 / 30 .. 34
+bool skinny_ok(const GemmArgs &g);
+int launch_skinny_linear(const GemmArgs &g, int variant, hipStream_t s);
+int launch_skinny_gates(const GemmArgs &g, int variant, hipStream_t s);
 // last embedding layer (producer) + LSTM gates (consumer) in ONE launch with per-row-tile arrival counters (gemm_f32_mfma.hip):
 // flags = [ceil(M/32) + 1] unsigned zeroed at the start of the forward pass, epoch = 1, 2, ... per step.  Returns 1 when the
 // pair of shapes is not eligible (the caller then launches the two kernels on their own).

@@ -321,7 +321,7 @@ class LSTM(torch.nn.Module):
         # the recurrent state and scratch buffers
         if not isinstance(self._ws, dict):
             self._ws = {}
-        sk = torch.cuda.current_stream().cuda_stream          # what _lib.stream_ptr() launches on
+        sk = _lib.raw_stream()                                # what _lib.stream_ptr() launches on
         ws = self._ws.get(sk)
         if ws is None or ws.numel() < need or ws.device != dev:
             if len(self._ws) >= 8:                # streams come and go: keep the most recently created workspaces only
@@ -439,7 +439,7 @@ class LSTM(torch.nn.Module):
         # ... and the scene structure enters by CONTENT (SceneIndex.key), not by object identity: clearing SceneIndex._cache
         # must not orphan captured graphs (they would pin their private pools until evicted)
         key = (bytes(m), getattr(idx, 'key', idx), T_obs, T_dec, truth is not None, goals_t is not None,
-               torch.cuda.current_stream().cuda_stream)
+               _lib.raw_stream())
         if not isinstance(self._graphs, dict):
             self._graphs = {}
         e = self._graphs.get(key)
