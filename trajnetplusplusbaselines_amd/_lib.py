@@ -257,19 +257,42 @@ def h2d_async(t, device):
     s = _staging
     k = s.k
     s.k = (k + 1) % len(s.slots)
-    if s.events[k] is not None:
-        s.events[k].synchronize()
+    ev = s.events[k]
+    if ev is not None:
+        ev.synchronize()
+    else:
+        ev = s.events[k] = torch.cuda.Event()          # one event per slot, re-recorded: no construction per copy
     buf = s.slots[k]
     if buf is None or buf.numel() < nbytes:
         buf = s.slots[k] = torch.empty(max(1 << 16, 1 << (nbytes - 1).bit_length()), dtype=torch.uint8, pin_memory=True)
     view = buf[:nbytes].view(t.dtype).view(t.shape)
     view.copy_(t)
-    with torch.cuda.device(device):
+    device = torch.device(device)
+    if device.index is None or device.index == torch._C._cuda_getDevice():
+        # (already the current device, the usual case: `with torch.cuda.device(...)` and the Stream object behind a bare
+        # Event.record() are ~10 us each, five copies per optimisation step)
         out = view.to(device, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-    s.events[k] = ev
+        ev.record(_stream_object())
+    else:
+        with torch.cuda.device(device):
+            out = view.to(device, non_blocking=True)
+            ev.record()
     return out
+
+
+_stream_objs = {}
+
+
+def _stream_object():
+    """torch Stream object of the current device's current stream, cached by its raw handle"""
+    raw = raw_stream()
+    key = (torch._C._cuda_getDevice(), raw)
+    so = _stream_objs.get(key)
+    if so is None:
+        if len(_stream_objs) > 64:
+            _stream_objs.clear()
+        so = _stream_objs[key] = torch.cuda.current_stream()
+    return so
 
 
 def f32c(t, device=None):
@@ -399,8 +422,10 @@ class SceneIndex(object):
             tabs = [(off + self._row_base_host[None]).reshape(-1), self._row_count_host.repeat(S)]
             if self._slots_host is not None:
                 tabs.append(torch.from_numpy(np.repeat(self._slots_host.numpy(), self._sizes_host.numpy()).astype(np.int32)).repeat(S))
-            if dev.type == 'cuda':
-                tabs = [h2d_async(t, dev) for t in tabs]
+            if dev.type == 'cuda':             # ONE pinned copy for the two / three tables
+                flat = h2d_async(torch.cat(tabs), dev)
+                n = tabs[0].numel()
+                tabs = [flat[i * n:(i + 1) * n] for i in range(len(tabs))]
             else:
                 tabs = [t.to(dev) for t in tabs]
             if len(tabs) == 2:

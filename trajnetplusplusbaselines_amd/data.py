@@ -188,8 +188,13 @@ class SceneBatcher(object):
         self.sizes = np.array([x.shape[1] for x in xs], dtype=np.int64)
         self.starts = np.concatenate([[0], np.cumsum(self.sizes)])
         self.device = torch.device(device)
+        self._xy_host = np.ascontiguousarray(np.concatenate(xs, axis=1).astype(np.float32).transpose(1, 0, 2))   # [sum N, T, 2]
+        self._goals_host = np.concatenate(gs, axis=0).astype(np.float32)
         self.xy = torch.tensor(np.concatenate(xs, axis=1), dtype=torch.float32, device=self.device)     # [T, sum N, 2]
         self.goals = torch.tensor(np.concatenate(gs, axis=0), dtype=torch.float32, device=self.device)  # [sum N, 2]
+
+    #: batches up to this many tracks are gathered / rotated on the host and sent in one copy (see ``batch``)
+    HOST_ASSEMBLY_TRACKS = 2048
 
     def __len__(self):
         return len(self.sizes)
@@ -204,6 +209,27 @@ class SceneBatcher(object):
         import random
         import torch
         ids = list(ids)
+        n_tracks = int(self.sizes[ids].sum())
+        if n_tracks <= self.HOST_ASSEMBLY_TRACKS:
+            # small batches (the trainer's default batch_size 8: ~300 tracks, 50 KB): gather and rotate on the host, ONE pinned
+            # asynchronous copy -- the device form below is a dozen small launches (index, stack, multiply ...) whose host cost
+            # (0.27 ms) exceeds the whole batch's transfer; float32 arithmetic in the same order as the device form
+            cols = np.concatenate([np.arange(self.starts[i], self.starts[i + 1]) for i in ids])
+            xy = self._xy_host[cols]                                        # [M, T, 2]
+            goals = self._goals_host[cols]
+            if augment:
+                theta = np.array([random.random() * 2.0 * math.pi for _ in ids], dtype=np.float64)
+                per_track = np.repeat(theta, self.sizes[ids])
+                ct, st = np.cos(per_track).astype(np.float32), np.sin(per_track).astype(np.float32)
+                x, y = xy[..., 0], xy[..., 1]
+                xy = np.stack([x * ct[:, None] - y * st[:, None], x * st[:, None] + y * ct[:, None]], axis=-1)
+                gx, gy = goals[:, 0], goals[:, 1]
+                goals = np.stack([gx * ct - gy * st, gx * st + gy * ct], axis=-1)
+            T = xy.shape[1]
+            flat = np.concatenate([np.ascontiguousarray(xy.transpose(1, 0, 2)).reshape(-1), goals.reshape(-1)])
+            dev_flat = self._h2d(torch.from_numpy(flat))
+            split = torch.from_numpy(np.concatenate([[0], np.cumsum(self.sizes[ids])]).astype(np.int64))
+            return dev_flat[:T * n_tracks * 2].view(T, n_tracks, 2), dev_flat[T * n_tracks * 2:].view(n_tracks, 2), split
         cols = self._h2d(torch.from_numpy(np.concatenate([np.arange(self.starts[i], self.starts[i + 1]) for i in ids])))
         xy, goals = self.xy[:, cols], self.goals[cols]
         split = torch.tensor(np.concatenate([[0], np.cumsum(self.sizes[ids])]), dtype=torch.int64)
