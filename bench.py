@@ -493,11 +493,31 @@ def classical_leg(device, scenes=4096, agents=128):
         torch.cuda.synchronize()
     per = {k: ev[i].elapsed_time(ev[i + 1]) for i, k in enumerate(('socialforce', 'orca', 'kalman'))}
     tot = sum(per.values())
+    # Roofline of each rollout on an INSTRUCTION-ISSUE basis: these kernels touch 63 MB of HBM per batch and run no matrix
+    # instruction; what bounds them is the vector pipe's issue rate -- one wave64 VALU instruction per 4 cycles per SIMD (fp32 and
+    # fp64 FMA alike), 1024 SIMDs.  `achieved` = vector instructions per launch (SQ_INSTS_VALU, a property of the workload:
+    # profiles/round6_pmc_classical.md, this very batch) x 64 lanes / the launch time measured HERE; `peak` = 1024 SIMDs x 16
+    # lanes x the boost clock.  frac = share of the launch during which the vector pipes issue.
+    roof = None
+    if (S, A) == (4096, 128):
+        peak = 1024 * 16 * BOOST_CLOCK_GHZ * 1e9
+        roof = {}
+        for k, n_instr in CLASSICAL_VALU_INSTS.items():
+            ach = n_instr * 64 / (per[k] * 1e-3)
+            roof[k] = {'bound': 'valu-issue', 'achieved': ach / 1e12, 'peak': peak / 1e12, 'unit': 'T lane-ops/s', 'frac': ach / peak,
+                       'valu_instructions_per_launch': n_instr, 'launch_ms': per[k],
+                       'source': 'SQ_INSTS_VALU of profiles/round6_pmc_classical.md (rocprofv3 --pmc over bench.py --config classical)'}
     return dict(workload='classical.socialforce + ORCA + Kalman, %d scenes x %d agents, 9 obs + 12 pred, second pass timed' % (S, A),
+                roofline=roof,
                 ms_per_predictor=per, scene_steps_per_s_per_predictor={k: S * 21 / (v * 1e-3) for k, v in per.items()},
                 value=S * 21 / (tot * 1e-3), unit='scene-steps/s (all three predictors over the batch)',
                 finite=bool(torch.isfinite(out_sf).all() and torch.isfinite(out_orca).all() and torch.isfinite(out_k).all()))
 
+
+# vector instructions per launch at BASELINE config 5 (4096 x 128), profiles/round6_pmc_classical.md; ORCA before round 6's
+# register form: 4.628e10 (profiles/archive/round3_d_pmc_classical.md)
+CLASSICAL_VALU_INSTS = {'socialforce': 3.636e10, 'orca': 4.641e9, 'kalman': 1.417e9}
+BOOST_CLOCK_GHZ = 2.4
 
 # the Python reference at its real operating point, measured in the build container (8 vCPUs) by tools/ref_operating_point.py
 REF_TRAINER_DEFAULT_MS, REF_PER_SCENE_MS = 1418.4, 81.2      # (a second run read 1249.1 / 86.4)

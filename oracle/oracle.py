@@ -41,7 +41,10 @@ class _Model(ctypes.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, 'liboracle.so')
-    srcs = [os.path.join(_HERE, s) for s in ('trajnet_oracle.c', 'classical_oracle.c')]
+    # (classical_oracle.c includes the product's csrc/classical_core.h: the arithmetic it executes on the host)
+    srcs = [os.path.join(_HERE, s) for s in ('trajnet_oracle.c', 'classical_oracle.c', 'Makefile')] + \
+           [os.path.join(_HERE, '..', 'trajnetplusplusbaselines_amd', 'csrc', 'classical_core.h')]
+    srcs = [s for s in srcs if os.path.exists(s)]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
         subprocess.check_call(['make', '-C', _HERE, '-B', 'liboracle.so'], stdout=subprocess.DEVNULL)

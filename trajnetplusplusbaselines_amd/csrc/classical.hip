@@ -7,6 +7,9 @@
 // Compiled with -ffp-contract=off so that the float32 ORCA arithmetic is bit-identical to the host restatement.
 #include "tnp_internal.h"
 #include "classical_core.h"
+#include <stdlib.h>
+
+#define TNP_MAX_DEVICES 64
 
 namespace tnp {
 
@@ -102,9 +105,195 @@ __global__ void __launch_bounds__(256) orca_rollout_kernel(const float *pos0, co
     }
 }
 
+// ---- ORCA, register form (round 6) -----------------------------------------------------------------------------------
+// The generic orca_agent_new_velocity above is CPU code run one lane per agent: its neighbour list, half-planes and LP
+// projections are dynamically indexed private arrays (scratch memory: 7.3e7 VMEM reads per launch) and every lane runs the
+// insertion-shift loop whenever any lane of the wave has a candidate in range -- 58 k vector instructions per wave and
+// simulator step for ~3 k of useful work (profiles/archive/round3_d_pmc_classical.md).  Same arithmetic, GPU shape:
+//   * neighbour search in two phases per 64 candidates: an in-range bit per candidate (positions broadcast from LDS), then
+//     every lane walks ITS OWN set bits in ascending order and inserts into a sorted list of MN (dist^2, index) REGISTER
+//     pairs by a branch-free compare network -- the list insertAgentNeighbor builds (the MN smallest by (dist^2, visiting
+//     order), ties behind their equals, range shrinking to the last entry once full), entry for entry;
+//   * half-planes and linearProgram1/2 fully unrolled over MN compile-time slots: no indexed array, no scratch;
+//   * linearProgram3 (dense crowds only) keeps the generic code on a private copy of the lines.
+// MN must equal max_neighbors (the wrapper always passes RVO2's 10); other values take the generic kernel.
+template <int MN>
+__device__ __forceinline__ bool orca_lp1_reg(const orca_line (&L)[MN], const int line_no, float radius, float ox, float oy,
+                                             float *rx, float *ry) {
+    // linearProgram1, directionOpt = false (classical_core.h: orca_lp1, same expressions in the same order)
+    const orca_line Ln = L[line_no];
+    const float dot = Ln.px * Ln.dx + Ln.py * Ln.dy;
+    const float disc = dot * dot + radius * radius - (Ln.px * Ln.px + Ln.py * Ln.py);
+    if (disc < 0.0f) return false;
+    const float sq = sqrtf(disc);
+    float t_left = -dot - sq, t_right = -dot + sq;
+    bool feasible = true;
+#pragma unroll
+    for (int i = 0; i < MN; ++i) {
+        if (i < line_no && feasible) {
+            const float den = orca_det(Ln.dx, Ln.dy, L[i].dx, L[i].dy);
+            const float num = orca_det(L[i].dx, L[i].dy, Ln.px - L[i].px, Ln.py - L[i].py);
+            if (fabsf(den) <= ORCA_EPSILON) {
+                if (num < 0.0f) feasible = false;
+            } else {
+                const float t = num / den;
+                if (den >= 0.0f) t_right = fminf(t_right, t);
+                else t_left = fmaxf(t_left, t);
+                if (t_left > t_right) feasible = false;
+            }
+        }
+    }
+    if (!feasible) return false;
+    const float t = Ln.dx * (ox - Ln.px) + Ln.dy * (oy - Ln.py);
+    if (t < t_left) { *rx = Ln.px + t_left * Ln.dx; *ry = Ln.py + t_left * Ln.dy; }
+    else if (t > t_right) { *rx = Ln.px + t_right * Ln.dx; *ry = Ln.py + t_right * Ln.dy; }
+    else { *rx = Ln.px + t * Ln.dx; *ry = Ln.py + t * Ln.dy; }
+    return true;
+}
+
+template <int MN>
+__device__ __forceinline__ void orca_new_velocity_reg(int a, int ns, const float *pos, const float *vel, float prefx, float prefy,
+                                                      float max_speed, const orca_params &p, float *nvx, float *nvy, int *nbr_out) {
+    float nd[MN];
+    int nbr[MN];
+#pragma unroll
+    for (int i = 0; i < MN; ++i) { nd[i] = INFINITY; nbr[i] = -1; }
+    const float nd2 = p.neighbor_dist * p.neighbor_dist;
+    const float ax = pos[2 * a], ay = pos[2 * a + 1];
+    for (int base = 0; base < ns; base += 64) {
+        unsigned long long m = 0ull;
+        const int lim = min(64, ns - base);
+        for (int j = 0; j < lim; ++j) {                          // wave-uniform: pos[b] is one LDS broadcast
+            const int b = base + j;
+            const float ddx = ax - pos[2 * b], ddy = ay - pos[2 * b + 1];
+            const float dist_sq = ddx * ddx + ddy * ddy;
+            if (b != a && dist_sq < nd2) m |= 1ull << j;
+        }
+        while (m) {                                              // this lane's candidates, ascending
+            const int b = base + __builtin_ctzll(m);
+            m &= m - 1ull;
+            const float ddx = ax - pos[2 * b], ddy = ay - pos[2 * b + 1];
+            const float dist_sq = ddx * ddx + ddy * ddy;
+            if (dist_sq < fminf(nd2, nd[MN - 1])) {              // rangeSq: neighborDist^2 until the list is full, then its last entry
+#pragma unroll
+                for (int i = MN - 1; i >= 1; --i) {
+                    const bool shift = dist_sq < nd[i - 1];
+                    const bool place = !shift && dist_sq < nd[i];
+                    nbr[i] = shift ? nbr[i - 1] : (place ? b : nbr[i]);
+                    nd[i] = shift ? nd[i - 1] : (place ? dist_sq : nd[i]);
+                }
+                const bool place0 = dist_sq < nd[0];
+                nbr[0] = place0 ? b : nbr[0];
+                nd[0] = place0 ? dist_sq : nd[0];
+            }
+        }
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < MN; ++i) cnt += nbr[i] >= 0 ? 1 : 0;
+    if (nbr_out) {
+#pragma unroll
+        for (int i = 0; i < ORCA_MAX_NEIGHBORS; ++i) nbr_out[i] = i < MN ? nbr[i < MN ? i : 0] : -1;
+    }
+    orca_line L[MN];
+    const float inv_th = 1.0f / p.time_horizon;
+    const float vx = vel[2 * a], vy = vel[2 * a + 1];
+#pragma unroll
+    for (int k = 0; k < MN; ++k) {
+        L[k].px = 0.0f; L[k].py = 0.0f; L[k].dx = 0.0f; L[k].dy = 0.0f;
+        if (k < cnt) {
+            const int b = nbr[k];
+            const float rpx = pos[2 * b] - ax, rpy = pos[2 * b + 1] - ay;
+            const float rvx = vx - vel[2 * b], rvy = vy - vel[2 * b + 1];
+            L[k] = orca_make_line(rpx, rpy, rvx, rvy, vx, vy, inv_th, &p);
+        }
+    }
+    // linearProgram2, directionOpt = false (orca_lp2)
+    float rx, ry;
+    if (prefx * prefx + prefy * prefy > max_speed * max_speed) {
+        const float inv = 1.0f / sqrtf(prefx * prefx + prefy * prefy);
+        rx = prefx * inv * max_speed; ry = prefy * inv * max_speed;
+    } else { rx = prefx; ry = prefy; }
+    int fail = cnt;
+#pragma unroll
+    for (int i = 0; i < MN; ++i) {
+        if (i < fail) {                                          // (fail == cnt until a line fails, then the loop is over)
+            if (orca_det(L[i].dx, L[i].dy, L[i].px - rx, L[i].py - ry) > 0.0f) {
+                const float tx = rx, ty = ry;
+                if (!orca_lp1_reg<MN>(L, i, max_speed, prefx, prefy, &rx, &ry)) { rx = tx; ry = ty; fail = i; }
+            }
+        }
+    }
+    if (fail < cnt) {
+        // infeasible (dense crowds only): linearProgram3, the generic code on a private copy of the lines -- the only scratch
+        // memory of the kernel, touched by the lanes that get here (an LDS copy per thread would cost 40 KB per workgroup and
+        // with it half of the resident waves: 22.6 against 15 ms at BASELINE config 5)
+        orca_line sp[2 * MN];
+#pragma unroll
+        for (int k = 0; k < MN; ++k) sp[k] = L[k];
+        orca_lp3_buf(sp, cnt, fail, max_speed, &rx, &ry, sp + MN);
+    }
+    *nvx = rx; *nvy = ry;
+}
+
+template <int MN>
+__global__ void __launch_bounds__(256) orca_rollout_reg_kernel(const float *pos0, const float *vel0, const double *goals,
+                                                               const double *speed, const float *max_speed,
+                                                               const int32_t *scene_start, int M, int n_iter, int sample_every,
+                                                               orca_params prm, float *out, int *nbr_dbg) {
+    extern __shared__ __attribute__((aligned(16))) float ors[];
+    const int s = blockIdx.x;
+    const int lo = scene_start[s], ns = scene_start[s + 1] - lo;
+    float *pos = ors;                   // [ns][2]
+    float *vel = pos + (size_t)ns * 2;  // [ns][2]
+    float *nvl = vel + (size_t)ns * 2;  // [ns][2]
+    float *prf = nvl + (size_t)ns * 2;  // [ns][2] preferred velocity (0 before the first step, orca.py:99-119)
+    for (int a = threadIdx.x; a < ns; a += blockDim.x) {
+        pos[2 * a] = pos0[2 * (lo + a)]; pos[2 * a + 1] = pos0[2 * (lo + a) + 1];
+        vel[2 * a] = vel0[2 * (lo + a)]; vel[2 * a + 1] = vel0[2 * (lo + a) + 1];
+        prf[2 * a] = 0.0f; prf[2 * a + 1] = 0.0f;
+    }
+    __syncthreads();
+    int n_out = 0;
+    for (int count = 1; count <= n_iter; ++count) {
+        for (int a = threadIdx.x; a < ns; a += blockDim.x) {
+            int *dbg = (nbr_dbg && count == 1) ? nbr_dbg + (size_t)(lo + a) * ORCA_MAX_NEIGHBORS : nullptr;
+            orca_new_velocity_reg<MN>(a, ns, pos, vel, prf[2 * a], prf[2 * a + 1], max_speed[lo + a], prm, &nvl[2 * a],
+                                      &nvl[2 * a + 1], dbg);
+        }
+        __syncthreads();
+        for (int a = threadIdx.x; a < ns; a += blockDim.x) {
+            vel[2 * a] = nvl[2 * a]; vel[2 * a + 1] = nvl[2 * a + 1];          // Agent::update
+            pos[2 * a] += vel[2 * a] * prm.time_step; pos[2 * a + 1] += vel[2 * a + 1] * prm.time_step;
+            if (count % sample_every == 0) {                                    // orca.py:107
+                out[((size_t)n_out * M + lo + a) * 2 + 0] = pos[2 * a];
+                out[((size_t)n_out * M + lo + a) * 2 + 1] = pos[2 * a + 1];
+            }
+            // preferred velocity towards the goal, capped at the initial speed (orca.py:111-119), in float64
+            const double px = (double)pos[2 * a], py = (double)pos[2 * a + 1];
+            const double gx = goals[2 * (lo + a)], gy = goals[2 * (lo + a) + 1];
+            const double dx = gx - px, dy = gy - py;
+            const double dist = sqrt(dx * dx + dy * dy);
+            float pvx, pvy;
+            if (dist < 0.05) { pvx = 0.0f; pvy = 0.0f; }
+            else {
+                const double sp = speed[lo + a];
+                if (dist > sp) { pvx = (float)(sp * dx / dist); pvy = (float)(sp * dy / dist); }
+                else { pvx = (float)dx; pvy = (float)dy; }
+            }
+            prf[2 * a] = pvx; prf[2 * a + 1] = pvy;
+        }
+        if (count % sample_every == 0) ++n_out;
+        __syncthreads();
+    }
+}
+
 // ---- Kalman: one lane per track; obs [n_tracks][T][2] float64, z [n_tracks][n_samples][n_steps][6] ---------------------
-__global__ void __launch_bounds__(64) kalman_kernel(const double *obs, int n_tracks, int T, int n_iter, int n_steps,
-                                                    int n_samples, const double *z, double q0, double r0, double *out) {
+// One wave per SIMD on purpose: the EM pass keeps ~330 registers of 4 x 4 double matrices live; capping the allocation for 2 / 3 /
+// 4 waves per SIMD spills them to scratch memory and costs 7.8 / 14.2 / 22.6 ms against 6.5 (BASELINE config 5, round 6) -- the
+// 4 x 4 products carry enough independent fp64 FMAs to keep the pipe of one wave busy.
+__global__ void __launch_bounds__(64, 1) kalman_kernel(const double *obs, int n_tracks, int T, int n_iter, int n_steps,
+                                                       int n_samples, const double *z, double q0, double r0, double *out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tracks) return;
     const double *o = obs + (size_t)i * T * 2;
@@ -129,11 +318,13 @@ extern "C" TNP_API int tnp_sf_rollout(const double *state0, const int32_t *scene
     p.out_of_view = 0.5;
     const size_t smem = (size_t)n_max * (10 + 6) * sizeof(double);
     if (smem > 160 * 1024) TNP_FAIL(-1, "tnp_sf_rollout: %d agents in one scene exceed the LDS-staged limit", n_max);
-    static size_t attr = 0;
-    if (smem > attr) {
+    int dev = 0;
+    TNP_HIP(hipGetDevice(&dev));
+    static size_t attr[TNP_MAX_DEVICES] = {0};                               // per DEVICE (one process may drive several)
+    if (dev >= TNP_MAX_DEVICES || smem > attr[dev]) {
         TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tnp::sf_rollout_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = smem;
+        if (dev < TNP_MAX_DEVICES) attr[dev] = smem;
     }
     const int threads = n_max <= 64 ? 64 : (n_max <= 128 ? 128 : 256);
     hipLaunchKernelGGL(tnp::sf_rollout_kernel, dim3(B), dim3(threads), smem, (hipStream_t)stream, state0, scene_start, M,
@@ -152,15 +343,32 @@ extern "C" TNP_API int tnp_orca_rollout(const float *pos0, const float *vel0, co
     orca_params p;
     p.time_step = time_step; p.neighbor_dist = neighbor_dist; p.time_horizon = time_horizon; p.radius = radius;
     p.max_neighbors = max_neighbors;
+    const int threads = n_max <= 64 ? 64 : (n_max <= 128 ? 128 : 256);
+    int dev = 0;
+    TNP_HIP(hipGetDevice(&dev));
+    if (max_neighbors == 10) {           // RVO2's / the wrapper's value (classical/orca.py:95): the register form
+        constexpr int MN = 10;
+        const size_t smem = (size_t)n_max * 8 * sizeof(float);
+        if (smem > 160 * 1024) TNP_FAIL(-1, "tnp_orca_rollout: %d agents in one scene exceed the LDS-staged limit", n_max);
+        static size_t attr[TNP_MAX_DEVICES] = {0};                           // per DEVICE: the attribute belongs to the device's code object
+        if (dev >= TNP_MAX_DEVICES || smem > attr[dev]) {
+            TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tnp::orca_rollout_reg_kernel<MN>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            if (dev < TNP_MAX_DEVICES) attr[dev] = smem;
+        }
+        hipLaunchKernelGGL(tnp::orca_rollout_reg_kernel<MN>, dim3(B), dim3(threads), smem, (hipStream_t)stream, pos0, vel0, goals,
+                           speed, max_speed, scene_start, M, n_iter, sample_every, p, out, nbr_dbg);
+        TNP_HIP(hipGetLastError());
+        return 0;
+    }
     const size_t smem = (size_t)n_max * 8 * sizeof(float);
     if (smem > 160 * 1024) TNP_FAIL(-1, "tnp_orca_rollout: %d agents in one scene exceed the LDS-staged limit", n_max);
-    static size_t attr = 0;
-    if (smem > attr) {
+    static size_t attr[TNP_MAX_DEVICES] = {0};
+    if (dev >= TNP_MAX_DEVICES || smem > attr[dev]) {
         TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tnp::orca_rollout_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = smem;
+        if (dev < TNP_MAX_DEVICES) attr[dev] = smem;
     }
-    const int threads = n_max <= 64 ? 64 : (n_max <= 128 ? 128 : 256);
     hipLaunchKernelGGL(tnp::orca_rollout_kernel, dim3(B), dim3(threads), smem, (hipStream_t)stream, pos0, vel0, goals, speed,
                        max_speed, scene_start, M, n_iter, sample_every, p, out, nbr_dbg);
     TNP_HIP(hipGetLastError());

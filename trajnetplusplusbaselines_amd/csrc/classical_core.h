@@ -148,9 +148,9 @@ TNP_HD int orca_lp2(const orca_line *lines, int n_lines, float radius, float ox,
     return n_lines;
 }
 
-TNP_HD void orca_lp3(const orca_line *lines, int n_lines, int begin_line, float radius, float *rx, float *ry) {
+/* proj: ORCA_MAX_NEIGHBORS lines of scratch (the GPU kernel hands LDS, the host a local array) */
+TNP_HD void orca_lp3_buf(const orca_line *lines, int n_lines, int begin_line, float radius, float *rx, float *ry, orca_line *proj) {
     float distance = 0.0f;
-    orca_line proj[ORCA_MAX_NEIGHBORS];
     for (int i = begin_line; i < n_lines; ++i) {
         if (orca_det(lines[i].dx, lines[i].dy, lines[i].px - *rx, lines[i].py - *ry) > distance) {
             int np = 0;
@@ -174,6 +174,56 @@ TNP_HD void orca_lp3(const orca_line *lines, int n_lines, int begin_line, float 
             distance = orca_det(lines[i].dx, lines[i].dy, lines[i].px - *rx, lines[i].py - *ry);
         }
     }
+}
+
+TNP_HD void orca_lp3(const orca_line *lines, int n_lines, int begin_line, float radius, float *rx, float *ry) {
+    orca_line proj[ORCA_MAX_NEIGHBORS];
+    orca_lp3_buf(lines, n_lines, begin_line, radius, rx, ry, proj);
+}
+
+/* Agent::computeNewVelocity, the half-plane of ONE neighbour: rp = its position - ours, rv = our velocity - its velocity,
+ * (vx, vy) our velocity.  Shared by the generic form below and the register form of csrc/classical.hip. */
+TNP_HD orca_line orca_make_line(float rpx, float rpy, float rvx, float rvy, float vx, float vy, float inv_th,
+                                const orca_params *p) {
+    const float dist_sq = rpx * rpx + rpy * rpy;
+    const float cr = p->radius + p->radius;
+    const float cr_sq = cr * cr;
+    orca_line l;
+    float ux, uy;
+    if (dist_sq > cr_sq) {
+        const float wx = rvx - inv_th * rpx, wy = rvy - inv_th * rpy;
+        const float wlen_sq = wx * wx + wy * wy;
+        const float dot1 = wx * rpx + wy * rpy;
+        if (dot1 < 0.0f && dot1 * dot1 > cr_sq * wlen_sq) {
+            const float wlen = sqrtf(wlen_sq);
+            const float iw = 1.0f / wlen;
+            const float uwx = wx * iw, uwy = wy * iw;
+            l.dx = uwy; l.dy = -uwx;
+            const float s = cr * inv_th - wlen;
+            ux = s * uwx; uy = s * uwy;
+        } else {
+            const float leg = sqrtf(dist_sq - cr_sq);
+            const float ids = 1.0f / dist_sq;
+            if (orca_det(rpx, rpy, wx, wy) > 0.0f) {
+                l.dx = (rpx * leg - rpy * cr) * ids; l.dy = (rpx * cr + rpy * leg) * ids;
+            } else {
+                l.dx = -((rpx * leg + rpy * cr) * ids); l.dy = -((-rpx * cr + rpy * leg) * ids);
+            }
+            const float dot2 = rvx * l.dx + rvy * l.dy;
+            ux = dot2 * l.dx - rvx; uy = dot2 * l.dy - rvy;
+        }
+    } else {
+        const float inv_ts = 1.0f / p->time_step;
+        const float wx = rvx - inv_ts * rpx, wy = rvy - inv_ts * rpy;
+        const float wlen = sqrtf(wx * wx + wy * wy);
+        const float iw = 1.0f / wlen;
+        const float uwx = wx * iw, uwy = wy * iw;
+        l.dx = uwy; l.dy = -uwx;
+        const float s = cr * inv_ts - wlen;
+        ux = s * uwx; uy = s * uwy;
+    }
+    l.px = vx + 0.5f * ux; l.py = vy + 0.5f * uy;
+    return l;
 }
 
 /* new velocity of agent a from the OLD positions / velocities of the n agents of its scene.
@@ -207,44 +257,7 @@ TNP_HD void orca_agent_new_velocity(int a, int n, const float *pos, const float 
         const int b = nbr[k];
         const float rpx = pos[2 * b] - ax, rpy = pos[2 * b + 1] - ay;
         const float rvx = vx - vel[2 * b], rvy = vy - vel[2 * b + 1];
-        const float dist_sq = rpx * rpx + rpy * rpy;
-        const float cr = p->radius + p->radius;
-        const float cr_sq = cr * cr;
-        orca_line l;
-        float ux, uy;
-        if (dist_sq > cr_sq) {
-            const float wx = rvx - inv_th * rpx, wy = rvy - inv_th * rpy;
-            const float wlen_sq = wx * wx + wy * wy;
-            const float dot1 = wx * rpx + wy * rpy;
-            if (dot1 < 0.0f && dot1 * dot1 > cr_sq * wlen_sq) {
-                const float wlen = sqrtf(wlen_sq);
-                const float iw = 1.0f / wlen;
-                const float uwx = wx * iw, uwy = wy * iw;
-                l.dx = uwy; l.dy = -uwx;
-                const float s = cr * inv_th - wlen;
-                ux = s * uwx; uy = s * uwy;
-            } else {
-                const float leg = sqrtf(dist_sq - cr_sq);
-                const float ids = 1.0f / dist_sq;
-                if (orca_det(rpx, rpy, wx, wy) > 0.0f) {
-                    l.dx = (rpx * leg - rpy * cr) * ids; l.dy = (rpx * cr + rpy * leg) * ids;
-                } else {
-                    l.dx = -((rpx * leg + rpy * cr) * ids); l.dy = -((-rpx * cr + rpy * leg) * ids);
-                }
-                const float dot2 = rvx * l.dx + rvy * l.dy;
-                ux = dot2 * l.dx - rvx; uy = dot2 * l.dy - rvy;
-            }
-        } else {
-            const float inv_ts = 1.0f / p->time_step;
-            const float wx = rvx - inv_ts * rpx, wy = rvy - inv_ts * rpy;
-            const float wlen = sqrtf(wx * wx + wy * wy);
-            const float iw = 1.0f / wlen;
-            const float uwx = wx * iw, uwy = wy * iw;
-            l.dx = uwy; l.dy = -uwx;
-            const float s = cr * inv_ts - wlen;
-            ux = s * uwx; uy = s * uwy;
-        }
-        l.px = vx + 0.5f * ux; l.py = vy + 0.5f * uy;
+        const orca_line l = orca_make_line(rpx, rpy, rvx, rvy, vx, vy, inv_th, p);
         lines[k] = l;
     }
     float rx, ry;
@@ -276,7 +289,10 @@ TNP_HD int kf_inv4(const double *M, double *inv) {                            /*
         int piv = c; double best = fabs(a[c][c]);
         for (int r = c + 1; r < 4; ++r) if (fabs(a[r][c]) > best) { best = fabs(a[r][c]); piv = r; }
         if (best == 0.0) return 0;
-        if (piv != c) for (int j = 0; j < 8; ++j) { double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+        /* the pivot row is swapped in by comparing every candidate row's index with `piv`: all array indices stay
+         * compile-time constants once the loops are unrolled (a[piv][j] made the GPU keep `a` in scratch memory) */
+        for (int r = c + 1; r < 4; ++r)
+            if (r == piv) for (int j = 0; j < 8; ++j) { double t = a[c][j]; a[c][j] = a[r][j]; a[r][j] = t; }
         const double d = a[c][c];
         for (int j = 0; j < 8; ++j) a[c][j] /= d;
         for (int r = 0; r < 4; ++r) if (r != c) { const double f = a[r][c]; for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j]; }
@@ -294,10 +310,8 @@ TNP_HD void kf_APAt(const double *P, double *out) {       /* A P A^T */
     kf_mat4_mul_t(T, A, out);
 }
 
-/* forward filter + RTS smoother; obs [T][2].  Arrays [T][4] / [T][16]; Lg[t] = smoother gain of step t. */
-TNP_HD void kf_filter_smooth(const kf_model *md, const double *obs, int T, double *xf, double *Pf, double *xs, double *Ps,
-                             double *Lg) {
-    static const double A[16] = {1, 1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 1};
+/* forward filter; obs [T][2] -> filtered moments xf [T][4], Pf [T][16] */
+TNP_HD void kf_filter(const kf_model *md, const double *obs, int T, double *xf, double *Pf) {
     double xpt[4], Ppt[16];
     for (int t = 0; t < T; ++t) {
         double *xft = xf + 4 * t, *Pft = Pf + 16 * t;
@@ -321,63 +335,67 @@ TNP_HD void kf_filter_smooth(const kf_model *md, const double *obs, int T, doubl
         for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j)      /* P - K C P */
             Pft[i * 4 + j] = Ppt[i * 4 + j] - (K[i * 2] * Ppt[0 * 4 + j] + K[i * 2 + 1] * Ppt[2 * 4 + j]);
     }
-    for (int i = 0; i < 4; ++i) xs[4 * (T - 1) + i] = xf[4 * (T - 1) + i];
-    for (int i = 0; i < 16; ++i) Ps[16 * (T - 1) + i] = Pf[16 * (T - 1) + i];
-    for (int t = T - 2; t >= 0; --t) {
-        double inv[16], PAt[16], *L = Lg + 16 * t;
-        /* predicted moments of step t+1, recomputed from the filtered ones of step t */
-        kf_A_mul(xf + 4 * t, xpt);
-        kf_APAt(Pf + 16 * t, Ppt);
-        for (int i = 0; i < 16; ++i) Ppt[i] += md->Q[i];
-        kf_inv4(Ppt, inv);
-        kf_mat4_mul_t(Pf + 16 * t, A, PAt);            /* P_f A^T */
-        kf_mat4_mul(PAt, inv, L);
-        double d[4];
-        for (int i = 0; i < 4; ++i) d[i] = xs[4 * (t + 1) + i] - xpt[i];
-        for (int i = 0; i < 4; ++i) { double sacc = xf[4 * t + i]; for (int k = 0; k < 4; ++k) sacc += L[i * 4 + k] * d[k]; xs[4 * t + i] = sacc; }
-        double D[16], LD[16], LDLt[16];
-        for (int i = 0; i < 16; ++i) D[i] = Ps[16 * (t + 1) + i] - Ppt[i];
-        kf_mat4_mul(L, D, LD);
-        kf_mat4_mul_t(LD, L, LDLt);
-        for (int i = 0; i < 16; ++i) Ps[16 * t + i] = Pf[16 * t + i] + LDLt[i];
-    }
 }
 
-/* EM (n_iter iterations) on Q, R, m0, P0, then a final smoothing pass; returns the last smoothed state in x_last */
+/* EM (n_iter iterations) on Q, R, m0, P0, then a final filter pass; returns the last smoothed state (= the last FILTERED
+ * state: the RTS recursion starts from it) in x_last.
+ *
+ * Round 6: the RTS smoother runs backwards from t = T - 1 and the M-step sums are accumulated AS the smoothed moments appear
+ * (descending t) instead of in a second loop over stored xs / Ps / Lg arrays: per track only xf and Pf (20 doubles per frame)
+ * live across the passes instead of 56 -- on the GPU that is the difference between 7.4 KB and 2.6 KB of private memory per
+ * lane (profiles/round6_pmc_classical.md).  The sums are the same terms in the opposite order (last-bit differences). */
 TNP_HD void kf_em_smooth(const double *obs, int T, int n_iter, kf_model *md, double *x_last) {
     static const double A[16] = {1, 1, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 1};
-    double xf[KF_MAX_T * 4], Pf[KF_MAX_T * 16], xs[KF_MAX_T * 4], Ps[KF_MAX_T * 16], Lg[KF_MAX_T * 16];
+    double xf[KF_MAX_T * 4], Pf[KF_MAX_T * 16];
     for (int it = 0; it < n_iter; ++it) {
-        kf_filter_smooth(md, obs, T, xf, Pf, xs, Ps, Lg);
-        /* observation covariance */
-        double R[4] = {0, 0, 0, 0};
-        for (int t = 0; t < T; ++t) {
-            const double e0 = obs[2 * t] - xs[4 * t + 0], e1 = obs[2 * t + 1] - xs[4 * t + 2];
-            const double *P = Ps + 16 * t;
-            R[0] += e0 * e0 + P[0]; R[1] += e0 * e1 + P[2]; R[2] += e1 * e0 + P[8]; R[3] += e1 * e1 + P[10];
+        kf_filter(md, obs, T, xf, Pf);
+        double xn[4], Pn[16];                      /* smoothed moments of step t + 1 */
+        for (int i = 0; i < 4; ++i) xn[i] = xf[4 * (T - 1) + i];
+        for (int i = 0; i < 16; ++i) Pn[i] = Pf[16 * (T - 1) + i];
+        double R[4], Q[16];
+        {   /* observation covariance, term of t = T - 1 */
+            const double e0 = obs[2 * (T - 1)] - xn[0], e1 = obs[2 * (T - 1) + 1] - xn[2];
+            R[0] = e0 * e0 + Pn[0]; R[1] = e0 * e1 + Pn[2]; R[2] = e1 * e0 + Pn[8]; R[3] = e1 * e1 + Pn[10];
+        }
+        for (int i = 0; i < 16; ++i) Q[i] = 0.0;
+        for (int t = T - 2; t >= 0; --t) {
+            double xpt[4], Ppt[16], inv[16], PAt[16], L[16], xt[4], Pt[16];
+            /* predicted moments of step t + 1 from the filtered ones of step t, smoother gain L_t */
+            kf_A_mul(xf + 4 * t, xpt);
+            kf_APAt(Pf + 16 * t, Ppt);
+            for (int i = 0; i < 16; ++i) Ppt[i] += md->Q[i];
+            kf_inv4(Ppt, inv);
+            kf_mat4_mul_t(Pf + 16 * t, A, PAt);            /* P_f A^T */
+            kf_mat4_mul(PAt, inv, L);
+            double d[4];
+            for (int i = 0; i < 4; ++i) d[i] = xn[i] - xpt[i];
+            for (int i = 0; i < 4; ++i) { double sacc = xf[4 * t + i]; for (int k = 0; k < 4; ++k) sacc += L[i * 4 + k] * d[k]; xt[i] = sacc; }
+            double D[16], LD[16], LDLt[16];
+            for (int i = 0; i < 16; ++i) D[i] = Pn[i] - Ppt[i];
+            kf_mat4_mul(L, D, LD);
+            kf_mat4_mul_t(LD, L, LDLt);
+            for (int i = 0; i < 16; ++i) Pt[i] = Pf[16 * t + i] + LDLt[i];
+            /* M-step terms of this t */
+            const double e0 = obs[2 * t] - xt[0], e1 = obs[2 * t + 1] - xt[2];
+            R[0] += e0 * e0 + Pt[0]; R[1] += e0 * e1 + Pt[2]; R[2] += e1 * e0 + Pt[8]; R[3] += e1 * e1 + Pt[10];
+            double ax[4], err[4], APA[16], pair[16], VA[16];
+            kf_A_mul(xt, ax);
+            for (int i = 0; i < 4; ++i) err[i] = xn[i] - ax[i];
+            kf_APAt(Pt, APA);
+            kf_mat4_mul_t(Pn, L, pair);                    /* Cov(x_{t+1}, x_t) = P^s_{t+1} L_t^T */
+            kf_mat4_mul_t(pair, A, VA);                    /* V_{t+1,t} A^T */
+            for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j)
+                Q[i * 4 + j] += err[i] * err[j] + APA[i * 4 + j] + Pn[i * 4 + j] - VA[i * 4 + j] - VA[j * 4 + i];
+            for (int i = 0; i < 4; ++i) xn[i] = xt[i];
+            for (int i = 0; i < 16; ++i) Pn[i] = Pt[i];
         }
         for (int i = 0; i < 4; ++i) md->R[i] = R[i] / (double)T;
-        /* transition covariance */
-        if (T > 1) {
-            double Q[16];
-            for (int i = 0; i < 16; ++i) Q[i] = 0.0;
-            for (int t = 0; t < T - 1; ++t) {
-                double ax[4], err[4], APA[16], pair[16], VA[16];
-                kf_A_mul(xs + 4 * t, ax);
-                for (int i = 0; i < 4; ++i) err[i] = xs[4 * (t + 1) + i] - ax[i];
-                kf_APAt(Ps + 16 * t, APA);
-                kf_mat4_mul_t(Ps + 16 * (t + 1), Lg + 16 * t, pair);   /* Cov(x_{t+1}, x_t) = P^s_{t+1} L_t^T */
-                kf_mat4_mul_t(pair, A, VA);                             /* V_{t+1,t} A^T */
-                for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j)
-                    Q[i * 4 + j] += err[i] * err[j] + APA[i * 4 + j] + Ps[16 * (t + 1) + i * 4 + j] - VA[i * 4 + j] - VA[j * 4 + i];
-            }
-            for (int i = 0; i < 16; ++i) md->Q[i] = Q[i] / (double)(T - 1);
-        }
-        for (int i = 0; i < 4; ++i) md->m0[i] = xs[i];
-        for (int i = 0; i < 16; ++i) md->P0[i] = Ps[i];
+        if (T > 1) for (int i = 0; i < 16; ++i) md->Q[i] = Q[i] / (double)(T - 1);
+        for (int i = 0; i < 4; ++i) md->m0[i] = xn[i];
+        for (int i = 0; i < 16; ++i) md->P0[i] = Pn[i];
     }
-    kf_filter_smooth(md, obs, T, xf, Pf, xs, Ps, Lg);
-    for (int i = 0; i < 4; ++i) x_last[i] = xs[4 * (T - 1) + i];
+    kf_filter(md, obs, T, xf, Pf);
+    for (int i = 0; i < 4; ++i) x_last[i] = xf[4 * (T - 1) + i];
 }
 
 /* lower Cholesky factor of a symmetric PSD n x n matrix (n <= 4), zero pivots tolerated */
