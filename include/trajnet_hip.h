@@ -625,6 +625,31 @@ TNP_API int tnp_orca_rollout(const float *pos0, const float *vel0, const double 
 TNP_API int tnp_kalman_predict(const double *obs, int n_tracks, int T, int n_iter, int n_steps, int n_samples,
                        const double *z, double transition_var, double observation_var, double *out, void *stream);
 
+/* -------------------------------------------------------------------------------------------
+ * Evaluator feed, host side (no GPU work; csrc/ndjson_io.cpp).  Replaces, for the batched predictor feed
+ * data.predict_dataset, what the reference does per row in Python:
+ *   tnp_ndjson_parse        trajnetplusplustools.Reader's json.loads per line (lstm/trajnet_evaluator.py:29-36,
+ *                           evaluator/trajnet_evaluator.py:25-36): a TrajNet++ .ndjson buffer -> track columns
+ *                           (frame, pedestrian, x, y; rows with a non-null "prediction_number" skipped) and scene
+ *                           columns (id, primary, start, end), `cap` entries each.  Returns 0, or -(line number)
+ *                           of the first line it does not take (non-integer frame / id fields, malformed JSON):
+ *                           the caller falls back to its general reader.
+ *   tnp_format_predictions  evaluator/write_utils.py:42-81 through trajnetplusplustools.writers.trajnet: the lines
+ *                           of a batch's prediction file -- per scene one scene record (fps 2.5, tag 0), per mode
+ *                           the primary's rows then every neighbour's, coordinates as repr(round(float(x), 2)).
+ *                           pred [n_modes][pred_length][M][2] float64; scene s = columns split[s] .. split[s+1]
+ *                           (the first is its primary); first_frame[s] = frame of the first predicted row.
+ *                           Returns the bytes written or -1 if `cap` (tnp_format_predictions_bound) is too small.
+ * ----------------------------------------------------------------------------------------- */
+TNP_API int64_t tnp_ndjson_parse(const char *buf, size_t n, int64_t cap, int64_t *t_frame, int64_t *t_ped, double *t_x,
+                                 double *t_y, int64_t *n_tracks, int64_t *s_id, int64_t *s_ped, int64_t *s_start,
+                                 int64_t *s_end, int64_t *n_scenes);
+TNP_API int64_t tnp_format_predictions(const double *pred, int n_modes, int pred_length, int64_t M, int64_t n_scenes,
+                                       const int64_t *split, const int64_t *ped, const int64_t *scene_id,
+                                       const int64_t *first_frame, const int64_t *frame_diff, const int64_t *scene_start,
+                                       const int64_t *scene_end, char *out, size_t cap);
+TNP_API size_t tnp_format_predictions_bound(int n_modes, int pred_length, int64_t M, int64_t n_scenes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,3 +154,145 @@ def test_paths_to_xy_equals_the_row_loop_definition():
             self.frame, self.pedestrian, self.x, self.y = f, p, x, y
     objs = [[Row(10 * t, 1, float(t), 0.5) for t in range(4)], [Row(10 * t, 2, 2.0, float(t)) for t in (1, 2, 9)]]
     assert np.array_equal(trajdata.paths_to_xy(objs), rows_loop(objs), equal_nan=True)
+
+
+# ---- round 6: the columnar fast path (native reader / formatter, csrc/ndjson_io.cpp) ----------------------------------------
+def _general_arrays(path, obs_length=9):
+    out = []
+    for sid, paths in trajdata.read_ndjson_scenes(path):
+        paths = trajdata.preprocess_test(paths, obs_length)
+        out.append((sid, [p[0].pedestrian for p in paths], trajdata.paths_to_xy(paths), paths))
+    return out
+
+
+def _write_odd_file(path):
+    """A test file with everything the format allows: keys in any order, spaces, list-valued tags, extra keys, stored predictions,
+    a neighbour that enters after the observation, duplicate rows, scenes that overlap, a scene whose primary is absent."""
+    rng = np.random.RandomState(3)
+    lines = []
+    lines.append('{"scene": {"id": 0, "p": 7, "s": 0, "e": 200, "fps": 2.5, "tag": [1, [2, 3]]}}')
+    lines.append('{ "scene" : { "tag": 0, "e": 260, "s": 60, "p": 9, "id": 1, "fps": 2.5 } }')
+    lines.append('{"scene": {"id": 2, "p": 12345, "s": 0, "e": 200, "fps": 2.5, "tag": 0}}')      # primary never appears
+    for t in range(27):
+        for ped in (9, 7, 8, 11):
+            if ped == 8 and t < 3:
+                continue
+            if ped == 11 and t < 12:
+                continue                                                  # enters after scene 0's observation
+            x, y = (float(v) for v in rng.randn(2) * 3)
+            if (t + ped) % 5 == 0:
+                lines.append('{"track": {"y": %r, "x": %r, "p": %d, "f": %d, "extra": {"a": [1, "}"]}}}' % (round(y, 2), round(x, 2), ped, 10 * t))
+            else:
+                lines.append('{"track": {"f": %d, "p": %d, "x": %r, "y": %r}}' % (10 * t, ped, round(x, 2), round(y, 2)))
+            if t == 4 and ped == 8:                                       # the same (frame, track) twice: the later row stays
+                lines.append('{"track": {"f": %d, "p": %d, "x": 1.5, "y": -2.25}}' % (10 * t, ped))
+    lines.append('{"track": {"f": 50, "p": 7, "x": 0.0, "y": 0.0, "prediction_number": 0, "scene_id": 0}}')   # a stored prediction
+    lines.append('{"track": {"f": 50, "p": 8, "x": 9.0, "y": 9.0, "prediction_number": null}}')               # ... and a null one (kept)
+    lines.append('')
+    with open(path, 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+
+
+@pytest.mark.parametrize('which', ['golden', 'odd'])
+def test_native_reader_builds_the_scenes_the_general_reader_builds(tmp_path, which):
+    path = INP
+    if which == 'odd':
+        path = str(tmp_path / 'odd.ndjson')
+        _write_odd_file(path)
+    cols = trajdata.read_ndjson_columns(path)
+    assert cols is not None
+    got = trajdata.scenes_from_columns(cols, 9, 12)
+    want = _general_arrays(path)
+    assert len(got) == len(want) > 0
+    for sc, (sid, peds, xy, paths) in zip(got, want):
+        assert sc.scene_id == sid and list(sc.peds) == peds
+        assert sc.xy.shape == xy.shape and np.array_equal(sc.xy, xy, equal_nan=True)
+        assert sc.frame_diff == paths[0][1].frame - paths[0][0].frame
+        assert sc.first_frame == paths[0][8].frame + sc.frame_diff and sc.start == paths[0][0].frame
+
+
+def test_native_reader_hands_unusual_files_back(tmp_path):
+    p = str(tmp_path / 'f.ndjson')
+    open(p, 'w').write('{"scene": {"id": 0, "p": 1, "s": 0, "e": 10}}\n{"track": {"f": 1.5, "p": 1, "x": 0.0, "y": 0.0}}\n')
+    assert trajdata.read_ndjson_columns(p) is None                        # a non-integer frame: the general reader's business
+    open(p, 'w').write('{"track": {"f": 1, "p": 1, "x": 0.0, "y": 0.0}\n')
+    assert trajdata.read_ndjson_columns(p) is None                        # malformed
+
+
+def test_native_formatter_writes_the_general_writers_bytes(tmp_path):
+    """tnp_format_predictions against write_predictions (itself equal to the reference's writer, above) on the golden scenes
+    with awkward coordinates: exact .5 ties in the third decimal, negative zero, trailing zeros, NaN neighbours, float32 values."""
+    cols = trajdata.read_ndjson_columns(INP)
+    arrs = trajdata.scenes_from_columns(cols, 9, 12)
+    general = [(sid, paths) for sid, _, _, paths in _general_arrays(INP)]
+    rng = np.random.RandomState(0)
+    split = np.concatenate([[0], np.cumsum([len(sc.peds) for sc in arrs])])
+    M = int(split[-1])
+    pred = (rng.randn(2, 12, M, 2) * 7).astype(np.float32).astype(np.float64)
+    pred[0, 0, :, 0] = 0.125                       # exact tie: round-half-even -> 0.12
+    pred[0, 1, :, 0] = -0.001                      # -> -0.0
+    pred[0, 2, :, 1] = 2.5
+    pred[0, 3, :, 1] = 1234567.891
+    pred[1, :, 1::3] = np.nan                      # absent neighbours
+    pred[1, 4, 0, 0] = np.inf
+    preds = [{m: [pred[m, :, split[s]], pred[m, :, split[s] + 1:split[s + 1]]] for m in range(2)} for s in range(len(arrs))]
+    out = str(tmp_path / 'general.ndjson')
+    trajdata.write_predictions(preds, general, out, 9, 12, mode='w')
+    assert bytes(trajdata.format_predictions(pred, split, arrs)) == open(out, 'rb').read()
+
+
+def test_predict_dataset_columns_path_equals_the_general_path(tmp_path):
+    """The same predictor through both paths of predict_dataset (host-only predictor with both entries)."""
+    class Both(object):
+        def _values(self, xys):
+            M = sum(x.shape[1] for x in xys)
+            base = np.concatenate([x[8] for x in xys], axis=0)                       # last observed position per track
+            step = np.arange(1, 13)[:, None, None] * np.float32(0.37)
+            return (np.nan_to_num(base)[None] + step + np.where(np.isnan(base), np.nan, 0.0)[None]).astype(np.float32), M
+
+        def predict_batch(self, scenes, n_predict=12, modes=1, obs_length=9, start_length=0, args=None):
+            xys = [trajdata.paths_to_xy(p) for p, _ in scenes]
+            vals, _ = self._values(xys)
+            split = np.concatenate([[0], np.cumsum([x.shape[1] for x in xys])])
+            return [{m: [vals[:, split[s]] + m, vals[:, split[s] + 1:split[s + 1]] + m] for m in range(modes)} for s in range(len(xys))]
+
+    class Fast(Both):
+        def predict_xy_launch(self, xys, goals, n_predict=12, modes=1, obs_length=9, start_length=0, args=None):
+            vals, _ = self._values(xys)
+            return vals, np.concatenate([[0], np.cumsum([x.shape[1] for x in xys])]), modes
+
+        def predict_xy_finish(self, handle, n_predict=12):
+            vals, split, modes = handle
+            return np.stack([vals + np.float32(m) for m in range(modes)]).astype(np.float64), split
+
+    src = str(tmp_path / 'odd.ndjson')
+    _write_odd_file(src)
+    a, b = str(tmp_path / 'a.ndjson'), str(tmp_path / 'b.ndjson')
+    for flight in (1, 2, 3):
+        assert trajdata.predict_dataset(src, Both(), a, batch_scenes=1, modes=2) == 2
+        assert trajdata.predict_dataset(src, Fast(), b, batch_scenes=1, modes=2, in_flight=flight) == 2
+        assert open(a, 'rb').read() == open(b, 'rb').read() and os.path.getsize(a) > 1000
+    assert trajdata.predict_dataset(INP, Both(), a, batch_scenes=3) == trajdata.predict_dataset(INP, Fast(), b, batch_scenes=3)
+    assert open(a, 'rb').read() == open(b, 'rb').read()
+
+
+def test_native_coordinate_spelling_is_pythons_repr_of_round():
+    """put_coord (csrc/ndjson_io.cpp) against repr(round(float(x), 2)) -- what the reference's writer puts in the file -- on
+    60 k values: float32 predictions over ten decades, float32 and float64 neighbours of two-decimal ties, exact ties, zeros."""
+    import re
+    rng = np.random.RandomState(1)
+    vals = np.concatenate([
+        (rng.randn(30000) * 10 ** rng.uniform(-4, 6, 30000)).astype(np.float32).astype(np.float64),
+        (rng.randint(-100000, 100000, 20000) / 1000.0 + 0.005).astype(np.float32).astype(np.float64),
+        rng.randint(-100000, 100000, 10000) / 1000.0 + 0.005,
+        np.array([0.125, 0.375, -0.125, 2.675, 1e-9, -1e-9, 0.0, -0.0, 0.005, 0.015, 0.025, 1.005, 99999999.995, 123456789012.345,
+                  1e14 + 0.125, 5e15])])
+    M = (len(vals) + 1) // 2
+    pad = np.zeros(2 * M)
+    pad[:len(vals)] = vals
+    sc = trajdata.SceneArrays()
+    sc.scene_id, sc.peds, sc.xy, sc.first_frame, sc.frame_diff, sc.start, sc.end = 1, np.arange(M), None, 10, 10, 0, 200
+    lines = bytes(trajdata.format_predictions(pad.reshape(1, 1, M, 2), [0, M], [sc])).decode().split('\n')[1:-1]
+    got = [g for ln in lines for g in re.match(r'.*"x": (\S+), "y": (\S+), "pred', ln).groups()]
+    want = [repr(round(float(v), 2)) for v in pad]
+    assert got == want

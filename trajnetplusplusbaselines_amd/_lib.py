@@ -106,6 +106,14 @@ def lib():
     L.tnp_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     L.tnp_profile_dispatch_timed.argtypes = []
     L.tnp_tuning_set.argtypes = [ctypes.c_char_p, ctypes.c_long]
+    L.tnp_ndjson_parse.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64] + [_fp] * 4 + [ctypes.POINTER(ctypes.c_int64)] + \
+                                  [_fp] * 4 + [ctypes.POINTER(ctypes.c_int64)]
+    L.tnp_ndjson_parse.restype = ctypes.c_int64
+    L.tnp_format_predictions.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64] + [_fp] * 7 + \
+                                        [ctypes.c_char_p, ctypes.c_size_t]
+    L.tnp_format_predictions.restype = ctypes.c_int64
+    L.tnp_format_predictions_bound.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64]
+    L.tnp_format_predictions_bound.restype = ctypes.c_size_t
     L.tnp_constant_velocity.argtypes = [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp]
     L.tnp_pool_embed_sparse_workspace_bytes.restype = ctypes.c_size_t
     L.tnp_pool_embed_sparse_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]

@@ -9,7 +9,7 @@ PKG = os.path.dirname(HERE)
 OUT_DIR = os.path.join(PKG, 'lib')
 OUT = os.path.join(OUT_DIR, 'libtrajnet_hip.so')
 SOURCES = ['gemm_f32_mfma.hip', 'gemm_skinny.hip', 'gemm_wgrad.hip', 'pool_grid.hip', 'pool_embed_sparse.hip', 'pool_nongrid.hip', 'lstm_seq.hip', 'lstm_bwd.hip', 'loss.hip',
-           'optim.hip', 'classical.hip']
+           'optim.hip', 'classical.hip', 'ndjson_io.cpp']
 EXACT = ('classical.hip', 'pool_grid.hip', 'optim.hip')
 HEADERS = ['tnp_internal.h', 'lstm_cell.h', 'classical_core.h', os.path.join('..', '..', 'include', 'trajnet_hip.h'),
            os.path.join('..', '..', 'include', 'trajnet_hip_profile.h')]

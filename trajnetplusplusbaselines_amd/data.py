@@ -128,6 +128,114 @@ def read_ndjson_scenes(path, limit=None, scene_ids=None):
     return out
 
 
+def read_ndjson_columns(path):
+    """The test file as COLUMNS -- track rows (frame, pedestrian, x, y) in file order and scene rows (id, primary, start, end) --
+    parsed by the native reader (csrc/ndjson_io.cpp: tnp_ndjson_parse; one pass over the bytes instead of one Python dict per
+    row).  Returns a dict of numpy arrays, or None when the file holds something the native reader does not take (non-integer
+    frames / ids, malformed lines): the caller then uses ``read_ndjson_scenes``.  Track rows with a stored prediction are
+    skipped, as there."""
+    import ctypes
+    from . import _lib
+    with open(path, 'rb') as f:
+        buf = f.read()
+    cap = buf.count(b'\n') + 1
+    t_f, t_p = np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.int64)
+    t_x, t_y = np.empty(cap, dtype=np.float64), np.empty(cap, dtype=np.float64)
+    s_cols = [np.empty(cap, dtype=np.int64) for _ in range(4)]
+    nt, ns = ctypes.c_int64(0), ctypes.c_int64(0)
+    cp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = _lib.lib().tnp_ndjson_parse(buf, len(buf), cap, cp(t_f), cp(t_p), cp(t_x), cp(t_y), ctypes.byref(nt),
+                                     cp(s_cols[0]), cp(s_cols[1]), cp(s_cols[2]), cp(s_cols[3]), ctypes.byref(ns))
+    if rc != 0:
+        return None
+    nt, ns = nt.value, ns.value
+    return dict(frame=t_f[:nt], ped=t_p[:nt], x=t_x[:nt], y=t_y[:nt], scene_id=s_cols[0][:ns], scene_ped=s_cols[1][:ns],
+                scene_start=s_cols[2][:ns], scene_end=s_cols[3][:ns])
+
+
+class SceneArrays(object):
+    """One test scene as arrays, after ``preprocess_test``: what ``read_ndjson_scenes`` + ``preprocess_test`` + ``paths_to_xy``
+    + the bookkeeping of ``write_predictions`` derive from the scene's paths (see ``scenes_from_columns``)."""
+    __slots__ = ('scene_id', 'peds', 'xy', 'first_frame', 'frame_diff', 'start', 'end')
+
+
+def scenes_from_columns(cols, obs_length=9, pred_length=12, limit=None):
+    """``read_ndjson_scenes`` -> ``preprocess_test`` -> ``paths_to_xy`` on the columns of ``read_ndjson_columns``, scene by scene
+    with numpy instead of row objects: rows of the scene's frame range in (frame, file order); tracks in order of first
+    appearance, the primary first; tracks and rows after the primary's ``obs_length``-th frame dropped (evaluator/
+    write_utils.py:34-40); ``xy [T, N, 2]`` on the primary's frames, NaN = absent.  Returns a list of ``SceneArrays``, or None
+    when a scene needs the general path (a primary with two rows in one frame)."""
+    F, P, X, Y = cols['frame'], cols['ped'], cols['x'], cols['y']
+    order = np.argsort(F, kind='stable')
+    Fs = F[order]
+    los = np.searchsorted(Fs, cols['scene_start'], 'left')
+    his = np.searchsorted(Fs, cols['scene_end'], 'right')
+    out = []
+    seq_length = obs_length + pred_length
+    for k in range(len(los)):
+        idx = order[los[k]:his[k]]
+        f, pd = Fs[los[k]:his[k]], P[idx]
+        prim = cols['scene_ped'][k]
+        pf = f[pd == prim]
+        if pf.size == 0:
+            continue                                    # the reader drops scenes whose primary has no row in the range
+        if pf.size > 1 and (pf[1:] == pf[:-1]).any():
+            return None
+        last_obs = pf[min(obs_length, pf.size) - 1]
+        cut = np.searchsorted(f, last_obs, 'right')
+        f, pd, idx = f[:cut], pd[:cut], idx[:cut]
+        pf = pf[:min(obs_length, pf.size)]
+        u, first, inv = np.unique(pd, return_index=True, return_inverse=True)
+        rank = np.empty(u.size, dtype=np.int64)
+        by_first = np.argsort(first, kind='stable')
+        pi = int(np.searchsorted(u, prim))
+        by_first = np.concatenate([[pi], by_first[by_first != pi]])           # primary first, then order of first appearance
+        rank[by_first] = np.arange(u.size)
+        col = rank[inv]
+        T = pf.size
+        ti = np.minimum(np.searchsorted(pf, f), T - 1)
+        ok = pf[ti] == f
+        xy = np.full((T, u.size, 2), np.nan)
+        if not ok.all():
+            ti, col, idx = ti[ok], col[ok], idx[ok]
+        xy[ti, col, 0] = X[idx]
+        xy[ti, col, 1] = Y[idx]
+        sc = SceneArrays()
+        sc.scene_id, sc.peds, sc.xy = int(cols['scene_id'][k]), u[by_first], xy
+        if T >= 2:
+            sc.frame_diff = int(pf[1] - pf[0])
+            sc.first_frame = int(pf[min(obs_length, T) - 1]) + sc.frame_diff if T >= obs_length else None
+            sc.start, sc.end = int(pf[0]), int(pf[0]) + (seq_length - 1) * sc.frame_diff
+        else:
+            sc.frame_diff = sc.first_frame = sc.start = sc.end = None
+        out.append(sc)
+        if limit is not None and len(out) >= limit:
+            break
+    return out
+
+
+def format_predictions(pred, split, scenes):
+    """bytes of the prediction-file lines of a batch (``write_predictions``' layout) from ``pred`` float64
+    [modes, pred_length, M, 2] and the batch's ``SceneArrays``: csrc/ndjson_io.cpp, tnp_format_predictions."""
+    import ctypes
+    from . import _lib
+    pred = np.ascontiguousarray(pred, dtype=np.float64)
+    n_modes, pred_length, M = pred.shape[0], pred.shape[1], pred.shape[2]
+    i64 = lambda v: np.ascontiguousarray(v, dtype=np.int64)
+    split, ped = i64(split), i64(np.concatenate([sc.peds for sc in scenes]))
+    sid, ff, fd = i64([sc.scene_id for sc in scenes]), i64([sc.first_frame for sc in scenes]), i64([sc.frame_diff for sc in scenes])
+    st, en = i64([sc.start for sc in scenes]), i64([sc.end for sc in scenes])
+    L = _lib.lib()
+    cap = L.tnp_format_predictions_bound(n_modes, pred_length, M, len(scenes))
+    buf = np.empty(cap, dtype=np.uint8)              # (not zero-filled: the bound is ~2x what is written)
+    cp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    n = L.tnp_format_predictions(cp(pred), n_modes, pred_length, M, len(scenes), cp(split), cp(ped), cp(sid), cp(ff), cp(fd),
+                                 cp(st), cp(en), buf.ctypes.data_as(ctypes.c_char_p), cap)
+    if n < 0:
+        raise RuntimeError('tnp_format_predictions: buffer too small')
+    return buf[:n].data                              # a memoryview: file.write takes it as it is
+
+
 def batch_scenes(scenes_xy):
     """Concatenate per-scene ``[T, N_s, 2]`` arrays along the track axis -> (``[T, M, 2]``, ``batch_split [B+1]``);
     the batch assembly of reference lstm/trainer.py:120-131."""
@@ -310,6 +418,68 @@ def write_predictions(pred_list, scenes, filename, obs_length=9, pred_length=12,
                         f.write(rows(first_frame, frame_diff, neigh_ids[n], neigh_predictions[:, n], m, scene_id))
 
 
+def _predict_dataset_columns(ndjson_in, predictor, out_path, batch_scenes, obs_length, pred_length, modes, goals, in_flight, args,
+                             limit):
+    """``predict_dataset`` for predictors with an array-level entry (``predict_xy_launch`` / ``predict_xy_finish``): the test file
+    is parsed into columns by the native reader, scenes become arrays without a Python object per row, the prediction file's
+    lines are formatted natively, and the three stages overlap -- while the GPU runs batch k the host assembles batch k + 1, and
+    a writer thread formats and writes batch k - 1 (both native calls release the GIL).  ``in_flight`` = batches that stay queued
+    on the GPU while the next one is assembled and launched.  Output: byte for byte what the general path writes.  Returns None when the file
+    needs the general path."""
+    import os
+    import queue
+    import threading
+    cols = read_ndjson_columns(ndjson_in)
+    if cols is None:
+        return None
+    scenes = scenes_from_columns(cols, obs_length, pred_length, limit)
+    if scenes is None or any(sc.first_frame is None for sc in scenes):
+        return None          # (a primary with fewer than obs_length frames: the general path raises the reference's error)
+    d = os.path.dirname(os.path.abspath(out_path))
+    if not os.path.isdir(d):
+        os.makedirs(d)
+    q = queue.Queue(maxsize=4)
+    failure = []
+
+    def writer():
+        with open(out_path, 'wb') as f:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if failure:
+                    continue
+                try:
+                    f.write(format_predictions(*item))
+                except Exception as exc:          # surfaced by the main thread after the loop
+                    failure.append(exc)
+
+    th = threading.Thread(target=writer)
+    th.start()
+    pending = []
+    try:
+        for lo in range(0, len(scenes), batch_scenes):
+            chunk = scenes[lo:lo + batch_scenes]
+            scene_goals = [np.array([goals[int(p)] for p in sc.peds], dtype=np.float64) if goals is not None
+                           else np.zeros((len(sc.peds), 2)) for sc in chunk]
+            handle = predictor.predict_xy_launch([sc.xy for sc in chunk], scene_goals, n_predict=pred_length, modes=modes,
+                                                 obs_length=obs_length, args=args)
+            pending.append((handle, chunk))
+            while len(pending) > max(1, int(in_flight)):           # batch k is queued: read back batch k - in_flight
+                h, ch = pending.pop(0)
+                pred, split = predictor.predict_xy_finish(h, pred_length)
+                q.put((pred, split, ch))
+        for h, ch in pending:
+            pred, split = predictor.predict_xy_finish(h, pred_length)
+            q.put((pred, split, ch))
+    finally:
+        q.put(None)
+        th.join()
+    if failure:
+        raise failure[0]
+    return len(scenes)
+
+
 def predict_dataset(ndjson_in, predictor, out_path, batch_scenes=64, obs_length=9, pred_length=12, modes=1, goals=None,
                     in_flight=1, args=None, limit=None, predict_kwargs=None):
     """The evaluator's prediction loop for one test file (reference lstm/trajnet_evaluator.py:29-65 ``get_predictions`` +
@@ -326,6 +496,12 @@ def predict_dataset(ndjson_in, predictor, out_path, batch_scenes=64, obs_length=
     call as the reference's classical evaluator does (classical/trajnet_evaluator.py:14-27: no goal argument);
     ``predict_kwargs`` are handed on (``sf_params=``, ``orca_params=``, ...).  Returns the number of scenes written."""
     import os
+    kw = dict(predict_kwargs or {})
+    if hasattr(predictor, 'predict_xy_launch') and not kw:
+        n = _predict_dataset_columns(ndjson_in, predictor, out_path, batch_scenes, obs_length, pred_length, modes, goals, in_flight,
+                                     args, limit)
+        if n is not None:
+            return n
     scenes = read_ndjson_scenes(ndjson_in, limit=limit)
     scenes = [(sid, preprocess_test(paths, obs_length)) for sid, paths in scenes]
     scene_goals = [np.array([goals[p[0].pedestrian] for p in paths], dtype=np.float64) if goals is not None
@@ -336,7 +512,6 @@ def predict_dataset(ndjson_in, predictor, out_path, batch_scenes=64, obs_length=
     open(out_path, 'w').close()
     chunks = [list(range(lo, min(lo + batch_scenes, len(scenes)))) for lo in range(0, len(scenes), batch_scenes)]
     batches = [[(scenes[i][1], scene_goals[i]) for i in ids] for ids in chunks]
-    kw = dict(predict_kwargs or {})
     if hasattr(predictor, 'predict_scenes'):
         results = [predictor.predict_scenes(b, n_predict=pred_length, obs_length=obs_length, **kw) for b in batches]
     elif hasattr(predictor, 'predict_batches') and in_flight > 1:

@@ -701,29 +701,52 @@ class LSTMPredictor(object):
         the reference; scenes never interact (lstm/lstm.py:243-250) and the forward runs with ``pad_to='scene'`` (no padded
         slots: a per-scene call has none, whereas the reference's ragged batch would clobber cell (0, 0) of the shorter
         scenes' grids), so the result equals the per-scene calls."""
-        self.model.eval()
-        normalize = bool(getattr(args, 'normalize_scene', False))
-        xys, goals, frames = [], [], []
+        xys, goals = [], []
         for paths, scene_goal in scenes:
             xy = trajdata.paths_to_xy(paths)
+            xys.append(xy)
+            goals.append(np.zeros((xy.shape[1], 2)) if scene_goal is None else np.asarray(scene_goal))
+        if not xys:
+            return []
+        handle = self.predict_xy_launch(xys, goals, n_predict, modes, obs_length, start_length, args)
+        return self._unpack(handle[0], handle[1], handle[2], handle[3], n_predict)
+
+    def predict_xy_launch(self, xys, goals, n_predict=12, modes=1, obs_length=9, start_length=0, args=None):
+        """The array-level half of ``predict_batch``: ``xys`` = per-scene float64 [T, N_s, 2] arrays (what ``paths_to_xy`` gives,
+        primary in column 0), ``goals`` = per-scene [N_s, 2].  Queues the ``modes`` forward passes of the batch and returns a
+        handle WITHOUT waiting for the GPU; ``predict_xy_finish(handle, n_predict)`` reads the predictions back.
+        ``data.predict_dataset`` builds the arrays straight from the columns of the test file and keeps a batch in flight while
+        it prepares the next and writes the previous one."""
+        self.model.eval()
+        normalize = bool(getattr(args, 'normalize_scene', False))
+        obs_list, goal_list, frames = [], [], []
+        for xy, scene_goal in zip(xys, goals):
             if xy.shape[0] < obs_length:
                 raise ValueError('scene has %d frames, need at least obs_length=%d' % (xy.shape[0], obs_length))
-            scene_goal = np.zeros((xy.shape[1], 2)) if scene_goal is None else np.asarray(scene_goal)
             if normalize:
                 xy, rotation, center, scene_goal = trajdata.center_scene(xy, obs_length, goals=scene_goal)
                 frames.append((rotation, center))
-            xys.append(np.asarray(xy)[start_length:obs_length])
-            goals.append(scene_goal)
-        if not xys:
-            return []
-        xy, split = trajdata.batch_scenes(xys)
+            obs_list.append(np.asarray(xy)[start_length:obs_length])
+            goal_list.append(scene_goal)
+        xy, split = trajdata.batch_scenes(obs_list)
         with torch.no_grad():
             obs = torch.from_numpy(np.ascontiguousarray(xy, dtype=np.float32))   # (numpy converts: torch.tensor() of a float64 array wakes the CPU thread pool, ~5 ms on a 256-core host)
-            goal = torch.from_numpy(np.ascontiguousarray(np.concatenate(goals, axis=0), dtype=np.float32))
-            batch_split = torch.tensor(split, dtype=torch.int64)
+            goal = torch.from_numpy(np.ascontiguousarray(np.concatenate(goal_list, axis=0), dtype=np.float32))
+            batch_split = torch.from_numpy(np.asarray(split, dtype=np.int64))
             outputs = [self.model(obs, goal, batch_split, n_predict=n_predict, pad_to='scene', **self._graph_kw())[1]
                        for _ in range(modes)]
-        return self._unpack(outputs, split, frames, normalize, n_predict)
+        return outputs, split, frames, normalize
+
+    def predict_xy_finish(self, handle, n_predict=12):
+        """-> (float64 [modes, n_predict, M, 2] predictions in world coordinates, split): the values ``predict_batch`` returns
+        per scene, as one array (column ``split[s]`` = the primary of scene ``s``)."""
+        outputs, split, frames, normalize = handle
+        out = np.stack([o[-n_predict:].cpu().numpy() for o in outputs]).astype(np.float64)
+        if normalize:
+            for s in range(len(split) - 1):
+                for m in range(out.shape[0]):
+                    out[m, :, split[s]:split[s + 1]] = trajdata.inverse_scene(out[m, :, split[s]:split[s + 1]], *frames[s])
+        return out, split
 
     @staticmethod
     def _unpack(outputs, split, frames, normalize, n_predict):
