@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TNP_ABI_VERSION 6
+#define TNP_ABI_VERSION 7
 #define TNP_API __attribute__((visibility("default")))
 
 /* pooling types: GridBasedPooling(type_=...)  lstm/gridbased_pooling.py:16-19,55-66 */
@@ -210,6 +210,12 @@ typedef struct tnp_lstm_model {
                                     W''[c][o/64][ch/4][o%64][ch%4] = Wp[0][o][ch*n*n + c]  (needs dims[1] % 64 == 0 and
                                     C % 4 == 0; a wave's C x 64 weights of a cell are one contiguous 4 C x 64-byte block).
                                     NULL = that kernel reads Wp0_cell_major (slower: two scalar address ops per channel) */
+    int32_t pool_size;    /* GridBasedPooling(pool_size=, blur_size=) (lstm/gridbased_pooling.py:297-304; ABI 7): the grid is   */
+    int32_t blur_size;    /* built with n * pool_size cells per side (`cell`, `half_*` are the FINE grid's), blurred by
+                             avg_pool2d(blur_size, stride 1, padding blur_size / 2, count_include_pad) and summed over
+                             pool_size x pool_size windows (lp_pool2d, p = 1) down to n x n before the embedding MLP.
+                             0 or 1 = off (the trainer's defaults).  Inference only (tnp_lstm_forward / _step); the training
+                             entry points refuse a model with either set. */
 } tnp_lstm_model;
 
 /* bytes of scratch HBM tnp_lstm_forward / tnp_lstm_step need for M tracks in B scenes */

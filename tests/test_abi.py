@@ -21,12 +21,12 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 12
     for name in names:
         assert hasattr(L, name), name
-    assert L.tnp_abi_version() == _lib.ABI_VERSION == 6   # 2: tnp_lstm_model gained Wx / bx; 3: tnp_step_saves gained winners; 4: scene_slots; 5: Wp0_quad_major; 6: tnp_pool_pair_cells_autograd, tnp_bwd_sweep.cellwin_all
+    assert L.tnp_abi_version() == _lib.ABI_VERSION == 7   # 2: tnp_lstm_model gained Wx / bx; 3: tnp_step_saves gained winners; 4: scene_slots; 5: Wp0_quad_major; 6: tnp_pool_pair_cells_autograd, tnp_bwd_sweep.cellwin_all; 7: tnp_lstm_model.pool_size / blur_size, evaluator-feed entry points
 
 
 def test_struct_layout_matches_header_size():
     # 13 int32 + 4 float + 23 pointers + 1 int32 (+ padding) -- guards against drift between header and ctypes
-    assert ctypes.sizeof(_lib.LstmModel) == 13 * 4 + 4 * 4 + 4 + 23 * 8 + 8 + 6 * 8 + 8
+    assert ctypes.sizeof(_lib.LstmModel) == 13 * 4 + 4 * 4 + 4 + 23 * 8 + 8 + 6 * 8 + 8 + 2 * 4
 
 
 @pytest.mark.parametrize('kind', ['vanilla', 'occupancy', 'directional', 'social', 'social_goals'])

@@ -135,3 +135,32 @@ def test_graph_cache_is_bounded():
             for _ in range(4):
                 model(xy[:9], torch.zeros(xy.shape[1], 2), split, n_predict=12)
     assert len(_graphs(model)) == 3
+
+
+def test_replay_survives_a_cleared_scene_index_cache():
+    """a graph is keyed by the CONTENT of the scene structure, its captured kernels hold raw pointers into the
+    SceneIndex tables (starts / primary / slots).  The entry must keep that index alive: capture a shape, clear the index cache,
+    collect, churn the allocator with fresh tensors of the tables' sizes, replay -- the result must still be the eager one."""
+    import gc
+    from trajnetplusplusbaselines_amd import _lib, synth
+    model = _model('social')
+    xy, split = synth.ragged_crowd(6, 3, 30, seed=12)
+    goals = torch.zeros(xy.shape[1], 2)
+    with torch.no_grad():
+        eager = [t.cpu().numpy() for t in model(xy[:9], goals, split, n_predict=12)]
+        for _ in range(3):
+            model(xy[:9], goals, split, n_predict=12, graph=True)            # third call captures
+        assert len(_graphs(model)) == 1 and _graphs(model)[0].idx is not None
+        _lib.SceneIndex._cache.clear()
+        gc.collect()
+        torch.cuda.synchronize()
+        junk = [torch.full((n,), 12345, dtype=torch.int32, device='cuda') for n in (7, 7, 64, 64, 128, 128, 256, 512) for _ in range(8)]
+        junk += [torch.full((n,), 77, dtype=torch.uint8, device='cuda') for n in (64, 128, 256, 512) for _ in range(8)]
+        torch.cuda.synchronize()
+        other, osplit = synth.ragged_crowd(9, 2, 20, seed=13)                # new index tables land in recycled blocks
+        model(other[:9], torch.zeros(other.shape[1], 2), osplit, n_predict=12)
+        got = [t.cpu().numpy() for t in model(xy[:9], goals, split, n_predict=12, graph=True)]
+        assert _graphs(model)[0].replays >= 1
+    for a, b in zip(got, eager):
+        assert np.array_equal(a, b, equal_nan=True)
+    del junk

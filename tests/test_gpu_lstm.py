@@ -381,43 +381,6 @@ def test_config2_full_size_neighbours_counted_flip_rule():
     print('config 2 full size: rows beyond 2e-5 of 2048 (positions, normals):', f)
 
 
-def test_chained_second_layer_and_gates_launch_agrees_with_the_two_launches():
-    """The experimental chained launch (TNP_CHAIN=1: last embedding layer + LSTM gates in one kernel, consumers waiting on
-    per-row-tile arrival counters, csrc/gemm_f32_mfma.hip) against the two launches on a ragged config-2 crowd, both decoder
-    modes.  The chained kernel keeps the four-wave tiles it was written with; since round 5 the stand-alone launches run the
-    eight-wave tiles (another summation order), so the outputs agree to fp32 rounding, no longer bit for bit.  The switch is read
-    once per process, so the chained run is a child process."""
-    import subprocess
-    import sys
-    import tempfile
-    code = '''
-import sys, numpy as np, torch
-sys.path.insert(0, %r)
-from trajnetplusplusbaselines_amd import synth
-from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling
-torch.manual_seed(4)
-pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=16, out_dim=256, embedding_arch='two_layer', layer_dims=[1024], latent_dim=16)
-model = LSTM(pool=pool).eval().cuda()
-xy, split = synth.ragged_crowd(40, 5, 40, seed=21)
-with torch.no_grad():
-    a = model(xy[:9], torch.zeros(xy.shape[1], 2), split, n_predict=12)[1]
-    b = model(xy[:9], torch.zeros(xy.shape[1], 2), split, prediction_truth=xy[9:20].clone())[1]
-np.savez(sys.argv[1], a=a.cpu().numpy(), b=b.cpu().numpy())
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = {}
-    with tempfile.TemporaryDirectory() as tmp:
-        for tag, env in (('separate', {}), ('chain', {'TNP_CHAIN': '1'})):
-            path = os.path.join(tmp, tag + '.npz')
-            e = dict(os.environ, **env)
-            e.pop('TNP_CHAIN', None) if tag == 'separate' else None
-            r = subprocess.run([sys.executable, '-c', code, path], env=e, capture_output=True, text=True, timeout=600)
-            assert r.returncode == 0, r.stderr[-1500:]
-            z = np.load(path)
-            outs[tag] = (z['a'], z['b'])
-    for x, y in zip(outs['separate'], outs['chain']):
-        assert np.array_equal(np.isnan(x), np.isnan(y)) and np.abs(np.nan_to_num(x) - np.nan_to_num(y)).max() < 2e-5
-
-
 def test_two_batches_in_flight_on_two_streams_equal_sequential_runs():
     """One model, two HIP streams, a different batch on each (LSTMPredictor.predict_batches keeps two forward passes in
     flight): per-stream workspaces and stream-aware caches (_lib.StreamMark) -> every output bit-equal to the same forward
@@ -501,3 +464,34 @@ def test_round5_tiles_are_bitwise_repeatable(scenes, agents):
             rel, pred = model(obs, goals, split, n_predict=12)
             assert torch.equal(torch.nan_to_num(pred, nan=-7.0), torch.nan_to_num(first, nan=-7.0))
             assert torch.equal(torch.nan_to_num(rel, nan=-7.0), torch.nan_to_num(first_rel, nan=-7.0))
+
+
+@pytest.mark.parametrize('case', range(5))
+def test_forward_with_pool_size_and_blur_size_matches_reference(case):
+    """Round 6: GridBasedPooling(pool_size, blur_size) through LSTM.forward -- fine grid, avg_pool2d blur (odd and even windows),
+    lp_pool2d reduction (reference lstm/gridbased_pooling.py:297-304), csrc/pool_grid.hip grid_finish_kernel -- against the
+    reference's own outputs (tests/golden/lstm_poolblur.npz, oracle/gen_golden_r6.py): three grid types, dense and ragged
+    crowds, free-running and teacher-forced, 2e-5.  Training through these options raises."""
+    z = np.load(os.path.join(helpers.GOLDEN, 'lstm_poolblur.npz'))
+    pre = 'c%d_' % case
+    cfg = {k[len(pre) + 4:]: z[k] for k in z.files if k.startswith(pre + 'cfg_')}
+    sd = {k[len(pre) + 3:]: torch.tensor(z[k]) for k in z.files if k.startswith(pre + 'sd_')}
+    pool = GridBasedPooling(type_=str(cfg['type']), hidden_dim=128, cell_side=0.6, n=int(cfg['n']), pool_size=int(cfg['pool_size']),
+                            blur_size=int(cfg['blur_size']), out_dim=int(cfg['out_dim']), embedding_arch=str(cfg['arch']),
+                            layer_dims=[int(v) for v in np.atleast_1d(cfg['dims'])], latent_dim=int(cfg['latent']))
+    model = LSTM(pool=pool)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    for tag in ('lin', 'rag'):
+        xy, split = torch.tensor(z[pre + tag + '_xy']), torch.tensor(z[pre + tag + '_split'])
+        goals = torch.zeros(xy.shape[1], 2)
+        with torch.no_grad():
+            rel, pred = model(xy[:9], goals, split, n_predict=12)
+            helpers.assert_close_nan(rel.cpu().numpy(), z[pre + tag + '_rel_npredict'], 2e-5, 'rel n_predict')
+            helpers.assert_close_nan(pred.cpu().numpy(), z[pre + tag + '_pred_npredict'], 2e-5, 'pred n_predict')
+            rel, pred = model(xy[:9], goals, split, prediction_truth=xy[9:20].clone())
+            helpers.assert_close_nan(rel.cpu().numpy(), z[pre + tag + '_rel_truth'], 2e-5, 'rel truth')
+            helpers.assert_close_nan(pred.cpu().numpy(), z[pre + tag + '_pred_truth'], 2e-5, 'pred truth')
+    model.train()
+    with pytest.raises(NotImplementedError, match='pool_size'):
+        model(xy[:9], goals, split, prediction_truth=xy[9:20].clone())

@@ -6,7 +6,8 @@ import torch
 
 from trajnetplusplusbaselines_amd import ops  # noqa: F401  (registers the ops)
 
-NAMES = ['pool_grid_winners', 'pool_grid', 'linear', 'pool_embed_sparse', 'constant_velocity', 'sf_rollout', 'lstm_sequence']
+NAMES = ['pool_grid_winners', 'pool_grid', 'linear', 'pool_embed_sparse', 'constant_velocity', 'sf_rollout', 'orca_rollout',
+         'kalman_predict', 'lstm_step', 'lstm_sequence']
 
 
 def test_ops_are_registered_with_schemas():
@@ -34,6 +35,14 @@ def test_fake_implementations_propagate_shapes():
         assert torch.ops.trajnet.linear(y, torch.empty(24, N1), None, False).shape == (M, 24)
         assert torch.ops.trajnet.constant_velocity(torch.empty(5, 2, dtype=torch.float64), torch.empty(5, 2, dtype=torch.float64), 12).shape == (12, 5, 2)
         assert torch.ops.trajnet.sf_rollout(torch.empty(9, 6, dtype=torch.float64), starts, 4, 12, 2.1, 0.3, 0.5).shape == (12, 9, 2)
+        orc = torch.ops.trajnet.orca_rollout(torch.empty(9, 2), torch.empty(9, 2), torch.empty(9, 2, dtype=torch.float64),
+                                             torch.empty(9, dtype=torch.float64), starts, 4, 12, 1.5, 1.5, 0.4)
+        assert orc.shape == (12, 9, 2) and orc.dtype == torch.float32
+        kal = torch.ops.trajnet.kalman_predict(torch.empty(7, 9, 2, dtype=torch.float64), torch.empty(7, 5, 13, 6, dtype=torch.float64), 10)
+        assert kal.shape == (7, 13, 2) and kal.dtype == torch.float64
+        h2, c2, nrm = torch.ops.trajnet.lstm_step(torch.empty(M, 128), torch.empty(M, 128), obs, obs, None,
+                                                  torch.empty(4, dtype=torch.int64), True, 0, 0, [torch.empty(3)])
+        assert h2.shape == (M, 128) and c2.shape == (M, 128) and nrm.shape == (M, 5)
         rel, pred = torch.ops.trajnet.lstm_sequence(torch.empty(9, M, 2), None, torch.empty(4, dtype=torch.int64), None, 11, 0, 0,
                                                     [torch.empty(3)])
         assert rel.shape == (19, M, 5) and pred.shape == (19, M, 2)
@@ -95,6 +104,55 @@ def test_constant_velocity_op():
     out = torch.ops.trajnet.constant_velocity(last, prev, 3).cpu()
     want = torch.stack([last.cpu() + (k + 1) * (last.cpu() - prev.cpu()) for k in range(3)])
     assert torch.equal(out, want)
+
+
+@pytest.mark.gpu
+def test_orca_and_kalman_ops_equal_the_wrappers():
+    """trajnet::orca_rollout / trajnet::kalman_predict (round 6) against classical.orca.rollout_batch / classical.kalman.
+    predict_batch (the same C entry points behind the reference's wrapper logic): bit for bit; opcheck schema / fake tensors."""
+    from tests.test_classical import crowd
+    from trajnetplusplusbaselines_amd.classical import orca, kalman
+    pos, vel, goals, speed, sizes = crowd(6, 9, 5)
+    starts = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32).cuda()
+    dv = lambda a, dt: torch.tensor(np.asarray(a), dtype=dt).cuda()
+    args = (dv(pos, torch.float32), dv(vel, torch.float32), dv(goals, torch.float64), dv(speed, torch.float64), starts, int(max(sizes)),
+            12, 1.5, 1.5, 0.4)
+    got = torch.ops.trajnet.orca_rollout(*args).cpu().numpy()
+    assert np.array_equal(got, orca.rollout_batch(pos, vel, speed, goals, sizes))
+    torch.library.opcheck(torch.ops.trajnet.orca_rollout, args, test_utils=('test_schema', 'test_faketensor'))
+    rng = np.random.RandomState(2)
+    t = np.arange(9)[None, :, None]
+    obs = pos[:, None, :] + vel[:, None, :] * 0.4 * (t - 8) + rng.randn(len(pos), 9, 2) * 0.03
+    z = rng.standard_normal((len(pos), 5, 13, 6))
+    kargs = (dv(obs, torch.float64), dv(z, torch.float64), 10)
+    kal = torch.ops.trajnet.kalman_predict(*kargs).cpu().numpy()
+    assert np.array_equal(kal[:, 1:], kalman.predict_batch(obs, 12, noise=z))
+    torch.library.opcheck(torch.ops.trajnet.kalman_predict, kargs, test_utils=('test_schema', 'test_faketensor'))
+
+
+@pytest.mark.gpu
+def test_lstm_step_op_equals_the_module_step():
+    """trajnet::lstm_step == LSTM.step (dense state form) bit for bit, encoder and decoder cell, absent tracks passed through."""
+    from trajnetplusplusbaselines_amd import ops as tops, synth
+    from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling
+    torch.manual_seed(1)
+    pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=8, out_dim=64, embedding_arch='two_layer',
+                            layer_dims=[128], latent_dim=8)
+    model = LSTM(pool=pool).cuda().eval()
+    xy, split = synth.ragged_crowd(4, 2, 9, seed=5)
+    M = xy.shape[1]
+    h, c = torch.randn(M, 128).cuda(), torch.randn(M, 128).cuda()
+    o1, o2, goals = xy[7].cuda(), xy[8].cuda(), torch.zeros(M, 2).cuda()
+    assert torch.isnan(o2).any()
+    with torch.no_grad():
+        for dec in (False, True):
+            (h2, c2), nrm = model.step(model.decoder if dec else model.encoder, (h, c), o1, o2, goals, split)
+            args = (h, c, o1, o2, goals, split, dec, 0, tops.model_handle(model), list(model.parameters()))
+            g = torch.ops.trajnet.lstm_step(*args)
+            assert torch.equal(g[0], h2) and torch.equal(g[1], c2) and torch.equal(torch.nan_to_num(g[2]), torch.nan_to_num(nrm))
+            torch.library.opcheck(torch.ops.trajnet.lstm_step, args, test_utils=('test_schema', 'test_faketensor'))
+        absent = torch.isnan(o2[:, 0]) | torch.isnan(o1[:, 0])
+        assert torch.equal(g[0][absent], h[absent]) and torch.equal(g[1][absent], c[absent])
 
 
 @pytest.mark.gpu

@@ -59,7 +59,7 @@ def launch_v(x, w, b, y, stream, variant):
                                     x.shape[0], w.shape[0], x.shape[1], 1, variant, stream), 'linear')
 
 
-for v in (24, 27, 28, 25, 26):
+for v in (24, 27, 25, 26):
     try:
         t = timed(lambda: launch_v(x1, w1, b1, y1, c(p0), v))
         print('second-layer shape, variant %d: %.2f us' % (v, t))

@@ -18,7 +18,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'trajnet_hip.h')
 
 POOL_NONE, POOL_OCCUPANCY, POOL_DIRECTIONAL, POOL_SOCIAL = -1, 0, 1, 2
 POOL_NN, POOL_HIDDENMLP, POOL_ATTNMLP, POOL_NNLSTM, POOL_TRAJ = 4, 5, 6, 7, 8
-ABI_VERSION = 6   # TNP_ABI_VERSION of include/trajnet_hip.h this binding was written against
+ABI_VERSION = 7   # TNP_ABI_VERSION of include/trajnet_hip.h this binding was written against
 POOL_TYPES = {None: POOL_NONE, 'occupancy': POOL_OCCUPANCY, 'directional': POOL_DIRECTIONAL, 'social': POOL_SOCIAL}
 
 _fp = ctypes.c_void_p
@@ -40,6 +40,7 @@ class LstmModel(ctypes.Structure):
         ('variant', ctypes.c_int32),
         ('Wx', _fp * 3), ('bx', _fp * 3),
         ('Wp0_quad_major', _fp),
+        ('pool_size', ctypes.c_int32), ('blur_size', ctypes.c_int32),
     ]
 
 

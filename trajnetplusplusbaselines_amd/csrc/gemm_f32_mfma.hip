@@ -186,7 +186,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[AN], i
                 }
             }
         }
-    } else {
+    } else if constexpr (AN == 4) {   // (the gate-split tiles, AN == 1, swap their gate blocks through LDS and never come here)
         const int H = g.H;
         const int unit = tn * 32 + (lane & 31);
         if (unit < H) {
@@ -532,19 +532,8 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_fast(const GemmArgs
 // ---------------------------------------------------------------------------------------------------------
 // Template switches beyond the tile shape are for tools/experiments/gemm_probe.hip: DBG shader-clock stamps per wave (buffer
 // passed as g.gates_out, g.C for the LSTM epilogue), ACC2 two accumulator chains per tile, GABL timing ablations.
-// CHAIN (chain_l2_gates_kernel below): 0 = a kernel of its own; 1 = PRODUCER role: the result tile leaves through LDS as
-// 16-byte write-through (sc1) stores, then the tile's arrival counter is bumped; 2 = CONSUMER role: the workgroup waits for
-// the counter of its row tile before it loads the first K tile that holds the producer's output.
-struct ChainCtl {
-    unsigned *flags;      // [tiles_m] arrival counters of the producer's 32-row tiles (monotonic over the steps of a forward)
-    unsigned target;      // value a counter has when every producer workgroup of the row tile has published
-    int kt_wait;          // consumer: first K tile that reads the producer's columns
-    unsigned *giveup;     // set to 1 if a wait ran out of patience (never in a correct launch)
-};
-
-template <int WM, int WN, int WK, int AN, int BK, int EPI, bool DUAL, int DBG = 0, bool ACC2 = false, int SCHED = 0, int GABL = 0,
-          int CHAIN = 0>
-__device__ __forceinline__ void gemm_nt_pipe_body(const GemmArgs &g, const int bid, const ChainCtl cc) {
+template <int WM, int WN, int WK, int AN, int BK, int EPI, bool DUAL, int DBG = 0, bool ACC2 = false, int SCHED = 0, int GABL = 0>
+__device__ __forceinline__ void gemm_nt_pipe_body(const GemmArgs &g, const int bid) {
 #define GP_T(k) do { if constexpr (DBG) { if ((threadIdx.x & 63) == 0) reinterpret_cast<long long *>(EPI == EPI_LSTM ? (float *)g.C : g.gates_out)[(blockIdx.x * (WM * WN * WK) + (threadIdx.x >> 6)) * 8 + (k)] = (long long)__builtin_readcyclecounter(); } } while (0)
     GP_T(0);
     constexpr int BM = 32 * WM;
@@ -587,22 +576,6 @@ __device__ __forceinline__ void gemm_nt_pipe_body(const GemmArgs &g, const int b
     const int K1 = g.K1;
     const int Kg = (g.K1 + g.K2) / WK;  // multiple of BK
     const int KT = Kg / BK;
-
-    // consumer of a chained launch: block until every producer workgroup of this row tile has published its columns
-    auto chain_wait = [&]() {
-        if constexpr (CHAIN == 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (tid == 0) {
-                int it = 0;
-                while ((int)(__hip_atomic_load(cc.flags + tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - cc.target) < 0) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++it > (1 << 24)) { *cc.giveup = 1u; break; }
-                }
-            }
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
 
     const float *cur[CH];
     const float *alt[CH];
@@ -670,7 +643,6 @@ __device__ __forceinline__ void gemm_nt_pipe_body(const GemmArgs &g, const int b
     if (g.prio && __builtin_amdgcn_readfirstlane(wave) >= (WM * WN * WK) / 2) __builtin_amdgcn_s_setprio(1);
 
     // prologue: tile 0 in LDS buffer 0, tile 1 in registers, first fragments of tile 0 in flight
-    if constexpr (CHAIN == 2) { if (cc.kt_wait <= 1) chain_wait(); }
     load_stage(0);
     // epilogue operands (bias, previous cell state, presence mask) are fetched now: every workgroup runs in lockstep, so a
     // load issued after the main loop would expose its full latency on the whole chip
@@ -719,7 +691,6 @@ __device__ __forceinline__ void gemm_nt_pipe_body(const GemmArgs &g, const int b
             if constexpr (SCHED) {
                 // the global loads of tile t+2 are issued in the same k8 step as the LDS writes of tile t+1 (the stage
                 // registers are free as soon as those writes have issued) and everything is interleaved with the MFMAs
-                if constexpr (CHAIN == 2) { if (k8 == WRITE_AT && kt + 2 == cc.kt_wait && kt + 2 < KT) chain_wait(); }
                 if constexpr (!(GABL & 1)) if (k8 == WRITE_AT && kt + 2 < KT) load_stage(kt + 2);
             } else {
                 __builtin_amdgcn_sched_barrier(0);
@@ -816,44 +787,6 @@ __device__ __forceinline__ void gemm_nt_pipe_body(const GemmArgs &g, const int b
         }
     }
     GP_T(4);
-    if constexpr (CHAIN == 1) {
-        // PRODUCER of a chained launch: the consumer workgroups (possibly on another XCD, whose L2 is not coherent with
-        // this one) read this tile inside the same launch.  Bias + ReLU, then the tile goes through LDS so that it leaves as
-        // 16-byte write-through (sc1) stores -- per-lane dword sc1 stores are one fabric write each, ~6x the time per byte
-        // (microarchitecture guide, hand-off price list) -- every lane drains its stores, and one lane bumps the row tile's
-        // arrival counter (relaxed, agent scope).
-        static_assert(EPI == EPI_BIAS, "producer role: plain dense layer");
-        constexpr int CT_LD = BN + 4;
-        float *ct = smem;                                   // [BM][CT_LD]; the tile ring is free (barrier below / above)
-        __syncthreads();                                    // ring / reduction buffer no longer read
-        if (kg == 0) {
-#pragma unroll
-            for (int an = 0; an < AN; ++an) {
-                const int cl = (wn * AN + an) * 32 + (lane & 31);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[an][r] + ebias[an];
-                    if (g.relu) v = v > 0.0f ? v : 0.0f;
-                    ct[(wm * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2)) * CT_LD + cl] = v;
-                }
-            }
-        }
-        __syncthreads();
-        constexpr int Q = BM * BN / 4;
-        for (int q = tid; q < Q; q += NT) {
-            const int rr = q / (BN / 4), c4 = q - rr * (BN / 4);
-            const int row = m0 + rr, col = n0 + 4 * c4;
-            if (row < g.M && col + 3 < g.N) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(ct + rr * CT_LD + 4 * c4);
-                float *dst = g.C + (size_t)row * g.ldc + col;
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" :: "v"(dst), "v"(v) : "memory");
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(cc.flags + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
     if (kg != 0) return;
     epilogue<AN, EPI>(g, acc, m0 + wm * 32 + 4 * (lane >> 5), n0, wn, tn, lane, EPI == EPI_BIAS ? ebias : nullptr);
     GP_T(5);
@@ -862,26 +795,7 @@ __device__ __forceinline__ void gemm_nt_pipe_body(const GemmArgs &g, const int b
 
 template <int WM, int WN, int WK, int AN, int BK, int EPI, bool DUAL, int DBG = 0, bool ACC2 = false, int SCHED = 0, int GABL = 0>
 __global__ void __launch_bounds__(64 * WM * WN * WK) gemm_nt_pipe(const GemmArgs g) {
-    gemm_nt_pipe_body<WM, WN, WK, AN, BK, EPI, DUAL, DBG, ACC2, SCHED, GABL, 0>(g, blockIdx.x, ChainCtl{nullptr, 0u, 0, nullptr});
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Chained launch: the LAST embedding layer (producer: [tracks, K] x [P, K]^T + bias, ReLU, written into the pooled columns
-// of the LSTM input X) and the LSTM gates GEMM (consumer: [h | X] x [W_hh | W_ih]^T + cell update) in ONE launch of
-// 2 x 256-thread workgroups per 32-track x {64 | 128}-column tile.  Producers have the lower block ids (dispatched first),
-// consumers wait on the arrival counter of their 32-track tile right before their first K tile that reads the pooled
-// columns -- everything before that (launch ramp, kernel arguments, weight and state tiles, the h and input-embedding part of
-// the contraction) runs while the producers work, on the SAME CUs: each of the two kernels alone keeps one wave per SIMD busy
-// half the time (matrix pipe 50 % busy), two co-resident workgroups fill each other's stalls.  Measured with independent
-// operands on two streams: 22.2 us for the pair against 28.8 us back to back (tools/diag/gemm_overlap_probe.py).
-// Both roles need <= 80 KB of LDS (two workgroups per CU): the producer's K tile is BKP wide (16: 46 KB).
-// ---------------------------------------------------------------------------------------------------------
-template <int BKP, bool DUALC>
-__global__ void __launch_bounds__(256) chain_l2_gates_kernel(const GemmArgs gp, const GemmArgs gc, const ChainCtl cc, const int n_prod) {
-    if ((int)blockIdx.x < n_prod)
-        gemm_nt_pipe_body<1, 2, 2, 1, BKP, EPI_BIAS, false, 0, false, 1, 0, 1>(gp, blockIdx.x, cc);
-    else
-        gemm_nt_pipe_body<1, 4, 1, 1, 32, EPI_LSTM, DUALC, 0, false, 1, 0, 2>(gc, (int)blockIdx.x - n_prod, cc);
+    gemm_nt_pipe_body<WM, WN, WK, AN, BK, EPI, DUAL, DBG, ACC2, SCHED, GABL>(g, blockIdx.x);
 }
 
 template <typename KernT>
@@ -1030,13 +944,11 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
         case 25: TNP_TRY_PIPE(1, 4, 1, 1, 32, EPI_BIAS); break;  // pipelined: 32x128, four waves over the whole K
         case 26: TNP_TRY_PIPE(1, 2, 2, 2, 32, EPI_BIAS); break;  // pipelined: 32x128, split-K 2, two blocks per wave
         case 27: TNP_TRY_PIPE(1, 1, 4, 1, 16, EPI_BIAS); break;  // 32x32, split-K 4, 61 KB (two workgroups per CU): small batches when K % 128 != 0
-        case 28: TNP_TRY_PIPE(1, 1, 4, 1, 32, EPI_BIAS); break;  // probe: 32x32, split-K 4, K tile 32 (110 KB: one per CU)
         case 29: TNP_TRY_PIPE(1, 1, 8, 1, 16, EPI_BIAS); break;  // 32x32, split-K 8 (eight waves, 120 KB): small batches, long K
-        case 32: TNP_TRY_PIPE(2, 2, 2, 1, 16, EPI_BIAS); break;  // probe: 64x64, K range over two wave quartets (eight waves)
         case 33: TNP_TRY_PIPE(2, 2, 1, 1, 32, EPI_BIAS); break;  // 64x64 pipelined, four waves: up to four rounds of workgroups
         case 31: TNP_TRY_PIPE(1, 4, 2, 1, 32, EPI_BIAS); break;  // 32x128, K range over two wave quartets (eight waves)
         case 30: TNP_TRY_PIPE(1, 2, 4, 1, 16, EPI_BIAS); break;  // 32x64, split-K 4 (eight waves): long K at one workgroup per CU
-        default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d (0 = automatic, 12, 24 .. 33)", variant);
+        default: TNP_FAIL(-1, "tnp_linear_forward: unknown variant %d (0 = automatic, 12, 24 .. 27, 29 .. 31, 33, 40 .. 45)", variant);
     }
     // shape not eligible for the fast path: masked general kernel
     if (big_tiles >= 192) return launch_general<4, 2, 1, 1, 32, EPI_BIAS>(g, s);
@@ -1044,69 +956,11 @@ int launch_linear(const GemmArgs &g_in, int variant, hipStream_t s) {
 }
 
 // [x | h] x [W_ih | W_hh]^T is contracted h FIRST ([h | x] x [W_hh | W_ih]^T: the same sum in another order) in every
-// variant, so that the chained launch -- whose consumer must see the pooled columns of x as late as possible -- and the
-// kernels on their own give bit-identical results.
+// variant: the pooled columns of x -- the last thing the step produces -- enter the sum last.
 static void gates_h_first(GemmArgs &g) {
     if (g.K2 <= 0) return;
     std::swap(g.A1, g.A2); std::swap(g.lda1, g.lda2); std::swap(g.K1, g.K2);
     std::swap(g.B1, g.B2); std::swap(g.ldb1, g.ldb2); std::swap(g.bias1, g.bias2);
-}
-
-template <int BKP>
-static int launch_chain_impl(GemmArgs &gp, GemmArgs &gc, const ChainCtl &cc, hipStream_t s) {
-    constexpr size_t smem_p = (size_t)3 * 2 * (32 + 64) * (BKP + 4) * sizeof(float);
-    constexpr size_t smem_c = (size_t)3 * (32 + 128) * (32 + 4) * sizeof(float);
-    constexpr size_t smem_t = (size_t)32 * (64 + 4) * sizeof(float);
-    constexpr size_t smem = smem_p > smem_c ? (smem_p > smem_t ? smem_p : smem_t) : smem_c;
-    static_assert(smem <= 163840, "LDS");          // BKP = 16: two workgroups per CU; BKP = 32 (83 KB): one (no co-residency)
-    static bool attr = false;
-    auto kern = chain_l2_gates_kernel<BKP, true>;
-    if (!attr) {
-        TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
-    }
-    const int n_prod = gp.tiles_m * gp.tiles_n, n_cons = gc.tiles_m * gc.tiles_n;
-    hipLaunchKernelGGL(kern, dim3(n_prod + n_cons), dim3(256), smem, s, gp, gc, cc, n_prod);
-    TNP_HIP(hipGetLastError());
-    return 0;
-}
-
-// 0 = launched; 1 = this pair of shapes is not eligible (the caller launches the two kernels on their own); < 0 error
-bool chain_l2_gates_enabled() {
-    static const bool enabled = getenv("TNP_CHAIN") != nullptr && getenv("TNP_CHAIN")[0] == '1';
-    return enabled;
-}
-
-int launch_chain_l2_gates(const GemmArgs &gp_in, const GemmArgs &gc_in, unsigned *flags, unsigned epoch, hipStream_t s) {
-    // EXPERIMENTAL, off by default (measured slower than the two launches: docs/history.md section 9): TNP_CHAIN=1 turns it on,
-    // TNP_CHAIN_BK=32 selects the 32-wide producer K tile (83 KB of LDS: one workgroup per CU, no co-residency),
-    // TNP_CHAIN_NOWAIT=1 drops the consumer's wait (wrong results; timing of pure co-residency)
-    const bool enabled = chain_l2_gates_enabled();
-    static const bool bk32 = getenv("TNP_CHAIN_BK") != nullptr && atoi(getenv("TNP_CHAIN_BK")) == 32;
-    static const bool nowait = getenv("TNP_CHAIN_NOWAIT") != nullptr;
-    if (!enabled || !flags) return 1;
-    GemmArgs gp = gp_in, gc = gc_in;
-    check_vec(gp);
-    check_vec(gc);
-    gates_h_first(gc);
-    const int BKP = bk32 ? 32 : 16;
-    if (gp.K2 != 0 || gp.nseg != 0 || gp.mask_act || gp.N % 64 != 0 || !fast_ok(gp, 2, BKP) || gp.M != gc.M) return 1;
-    if (gc.K2 <= 0 || gc.H % 32 != 0 || !fast_ok(gc, 1, 32) || gc.M >= 4096) return 1;
-    // the producer writes the LAST gp.N columns of the consumer's second operand X (leading dimension lda2)
-    const long off = gp.C - gc.A2;
-    if (gp.ldc != gc.lda2 || off < 0 || off + gp.N != gc.K2 || (gc.K1 + off) % 32 != 0) return 1;
-    gp.tiles_m = (gp.M + 31) / 32; gp.tiles_n = gp.N / 64;
-    gc.tiles_m = gp.tiles_m; gc.tiles_n = gc.H / 32;
-    if ((gp.tiles_m * gp.tiles_n) % 8 != 0) return 1;       // consumers keep their XCD residue
-    // every workgroup must be resident or dispatched after what it waits for: producers come first in block order, and
-    // (n_prod + n_cons) workgroups of 256 threads fit two per CU whenever each kernel alone fits one per CU
-    if (gp.tiles_m * gp.tiles_n > 2 * compute_units()) return 1;
-    gp.prio = 0; gc.prio = 0;
-    ChainCtl cc;
-    cc.flags = flags; cc.giveup = flags + gp.tiles_m;
-    cc.target = epoch * (unsigned)gp.tiles_n;
-    cc.kt_wait = nowait ? (1 << 20) : (int)((gc.K1 + off) / 32);
-    return bk32 ? launch_chain_impl<32>(gp, gc, cc, s) : launch_chain_impl<16>(gp, gc, cc, s);
 }
 
 int launch_lstm_gates(const GemmArgs &g_in, int variant, hipStream_t s) {
@@ -1136,7 +990,7 @@ int launch_lstm_gates(const GemmArgs &g_in, int variant, hipStream_t s) {
         case 20: TNP_TRY_PIPE(1, 1, 4, 4, 16, EPI_LSTM); break;  // pipelined: 32 tracks x 32 units, split-K 4
         case 21: TNP_TRY_PIPE(1, 4, 1, 1, 32, EPI_LSTM); TNP_TRY_PIPE(1, 1, 4, 4, 16, EPI_LSTM); break;   // gate split
         case 22: TNP_TRY_PIPE(1, 4, 2, 1, 32, EPI_LSTM); TNP_TRY_PIPE(1, 4, 1, 1, 32, EPI_LSTM); TNP_TRY_PIPE(1, 1, 4, 4, 16, EPI_LSTM); break;   // gate split x K split 2 (eight waves)
-        default: TNP_FAIL(-1, "lstm gates: unknown variant %d (0 = automatic, 5, 20, 21, 22)", variant);
+        default: TNP_FAIL(-1, "lstm gates: unknown variant %d (0 = automatic, 5, 20, 21, 22, 30 .. 34)", variant);
     }
     if (g.M >= 4096) return launch_general<2, 1, 2, 4, 32, EPI_LSTM>(g, s);
     return launch_general<1, 1, 4, 4, 16, EPI_LSTM>(g, s);

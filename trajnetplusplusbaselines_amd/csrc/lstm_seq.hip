@@ -407,9 +407,8 @@ struct Workspace {
     int32_t *row_end;                             // sparse path: one past the last row of every row's scene
     int32_t *row_padded;                          // sparse path: slots the reference pads the row's scene to
     int fuse_grid, save_winners;                  // winner tile built inside the sparse kernel; table wanted by the caller
-    unsigned *chain_flags;                        // chained last-embedding-layer + gates launch: arrival counters (+ give-up word)
-    unsigned chain_epoch;                         // steps launched since the counters were zeroed
     size_t bytes;
+    bool fine; float *grid_fine; int ldg_fine;   // pool_size / blur_size != 1: the fine grid in front of grid_finish_kernel
 };
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -433,13 +432,19 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     w.h[1] = (float *)take((size_t)M * H * 4);
     w.c = (float *)take((size_t)M * H * 4);
     // (right behind h[0], h[1], c: the one fill that zeroes the state at the start of a forward pass zeroes these as well)
-    w.chain_flags = (unsigned *)take(((size_t)(M + 31) / 32 + 16) * sizeof(unsigned));
-    w.chain_epoch = 0;
     w.obs1 = (float *)take((size_t)M * 2 * 4);
     w.obs2 = (float *)take((size_t)M * 2 * 4);
     w.X = (float *)take((size_t)M * w.I * 4);
     w.enc = (float *)take((size_t)M * (md->C > 0 ? md->C : 1) * 4);
     w.grid = (float *)take((size_t)M * (w.ldg > 0 ? w.ldg : 4) * 4);
+    // pool_size / blur_size (lstm/gridbased_pooling.py:297-304): the fine grid and, for an even blur_size, the (G + 1)^2 blurred map
+    w.fine = grid_pool && (md->pool_size > 1 || md->blur_size > 1);
+    w.grid_fine = nullptr;
+    if (w.fine) {
+        const int G = md->n * (md->pool_size > 1 ? md->pool_size : 1);
+        w.ldg_fine = (md->C * G * G + 3) & ~3;
+        w.grid_fine = (float *)take((size_t)M * w.ldg_fine * 4);
+    }
     int maxmid = 4;
     for (int l = 1; grid_pool && l < md->n_layers; ++l) if (md->dims[l] > maxmid) maxmid = md->dims[l];
     if (md->pool_type == TNP_POOL_HIDDENMLP) maxmid = md->dims[0] + md->dims[1] + md->dims[2];   // pooled [M, mlp_dim]
@@ -448,7 +453,7 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     w.y[0] = (float *)take((size_t)M * maxmid * 4);
     w.y[1] = (float *)take((size_t)M * maxmid * 4);
     w.mask = (uint8_t *)take((size_t)M);
-    w.sparse = grid_pool && md->pool_type == TNP_POOL_SOCIAL && md->Wp0_cell_major != nullptr && md->constant == 0.0f &&
+    w.sparse = grid_pool && !w.fine && md->pool_type == TNP_POOL_SOCIAL && md->Wp0_cell_major != nullptr && md->constant == 0.0f &&
                ((md->variant >> 16) & 1) == 0 && sparse_supported(md->C, md->dims[1], md->n * md->n) && (w.I % 4 == 0);
     w.winners = nullptr; w.row_base = nullptr; w.partial = nullptr; w.row_end = nullptr; w.row_padded = nullptr; w.fuse_grid = 0;
     w.save_winners = 0;
@@ -627,9 +632,15 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
         ga.B = B; ga.n_max = n_max; ga.scene_slots = scene_slots; ga.type = md->pool_type; ga.n = md->n; ga.C = md->C;
         ga.cell = md->cell; ga.half_x = md->half_x; ga.half_y = md->half_y; ga.constant = md->constant;
         ga.grid = w.sparse ? nullptr : w.grid; ga.ldg = w.ldg; ga.winners = w.sparse ? w.winners : nullptr;
+        if (w.fine) { ga.n = md->n * (md->pool_size > 1 ? md->pool_size : 1); ga.grid = w.grid_fine; ga.ldg = w.ldg_fine; }
         const bool fused_grid = w.sparse && w.fuse_grid && n_max <= 32767;
         int rc = fused_grid ? 0 : launch_grid(ga, s);
         if (rc) return rc;
+        if (w.fine) {
+            rc = launch_grid_finish(w.grid_fine, w.ldg_fine, M, md->C, md->n, md->pool_size > 1 ? md->pool_size : 1,
+                                    md->blur_size > 1 ? md->blur_size : 1, w.grid, w.ldg, s);
+            if (rc) return rc;
+        }
         const float *src = w.grid;
         int lds = w.ldg;
         int l0 = 0;
@@ -665,17 +676,6 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
             if (last) { g.C = w.pdst; g.ldc = w.pld; }
             else { g.C = w.y[l & 1]; g.ldc = md->dims[l + 1]; }
             const int cls = (l == 0) ? PROF_GEMM1 : PROF_ALL_GEMM;
-            // the last layer feeds the LSTM input directly: chained with the gates GEMM in one launch when the shapes allow
-            // it (gemm_f32_mfma.hip: launch_chain_l2_gates -- experimental, enabled by TNP_CHAIN=1, measured slower; variant bit 18 forbids it)
-            if (last && chain_l2_gates_enabled() && !w.to_hidden && ((md->variant >> 18) & 1) == 0 && ((md->variant >> 8) & 0xff) == 0 &&
-                (l > 0 || (md->variant & 0xff) == 0)) {
-                GemmArgs gg;
-                fill_gates_args(gg, md, decoder, w, h_in, h_out, c_in, c_out, M);
-                prof_before(cls, s);
-                rc = launch_chain_l2_gates(g, gg, w.chain_flags, w.chain_epoch + 1, s);
-                if (rc == 0) { prof_after(cls, s); ++w.chain_epoch; return 0; }
-                if (rc < 0) return rc;
-            }
             prof_before(cls, s);
             rc = launch_linear(g, (l == 0) ? (md->variant & 0xff) : 0, s);
             prof_after(cls, s);
@@ -763,6 +763,8 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
         TNP_FAIL(-1, "tnp_lstm_forward_train: stateful interaction encoders need ph_all, pc_all, pgates_all, act_all[0]");
     if (sv && md->pool_type != TNP_POOL_NONE && ((md->variant >> 17) & 1) && !sv->pvec_all)
         TNP_FAIL(-1, "tnp_lstm_forward_train: pool_to_input=False needs pvec_all");
+    if (sv && (md->pool_size > 1 || md->blur_size > 1))
+        TNP_FAIL(-1, "tnp_lstm_forward_train: pool_size / blur_size != 1 run in inference only (no backward through the blur / pooling reduction)");
     if (sv && (!sv->h_all || !sv->c_all || !sv->X_all || !sv->gates_all || !sv->obs1_all || !sv->obs2_all))
         TNP_FAIL(-1, "tnp_lstm_forward_train: h_all, c_all, X_all, gates_all, obs1_all, obs2_all are required");
     if (T_obs < 2) TNP_FAIL(-1, "need at least 2 observed frames (got %d)", T_obs);
@@ -787,13 +789,11 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
     const size_t MH = (size_t)M * H;
     // training: the states of all steps stay in the caller's [steps + 1, M, H] buffers instead of the ping-pong pair
     float *hcur = sv ? sv->h_all : w.h[0];
-    const size_t flag_bytes = ((size_t)(M + 31) / 32 + 16) * sizeof(unsigned);
-    if (!sv && w.c > w.h[0]) {      // lstm.py:207-210; h[0], h[1], c, the chain counters lie one after the other: one fill
-        rc = fill_bytes(hcur, 0, (size_t)(reinterpret_cast<char *>(w.chain_flags) + flag_bytes - reinterpret_cast<char *>(w.h[0])), s); if (rc) return rc;
+    if (!sv && w.c > w.h[0]) {      // lstm.py:207-210; h[0], h[1], c lie one after the other: one fill
+        rc = fill_bytes(hcur, 0, (size_t)(reinterpret_cast<char *>(w.c) + MH * 4 - reinterpret_cast<char *>(w.h[0])), s); if (rc) return rc;
     } else {
         rc = fill_bytes(hcur, 0, MH * 4, s); if (rc) return rc;
         rc = fill_bytes(sv ? sv->c_all : w.c, 0, MH * 4, s); if (rc) return rc;
-        rc = fill_bytes(w.chain_flags, 0, flag_bytes, s); if (rc) return rc;
     }
     if (w.ph[0]) {  // pool.reset() (lstm/lstm.py:213-216): zero interaction-encoder state, all tracks "present"
         rc = fill_bytes((sv && stateful) ? sv->ph_all : w.ph[0], 0, (size_t)M * md->dims[0] * 4, s); if (rc) return rc;
@@ -960,6 +960,8 @@ static int lstm_step_impl(const tnp_lstm_model *md, int decoder, const float *h_
     if (h_in == h_out) TNP_FAIL(-1, "tnp_lstm_step: h_in and h_out must not alias");
     if (md->pool_type == TNP_POOL_NNLSTM || md->pool_type == TNP_POOL_TRAJ)
         TNP_FAIL(-1, "tnp_lstm_step: stateful interaction encoders (pool_lstm) only run inside tnp_lstm_forward");
+    if (sv && (md->pool_size > 1 || md->blur_size > 1))
+        TNP_FAIL(-1, "tnp_lstm_step_train: pool_size / blur_size != 1 run in inference only");
     Workspace w;
     plan_workspace(md, M, workspace, w);
     if (workspace == nullptr || workspace_bytes < w.bytes)
@@ -974,7 +976,6 @@ static int lstm_step_impl(const tnp_lstm_model *md, int decoder, const float *h_
         if (sv->winners && w.sparse) { w.winners = sv->winners; w.save_winners = 1; }
     }
     if (w.sparse) { rc = launch_row_base(scene_start, B, w.row_base, s, w.row_end, w.row_padded, scene_slots, n_max); if (rc) return rc; }
-    { int rcc = fill_bytes(w.chain_flags, 0, ((size_t)(M + 31) / 32 + 16) * sizeof(unsigned), s); if (rcc) return rcc; }   // chained launch: fresh counters
     PrepArgs p;
     fill_prep_common(p, md, w, M);
     p.h = h_in; p.goals = goals;

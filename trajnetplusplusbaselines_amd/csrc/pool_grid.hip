@@ -145,6 +145,47 @@ int launch_grid(const GridArgs &a, hipStream_t s) {
     return 0;
 }
 
+// GridBasedPooling(pool_size, blur_size) behind the scatter (reference lstm/gridbased_pooling.py:297-304): the fine grid
+// [M][C][G][G], G = n pool_size, is blurred by avg_pool2d(blur, stride 1, padding blur / 2, count_include_pad = True) -- a
+// (G + 1)^2 map for an even blur -- and reduced by lp_pool2d(p = 1, pool_size) = avg_pool2d(pool_size) * pool_size^2 to
+// [M][C][n][n].  ATen's order of operations: window sums row-major in float32, one IEEE divide by the FULL window size (padded
+// elements count), the multiply after the second average.  One thread per output element; inference only.
+__global__ void __launch_bounds__(256) grid_finish_kernel(const float *fine, int ldf, long total, int C, int n, int ps, int blur,
+                                                          float *out, int ldo) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= total) return;
+    const int j = (int)(q % n), i = (int)((q / n) % n), ch = (int)((q / ((long)n * n)) % C);
+    const long row = q / ((long)n * n * C);
+    const int G = n * ps, pad = blur / 2;
+    const float *src = fine + (size_t)row * ldf + (size_t)ch * G * G;
+    float acc = 0.0f;
+    for (int y = i * ps; y < i * ps + ps; ++y)
+        for (int x = j * ps; x < j * ps + ps; ++x) {
+            float v;
+            if (blur == 1) v = src[y * G + x];
+            else {
+                float b = 0.0f;
+                for (int yy = max(y - pad, 0); yy < min(y - pad + blur, G); ++yy)
+                    for (int xx = max(x - pad, 0); xx < min(x - pad + blur, G); ++xx) b = __fadd_rn(b, src[yy * G + xx]);
+                v = __fdiv_rn(b, (float)(blur * blur));
+            }
+            acc = __fadd_rn(acc, v);
+        }
+    float r = acc;
+    if (ps > 1) r = __fmul_rn(__fdiv_rn(acc, (float)(ps * ps)), (float)(ps * ps));
+    out[(size_t)row * ldo + (size_t)ch * n * n + i * n + j] = r;
+}
+
+int launch_grid_finish(const float *fine, int ldf, int M, int C, int n, int pool_size, int blur_size, float *out, int ldo,
+                       hipStream_t s) {
+    const long total = (long)M * C * n * n;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(grid_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, fine, ldf, total, C, n, pool_size,
+                       blur_size, out, ldo);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
 // Cell of every ordered pair (ego, neighbour slot) for the scatter's backward pass: the reference's autograd gives
 // EVERY in-range neighbour the gradient of its cell, overwritten duplicates included.
 // out[row][j] = cell id of neighbour j of the row's scene as seen from the ego, -1 if j is the ego itself, absent,

@@ -64,12 +64,6 @@ int launch_lstm_gates(const GemmArgs &g, int variant, hipStream_t s);
 bool skinny_ok(const GemmArgs &g);
 int launch_skinny_linear(const GemmArgs &g, int variant, hipStream_t s);
 int launch_skinny_gates(const GemmArgs &g, int variant, hipStream_t s);
-// last embedding layer (producer) + LSTM gates (consumer) in ONE launch with per-row-tile arrival counters (gemm_f32_mfma.hip):
-// flags = [ceil(M/32) + 1] unsigned zeroed at the start of the forward pass, epoch = 1, 2, ... per step.  Returns 1 when the
-// pair of shapes is not eligible (the caller then launches the two kernels on their own).
-int launch_chain_l2_gates(const GemmArgs &producer, const GemmArgs &gates, unsigned *flags, unsigned epoch, hipStream_t s);
-bool chain_l2_gates_enabled();   // TNP_CHAIN=1 (read once per process)
-
 // ---- grid pooling ---------------------------------------------------------------------------
 struct GridArgs {
     const float *obs1, *obs2;
@@ -83,6 +77,9 @@ struct GridArgs {
     int vec4;  // set by launch_grid
 };
 int launch_grid(const GridArgs &a, hipStream_t s);
+// pool_size / blur_size reduction of a fine grid [M][C][(n ps)^2] to [M][C][n^2] (lstm/gridbased_pooling.py:297-304)
+int launch_grid_finish(const float *fine, int ldf, int M, int C, int n, int pool_size, int blur_size, float *out, int ldo,
+                       hipStream_t s);
 
 // ---- sparse pooling embedding (first MLP layer on the winner table) ---------------------------
 bool sparse_supported(int C, int N1, int ncell);

@@ -240,8 +240,10 @@ class LSTM(torch.nn.Module):
                 raise NotImplementedError('interaction module %s does not run on the MI355X path (supported: '
                                           'GridBasedPooling, NearestNeighborMLP, HiddenStateMLPPooling)'
                                           % type(pool).__name__)
-            if pool.pool_size != 1 or pool.blur_size != 1:
-                raise NotImplementedError('the fused step supports pool_size = blur_size = 1 (the trainer defaults)')
+            # pool_size / blur_size (never set by the trainer; reference gridbased_pooling.py:297-304): the fine grid of
+            # n * pool_size cells per side is blurred and summed down to n x n by csrc/pool_grid.hip grid_finish_kernel in
+            # front of the embedding MLP -- inference; the backward sweep has no such kernel (run_sequence_with_grad raises)
+            m.pool_size, m.blur_size = int(pool.pool_size), int(pool.blur_size)
             m.pool_type = _lib.POOL_TYPES[pool.type_]
             G, cell, half_x, half_y = pool._geometry()
             m.n, m.C, m.P = pool.n, pool.pooling_dim, pool.out_dim

@@ -865,6 +865,10 @@ def _param_lists(model):
 def run_sequence_with_grad(model, observed, goals, batch_split, truth, T_dec, opts=None):
     """(rel_pred, pred, h_last) attached to the autograd graph of the model's parameters (and of `observed` when
     opts['input_grad'] is set and it requires grad)."""
+    pool = getattr(model, 'pool', None)
+    if getattr(pool, 'pool_size', 1) != 1 or getattr(pool, 'blur_size', 1) != 1:
+        raise NotImplementedError('training through GridBasedPooling(pool_size != 1 or blur_size != 1) is not available on the MI355X '
+                                  'path (the trainer never sets them); inference (model.eval() / torch.no_grad()) is')
     params = _param_lists(model)[1]
     if opts is not None and opts.get('h_scale') is not None:      # VAE: a differentiable [M, H] multiplier of the encoder's state
         opts = dict(opts, h_scale_arg=True)

@@ -201,6 +201,53 @@ def _(state, scene_start, n_max, n_predict, v0, sigma, tau):
     return state.new_empty((n_predict, state.shape[0], 2), dtype=torch.float64)
 
 
+@torch.library.custom_op('trajnet::orca_rollout', mutates_args=())
+def orca_rollout(pos: torch.Tensor, vel: torch.Tensor, goals: torch.Tensor, speed: torch.Tensor, scene_start: torch.Tensor,
+                 n_max: int, n_predict: int, neighbor_dist: float, time_horizon: float, radius: float) -> torch.Tensor:
+    """ORCA rollout of many scenes (classical/orca.py:90-119: RVO2 with 10 neighbours, time step 1/20 s, max speed 1.3 x the
+    initial speed, preferred velocity towards the goal capped at the initial speed; 8 n_predict + 1 simulator steps, one output
+    row every 8): pos, vel [M, 2], goals [M, 2], speed [M] -> [n_predict, M, 2] float32."""
+    dev = _dev(pos, 'pos')
+    p0, v0 = _lib.f32c(pos, dev), _lib.f32c(vel, dev)
+    g, sp = goals.to(device=dev, dtype=torch.float64).contiguous(), speed.to(device=dev, dtype=torch.float64).contiguous()
+    vmax = (1.3 * sp).to(torch.float32)
+    st = _starts(scene_start, dev)
+    M = p0.shape[0]
+    out = torch.empty(n_predict, M, 2, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().tnp_orca_rollout(_lib.ptr(p0), _lib.ptr(v0), _lib.ptr(g), _lib.ptr(sp), _lib.ptr(vmax), _lib.ptr(st),
+                                           st.numel() - 1, M, int(n_max), 8 * int(n_predict) + 1, 8, 1.0 / 20, float(neighbor_dist), 10,
+                                           float(time_horizon), float(radius), _lib.ptr(out), None, _lib.stream_ptr()),
+               'tnp_orca_rollout')
+    return out
+
+
+@orca_rollout.register_fake
+def _(pos, vel, goals, speed, scene_start, n_max, n_predict, neighbor_dist, time_horizon, radius):
+    return pos.new_empty((n_predict, pos.shape[0], 2), dtype=torch.float32)
+
+
+@torch.library.custom_op('trajnet::kalman_predict', mutates_args=())
+def kalman_predict(obs: torch.Tensor, noise: torch.Tensor, n_iter: int) -> torch.Tensor:
+    """Constant-velocity Kalman predictor (classical/kalman.py:22-60): EM (``n_iter`` iterations; the reference: 10) on the
+    observed track, then the mean of ``noise.shape[1]`` sampled continuations from the last smoothed state.  obs [N, T, 2]
+    float64 complete tracks, noise [N, n_samples, n_steps, 6] standard-normal draws (4 state + 2 observation components per
+    step) -> [N, n_steps, 2] float64 (row 0 = the last observed step, as pykalman's sample(initial_state=) returns it)."""
+    dev = _dev(obs, 'obs')
+    o = obs.to(torch.float64).contiguous()
+    z = noise.to(device=dev, dtype=torch.float64).contiguous()
+    N, T = o.shape[0], o.shape[1]
+    n_samples, n_steps = z.shape[1], z.shape[2]
+    out = torch.empty(N, n_steps, 2, dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().tnp_kalman_predict(_lib.ptr(o), N, T, int(n_iter), n_steps, n_samples, _lib.ptr(z), 1e-5, 0.05 ** 2,
+                                             _lib.ptr(out), _lib.stream_ptr()), 'tnp_kalman_predict')
+    return out
+
+
+@kalman_predict.register_fake
+def _(obs, noise, n_iter):
+    return obs.new_empty((obs.shape[0], noise.shape[2], 2), dtype=torch.float64)
+
+
 # ---- the recurrent sequence (inference) ----------------------------------------------------------------------------------
 # An op schema carries tensors and scalars; the model's hyper-parameters (interaction module, grid size, ...) and cached
 # device buffers live in the module.  The op therefore takes an integer handle of the module (a weak registry: the handle
@@ -212,6 +259,26 @@ def model_handle(model) -> int:
     h = id(model)
     _MODELS[h] = model
     return h
+
+
+@torch.library.custom_op('trajnet::lstm_step', mutates_args=())
+def lstm_step(h: torch.Tensor, c: torch.Tensor, obs1: torch.Tensor, obs2: torch.Tensor, goals: Optional[torch.Tensor],
+              batch_split: torch.Tensor, decoder: bool, pad_to: int, model: int,
+              params: List[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """One masked recurrent step, LSTM.step (reference lstm/lstm.py:91-168), without gradients: dense state h, c [M, H], the two
+    last positions obs1, obs2 [M, 2] (NaN = absent: the track's state passes through) -> (h', c', normal [M, 5]).  ``decoder``
+    picks the decoder cell; ``model`` = ops.model_handle(module); ``params`` = list(module.parameters()) (read)."""
+    m = _MODELS.get(model)
+    if m is None:
+        raise RuntimeError('trajnet::lstm_step: unknown model handle (the module was garbage collected)')
+    (h2, c2), normal = m.step(m.decoder if decoder else m.encoder, (h, c), obs1, obs2, goals, batch_split,
+                              pad_to=(int(pad_to) if pad_to > 0 else None))
+    return h2, c2, normal
+
+
+@lstm_step.register_fake
+def _(h, c, obs1, obs2, goals, batch_split, decoder, pad_to, model, params):
+    return torch.empty_like(h), torch.empty_like(c), h.new_empty((h.shape[0], 5))
 
 
 @torch.library.custom_op('trajnet::lstm_sequence', mutates_args=())
