@@ -73,6 +73,30 @@ def build_model(cfg, device, seed=0):
     return LSTM(pool=pool).eval().to(device)
 
 
+def step_flops(model, M, agents, sparse_gather=True):
+    """Algorithmic FLOPs of ONE recurrent step of `model` over M tracks: first embedding layer (the sparse gather
+    bound 2 M (A - 1) C N1 for social grids, the dense GEMM otherwise), the other embedding layers, the LSTM gates, Hidden2Normal /
+    social encoding / input embedding.  What `roofline.frac` of every timed leg prices against the fp32 peak."""
+    H = model.hidden_dim
+    pool = getattr(model, 'pool', None)
+    fl = 2.0 * M * (model.encoder.weight_ih.shape[1] + H) * 4 * H + 2.0 * M * H * 5 + 2.0 * M * 2 * 62
+    if pool is not None and hasattr(pool, 'embedding_layers'):
+        layers = pool.embedding_layers()
+        dims = [layers[0].weight.shape[1]] + [l.weight.shape[0] for l in layers]
+        social = pool.type_ == 'social'
+        C = pool.pooling_dim
+        fl += (2.0 * M * (agents - 1) * C * dims[1]) if (social and sparse_gather) else 2.0 * M * dims[0] * dims[1]
+        fl += sum(2.0 * M * dims[i] * dims[i + 1] for i in range(1, len(dims) - 1))
+        if social:
+            fl += 2.0 * M * H * C
+    return fl
+
+
+def leg_roofline(flops, seconds, what):
+    return dict(bound='mfma-f32', achieved=flops / seconds / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                frac=flops / seconds / 1e12 / FP32_MFMA_PEAK_TFLOPS, flops=flops, basis=what)
+
+
 def cpu_baseline(cfg, xy, split, budget_s=20.0):
     """Oracle (kind 'port') on the host cores, same workload, bounded to ~budget_s seconds."""
     import numpy as np
@@ -391,13 +415,38 @@ def strong_scaling_leg(args, device, rank, world, barrier, global_scenes=256):
         t_tr = timed(lambda: train_batch(tmodel, optimizer, criterion, scene_dev, goals, split, 9, 12, batch_size=shard.n_scenes_global,
                                          n_global_scenes=shard.n_scenes_global, pad_to=shard.pad_to, overlap=True), t_steps, 3)
     grad_bytes = sum(p.numel() * 4 for p in tmodel.parameters() if p.grad is not None)
+    # roofline of both legs: algorithmic FLOPs of the shard this rank ran (19 recurrent steps; training = forward + a backward of
+    # twice the forward's multiply-adds) over its time; the ranks run concurrently, so the fraction is per GPU
+    fl = step_flops(model, xy.shape[1], cfg['agents']) * 19
+    predicted = None
+    if world == 1 and rank == 0:
+        # What an 8-GPU run of this leg can reach at best: the time of ONE rank's shard (32 of the 256 scenes, padded as the
+        # full batch pads) against the time of the whole batch here -- kernels of a small shard do not shrink in proportion
+        # (launch floors), which is what caps strong scaling before any communication does.  Training adds the gradient
+        # all-reduce, not modelled: an upper bound.
+        sh8 = parallel.shard_batch(gxy, torch.zeros(gxy.shape[1], 2), gsplit, 0, 8)
+        lo8, hi8 = sh8.track_range
+        x8 = gxy[:, lo8:hi8].contiguous().to(device)
+        g8 = torch.zeros(x8.shape[1], 2, device=device)
+        with torch.no_grad():
+            t8_inf = timed(lambda: model(x8[:9], g8, sh8.batch_split, n_predict=12, pad_to=sh8.pad_to), steps, 3)
+        with torch.enable_grad():
+            t8_tr = timed(lambda: train_batch(tmodel, optimizer, criterion, x8, g8, sh8.batch_split, 9, 12, batch_size=sh8.n_scenes_global,
+                                              pad_to=sh8.pad_to), t_steps, 3)
+        predicted = dict(shard='%d of %d scenes' % (sh8.n_scenes, global_scenes), inference_ms_shard=t8_inf / steps * 1e3,
+                         training_ms_shard=t8_tr / t_steps * 1e3, inference_speedup_upper_bound=t_inf / t8_inf * steps / steps,
+                         training_speedup_upper_bound=(t_tr / t_steps) / (t8_tr / t_steps),
+                         note='time of the whole batch on this GPU / time of one of eight shards on this GPU; north_star asks for >= 6x at 8 GPUs')
     return dict(workload='%s, ONE batch of %d scenes x %d agents x (9 obs + 12 pred) sharded over %d GPU(s)' % (
                     cfg['name'], global_scenes, cfg['agents'], world),
                 scaling='strong', n_gpus=world, global_scenes=global_scenes, scenes_this_rank=shard.n_scenes,
-                inference=dict(value=global_scenes * 21 * steps / t_inf, unit='scene-steps/s', steps=steps, ms_per_step=t_inf / steps * 1e3),
+                inference=dict(value=global_scenes * 21 * steps / t_inf, unit='scene-steps/s', steps=steps, ms_per_step=t_inf / steps * 1e3,
+                               roofline=leg_roofline(fl, t_inf / steps, 'one forward of this rank\'s shard: 19 recurrent steps, dense first layer')),
                 training=dict(value=global_scenes * 21 * t_steps / t_tr, unit='scene-steps/s', steps=t_steps, ms_per_step=t_tr / t_steps * 1e3,
                               allreduce_bytes=grad_bytes if world > 1 else 0,
-                              overlap='in-backward (parallel.GradReducer)' if world > 1 else None))
+                              overlap='in-backward (parallel.GradReducer)' if world > 1 else None,
+                              roofline=leg_roofline(3 * fl, t_tr / t_steps, 'forward + data and weight gradients = 3 x the forward\'s FLOPs')),
+                predicted_8gpu=predicted)
 
 
 def sgan_strong_leg(args, device, rank, world, barrier, global_scenes=128):
@@ -449,14 +498,24 @@ def sgan_strong_leg(args, device, rank, world, barrier, global_scenes=128):
     with torch.enable_grad():
         t_tr = timed(dg, t_steps, 2)
     rec = 3 * 19 + 2 * 20            # recurrent steps of one SGAN.forward: 3 generator samples + 2 discriminator encodings
+    Ml = xy.shape[1]
+    fl_fwd = step_flops(model.generator, Ml, cfg['agents']) * 3 * 19 + step_flops(model.discriminator, Ml, cfg['agents']) * 2 * 20
+    # one d step + one g step: the d step runs the generator without gradients (3 x 19 steps) and trains the discriminator on
+    # real + fake (2 x 20 steps, x 3 with its backward); the g step trains the generator (3 x 19 steps x 3) through the
+    # discriminator's fake score (20 steps forward + data gradient: x 2)
+    fl_dg = (step_flops(model.generator, Ml, cfg['agents']) * 3 * 19 * (1 + 3) +
+             step_flops(model.discriminator, Ml, cfg['agents']) * 20 * (2 * 3 + 2))
     return dict(workload='%s, ONE batch of %d scenes x %d agents sharded over %d GPU(s)' % (cfg['name'], global_scenes, cfg['agents'], world),
                 scaling='strong', n_gpus=world, global_scenes=global_scenes, scenes_this_rank=shard.n_scenes,
                 recurrent_steps_per_forward=rec,
                 inference=dict(value=global_scenes * 21 * steps / t_inf, unit='scene-steps/s (one SGAN.forward = 21 frames per scene)',
-                               steps=steps, ms_per_step=t_inf / steps * 1e3),
+                               steps=steps, ms_per_step=t_inf / steps * 1e3,
+                               roofline=leg_roofline(fl_fwd, t_inf / steps, '3 x 19 generator steps + 2 x 20 discriminator steps of this rank\'s shard')),
                 training=dict(value=global_scenes * 21 * t_steps / t_tr, unit='scene-steps/s (one d step + one g step = 21 frames per scene)',
                               steps=t_steps, ms_per_step=t_tr / t_steps * 1e3,
-                              allreduce_bytes=(sum(p.numel() * 4 for p in model.parameters()) if world > 1 else 0)))
+                              allreduce_bytes=(sum(p.numel() * 4 for p in model.parameters()) if world > 1 else 0),
+                              roofline=leg_roofline(fl_dg, t_tr / t_steps, 'd step (generator forward, discriminator forward + backward) + g step '
+                                                                           '(generator forward + backward through the discriminator\'s score)')))
 
 
 def classical_leg(device, scenes=4096, agents=128):
@@ -915,6 +974,9 @@ def main():
             grad_bytes = sum(p.numel() * 4 for p in tmodel.parameters() if p.grad is not None)
             training = dict(value=scenes_total * 21 * t_steps / t_el, unit='scene-steps/s', steps=t_steps, warmup=t_warm,
                             ms_per_step=t_el / t_steps * 1e3, loss_last=loss_last, loss_first=loss_first,
+                            roofline=leg_roofline(3 * 19 * step_flops(tmodel, M, cfg['agents']), t_el / t_steps,
+                                                  'forward (sparse first layer: gather bound) + data and weight gradients = 3 x the forward\'s '
+                                                  'FLOPs, this rank\'s shard'),
                             workload='Trainer.train_batch of the same model on the same shard: teacher-forced forward, NLL loss, '
                                      'backward, Adam (' + type(optimizer).__module__ + ')%s' % (' + SUM all-reduce of %.1f MB of fp32 gradients over RCCL (%s)' % (
                                          grad_bytes / 1e6, 'launched from inside the backward pass as each gradient is enqueued, largest first'

@@ -16,3 +16,13 @@ d = json.load(open(sys.argv[1]))
 print(sys.argv[1].split('/')[-1], round(d['value']), 'scene-steps/s', round(d['ms_per_step'], 3), 'ms', (d.get('roofline') or {}).get('frac'), (d.get('training') or {}).get('ms_per_step'))
 P
 done
+# round 6: the small-batch regime (one scene per call, batch_size 8) and the evaluator feed
+R=$PWD
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_sp -o t -- python $R/tools/diag/small_batch_workload.py predict 60 > /dev/null 2>&1)
+python tools/rocprof_summary.py gpurun_out/prof_sp/*.db > gpurun_out/${TAG}_small_predict_kernel_stats.md 2>&1; rm -rf gpurun_out/prof_sp
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_st -o t -- python $R/tools/diag/small_batch_workload.py train 60 > /dev/null 2>&1)
+python tools/rocprof_summary.py gpurun_out/prof_st/*.db > gpurun_out/${TAG}_small_train_kernel_stats.md 2>&1; rm -rf gpurun_out/prof_st
+python tools/diag/predict_dataset_throughput.py 1024 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_predict_dataset_throughput.txt
+python tools/diag/small_batch_workload.py train_timeline 300 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_train_host_timeline.txt
+python tests/parity_margin.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_parity_margin.txt
+head -8 gpurun_out/${TAG}_small_predict_kernel_stats.md | cut -c1-150; cat gpurun_out/${TAG}_predict_dataset_throughput.txt
