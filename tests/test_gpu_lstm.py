@@ -279,13 +279,14 @@ def test_gates_kernel_variants_agree():
     goals = torch.zeros(xy.shape[1], 2)
     outs = {}
     with torch.no_grad():
-        for v in (0, 5, 20, 21, 22, 30, 31, 32, 33, 34):
+        for v in (0, 5, 6, 20, 21, 22, 30, 31, 32, 33, 34):
             model.kernel_variant = v << 8
             outs[v] = model(xy[:9], goals, split, n_predict=12)[1]
     model.kernel_variant = 0
     assert torch.equal(torch.nan_to_num(outs[0]), torch.nan_to_num(outs[34]))
-    for v in (5, 20, 21, 30, 31, 32, 33, 34):
+    for v in (5, 6, 20, 21, 30, 31, 32, 33, 34):
         assert (torch.nan_to_num(outs[v]) - torch.nan_to_num(outs[22])).abs().max().item() < 2e-5
+    assert torch.equal(torch.nan_to_num(outs[5]), torch.nan_to_num(outs[6]))        # the same 128-track tile, pipelined
     # the K split of a 16-track tile does not depend on how many column groups share the workgroup
     assert torch.equal(torch.nan_to_num(outs[30]), torch.nan_to_num(outs[31])) and torch.equal(torch.nan_to_num(outs[32]), torch.nan_to_num(outs[33]))
     assert torch.equal(torch.nan_to_num(outs[30]), torch.nan_to_num(outs[34]))

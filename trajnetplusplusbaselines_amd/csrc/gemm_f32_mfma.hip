@@ -974,23 +974,25 @@ int launch_lstm_gates(const GemmArgs &g_in, int variant, hipStream_t s) {
     // round 5 (tools/diag/gates_variant_sweep.py, profiles/round5_gates_variant_sweep.txt): one round of workgroups (M <= 2048 at
     // H = 128) -> the gate split with the K range over two wave quartets (22: eight waves, two per SIMD; 1.046 -> 1.068 M
     // scene-steps/s on the headline); several rounds -> the four-wave gate split (21: two workgroups co-resident per CU; at
-    // 4096 tracks 2.13 ms per forward against 2.47 with the 128-track tiles); from 8192 tracks the 128-track kernel (5)
+    // 4096 tracks 2.13 ms per forward against 2.47 with the 128-track tiles); from 8192 tracks the 128-track kernel (5; round 6: its pipelined form 6)
     if (variant >= 30 && variant <= 34) return launch_skinny_gates(g, variant, s);
     // up to 512 tracks the 16-track gates kernel (16 tracks x 4 units per workgroup, K over four waves: variant 34) -- one
     // 36-agent scene 8.0 us against 14.2, a batch_size-8 training batch (310 tracks) 11.2 against 14.7 (profiles/round6_small_*)
     if (variant == 0 && g.M <= tuning().skinny_gates_max_rows && g.H % 4 == 0 && skinny_ok(g)) return launch_skinny_gates(g, 34, s);
     if (variant == 0) {
         const long wgs = (long)((g.M + 31) / 32) * ((g.H + 31) / 32);
-        if (g.M >= 8192) variant = 5;
+        if (g.M >= 8192) variant = 6;   // 128-track tiles, pipelined: config 3 (16384 tracks) 2.47 -> 2.31 ms per forward, 8192 tracks 1.37 -> 1.27
+                                        // (tools/diag/gates_big_probe.py; bit-identical to variant 5: same tile, same sum order)
         else if (wgs <= compute_units() && fast_ok(g, 2, 32)) variant = 22;
         else variant = fast_ok(g, 1, 32) ? 21 : 20;
     }
     switch (variant) {
         case 5: TNP_TRY_FAST(4, 1, 2, 4, 16, EPI_LSTM); break;   // 128 tracks x 32 units, 8 waves
+        case 6: TNP_TRY_PIPE(4, 1, 2, 4, 16, EPI_LSTM); TNP_TRY_FAST(4, 1, 2, 4, 16, EPI_LSTM); break;   // the same tile on the three-stage ring (round 6)
         case 20: TNP_TRY_PIPE(1, 1, 4, 4, 16, EPI_LSTM); break;  // pipelined: 32 tracks x 32 units, split-K 4
         case 21: TNP_TRY_PIPE(1, 4, 1, 1, 32, EPI_LSTM); TNP_TRY_PIPE(1, 1, 4, 4, 16, EPI_LSTM); break;   // gate split
         case 22: TNP_TRY_PIPE(1, 4, 2, 1, 32, EPI_LSTM); TNP_TRY_PIPE(1, 4, 1, 1, 32, EPI_LSTM); TNP_TRY_PIPE(1, 1, 4, 4, 16, EPI_LSTM); break;   // gate split x K split 2 (eight waves)
-        default: TNP_FAIL(-1, "lstm gates: unknown variant %d (0 = automatic, 5, 20, 21, 22, 30 .. 34)", variant);
+        default: TNP_FAIL(-1, "lstm gates: unknown variant %d (0 = automatic, 5, 6, 20, 21, 22, 30 .. 34)", variant);
     }
     if (g.M >= 4096) return launch_general<2, 1, 2, 4, 32, EPI_LSTM>(g, s);
     return launch_general<1, 1, 4, 4, 16, EPI_LSTM>(g, s);
