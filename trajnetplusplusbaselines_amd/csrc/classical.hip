@@ -14,6 +14,49 @@
 namespace tnp {
 
 // ---- social force: state0 [M][6] = x, y, vx, vy, gx, gy (float64); out [n_out][M][2] --------------------------------
+// sf_agent_step_terms (classical_core.h) with the five fp64 divides per ordered pair -- three "-b / sigma", two "/ delta" -- as
+// multiplications by reciprocals formed once per launch: 60 of the ~364 vector instructions a pair costs (round 6: 95 -> 82 ms
+// at 4096 x 128).  A quotient and the product with the rounded reciprocal differ in the last bit; the host execution keeps the
+// literal formula and the two agree to 1e-11 as before (the exp / sqrt implementations of the two sides differ anyway).
+__device__ __forceinline__ double sf_potential_gpu(double rx, double ry, const sf_agent_terms *tb, double v0, double neg_inv_sigma) {
+    const double n1 = sqrt(rx * rx + ry * ry);
+    const double sx = rx - tb->dex, sy = ry - tb->dey;
+    const double n2 = sqrt(sx * sx + sy * sy);
+    const double in_sqrt = (n1 + n2) * (n1 + n2) - tb->d2;
+    const double b = 0.5 * sqrt(in_sqrt);
+    return v0 * exp(b * neg_inv_sigma);
+}
+
+__device__ __forceinline__ void sf_agent_step_gpu(int a, int n, const double *st, const sf_agent_terms *terms, double initial_speed,
+                                                  double max_speed, const sf_params *p, double neg_inv_sigma, double *vx_new,
+                                                  double *vy_new) {
+    const double *sa = st + 7 * a;
+    const double eax = terms[a].ex, eay = terms[a].ey;
+    const double tau = sa[6];
+    double Fx = 1.0 / tau * (initial_speed * eax - sa[2]);
+    double Fy = 1.0 / tau * (initial_speed * eay - sa[3]);
+    const double delta = 1e-3, inv_delta = 1.0 / delta;
+    double sum_x = 0.0, sum_y = 0.0;
+    for (int b = 0; b < n; ++b) {
+        if (b == a) continue;
+        const double *sb = st + 7 * b;
+        const sf_agent_terms *tb = terms + b;
+        const double rx = sa[0] - sb[0], ry = sa[1] - sb[1];
+        const double v = sf_potential_gpu(rx, ry, tb, p->v0, neg_inv_sigma);
+        const double dvdx = (sf_potential_gpu(rx + delta, ry, tb, p->v0, neg_inv_sigma) - v) * inv_delta;
+        const double dvdy = (sf_potential_gpu(rx, ry + delta, tb, p->v0, neg_inv_sigma) - v) * inv_delta;
+        const double fx = -1.0 * dvdx, fy = -1.0 * dvdy;
+        const double in_sight = (eax * (-fx) + eay * (-fy)) > sqrt(fx * fx + fy * fy) * p->cosphi;
+        const double w = in_sight ? 1.0 : p->out_of_view;
+        sum_x += w * fx; sum_y += w * fy;
+    }
+    Fx += sum_x; Fy += sum_y;
+    const double wx = sa[2] + p->delta_t * Fx, wy = sa[3] + p->delta_t * Fy;
+    const double ws = sqrt(wx * wx + wy * wy);
+    const double factor = fmin(1.0, max_speed / ws);
+    *vx_new = wx * factor; *vy_new = wy * factor;
+}
+
 __global__ void __launch_bounds__(256) sf_rollout_kernel(const double *state0, const int32_t *scene_start, int M,
                                                          int n_steps, int sample_every, double tau, sf_params prm,
                                                          double max_speed_mult, double *out) {
@@ -33,9 +76,10 @@ __global__ void __launch_bounds__(256) sf_rollout_kernel(const double *state0, c
     }
     __syncthreads();
     int n_out = 0;
+    const double neg_inv_sigma = -1.0 / prm.sigma;
     for (int step = 0; step < n_steps; ++step) {
         for (int a = threadIdx.x; a < ns; a += blockDim.x)
-            sf_agent_step_terms(a, ns, st, terms, isp[a], max_speed_mult * isp[a], &prm, &nv[2 * a], &nv[2 * a + 1]);
+            sf_agent_step_gpu(a, ns, st, terms, isp[a], max_speed_mult * isp[a], &prm, neg_inv_sigma, &nv[2 * a], &nv[2 * a + 1]);
         __syncthreads();
         for (int a = threadIdx.x; a < ns; a += blockDim.x) {
             st[a * 7 + 0] += nv[2 * a] * prm.delta_t;
