@@ -296,3 +296,24 @@ def test_native_coordinate_spelling_is_pythons_repr_of_round():
     got = [g for ln in lines for g in re.match(r'.*"x": (\S+), "y": (\S+), "pred', ln).groups()]
     want = [repr(round(float(v), 2)) for v in pad]
     assert got == want
+
+
+def test_native_feed_functions_under_address_sanitizer(tmp_path):
+    """csrc/ndjson_io.cpp + tests/c/ndjson_asan.c built for the HOST with -fsanitize=address,undefined (sanitizers run on the CPU
+    build only): hostile and truncated buffers without a terminating NUL, every prefix of a well-formed buffer, the formatter
+    with exact and too-small bounds."""
+    import shutil
+    import subprocess
+    if shutil.which('g++') is None:
+        pytest.skip('no host compiler')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'ndjson_asan')
+    cmd = ['g++', '-std=c++17', '-g', '-O1', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-I', os.path.join(root, 'include'),
+           '-x', 'c++', os.path.join(root, 'trajnetplusplusbaselines_amd', 'csrc', 'ndjson_io.cpp'),
+           '-x', 'c++', os.path.join(root, 'tests', 'c', 'ndjson_asan.c'), '-o', exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and 'asan' in (r.stderr or '').lower():
+        pytest.skip('sanitizer runtime not installed')
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS='detect_leaks=1'))
+    assert r.returncode == 0 and r.stdout.startswith('ok'), (r.stdout + r.stderr)[-3000:]
