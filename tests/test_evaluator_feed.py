@@ -317,3 +317,47 @@ def test_native_feed_functions_under_address_sanitizer(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS='detect_leaks=1'))
     assert r.returncode == 0 and r.stdout.startswith('ok'), (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_columns_path_equals_general_path_on_random_files(tmp_path, seed):
+    """Random test files (random frame steps, tracks entering and leaving, overlapping scenes, primaries with fewer than obs_length
+    rows in range, duplicate rows of neighbours, shuffled line order inside a frame, negative coordinates, ids up to 1e9):
+    scenes_from_columns == read_ndjson_scenes + preprocess_test + paths_to_xy, scene by scene; files the fast path hands back
+    (a primary with two rows in one frame) are recognised as such."""
+    rng = np.random.RandomState(100 + seed)
+    lines, n_scenes = [], int(rng.randint(3, 9))
+    step = int(rng.choice([1, 5, 10]))
+    peds = sorted(set(int(v) for v in rng.randint(0, 10 ** 9, size=int(rng.randint(4, 15)))))
+    life = {p: (int(rng.randint(0, 30)), int(rng.randint(31, 60))) for p in peds}
+    for k in range(n_scenes):
+        p = int(rng.choice(peds))
+        s0 = int(rng.randint(life[p][0], life[p][0] + 25))
+        lines.append(json.dumps({'scene': {'id': int(rng.randint(0, 10 ** 6)), 'p': p, 's': s0 * step, 'e': (s0 + 20) * step, 'fps': 2.5, 'tag': 0}}))
+    rows = []
+    for t in range(0, 60):
+        here = [p for p in peds if life[p][0] <= t <= life[p][1] and rng.rand() > 0.05]
+        rng.shuffle(here)
+        for p in here:
+            rows.append(json.dumps({'track': {'f': t * step, 'p': p, 'x': round(float(rng.randn() * 9), 2), 'y': round(float(rng.randn() * 9), 2)}}))
+    if seed % 3 == 2:                                                    # duplicate rows of a non-primary track
+        rows += rows[3:6]
+    path = str(tmp_path / 'r.ndjson')
+    open(path, 'w').write('\n'.join(lines + rows) + '\n')
+    cols = trajdata.read_ndjson_columns(path)
+    assert cols is not None
+    got = trajdata.scenes_from_columns(cols, 9, 12)
+    general = [(sid, trajdata.preprocess_test(paths, 9)) for sid, paths in trajdata.read_ndjson_scenes(path)]
+    primaries_dup = any(len(set(r.frame for r in paths[0])) != len(paths[0]) for _, paths in general)
+    if got is None:
+        assert primaries_dup
+        return
+    assert len(got) == len(general)
+    for sc, (sid, paths) in zip(got, general):
+        xy = trajdata.paths_to_xy(paths)
+        assert sc.scene_id == sid and list(sc.peds) == [p[0].pedestrian for p in paths]
+        assert sc.xy.shape == xy.shape and np.array_equal(sc.xy, xy, equal_nan=True)
+        if len(paths[0]) >= 9:
+            assert sc.first_frame == paths[0][8].frame + (paths[0][1].frame - paths[0][0].frame)
+        else:
+            assert sc.first_frame is None                               # predict_dataset then takes the general path

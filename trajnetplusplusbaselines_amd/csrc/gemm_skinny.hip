@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(64 * CT * KS) gemm_skinny_kernel(const GemmArg
         const float *b1 = g.B1 + (size_t)wr * g.ldb1, *b2 = g.K2 > 0 ? g.B2 + (size_t)wr * g.ldb2 : b1;
         if (EPI == EPI_LSTM) { p1 = b1; p2 = b2; q1 = a1; q2 = a2; }
         else { p1 = a1; p2 = a2; q1 = b1; q2 = b2; }
-        p1 += 4 * kq; q1 += 4 * kq; p2 += 4 * kq - K1; q2 += 4 * kq - K1;   // second source indexed by the global k as well
+        p1 += 4 * kq; q1 += 4 * kq; p2 += 4 * kq; q2 += 4 * kq;
     }
     // epilogue operands of the waves that run it (k group 0), requested BEFORE the main loop: behind it they would be one more
     // exposed global round trip at the tail of a kernel that is nothing but its latency chain
@@ -77,8 +77,8 @@ __global__ void __launch_bounds__(64 * CT * KS) gemm_skinny_kernel(const GemmArg
         for (int i = 0; i < MAXC; ++i) {
             const int k = min(c0 + i, ce - 1) * 16;                             // wave-uniform; a chunk never straddles the sources
             const bool first = k < K1;
-            pv[i] = *reinterpret_cast<const sk_f32x4 *>((first ? p1 : p2) + k);
-            qv[i] = *reinterpret_cast<const sk_f32x4 *>((first ? q1 : q2) + k);
+            pv[i] = *reinterpret_cast<const sk_f32x4 *>(first ? p1 + k : p2 + (k - K1));
+            qv[i] = *reinterpret_cast<const sk_f32x4 *>(first ? q1 + k : q2 + (k - K1));
         }
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
