@@ -18,12 +18,27 @@ namespace tnp {
 // multiplications by reciprocals formed once per launch: 60 of the ~364 vector instructions a pair costs (round 6: 95 -> 82 ms
 // at 4096 x 128).  A quotient and the product with the rounded reciprocal differ in the last bit; the host execution keeps the
 // literal formula and the two agree to 1e-11 as before (the exp / sqrt implementations of the two sides differ anyway).
+// sqrt for the squared distances of a crowd (metres: never denormal, never near overflow): v_rsq_f64 + the usual two coupled
+// Newton steps and a final residual correction, WITHOUT the library's range scaling (two v_ldexp, a compare and the selects
+// around them: 5 of its ~16 instructions, ten square roots per ordered pair).  Zero maps to zero; NaN / negative inputs give NaN
+// as sqrt does.
+__device__ __forceinline__ double sf_sqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return x == 0.0 ? 0.0 : g;
+}
+
 __device__ __forceinline__ double sf_potential_gpu(double rx, double ry, const sf_agent_terms *tb, double v0, double neg_inv_sigma) {
-    const double n1 = sqrt(rx * rx + ry * ry);
+    const double n1 = sf_sqrt(rx * rx + ry * ry);
     const double sx = rx - tb->dex, sy = ry - tb->dey;
-    const double n2 = sqrt(sx * sx + sy * sy);
+    const double n2 = sf_sqrt(sx * sx + sy * sy);
     const double in_sqrt = (n1 + n2) * (n1 + n2) - tb->d2;
-    const double b = 0.5 * sqrt(in_sqrt);
+    const double b = 0.5 * sf_sqrt(in_sqrt);
     return v0 * exp(b * neg_inv_sigma);
 }
 
@@ -46,7 +61,7 @@ __device__ __forceinline__ void sf_agent_step_gpu(int a, int n, const double *st
         const double dvdx = (sf_potential_gpu(rx + delta, ry, tb, p->v0, neg_inv_sigma) - v) * inv_delta;
         const double dvdy = (sf_potential_gpu(rx, ry + delta, tb, p->v0, neg_inv_sigma) - v) * inv_delta;
         const double fx = -1.0 * dvdx, fy = -1.0 * dvdy;
-        const double in_sight = (eax * (-fx) + eay * (-fy)) > sqrt(fx * fx + fy * fy) * p->cosphi;
+        const double in_sight = (eax * (-fx) + eay * (-fy)) > sf_sqrt(fx * fx + fy * fy) * p->cosphi;
         const double w = in_sight ? 1.0 : p->out_of_view;
         sum_x += w * fx; sum_y += w * fy;
     }
