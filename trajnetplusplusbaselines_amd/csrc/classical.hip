@@ -348,8 +348,8 @@ __global__ void __launch_bounds__(256) orca_rollout_reg_kernel(const float *pos0
 }
 
 // ---- Kalman: one lane per track; obs [n_tracks][T][2] float64, z [n_tracks][n_samples][n_steps][6] ---------------------
-// One wave per SIMD on purpose: the EM pass keeps ~330 registers of 4 x 4 double matrices live; capping the allocation for 2 / 3 /
-// 4 waves per SIMD spills them to scratch memory and costs 7.8 / 14.2 / 22.6 ms against 6.5 (BASELINE config 5, round 6) -- the
+// One wave per SIMD on purpose: the EM pass keeps ~310 registers of 4 x 4 double matrices live; capping the allocation for 2 / 3 /
+// 4 waves per SIMD spills them to scratch memory and costs 7.1 / 14.2 / 22.6 ms against 5.8 (BASELINE config 5, round 6) -- the
 // 4 x 4 products carry enough independent fp64 FMAs to keep the pipe of one wave busy.
 __global__ void __launch_bounds__(64, 1) kalman_kernel(const double *obs, int n_tracks, int T, int n_iter, int n_steps,
                                                        int n_samples, const double *z, double q0, double r0, double *out) {
