@@ -496,3 +496,30 @@ def test_forward_with_pool_size_and_blur_size_matches_reference(case):
     model.train()
     with pytest.raises(NotImplementedError, match='pool_size'):
         model(xy[:9], goals, split, prediction_truth=xy[9:20].clone())
+
+
+def test_predictor_modes_of_a_deterministic_model_share_one_forward():
+    """LSTMPredictor(modes=3): the reference runs the same deterministic forward three times (lstm/lstm.py:299-311); here the plain
+    LSTM runs it once per scene / batch and hands every mode its own copy -- per-scene call, predict_batch and the array-level
+    entry of data.predict_dataset.  Same values as three forwards, independent arrays."""
+    from trajnetplusplusbaselines_amd import data as trajdata
+    from trajnetplusplusbaselines_amd.lstm import LSTMPredictor
+    torch.manual_seed(5)
+    pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=8, out_dim=64, embedding_arch='two_layer', layer_dims=[128], latent_dim=8)
+    pred = LSTMPredictor(LSTM(pool=pool).cuda().eval())
+    xy, split = synth.ragged_crowd(3, 3, 9, seed=2, nan_frac=0.0)
+    scenes = [trajdata.xy_to_paths(xy[:, split[s]:split[s + 1]].numpy()) for s in range(3)]
+    goals = [np.zeros((len(p), 2)) for p in scenes]
+    one = pred(scenes[0], goals[0], n_predict=12, modes=1)
+    three = pred(scenes[0], goals[0], n_predict=12, modes=3)
+    assert sorted(three) == [0, 1, 2]
+    for m in range(3):
+        assert np.array_equal(three[m][0], one[0][0]) and np.array_equal(three[m][1], one[0][1], equal_nan=True)
+    three[1][0][:] = 0.0
+    assert not np.array_equal(three[0][0], three[1][0])                    # every mode owns its arrays
+    batch = pred.predict_batch(list(zip(scenes, goals)), n_predict=12, modes=3)
+    assert len(batch) == 3 and all(sorted(b) == [0, 1, 2] for b in batch)
+    for b in batch:
+        assert np.array_equal(b[0][0], b[2][0])
+    arr, sp = pred.predict_xy_finish(pred.predict_xy_launch([trajdata.paths_to_xy(p) for p in scenes], goals, n_predict=12, modes=3), 12)
+    assert arr.shape[0] == 3 and np.array_equal(arr[0], arr[2], equal_nan=True)

@@ -654,6 +654,10 @@ class LSTMPredictor(object):
         # override forward() without it
         return {'graph': True} if (self.graph_replay and type(self.model).forward is LSTM.forward) else {}
 
+    def _deterministic(self):
+        """the plain LSTM in eval mode has no source of randomness: its `modes` forwards of one scene are the same forward"""
+        return type(self.model) is LSTM
+
     def save(self, state, filename):
         with open(filename, 'wb') as f:
             torch.save(self, f)
@@ -683,10 +687,14 @@ class LSTMPredictor(object):
             batch_split = torch.tensor(batch_split, dtype=torch.int64)
 
             multimodal_outputs = {}
+            first = None
             for num_p in range(modes):
-                _, output_scenes = self.model(xy[start_length:obs_length], scene_goal, batch_split,
-                                              n_predict=n_predict, **self._graph_kw())
-                output_scenes = output_scenes.cpu().numpy()
+                if first is not None and self._deterministic():
+                    output_scenes = first.copy()      # (the reference runs the same deterministic forward `modes` times, lstm/lstm.py:299-311)
+                else:
+                    _, output_scenes = self.model(xy[start_length:obs_length], scene_goal, batch_split,
+                                                  n_predict=n_predict, **self._graph_kw())
+                    output_scenes = first = output_scenes.cpu().numpy()
                 if normalize:
                     output_scenes = trajdata.inverse_scene(output_scenes, rotation, center)
                 output_primary = output_scenes[-n_predict:, 0]
@@ -736,7 +744,8 @@ class LSTMPredictor(object):
             goal = torch.from_numpy(np.ascontiguousarray(np.concatenate(goal_list, axis=0), dtype=np.float32))
             batch_split = torch.from_numpy(np.asarray(split, dtype=np.int64))
             outputs = [self.model(obs, goal, batch_split, n_predict=n_predict, pad_to='scene', **self._graph_kw())[1]
-                       for _ in range(modes)]
+                       for _ in range(1 if self._deterministic() else modes)]
+            outputs = outputs * modes if len(outputs) < modes else outputs      # deterministic model: one forward serves every mode
         return outputs, split, frames, normalize
 
     def predict_xy_finish(self, handle, n_predict=12):
@@ -804,7 +813,8 @@ class LSTMPredictor(object):
                 goal = torch.from_numpy(np.ascontiguousarray(np.concatenate(goals, axis=0), dtype=np.float32))
                 batch_split = torch.tensor(split, dtype=torch.int64)
                 outputs = [self.model(obs, goal, batch_split, n_predict=n_predict, pad_to='scene', **self._graph_kw())[1]
-                           for _ in range(modes)]
+                           for _ in range(1 if self._deterministic() else modes)]
+                outputs = outputs * modes if len(outputs) < modes else outputs
             pending.append((outputs, split, frames))
         for st in streams:
             st.synchronize()
