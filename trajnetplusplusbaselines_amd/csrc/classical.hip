@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #define TNP_MAX_DEVICES 64
+#define ORCA_LP3_SLOTS 16      /* lanes of a wave that run linearProgram3 at a time (their lines live in LDS) */
 
 namespace tnp {
 
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(256) orca_rollout_kernel(const float *pos0, co
 //     pairs by a branch-free compare network -- the list insertAgentNeighbor builds (the MN smallest by (dist^2, visiting
 //     order), ties behind their equals, range shrinking to the last entry once full), entry for entry;
 //   * half-planes and linearProgram1/2 fully unrolled over MN compile-time slots: no indexed array, no scratch;
-//   * linearProgram3 (dense crowds only) keeps the generic code on a private copy of the lines.
+//   * linearProgram3 (dense crowds) keeps the generic code, on LDS copies of the lines of the few lanes that need it.
 // MN must equal max_neighbors (the wrapper always passes RVO2's 10); other values take the generic kernel.
 template <int MN>
 __device__ __forceinline__ bool orca_lp1_reg(const orca_line (&L)[MN], const int line_no, float radius, float ox, float oy,
@@ -212,7 +213,8 @@ __device__ __forceinline__ bool orca_lp1_reg(const orca_line (&L)[MN], const int
 
 template <int MN>
 __device__ __forceinline__ void orca_new_velocity_reg(int a, int ns, const float *pos, const float *vel, float prefx, float prefy,
-                                                      float max_speed, const orca_params &p, float *nvx, float *nvy, int *nbr_out) {
+                                                      float max_speed, const orca_params &p, float *nvx, float *nvy, int *nbr_out,
+                                                      orca_line *slots /* this WAVE's ORCA_LP3_SLOTS x 2 MN lines of LDS */) {
     float nd[MN];
     int nbr[MN];
 #pragma unroll
@@ -283,14 +285,26 @@ __device__ __forceinline__ void orca_new_velocity_reg(int a, int ns, const float
             }
         }
     }
-    if (fail < cnt) {
-        // infeasible (dense crowds only): linearProgram3, the generic code on a private copy of the lines -- the only scratch
-        // memory of the kernel, touched by the lanes that get here (an LDS copy per thread would cost 40 KB per workgroup and
-        // with it half of the resident waves: 22.6 against 15 ms at BASELINE config 5)
-        orca_line sp[2 * MN];
+    // linearProgram3 (infeasible half-planes: dense crowds -- at BASELINE config 5 some lane of a wave needs it in a third of the
+    // wave-steps, and then usually several at once: jams are local; without it the kernel takes 7.3 ms): the generic code on a
+    // copy of the lines in LDS.  The lanes that need it take one of ORCA_LP3_SLOTS per-wave slots (rank among the needing lanes:
+    // ballot + mbcnt; more than ORCA_LP3_SLOTS of them go in rounds), so the dynamically indexed `lines[]` / `proj[]` of the
+    // generic code are LDS accesses and the kernel has no scratch memory.  Measured at 4096 x 128 (round 6): private arrays
+    // (scratch) 14.4 ms; 4 slots 18.5 (rounds: a divergent linearProgram3 pass costs the same for one lane as for sixteen);
+    // 16 slots 13.5; 32 slots 13.9; one copy per THREAD 22.6 (40 KB per workgroup: half of the resident waves).
+    const bool need = fail < cnt;
+    const unsigned long long nm = __ballot(need);
+    if (nm) {
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(nm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nm, 0u));
+        const int total = __popcll(nm);
+        for (int base = 0; base < total; base += ORCA_LP3_SLOTS) {
+            if (need && rank >= base && rank < base + ORCA_LP3_SLOTS) {
+                orca_line *sp = slots + (rank - base) * 2 * MN;
 #pragma unroll
-        for (int k = 0; k < MN; ++k) sp[k] = L[k];
-        orca_lp3_buf(sp, cnt, fail, max_speed, &rx, &ry, sp + MN);
+                for (int k = 0; k < MN; ++k) sp[k] = L[k];
+                orca_lp3_buf(sp, cnt, fail, max_speed, &rx, &ry, sp + MN);
+            }
+        }
     }
     *nvx = rx; *nvy = ry;
 }
@@ -307,6 +321,7 @@ __global__ void __launch_bounds__(256) orca_rollout_reg_kernel(const float *pos0
     float *vel = pos + (size_t)ns * 2;  // [ns][2]
     float *nvl = vel + (size_t)ns * 2;  // [ns][2]
     float *prf = nvl + (size_t)ns * 2;  // [ns][2] preferred velocity (0 before the first step, orca.py:99-119)
+    orca_line *slots = reinterpret_cast<orca_line *>(prf + (((size_t)ns * 2 + 3) & ~(size_t)3)) + (size_t)(threadIdx.x >> 6) * ORCA_LP3_SLOTS * 2 * MN;
     for (int a = threadIdx.x; a < ns; a += blockDim.x) {
         pos[2 * a] = pos0[2 * (lo + a)]; pos[2 * a + 1] = pos0[2 * (lo + a) + 1];
         vel[2 * a] = vel0[2 * (lo + a)]; vel[2 * a + 1] = vel0[2 * (lo + a) + 1];
@@ -318,7 +333,7 @@ __global__ void __launch_bounds__(256) orca_rollout_reg_kernel(const float *pos0
         for (int a = threadIdx.x; a < ns; a += blockDim.x) {
             int *dbg = (nbr_dbg && count == 1) ? nbr_dbg + (size_t)(lo + a) * ORCA_MAX_NEIGHBORS : nullptr;
             orca_new_velocity_reg<MN>(a, ns, pos, vel, prf[2 * a], prf[2 * a + 1], max_speed[lo + a], prm, &nvl[2 * a],
-                                      &nvl[2 * a + 1], dbg);
+                                      &nvl[2 * a + 1], dbg, slots);
         }
         __syncthreads();
         for (int a = threadIdx.x; a < ns; a += blockDim.x) {
@@ -407,7 +422,7 @@ extern "C" TNP_API int tnp_orca_rollout(const float *pos0, const float *vel0, co
     TNP_HIP(hipGetDevice(&dev));
     if (max_neighbors == 10) {           // RVO2's / the wrapper's value (classical/orca.py:95): the register form
         constexpr int MN = 10;
-        const size_t smem = (size_t)n_max * 8 * sizeof(float);
+        const size_t smem = (((size_t)n_max * 8 + 3) & ~(size_t)3) * sizeof(float) + (size_t)(threads / 64) * ORCA_LP3_SLOTS * 2 * MN * sizeof(orca_line);
         if (smem > 160 * 1024) TNP_FAIL(-1, "tnp_orca_rollout: %d agents in one scene exceed the LDS-staged limit", n_max);
         static size_t attr[TNP_MAX_DEVICES] = {0};                           // per DEVICE: the attribute belongs to the device's code object
         if (dev >= TNP_MAX_DEVICES || smem > attr[dev]) {
