@@ -442,7 +442,6 @@ def _predict_dataset_columns(ndjson_in, predictor, out_path, batch_scenes, obs_l
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=3)
     futures = []
-    failure = []
     pending = []
     with open(out_path, 'wb') as f:
         def drain(block):
