@@ -302,6 +302,8 @@ TNP_API int tnp_lstm_step(const tnp_lstm_model *model, int decoder, const float 
  *                          gate order i,f,g,o), dc_prev, and dh_pass = gradient that bypasses the cell for absent
  *                          tracks (their state is copied through, lstm/lstm.py:158-166)
  *   tnp_relu_mask:         out = dy * (act > 0) on column slices (leading dimensions given)
+ *   tnp_scaled_diff:       out = nan_to_num(a - b) * scale over n elements (torch.nan_to_num defaults) -- the input
+ *                          embedding's operand 4 (obs2 - obs1) of the weight gradients (lstm/lstm.py:127-131 under autograd)
  *   tnp_social_scatter_backward: d(social encoding)[j] = sum over the egos i of j's scene of dgrid[i, :, cell(i,j)]
  *                          with cells from tnp_pool_pair_cells_autograd (every in-range neighbour of a cell whose value
  *                          is not the constant 0, SURVEY.md 8a quirk 4 + lp_pool2d's zero derivative at 0)
@@ -417,6 +419,7 @@ TNP_API int tnp_h2n_cell_backward(const float *h_out, const float *Wn, const flo
 TNP_API int tnp_lstm_cell_backward(const float *gates, const float *c_prev, const float *dh_tot, const float *dc,
                                    const float *obs1, const float *obs2, int M, int H, float *dG, float *dc_prev,
                                    float *dh_pass, void *stream);
+TNP_API int tnp_scaled_diff(const float *a, const float *b, long n, float scale, float *out, void *stream);
 TNP_API int tnp_relu_mask(const float *dy, int ld_dy, const float *act, int ld_act, int M, int N, float *out, int ld_out,
                           void *stream);
 TNP_API int tnp_social_scatter_backward(const float *dgrid, int ldg, const int32_t *cells, const int32_t *row_base,
@@ -466,7 +469,7 @@ typedef struct tnp_wgrad_problem {
     int K, Mo, No;
     float *dw; int ld_dw;            /* [Mo, No] out           */
     float *dbias;                    /* [Mo] column sums of dy, or NULL */
-} tnp_wgrad_problem;
+} tnp_wgrad_problem;                 /* No == 0 with dbias: the column sums only (x and dw are not read) */
 TNP_API size_t tnp_wgrad_grouped_workspace_bytes(const tnp_wgrad_problem *problems, int n);
 TNP_API int tnp_wgrad_grouped(const tnp_wgrad_problem *problems, int n, void *workspace, size_t workspace_bytes, void *stream);
 /* Backward of HiddenStateMLPPooling's max-pool (lstm/non_gridbased_pooling.py:196-239 under autograd): d_pooled [M, ldp]

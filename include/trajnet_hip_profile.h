@@ -40,8 +40,14 @@ TNP_API int tnp_profile_end(void);
  *   "skinny_max_rows" / "skinny_gates_max_rows"
  *                     tracks up to which the 16-track register-operand GEMMs (csrc/gemm_skinny.hip) run the
  *                     step's dense layers / LSTM gates (defaults 160 / 512; 0 = never)
+ *   "sparse_wgrad_plan"
+ *                     sparse first layer's weight gradient: 16 * waves + batches per trip (waves 4 / 8 / 16,
+ *                     batches 1 / 2); 0 = by size (8 x 1 up to 16384 stacked rows, 4 x 1 beyond)
+ *   "wgrad_min_rows" / "wgrad_target_wgs"
+ *                     dense weight gradients: fewest rows of K per split (default 128) and the workgroup
+ *                     count a contraction is split towards (512).  Plans only change the order of the sums.
  * Initial values: environment TNP_SPARSE_TILE="te,ncs", TNP_SPARSE_MIN_WG, TNP_SKINNY_MAX_M (both),
- * TNP_SKINNY_GATES_MAX_M.
+ * TNP_SKINNY_GATES_MAX_M, TNP_SPARSE_WGRAD_PLAN, TNP_WGRAD_MIN_ROWS, TNP_WGRAD_TARGET.
  * ----------------------------------------------------------------------------------------- */
 TNP_API int tnp_tuning_set(const char *key, long value);
 

@@ -502,6 +502,55 @@ def test_grouped_wgrad_is_bitwise_the_stand_alone_wgrad():
         assert (dw.double() - ref).abs().max() <= 1e-3 * max(1.0, float(ref.abs().max()))
 
 
+def test_grouped_wgrad_column_sums_without_a_weight_part():
+    """A problem with No == 0 and a bias pointer is the column sums of dy alone (the sparse first layer's bias gradient rides in
+    the grouped launch instead of an ATen sum behind the sweep): equal to the double-precision sums to rounding, the same bits
+    twice, beside ordinary contractions and for ragged K / Mo."""
+    from trajnetplusplusbaselines_amd import _lib
+    from trajnetplusplusbaselines_amd.lstm.training import WgradProblem
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(8)
+    outs = []
+    for _ in range(2):
+        probs, keep = [], []
+        g.manual_seed(8)
+        for K, Mo, No in [(5890, 1024, 0), (777, 100, 0), (5, 130, 0), (3000, 512, 128), (1, 64, 0), (38912, 256, 0)]:
+            dy = torch.randn(K, Mo, generator=g).cuda()
+            x = torch.randn(K, No, generator=g).cuda() if No else None
+            dw = torch.empty(Mo, No, device='cuda') if No else None
+            db = torch.full((Mo,), float('nan'), device='cuda')
+            probs.append(WgradProblem(dy.data_ptr(), Mo, x.data_ptr() if No else None, No, K, Mo, No, dw.data_ptr() if No else None, No,
+                                      db.data_ptr()))
+            keep.append((dy, x, dw, db))
+        table = (WgradProblem * len(probs))(*probs)
+        nb = L.tnp_wgrad_grouped_workspace_bytes(table, len(probs))
+        assert nb > 0
+        ws = torch.empty(nb, dtype=torch.uint8, device='cuda')
+        _lib.check(L.tnp_wgrad_grouped(table, len(probs), _lib.ptr(ws), nb, _lib.stream_ptr()), 'tnp_wgrad_grouped')
+        torch.cuda.synchronize()
+        outs.append([k[3].clone() for k in keep])
+        for dy, x, dw, db in keep:
+            ref = dy.double().sum(0)
+            assert (db.double() - ref).abs().max() <= 2e-5 * max(1.0, float(dy.abs().sum(0).max()))
+            if dw is not None:
+                refw = dy.double().t() @ x.double()
+                assert (dw.double() - refw).abs().max() <= 1e-3 * max(1.0, float(refw.abs().max()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    # a problem with neither a weight part nor a bias is skipped, as before
+    empty = (WgradProblem * 1)(WgradProblem(keep[0][0].data_ptr(), 1024, None, 0, 5890, 1024, 0, None, 0, None))
+    assert L.tnp_wgrad_grouped_workspace_bytes(empty, 1) == 0
+
+
+def test_scaled_diff_is_nan_to_num_times_scale():
+    from trajnetplusplusbaselines_amd import _lib
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.randn(19, 333, 2, generator=g).cuda(), torch.randn(19, 333, 2, generator=g).cuda()
+    a[0, :7] = float('nan'); b[3, 5] = float('nan'); a[4, 0, 0] = float('inf'); b[5, 1, 1] = float('inf'); a[6, 2] = 3e38; b[6, 2] = -3e38
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().tnp_scaled_diff(_lib.ptr(a), _lib.ptr(b), a.numel(), 4.0, _lib.ptr(out), _lib.stream_ptr()), 'scaled_diff')
+    assert torch.equal(out, torch.nan_to_num(a - b) * 4.0)
+
+
 def test_sharded_loss_with_the_real_collision_term_sums_to_the_single_process_gradient():
     """Scene-sharded training with PredictionLoss(col_wt > 0): the NLL term is a mean over frames x scenes, the
     collision term a sum over scenes (lstm/loss.py:85-91, :147-161); `train_step.batch_loss` scales them separately.  On one

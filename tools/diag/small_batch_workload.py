@@ -32,6 +32,29 @@ elif mode == "train":
         bxy, bgoals, bsplit = batcher.batch(ids, augment=True)
         train_batch(model, optimizer, PredictionLoss(), bxy, bgoals, bsplit, 9, 12, batch_size=8)
 torch.cuda.synchronize()
+if mode == 'train_time':
+    # wall clock of the pipelined batch_size-8 loop (what bench.py's trainer_default reports), three times
+    import time
+    optimizer = bench.make_adam(model.parameters())
+    batcher = trajdata.SceneBatcher(scenes, device=device, drop_distant_r=None)
+    rng = random.Random(7)
+    crit = PredictionLoss()
+    def one():
+        ids = [rng.randrange(len(scenes)) for _ in range(8)]
+        bxy, bgoals, bsplit = batcher.batch(ids, augment=True)
+        return train_batch(model, optimizer, crit, bxy, bgoals, bsplit, 9, 12, batch_size=8)
+    for _ in range(80):
+        one()
+    torch.cuda.synchronize()
+    res = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            one()
+        th = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        res.append('%.3f / %.3f' % (th / n * 1e3, (time.perf_counter() - t0) / n * 1e3))
+    print('%s: host enqueue / wall ms per step: %s' % (os.environ.get('TAG', ''), '   '.join(res)))
 if mode == 'train_hostprofile':
     # where the HOST spends a batch_size-8 optimisation step (the loop is host-enqueue bound)
     import cProfile, pstats, time

@@ -126,6 +126,7 @@ def lib():
     L.tnp_h2n_backward.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]
     L.tnp_h2n_cell_backward.argtypes = [_fp] * 11 + [ctypes.c_int, ctypes.c_int] + [_fp] * 5
     L.tnp_lstm_cell_backward.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]
+    L.tnp_scaled_diff.argtypes = [_fp, _fp, ctypes.c_long, ctypes.c_float, _fp, _fp]
     L.tnp_relu_mask.argtypes = [_fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp]
     L.tnp_social_scatter_backward.argtypes = [_fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, _fp, _fp]

@@ -157,6 +157,33 @@ __device__ __forceinline__ void wgrad_tn_block(const float *__restrict__ A, int 
     finish();
 }
 
+// A contraction WITHOUT a weight part (No == 0): column sums of dY only -- the bias gradient of a layer whose weight gradient is
+// formed elsewhere (the sparse first embedding layer, lstm_bwd.hip).  It used to be an ATen `sum(0)` behind the sweep (a
+// semaphore fill + a 21-38 us reduce launch on an otherwise idle chip); here its workgroups stream dY beside the matrix-pipe
+// work of the grouped launch.  Region = 128 columns, thread t takes column t & 127 and every second row of the split
+// (512-byte coalesced rows), eight loads in flight; the two halves are added through LDS, the splits by the reduce launch in
+// split order: deterministic.
+__device__ __forceinline__ void wgrad_bias_block(const float *__restrict__ A, int lda, int Mo, int K, int kchunk,
+                                                 float *__restrict__ bias_part, int region, int ks) {
+    __shared__ float half_sum[128];
+    const int t = threadIdx.x, col = region * 128 + (t & 127), half = t >> 7;
+    const int kb = ks * kchunk, ke = min(K, kb + kchunk);
+    const int c = min(col, Mo - 1);
+    float acc = 0.f;
+    int k = kb + half;
+    for (; k + 14 < ke; k += 16) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = A[(size_t)(k + 2 * u) * lda + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; k < ke; k += 2) acc += A[(size_t)k * lda + c];
+    if (half) half_sum[t & 127] = acc;
+    __syncthreads();
+    if (!half && col < Mo) bias_part[(size_t)ks * Mo + col] = acc + half_sum[t];
+}
+
 __global__ void __launch_bounds__(256) wgrad_tn_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B,
                                                        int ldb, int Mo, int No, int K, int kchunk,
                                                        float *__restrict__ part, float *__restrict__ bias_part) {
@@ -186,6 +213,7 @@ __global__ void __launch_bounds__(256) wgrad_tn_group_kernel(const WgradGroup g)
     while (q + 1 < g.count && (int)blockIdx.x >= g.first_block[q + 1]) ++q;
     const int local = (int)blockIdx.x - g.first_block[q], p = g.tn_order[q];
     const int region = local % g.regions[p], ks = local / g.regions[p];
+    if (g.No[p] == 0) { wgrad_bias_block(g.A[p], g.lda[p], g.Mo[p], g.K[p], g.kchunk[p], g.bias_part[p], region, ks); return; }
     wgrad_tn_block(g.A[p], g.lda[p], g.B[p], g.ldb[p], g.Mo[p], g.No[p], g.K[p], g.kchunk[p], g.part[p], g.bias_part[p], region, ks);
 }
 
@@ -228,11 +256,12 @@ __global__ void __launch_bounds__(256) wgrad_reduce_group_kernel(const WgradGrou
 }
 
 static void wgrad_plan(int Mo, int No, int K, int &regions, int &SK, int &kchunk) {
-    regions = ((Mo + 127) / 128) * ((No + 127) / 128);
-    int want = (512 + regions - 1) / regions;      // ~2 workgroups per CU; in the grouped launch 256 - 512 measure the same
+    regions = ((Mo + 127) / 128) * (No > 0 ? (No + 127) / 128 : 1);      // No == 0: column sums only (wgrad_bias_block)
+    const int target = tuning().wgrad_target_wgs, min_rows = tuning().wgrad_min_rows;
+    int want = (target + regions - 1) / regions;   // 512: ~2 workgroups per CU; in the grouped launch 256 - 512 measure the same
                                                    // (365 us), 768 / 1024 / 2048: 384 / 389 / 410 us (round 3 sweep run_r3w, git history)
     if (want > 128) want = 128;
-    const int maxsk = (K + 255) / 256;
+    const int maxsk = (K + min_rows - 1) / min_rows;   // min_rows 128 (256 until round 6: batch_size 8, K ~ 5900: 100 + 11 -> 87 + 16 us)
     if (want > maxsk) want = maxsk;
     if (want < 1) want = 1;
     kchunk = (K + want - 1) / want;
@@ -280,7 +309,8 @@ static size_t wgrad_problem_bytes(int Mo, int No, int K) {
 extern "C" TNP_API size_t tnp_wgrad_grouped_workspace_bytes(const tnp_wgrad_problem *problems, int n) {
     size_t total = 0;
     for (int i = 0; i < n; ++i)
-        if (problems[i].Mo > 0 && problems[i].No > 0 && problems[i].K > 0) total += wgrad_problem_bytes(problems[i].Mo, problems[i].No, problems[i].K);
+        if (problems[i].Mo > 0 && (problems[i].No > 0 || (problems[i].No == 0 && problems[i].dbias)) && problems[i].K > 0)
+            total += wgrad_problem_bytes(problems[i].Mo, problems[i].No, problems[i].K);
     return total;
 }
 
@@ -298,8 +328,10 @@ extern "C" TNP_API int tnp_wgrad_grouped(const tnp_wgrad_problem *problems, int 
         g.count = 0; g.first_block[0] = 0; g.first_rblock[0] = 0;
         for (; done < n && g.count < WG_MAX_PROBLEMS; ++done) {
             const tnp_wgrad_problem &q = problems[done];
-            if (q.Mo <= 0 || q.No <= 0) continue;
-            if (q.K <= 0 || !q.dy || !q.x || !q.dw) TNP_FAIL(-1, "tnp_wgrad_grouped: problem %d: K = %d or a NULL pointer", done, q.K);
+            const bool bias_only = q.No == 0 && q.dbias != nullptr;
+            if (q.Mo <= 0 || (q.No <= 0 && !bias_only)) continue;
+            if (q.K <= 0 || !q.dy || (!bias_only && (!q.x || !q.dw)))
+                TNP_FAIL(-1, "tnp_wgrad_grouped: problem %d: K = %d or a NULL pointer", done, q.K);
             const int c = g.count;
             int regions, SK, kchunk;
             tnp::wgrad_plan(q.Mo, q.No, q.K, regions, SK, kchunk);
@@ -322,7 +354,7 @@ extern "C" TNP_API int tnp_wgrad_grouped(const tnp_wgrad_problem *problems, int 
             long cost[WG_MAX_PROBLEMS];
             for (int c = 0; c < g.count; ++c) {
                 const bool edge = g.Mo[c] % 64 != 0 || g.No[c] % 64 != 0;
-                cost[c] = (long)g.kchunk[c] * (edge ? 3 : 1);
+                cost[c] = g.No[c] == 0 ? (long)g.kchunk[c] / 8 : (long)g.kchunk[c] * (edge ? 3 : 1);
                 g.tn_order[c] = c;
             }
             for (int a = 1; a < g.count; ++a)                       // insertion sort, stable: equal costs keep the queue order

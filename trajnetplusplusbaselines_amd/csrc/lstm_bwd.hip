@@ -749,22 +749,6 @@ __global__ void __launch_bounds__(256) dgrid_cells_xcd_kernel(const float *__res
     const int2 *L = list + (size_t)c * R + (size_t)seg * M;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane & 15, kq = lane >> 4;
     const int ncol = N1 >> 3, T = TT ? TT : ncol >> 4, k0 = x * ncol;
-    // T <= 8 for N1 <= 1024: one or two 16-byte loads per thread, both in flight before the first is stored (channels
-    // >= C read channel 0 and store zeros: a load under `if (ch < C)` is waited for where the branch joins)
-    for (int q0 = tid; q0 < T * 64; q0 += 512) {
-        float4 v[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int q = q0 + 256 * h, t = (q < T * 64 ? q : q0) >> 6, l = q & 63, ch = l & 15, kk = l >> 4;
-            v[h] = *reinterpret_cast<const float4 *>(Wc + ((size_t)c * C + (ch < C ? ch : 0)) * N1 + k0 + 16 * t + 4 * kk);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int q = q0 + 256 * h;
-            if (q < T * 64) xcd_lds[q] = ((q & 15) < C) ? v[h] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    __syncthreads();
     const int row_off = seg * M;
     float *out = dcell8 + (size_t)x * M * ncell * C;
     // software pipeline over the wave's groups: list entries two groups ahead, dy operands one group ahead (a group is
@@ -781,6 +765,22 @@ __global__ void __launch_bounds__(256) dgrid_cells_xcd_kernel(const float *__res
         for (int u = 0; u < 8; ++u)
             if (t0 + u < T) a[u] = *reinterpret_cast<const float4 *>(src + 16 * (t0 + u));
     };
+    // T <= 8 for N1 <= 1024: one or two 16-byte loads per thread, both in flight before the first is stored (channels
+    // >= C read channel 0 and store zeros: a load under `if (ch < C)` is waited for where the branch joins)
+    for (int q0 = tid; q0 < T * 64; q0 += 512) {
+        float4 v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = q0 + 256 * h, t = (q < T * 64 ? q : q0) >> 6, l = q & 63, ch = l & 15, kk = l >> 4;
+            v[h] = *reinterpret_cast<const float4 *>(Wc + ((size_t)c * C + (ch < C ? ch : 0)) * N1 + k0 + 16 * t + 4 * kk);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = q0 + 256 * h;
+            if (q < T * 64) xcd_lds[q] = ((q & 15) < C) ? v[h] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
     int g = wave;
     if (g >= ngroups) return;
     int rl0, ro0[4], rl1, ro1[4];
@@ -889,10 +889,17 @@ __global__ void __launch_bounds__(256) social_scatter_combine_kernel(const float
     const int lo = row_base[j], ns = row_count[j], jj = j - lo;
     const size_t slice = (size_t)M * ncell * C;
     float acc = 0.0f;
-    for (int i0 = lo + sub; i0 < lo + ns; i0 += 16) {
-        int cc[4];
+    // the cell indices of trip t + 1 are requested before the gathers of trip t (cells -> dcell8 is a chain of two round
+    // trips per trip otherwise; a 39-agent scene has three trips)
+    auto cells_of = [&](int i0, int (&cc)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const int i = i0 + 4 * u; cc[u] = i < lo + ns ? cells[(size_t)i * n_max + jj] : -1; }
+    };
+    int cc[4];
+    cells_of(lo + sub, cc);
+    for (int i0 = lo + sub; i0 < lo + ns; i0 += 16) {
+        int cn[4];
+        cells_of(i0 + 16, cn);
         float v[4][8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -909,6 +916,8 @@ __global__ void __launch_bounds__(256) social_scatter_combine_kernel(const float
                 for (int xx = 1; xx < 8; ++xx) sum += v[u][xx];
                 acc += sum;
             }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cc[u] = cn[u];
     }
     acc += __shfl_xor(acc, 16);
     acc += __shfl_xor(acc, 32);
@@ -956,16 +965,17 @@ static int launch_dgrid_cells_xcd(const float *dy, int ldy, const float *Wc, con
 // against (a lazily hipMalloc'ed + NULL-stream hipMemset buffer was not ordered before a launch on a non-blocking stream,
 // not thread-safe and not capturable -- ADVICE round 3).
 __device__ __attribute__((aligned(256))) float g_swg_zeros[64] = {};
+#define TNP_SWG_SMALL_PLAN (16 * 8 + 1)          // batch_size 8: 4x1 72.9, 4x2 72.2, 8x1 55.8, 8x2 61.0, 16x1 59.1, 16x2 65.5 us (tools/diag/small_train_ab.sh)
 
-template <int C>
-__global__ void __launch_bounds__(256) sparse_wgrad_mfma_kernel(const float *__restrict__ dy, int ldy,
+template <int C, int NW, int U>                                     // waves per workgroup, batches per trip (see below)
+__global__ void __launch_bounds__(64 * NW) sparse_wgrad_mfma_kernel(const float *__restrict__ dy, int ldy,
                                                                 const float *__restrict__ enc, int lde,
                                                                 const int2 *__restrict__ list, const int32_t *__restrict__ count,
                                                                 int R, int N1, int ncell, float *__restrict__ dWc) {
     const float *swg_zeros = g_swg_zeros;
     static_assert(C <= 16, "one 16-channel A tile");
     typedef float f4 __attribute__((ext_vector_type(4)));
-    constexpr int NW = 4, U = 1;                                    // waves per workgroup, batches per trip (see below)
+    static_assert((NW & (NW - 1)) == 0, "pairwise reduction over the waves");
     __shared__ float red[NW - 1][16][64];
     int c, chunk;
     {
@@ -1054,8 +1064,19 @@ static int launch_sparse_wgrad(const float *dy, int ldy, const float *enc, int l
                                int ncell, int N1, float *dWc, hipStream_t s) {
     if constexpr (C <= 16) {
         if (ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(dWc) & 15) == 0) {
-            hipLaunchKernelGGL(sparse_wgrad_mfma_kernel<C>, dim3(ncell * (N1 / 64)), dim3(256), 0, s, dy, ldy, enc, lde, list, count, R, N1, ncell,
-                               dWc);
+            // Waves per (cell, 64-column chunk): four at training batches (more evict each other's rows from the XCD's L2, see
+            // the kernel); at small ones (batch_size 8: ~275 hits per cell, 24 MB of dy) the launch is the longest cell's chain
+            // of dependent gathers, and more waves / more batches per trip shorten exactly that.
+            int plan = tuning().sparse_wgrad_plan;                                // 16 * waves + batches per trip, 0 = by size
+            if (plan == 0) plan = R <= 16384 ? TNP_SWG_SMALL_PLAN : 16 * 4 + 1;
+            const dim3 grid(ncell * (N1 / 64));
+#define TNP_SWG(nw, u) case 16 * nw + u: hipLaunchKernelGGL((sparse_wgrad_mfma_kernel<C, nw, u>), grid, dim3(64 * nw), 0, s, dy, ldy, enc, lde, \
+                                                              list, count, R, N1, ncell, dWc); break
+            switch (plan) {
+                TNP_SWG(4, 1); TNP_SWG(4, 2); TNP_SWG(8, 1); TNP_SWG(8, 2); TNP_SWG(16, 1); TNP_SWG(16, 2);
+                default: TNP_FAIL(-1, "tnp_sparse_wgrad: plan %d (16 * waves + batches per trip: waves 4 / 8 / 16, batches 1 / 2)", plan);
+            }
+#undef TNP_SWG
             TNP_HIP(hipGetLastError());
             return 0;
         }
@@ -1252,6 +1273,29 @@ extern "C" TNP_API int tnp_lstm_cell_backward(const float *gates, const float *c
     const long tot = (long)M * H;
     hipLaunchKernelGGL(tnp::lstm_cell_backward_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        gates, c_prev, dh_tot, dc, obs1, obs2, M, H, dG, dc_prev, dh_pass);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
+// out = nan_to_num(a - b) * scale (torch.nan_to_num's defaults: NaN -> 0, +-inf -> +-FLT_MAX), one launch for the three ATen
+// launches the input embedding's operand `nan_to_num(obs2 - obs1) * 4` cost behind every backward sweep
+namespace tnp {
+__global__ void __launch_bounds__(256) scaled_diff_kernel(const float *__restrict__ a, const float *__restrict__ b, long n, float scale,
+                                                          float *__restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float d = a[i] - b[i];
+    if (d != d) d = 0.0f;
+    else if (d > 3.402823466e+38f) d = 3.402823466e+38f;
+    else if (d < -3.402823466e+38f) d = -3.402823466e+38f;
+    out[i] = d * scale;
+}
+}  // namespace tnp
+
+extern "C" TNP_API int tnp_scaled_diff(const float *a, const float *b, long n, float scale, float *out, void *stream) {
+    if (n <= 0) return 0;
+    if (!a || !b || !out) TNP_FAIL(-1, "tnp_scaled_diff: NULL pointer");
+    hipLaunchKernelGGL(tnp::scaled_diff_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, n, scale, out);
     TNP_HIP(hipGetLastError());
     return 0;
 }

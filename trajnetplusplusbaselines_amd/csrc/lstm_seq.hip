@@ -23,12 +23,15 @@ namespace tnp {
 
 Tuning &tuning() {
     static Tuning t = [] {
-        Tuning v = {0, 0, 0, 160, 512};
+        Tuning v = {0, 0, 0, 160, 512, 0, 128, 512};
         const char *e = getenv("TNP_SPARSE_TILE");
         if (e && sscanf(e, "%d,%d", &v.sparse_te, &v.sparse_ncs) != 2) v.sparse_te = v.sparse_ncs = 0;
         if ((e = getenv("TNP_SPARSE_MIN_WG")) != nullptr) v.sparse_min_wg = atol(e);
         if ((e = getenv("TNP_SKINNY_MAX_M")) != nullptr) v.skinny_max_rows = v.skinny_gates_max_rows = atoi(e);
         if ((e = getenv("TNP_SKINNY_GATES_MAX_M")) != nullptr) v.skinny_gates_max_rows = atoi(e);
+        if ((e = getenv("TNP_SPARSE_WGRAD_PLAN")) != nullptr) v.sparse_wgrad_plan = atoi(e);
+        if ((e = getenv("TNP_WGRAD_MIN_ROWS")) != nullptr && atoi(e) > 0) v.wgrad_min_rows = atoi(e);
+        if ((e = getenv("TNP_WGRAD_TARGET")) != nullptr && atoi(e) > 0) v.wgrad_target_wgs = atoi(e);
         return v;
     }();
     return t;
@@ -1032,7 +1035,11 @@ extern "C" TNP_API int tnp_tuning_set(const char *key, long value) {
     else if (k == "sparse_min_wg") t.sparse_min_wg = value;
     else if (k == "skinny_max_rows") t.skinny_max_rows = (int)value;
     else if (k == "skinny_gates_max_rows") t.skinny_gates_max_rows = (int)value;
-    else TNP_FAIL(-1, "tnp_tuning_set: unknown key '%s' (sparse_tile, sparse_min_wg, skinny_max_rows, skinny_gates_max_rows)", k.c_str());
+    else if (k == "sparse_wgrad_plan") t.sparse_wgrad_plan = (int)value;
+    else if (k == "wgrad_min_rows") { if (value <= 0) TNP_FAIL(-1, "tnp_tuning_set: wgrad_min_rows must be positive"); t.wgrad_min_rows = (int)value; }
+    else if (k == "wgrad_target_wgs") { if (value <= 0) TNP_FAIL(-1, "tnp_tuning_set: wgrad_target_wgs must be positive"); t.wgrad_target_wgs = (int)value; }
+    else TNP_FAIL(-1, "tnp_tuning_set: unknown key '%s' (sparse_tile, sparse_min_wg, skinny_max_rows, skinny_gates_max_rows, "
+                  "sparse_wgrad_plan, wgrad_min_rows, wgrad_target_wgs)", k.c_str());
     return 0;
 }
 

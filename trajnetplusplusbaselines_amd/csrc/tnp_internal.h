@@ -22,6 +22,9 @@ struct Tuning {
     long sparse_min_wg;          // workgroups a tile must reach before a smaller one is tried (0 = one per CU)   TNP_SPARSE_MIN_WG
     int skinny_max_rows;         // rows up to which gemm_skinny.hip takes the dense layers                        TNP_SKINNY_MAX_M
     int skinny_gates_max_rows;   // ... and the LSTM gates                                                          TNP_SKINNY_GATES_MAX_M
+    int sparse_wgrad_plan;       // sparse first layer's weight gradient: 16 * waves + batches per trip (0 = by size)  TNP_SPARSE_WGRAD_PLAN
+    int wgrad_min_rows;          // dense weight gradients: fewest rows of K per split ...                          TNP_WGRAD_MIN_ROWS
+    int wgrad_target_wgs;        // ... and the workgroup count a contraction is split towards                       TNP_WGRAD_TARGET
 };
 Tuning &tuning();
 

@@ -10,9 +10,10 @@ class _PrimaryLossFn(torch.autograd.Function):
     instead of the ~60 elementwise kernels of the same expression written with tensor ops."""
 
     @staticmethod
-    def forward(ctx, inputs, targets, batch_split, mode, background_rate, keep_batch_dim, scale):
+    def forward(ctx, inputs, targets, batch_split, mode, background_rate, keep_batch_dim, scale, tail=None):
         dev = inputs.device
-        inp = _lib.f32c(inputs.detach())
+        full = _lib.f32c(inputs.detach())
+        inp = full if tail is None else full[full.size(0) - tail:]      # the last `tail` frames (contiguous: leading dimension)
         tgt = _lib.f32c(targets.detach(), dev)
         T, M = inp.size(0), inp.size(1)
         idx = _lib.SceneIndex.get(batch_split, dev)
@@ -22,27 +23,35 @@ class _PrimaryLossFn(torch.autograd.Function):
                                                        float(background_rate), int(keep_batch_dim), float(scale),
                                                        _lib.ptr(ws), _lib.ptr(out), _lib.stream_ptr()),
                    'tnp_primary_loss_forward')
-        ctx.args = (inp, tgt, idx, mode, float(background_rate), int(keep_batch_dim), float(scale))
+        ctx.args = (inp, tgt, idx, mode, float(background_rate), int(keep_batch_dim), float(scale), full.size(0))
         return out if keep_batch_dim else out[0]
 
     @staticmethod
     def backward(ctx, grad_out):
-        inp, tgt, idx, mode, bg, keep, scale = ctx.args
+        inp, tgt, idx, mode, bg, keep, scale, frames = ctx.args
         T, M = inp.size(0), inp.size(1)
         g = _lib.f32c(grad_out.detach(), inp.device).reshape(-1)
-        d_inputs = torch.empty(T, M, 5, dtype=torch.float32, device=inp.device)
+        # gradient of ALL frames handed in: the kernel fills the last T, the frames in front of them (`tail`) get zeros -- what
+        # slicing outside (inputs[-T:]) costs as a zero fill of everything plus a copy under autograd
+        d_full = torch.empty(frames, M, 5, dtype=torch.float32, device=inp.device)
+        if frames > T:
+            d_full[:frames - T].zero_()
+        d_inputs = d_full[frames - T:]
         _lib.check(_lib.lib().tnp_primary_loss_backward(mode, _lib.ptr(inp), _lib.ptr(tgt), _lib.ptr(idx.starts), idx.B, T, M, bg,
                                                         keep, scale, _lib.ptr(g), _lib.ptr(d_inputs), _lib.stream_ptr()),
                    'tnp_primary_loss_backward')
-        return d_inputs, None, None, None, None, None, None
+        return d_full, None, None, None, None, None, None, None
 
 
-def _primary_loss(mode, inputs, targets, batch_split, background_rate, keep_batch_dim, scale):
+def _primary_loss(mode, inputs, targets, batch_split, background_rate, keep_batch_dim, scale, tail=None):
+    """``tail``: evaluate on the last ``tail`` frames of ``inputs`` (== passing inputs[-tail:], without autograd's slice node)"""
     _lib.require_device(inputs, 'inputs')
     if inputs.requires_grad and torch.is_grad_enabled():
-        return _PrimaryLossFn.apply(inputs, targets, batch_split, mode, background_rate, keep_batch_dim, scale)
+        return _PrimaryLossFn.apply(inputs, targets, batch_split, mode, background_rate, keep_batch_dim, scale, tail)
     dev = inputs.device
     inputs = _lib.f32c(inputs.detach())
+    if tail is not None:
+        inputs = inputs[inputs.size(0) - tail:]
     targets = _lib.f32c(targets.detach(), dev)
     T, M = inputs.size(0), inputs.size(1)
     idx = _lib.SceneIndex.get(batch_split, dev)
@@ -109,16 +118,18 @@ class PredictionLoss(torch.nn.Module):
         self.col_wt = col_wt
         self.col_distance = col_distance
 
-    def terms(self, inputs, targets, batch_split, positions=None):
+    def terms(self, inputs, targets, batch_split, positions=None, tail=None, times=1.0):
         """(mean term, sum term or None): the primaries' NLL is a mean over frames x scenes (:85-91), the collision penalty
         a sum over scenes added un-normalised (:90) -- scene-sharded training scales the two differently
-        (lstm/train_step.batch_loss)."""
+        (lstm/train_step.batch_loss).  ``tail`` / ``times`` (train_step only): the loss of inputs[-tail:], multiplied by
+        ``times`` -- the trainer's ``criterion(rel_outputs[-pred_length:], ...) * batch_size`` (lstm/trainer.py:262-264)
+        without the slice and multiplication nodes in the autograd graph."""
         loss = _primary_loss(0, inputs, targets, batch_split, self.background_rate, self.keep_batch_dim,
-                             self.loss_multiplier)
+                             self.loss_multiplier * times, tail)
         if self.keep_batch_dim or not self.col_wt:
             return loss, None
         assert positions is not None, "Prediction positions required to calculate collision loss"
-        return loss, CollisionLoss(positions, batch_split, self.col_wt, self.col_distance) * self.loss_multiplier
+        return loss, CollisionLoss(positions, batch_split, self.col_wt, self.col_distance) * (self.loss_multiplier * times)
 
     def forward(self, inputs, targets, batch_split, positions=None):
         loss, col = self.terms(inputs, targets, batch_split, positions)
@@ -135,14 +146,14 @@ class L2Loss(torch.nn.Module):
         self.col_wt = col_wt
         self.col_distance = col_distance
 
-    def terms(self, inputs, targets, batch_split, positions=None):
+    def terms(self, inputs, targets, batch_split, positions=None, tail=None, times=1.0):
         """(mean term, sum term or None), see PredictionLoss.terms"""
         # MSE over (t, scene, 2 coordinates): the kernel sums the two squared errors, hence the 1/2
-        loss = _primary_loss(1, inputs, targets, batch_split, 0.0, self.keep_batch_dim, 0.5 * self.loss_multiplier)
+        loss = _primary_loss(1, inputs, targets, batch_split, 0.0, self.keep_batch_dim, 0.5 * self.loss_multiplier * times, tail)
         if self.keep_batch_dim or not self.col_wt:
             return loss, None
         assert positions is not None, "Prediction positions required to calculate collision loss"
-        return loss, CollisionLoss(positions, batch_split, self.col_wt, self.col_distance) * self.loss_multiplier
+        return loss, CollisionLoss(positions, batch_split, self.col_wt, self.col_distance) * (self.loss_multiplier * times)
 
     def forward(self, inputs, targets, batch_split, positions=None):
         loss, col = self.terms(inputs, targets, batch_split, positions)

@@ -258,6 +258,9 @@ class SequenceFn(torch.autograd.Function):
             raise RuntimeError('LSTM parameters live on %s: move the model to a ROCm device (model.to("cuda")); '
                                'the MI355X path has no CPU fallback' % dev)
         opts = opts or {}
+        # outputs nobody differentiates (the positions and the last hidden state under the trainer's loss) arrive in backward()
+        # as None, not as zero tensors autograd filled for them (two fills and a copy per step)
+        ctx.set_materialize_grads(False)
         noise = opts.get('noise')
         h_scale = None
         if opts.get('h_scale_arg'):        # VAE: the [M, H] multiplier rides behind the parameters (it needs a gradient)
@@ -652,6 +655,26 @@ class SequenceFn(torch.autograd.Function):
 
         wg_ws = [None]
         wg_queue = []        # contractions waiting for the grouped launch: (name, bias_name, problem, tensors kept alive)
+        # Bias gradients are slices of ONE buffer: an LSTMCell's bias_hh gradient equals its bias_ih gradient, and one copy of
+        # the buffer serves every such pair of the step (a clone launch per pair before)
+        bias_arena = [torch.empty(8192, device=dev), 0, {}]        # buffer, floats used, name -> (offset, length)
+
+        def bias_vector(name, n):
+            buf, used, where = bias_arena
+            if used + n > buf.numel():
+                return torch.empty(n, device=dev)
+            where[name] = (used, n)
+            bias_arena[1] = (used + n + 63) // 64 * 64
+            return buf[used:used + n]
+
+        def wgrad_bias(bias_name, dy):
+            # the column sums alone (a layer whose weight gradient is formed elsewhere): a contraction without a weight part
+            # in the grouped launch (csrc/gemm_wgrad.hip: wgrad_bias_block)
+            dy2 = dy.reshape(-1, dy.shape[-1])
+            db = bias_vector(bias_name, dy2.shape[1])
+            grads[bias_name] = db
+            wg_queue.append((None, bias_name, WgradProblem(dy2.data_ptr(), dy2.stride(0), None, 0, dy2.shape[0], dy2.shape[1], 0,
+                                                           None, 0, db.data_ptr()), (dy2, None, None, db)))
 
         def wgrad(name, dy, x, bias_name, immediate=False):
             # dW = dy^T x over the stacked steps, operands as stored, K split across workgroups (csrc/gemm_wgrad.hip).
@@ -660,7 +683,9 @@ class SequenceFn(torch.autograd.Function):
             dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
             K, Mo, No = dy2.shape[0], dy2.shape[1], x2.shape[1]
             dw = torch.empty(Mo, No, device=dev)
-            db = torch.empty(Mo, device=dev) if bias_name is not None else None
+            db = None
+            if bias_name is not None:     # (immediate launches: intermediates the caller combines and publishes itself -- own storage)
+                db = torch.empty(Mo, device=dev) if immediate else bias_vector(bias_name, Mo)
             grads[name] = dw
             if bias_name is not None:
                 grads[bias_name] = db
@@ -687,7 +712,8 @@ class SequenceFn(torch.autograd.Function):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             _lib.check(L.tnp_wgrad_grouped(table, len(wg_queue), _lib.ptr(ws), nbytes, sp()), 'tnp_wgrad_grouped')
             for name, bias_name, _, keep in wg_queue:
-                publish(keep[2])
+                if keep[2] is not None:
+                    publish(keep[2])
                 if bias_name is not None:
                     publish(keep[3])
             del wg_queue[:]
@@ -714,8 +740,7 @@ class SequenceFn(torch.autograd.Function):
                 _lib.check(L.tnp_transpose_grouped(table, C, sp()), 'tnp_transpose_grouped')
                 grads[name + '.weight'] = gw
                 publish(grads[name + '.weight'])
-                grads[name + '.bias'] = dy_all[0].reshape(-1, N1).sum(0)
-                publish(grads[name + '.bias'])
+                wgrad_bias(name + '.bias', dy_all[0])          # column sums: ride along in the grouped launch (main stream)
                 return
             wgrad(name + '.weight', dy_all[li], grid_all if li == 0 else act_all[li - 1], name + '.bias')
         side_done = None
@@ -753,7 +778,8 @@ class SequenceFn(torch.autograd.Function):
                 wgrad(pre + '.weight_ih', dG_all[lo:hi], X_all[lo:hi], pre + '.bias_ih')
                 wgrad(pre + '.weight_hh', dG_all[lo:hi], hid_all[lo:hi], None)
                 hh_clones.append((pre + '.bias_hh', pre + '.bias_ih'))
-        vel_all = torch.nan_to_num(o2_all - o1_all) * 4.0
+        vel_all = torch.empty_like(o2_all)            # nan_to_num(o2 - o1) * 4: the input embedding's operand, one launch
+        _lib.check(L.tnp_scaled_diff(_lib.ptr(o2_all), _lib.ptr(o1_all), o2_all.numel(), 4.0, _lib.ptr(vel_all), sp()), 'scaled_diff')
         wgrad('input_embedding.input_embeddings.0.weight', de_all, vel_all, 'input_embedding.input_embeddings.0.bias')
         if GD:
             wgrad('goal_embedding.input_embeddings.0.weight', dgoal_all, gdir_all, 'goal_embedding.input_embeddings.0.bias')
@@ -797,6 +823,8 @@ class SequenceFn(torch.autograd.Function):
         flush_wgrads()
         if reduce_fn is not None:      # gradients formed outside wgrad() / layer_wgrad() (torch expressions) are reduced here
             done = set(id(t) for t in pending_tensors)
+            done.update(id(t._base) for t in pending_tensors if t._base is not None)     # bias vectors: slices of one buffer,
+                                                                                         # each already reduced on its own
             for n in ctx.param_names:
                 g = grads.get(n)
                 if g is None:
@@ -819,8 +847,16 @@ class SequenceFn(torch.autograd.Function):
             main.wait_event(side_done)                # join: the first layer's gradients are final for whatever comes next
             for n in (lay_names[0] + '.weight', lay_names[0] + '.bias'):
                 grads[n].record_stream(main)          # allocated on the side stream, consumed (optimizer, all-reduce) on this one
-        for dst_name, src_name in hh_clones:
-            grads[dst_name] = grads[src_name].clone()
+        if hh_clones:
+            where = bias_arena[2]
+            if all(src in where for _, src in hh_clones):
+                twin = bias_arena[0][:bias_arena[1]].clone()
+                for dst_name, src_name in hh_clones:
+                    off, n = where[src_name]
+                    grads[dst_name] = twin[off:off + n]
+            else:
+                for dst_name, src_name in hh_clones:
+                    grads[dst_name] = grads[src_name].clone()
         # parameters the forward never touches get no gradient (None, as autograd does for the reference), so that
         # optimizers skip them: a zero gradient would still let Adam + weight decay move them
         out = [None, d_obs, None, None, None, None, None]

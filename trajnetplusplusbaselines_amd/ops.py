@@ -312,6 +312,9 @@ class _SavedSequence(object):
     def save_for_backward(self, *tensors):
         self.saved_tensors = tensors
 
+    def set_materialize_grads(self, value):
+        pass            # the op's backward is handed its gradients explicitly
+
 
 _SAVED = collections.OrderedDict()     # handle -> _SavedSequence; bounded: a forward whose backward never runs must not leak
 _SAVED_MAX = 16
@@ -395,7 +398,8 @@ def lstm_sequence_backward(handle: torch.Tensor, d_rel: torch.Tensor, d_pred: to
     by_name = dict(zip(ctx.param_names, out[len(out) - len(ctx.param_names):]))
     grads = [by_name.get(n) for n in ctx.grad_names]
     # (a parameter the caller listed although the sequence does not touch it: zeros -- an op cannot return None in a list)
-    return [g if g is not None else torch.zeros_like(p) for g, p in zip(grads, params)]
+    # ... and its returns may not share storage: the bias gradients are slices of one buffer (lstm/training.py) -- own copies here
+    return [(g.clone() if g._base is not None else g) if g is not None else torch.zeros_like(p) for g, p in zip(grads, params)]
 
 
 @lstm_sequence_backward.register_fake

@@ -42,6 +42,49 @@ class Adam(torch.optim.Optimizer):
             for p in group['params']:
                 p.grad = None
 
+    # ---- the update -----------------------------------------------------------------------------------------------------
+    # A step of the reference's trainer updates ~20 small tensors with ONE launch, so what it costs is the host's walk over
+    # them (0.14 ms of a 2 ms batch_size-8 step when every parameter went through validation, a host-tensor `step += 1`, four
+    # data_ptr() calls and a new ctypes record).  Parameters that take the update together are kept as a `_Bucket`: the
+    # ctypes table with the constant pointers filled in, ONE step tensor shared by their states (same value, so the same
+    # state_dict; `state_dict()` hands out per-parameter copies), the list whose version counters move.  Per step and
+    # parameter only the gradient is looked at.  Buckets are rebuilt when the set of parameters with a gradient changes, a
+    # state is loaded or a group is added.
+    class _Bucket(object):
+        __slots__ = ('params', 'step', 'table', 'touched', 'device')
+
+    def _build_buckets(self, group, live):
+        buckets = {}
+        for p in live:
+            _lib.require_device(p, 'parameter')
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError('tnp Adam: float32 contiguous dense parameters only')
+            state = self.state[p]
+            if len(state) == 0:
+                state['step'] = torch.tensor(0.0, dtype=torch.float32)            # host tensor, like torch's default
+                state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            key = (float(state['step']), p.device)
+            b = buckets.get(key)
+            if b is None:
+                b = buckets[key] = Adam._Bucket()
+                b.params, b.step, b.device = [], state['step'], p.device
+            b.params.append(p)
+            state['step'] = b.step                                                # one tensor per bucket
+        out = list(buckets.values())
+        for b in out:
+            b.table = (AdamTensor * len(b.params))()
+            b.touched = []
+            for i, p in enumerate(b.params):
+                st = self.state[p]
+                m, v = st['exp_avg'], st['exp_avg_sq']
+                if m.device != p.device or v.device != p.device or m.dtype != torch.float32 or v.dtype != torch.float32 \
+                        or not m.is_contiguous() or not v.is_contiguous():
+                    raise RuntimeError('tnp Adam: optimiser state must be float32, contiguous and on the parameter\'s device')
+                b.table[i] = AdamTensor(p.data_ptr(), None, m.data_ptr(), v.data_ptr(), p.numel())
+                b.touched += [p, m, v]
+        return live, out
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -49,35 +92,58 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
-        for group in self.param_groups:
-            by_step = {}
-            for p in group['params']:
-                if p.grad is None:
-                    continue
-                _lib.require_device(p, 'parameter')
-                if p.dtype != torch.float32 or not p.is_contiguous() or p.grad.is_sparse:
-                    raise RuntimeError('tnp Adam: float32 contiguous dense parameters only')
-                if p.grad.dtype != torch.float32 or p.grad.device != p.device:
-                    # the kernel reads raw float pointers on the parameter's device
-                    raise RuntimeError('tnp Adam: gradient is %s on %s, parameter is float32 on %s'
-                                       % (p.grad.dtype, p.grad.device, p.device))
-                state = self.state[p]
-                if len(state) == 0:
-                    state['step'] = torch.tensor(0.0, dtype=torch.float32)            # host tensor, like torch's default
-                    state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                state['step'] += 1
-                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                by_step.setdefault((int(state['step']), p.device), []).append((p, grad, state['exp_avg'], state['exp_avg_sq']))
-            for (step, dev), items in by_step.items():
-                table = (AdamTensor * len(items))()
-                for i, (p, g, m, v) in enumerate(items):
-                    table[i] = AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
-                with torch.cuda.device(dev):
-                    _lib.check(L.tnp_adam_step(table, len(items), step, float(group['lr']), float(group['betas'][0]),
-                                               float(group['betas'][1]), float(group['eps']), float(group['weight_decay']),
-                                               _lib.stream_ptr()), 'tnp_adam_step')
+        plans = self.__dict__.setdefault('_plans', {})
+        f32 = torch.float32
+        for gi, group in enumerate(self.param_groups):
+            live = [p for p in group['params'] if p.grad is not None]
+            if not live:
+                continue
+            plan = plans.get(gi)
+            if plan is None or len(plan[0]) != len(live) or any(a is not b for a, b in zip(plan[0], live)):
+                plan = plans[gi] = self._build_buckets(group, live)
+            lr, (beta1, beta2) = float(group['lr']), group['betas']
+            for b in plan[1]:
+                table, keep = b.table, None
+                for i, p in enumerate(b.params):
+                    g = p.grad
+                    if g.dtype is not f32 or g.device != b.device or g.is_sparse:
+                        # the kernel reads raw float pointers on the parameter's device
+                        raise RuntimeError('tnp Adam: gradient is %s%s on %s, parameter is float32 on %s'
+                                           % (g.dtype, ' (sparse)' if g.is_sparse else '', g.device, p.device))
+                    if not g.is_contiguous():
+                        g = g.contiguous()
+                        keep = (keep or []) + [g]
+                    rec = table[i]
+                    rec.param, rec.grad = p.data_ptr(), g.data_ptr()
+                b.step += 1
+                step = int(b.step)
+                if torch.cuda.current_device() == b.device.index:
+                    rc = L.tnp_adam_step(table, len(b.params), step, lr, float(beta1), float(beta2), float(group['eps']),
+                                         float(group['weight_decay']), _lib.stream_ptr())
+                else:
+                    with torch.cuda.device(b.device):
+                        rc = L.tnp_adam_step(table, len(b.params), step, lr, float(beta1), float(beta2), float(group['eps']),
+                                             float(group['weight_decay']), _lib.stream_ptr())
+                _lib.check(rc, 'tnp_adam_step')
                 # the kernel wrote through raw pointers: tell autograd (and everything keyed on Tensor._version, e.g. the
                 # re-laid-out copies of the first embedding layer, lstm/lstm.py) that these tensors changed in place
-                torch.autograd.graph.increment_version([t for p, _, m, v in items for t in (p, m, v)])
+                torch.autograd.graph.increment_version(b.touched)
+                del keep
         return loss
+
+    def state_dict(self):
+        """torch.optim.Optimizer.state_dict; every parameter gets its OWN copy of the step counter (inside, parameters that are
+        updated together share one tensor)."""
+        sd = super(Adam, self).state_dict()
+        for st in sd['state'].values():
+            if isinstance(st.get('step'), torch.Tensor):
+                st['step'] = st['step'].clone()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super(Adam, self).load_state_dict(state_dict)
+        self.__dict__['_plans'] = {}
+
+    def add_param_group(self, param_group):
+        super(Adam, self).add_param_group(param_group)
+        self.__dict__['_plans'] = {}
