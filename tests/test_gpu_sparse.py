@@ -228,3 +228,28 @@ def test_small_batch_backward_kernels_agree(n1, scenes, lo, hi):
             _small_step_grads(model, xy, goals, split)
         finally:
             _lib.tuning_set('sparse_wgrad_plan', 0)
+
+
+def test_side_stream_weight_gradient_equals_the_single_stream_one(monkeypatch):
+    """Opt-in (lstm/training.py _SIDE_STREAM, measured slower): the sparse first layer's weight gradient on a side stream beside
+    the grouped weight-gradient launch.  Same kernels, same operands -- the same gradients bit for bit as on one stream, step
+    after step (buffers the side kernels use must survive until the join: a freed block would be handed to the main stream's
+    next allocation)."""
+    from trajnetplusplusbaselines_amd.lstm import training
+    torch.manual_seed(6)
+    pool = GridBasedPooling(type_='social', hidden_dim=128, cell_side=0.6, n=16, out_dim=256,
+                            embedding_arch='two_layer', layer_dims=[1024], latent_dim=16)
+    model = LSTM(pool=pool).cuda().train()
+    runs = {}
+    for mode in ('0', '1'):
+        monkeypatch.setattr(training, '_SIDE_STREAM', mode)
+        out = []
+        for seed in (1, 2, 3, 4):
+            xy, split = synth.ragged_crowd(8, 8, 60, seed=seed, nan_frac=0.15)
+            xy = xy.cuda()
+            out.append(_small_step_grads(model, xy, torch.zeros(xy.shape[1], 2, device='cuda'), split))
+        torch.cuda.synchronize()
+        runs[mode] = out
+    for mode in ('1',):
+        for a, b in zip(runs['0'], runs[mode]):
+            assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a), mode

@@ -21,7 +21,9 @@ R=$PWD
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_sp -o t -- python $R/tools/diag/small_batch_workload.py predict 60 > /dev/null 2>&1)
 python tools/rocprof_summary.py gpurun_out/prof_sp/*.db > gpurun_out/${TAG}_small_predict_kernel_stats.md 2>&1; rm -rf gpurun_out/prof_sp
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_st -o t -- python $R/tools/diag/small_batch_workload.py train 60 > /dev/null 2>&1)
-python tools/rocprof_summary.py gpurun_out/prof_st/*.db > gpurun_out/${TAG}_small_train_kernel_stats.md 2>&1; rm -rf gpurun_out/prof_st
+python tools/rocprof_summary.py gpurun_out/prof_st/*.db > gpurun_out/${TAG}_small_train_kernel_stats.md 2>&1
+python tools/diag/step_timeline.py gpurun_out/prof_st/*.db 3 > gpurun_out/${TAG}_small_train_step_timeline.txt 2>&1; rm -rf gpurun_out/prof_st
+python tools/diag/small_batch_workload.py train_time 200 2>&1 | grep "wall ms" > gpurun_out/${TAG}_small_train_wall.txt
 python tools/diag/predict_dataset_throughput.py 1024 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_predict_dataset_throughput.txt
 python tools/diag/small_batch_workload.py train_timeline 300 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_train_host_timeline.txt
 python tests/parity_margin.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_parity_margin.txt

@@ -23,19 +23,25 @@ import torch
 
 from .. import _lib
 
-#: the sparse first-layer weight gradient on a side stream beside the grouped weight-gradient launch.  OFF by default: measured
-#: SLOWER on MI355X (3.74 against 3.565 ms per optimisation step at config 2, three alternating runs each,
-#: tools/diag/ab_train_side_stream.sh / profiles/round5_train_side_stream.txt) -- the two matrix-pipe kernels stream 160 MB operands
-#: each and evict each other from the L2s; TNP_BWD_SIDE_STREAM=1 turns it on
-_SIDE_STREAM = os.environ.get('TNP_BWD_SIDE_STREAM', '0') not in ('0', '')
+#: The sparse first layer's weight gradient (hit lists -> per-cell contraction -> re-layout) on a side stream beside the grouped
+#: weight-gradient launch (they share no operand either WRITES).  OFF: measured slower twice.  At training batches (config 2,
+#: 38912 stacked rows) the two matrix-pipe kernels stream 160 MB operands each and evict each other from the L2s (3.74 against
+#: 3.565 ms per step, profiles/round5_train_side_stream.txt).  At the trainer's default batch_size 8 (~5900 rows) neither chain
+#: fills the chip and the kernels do overlap (~85 us of the step's 1.89 ms) -- but a second active stream makes EVERY launch of
+#: the process dearer on the host (tnp_lstm_backward_sweep 0.25 -> 0.375 ms, the forward 0.47 -> 0.55 ms for the same launches),
+#: and the step is host-bound there: 1.91 -> 2.06-2.10 ms (round 6, tools/diag/small_batch_workload.py train_time, alternating
+#: runs).  TNP_BWD_SIDE_STREAM=1 turns it on (single process only: a gradient reducer orders its collectives against the main
+#: stream); the lean form below allocates from the main stream's pool and keeps the buffers until the join.
+_SIDE_STREAM = os.environ.get('TNP_BWD_SIDE_STREAM', '0')
 _side_streams = {}
 
 
 def _side_stream(dev):
+    """(stream, fork event, join event) of the device, created once"""
     key = (dev.index if dev.index is not None else torch.cuda.current_device())
     st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=dev)
+        st = _side_streams[key] = (torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event())
     return st
 
 
@@ -718,7 +724,7 @@ class SequenceFn(torch.autograd.Function):
                     publish(keep[3])
             del wg_queue[:]
 
-        def layer_wgrad(li, name):
+        def layer_wgrad(li, name, sp=sp, keep_alive=None):
             if li == 0 and sparse_bwd:
                 # dW'[cell][ch][:] from the per-cell hit lists of the whole sweep, then back to the parameter's layout
                 N1 = dy_all[0].shape[2]
@@ -741,24 +747,24 @@ class SequenceFn(torch.autograd.Function):
                 grads[name + '.weight'] = gw
                 publish(grads[name + '.weight'])
                 wgrad_bias(name + '.bias', dy_all[0])          # column sums: ride along in the grouped launch (main stream)
+                if keep_alive is not None:     # side stream: nothing these kernels touch goes back to the allocator before the join
+                    keep_alive += [hit_t, hits, count, dwc, table]
                 return
             wgrad(name + '.weight', dy_all[li], grid_all if li == 0 else act_all[li - 1], name + '.bias')
-        side_done = None
+        side_done, side_keep = None, []
         if lay_names:
-            # first: the largest gradient (16.8 MB at config 2) gets the longest overlap with the collectives.  The sparse form
-            # (hit lists -> per-cell contraction -> re-layout -> bias column sums: ~330 us of kernels at config 2) shares no
-            # operand it WRITES with the grouped weight-gradient launch below (~400 us), so it CAN run on a side stream beside it
-            # (opt-in, see _SIDE_STREAM: measured slower).
-            side = _side_stream(dev) if (sparse_bwd and _SIDE_STREAM and dev.type == 'cuda') else None
-            if side is not None:
-                main = torch.cuda.current_stream(dev)
-                fork = torch.cuda.Event()
-                fork.record(main)
+            # first: the largest gradient (16.8 MB at config 2) gets the longest overlap with the collectives.  Opt-in (see
+            # _SIDE_STREAM: measured slower): on a side stream beside the grouped weight-gradient launch.  Buffers come from THIS
+            # stream's allocator (a side stream's own pool meets a new size every ragged batch: a hipMalloc per step) and are
+            # kept until the join; the kernels get the side stream's handle.
+            side = None
+            if sparse_bwd and dev.type == 'cuda' and reduce_fn is None and _SIDE_STREAM not in ('0', ''):
+                side, fork, side_done = _side_stream(dev)
+                fork.record(torch.cuda.current_stream(dev))
                 side.wait_event(fork)                 # everything the sweep left behind is complete for the side stream
-                with torch.cuda.stream(side):
-                    layer_wgrad(0, lay_names[0])
-                    side_done = torch.cuda.Event()
-                    side_done.record(side)
+                handle = ctypes.c_void_p(side.cuda_stream)
+                layer_wgrad(0, lay_names[0], sp=lambda: handle, keep_alive=side_keep)
+                side_done.record(side)
             else:
                 layer_wgrad(0, lay_names[0])
         h_out_all, h_prev_all = h_all[1:], h_all[:-1]
@@ -843,10 +849,8 @@ class SequenceFn(torch.autograd.Function):
             for w in pending:
                 w.wait()                  # the compute stream waits for RCCL's stream; no host synchronisation
         if side_done is not None:
-            main = torch.cuda.current_stream(dev)
-            main.wait_event(side_done)                # join: the first layer's gradients are final for whatever comes next
-            for n in (lay_names[0] + '.weight', lay_names[0] + '.bias'):
-                grads[n].record_stream(main)          # allocated on the side stream, consumed (optimizer, all-reduce) on this one
+            torch.cuda.current_stream(dev).wait_event(side_done)     # join: the first layer's gradient is final for what comes next
+            del side_keep[:]
         if hh_clones:
             where = bias_arena[2]
             if all(src in where for _, src in hh_clones):
