@@ -68,29 +68,56 @@ __device__ __forceinline__ void sf_agent_step_gpu(int a, int n, const double *st
     double Fy = 1.0 / tau * (initial_speed * eay - sa[3]);
     const double delta = 1e-3, inv_delta = 1.0 / delta;
     double sum_x = 0.0, sum_y = 0.0;
-    for (int b = 0; b < n; ++b) {
-        if (b == a) continue;
+    // Two neighbours per trip in STAGES: the finite difference of both (three elliptic distances, an exp, two polynomials each --
+    // straight-line code, so the two chains interleave and fill each other's fp64 latencies), then the rare literal form where
+    // a step crosses the potential's edge, then the field-of-view weights.  The sums are still taken in neighbour order.
+    // V(r + delta) - V(r) = V(r) (exp((b' - b) / -sigma) - 1): ONE exp per pair instead of three, and the difference without the
+    // cancellation of two nearly equal potentials (the host execution subtracts them as the package does; 1e-12 apart).
+    struct Diff { double arg, v, dx_, dy_, dvdx, dvdy; };
+    auto diff = [&](int b, Diff &d) {
         const double *sb = st + 7 * b;
         const sf_agent_terms *tb = terms + b;
         const double rx = sa[0] - sb[0], ry = sa[1] - sb[1];
-        // V(r + delta) - V(r) = V(r) (exp((b' - b) / -sigma) - 1): ONE exp per pair instead of three, and the difference without the
-        // cancellation of two nearly equal potentials (the host execution subtracts them as the package does; 1e-12 apart).  A step
-        // across the potential's edge (b' - b large: the neighbour sits on the other's stride) takes the literal form.
         const double b0 = sf_b_gpu(rx, ry, tb);
-        const double v = p->v0 * exp(b0 * neg_inv_sigma);
-        const double dx_ = (sf_b_gpu(rx + delta, ry, tb) - b0) * neg_inv_sigma, dy_ = (sf_b_gpu(rx, ry + delta, tb) - b0) * neg_inv_sigma;
-        double dvdx, dvdy;
-        if (fabs(dx_) <= 0.0625 && fabs(dy_) <= 0.0625) {
-            dvdx = v * sf_expm1_small(dx_) * inv_delta;
-            dvdy = v * sf_expm1_small(dy_) * inv_delta;
-        } else {
-            dvdx = (p->v0 * exp((b0 * neg_inv_sigma) + dx_) - v) * inv_delta;
-            dvdy = (p->v0 * exp((b0 * neg_inv_sigma) + dy_) - v) * inv_delta;
+        d.arg = b0 * neg_inv_sigma;
+        d.v = p->v0 * exp(d.arg);
+        d.dx_ = (sf_b_gpu(rx + delta, ry, tb) - b0) * neg_inv_sigma;
+        d.dy_ = (sf_b_gpu(rx, ry + delta, tb) - b0) * neg_inv_sigma;
+        d.dvdx = d.v * sf_expm1_small(d.dx_) * inv_delta;
+        d.dvdy = d.v * sf_expm1_small(d.dy_) * inv_delta;
+    };
+    auto edge = [&](Diff &d) {                 // |argument| beyond the polynomial's range: the literal difference of two potentials
+        if (!(fabs(d.dx_) <= 0.0625 && fabs(d.dy_) <= 0.0625)) {
+            d.dvdx = (p->v0 * exp(d.arg + d.dx_) - d.v) * inv_delta;
+            d.dvdy = (p->v0 * exp(d.arg + d.dy_) - d.v) * inv_delta;
         }
-        const double fx = -1.0 * dvdx, fy = -1.0 * dvdy;
+    };
+    auto weigh = [&](const Diff &d, double &cx, double &cy) {
+        const double fx = -1.0 * d.dvdx, fy = -1.0 * d.dvdy;
         const double in_sight = (eax * (-fx) + eay * (-fy)) > sf_sqrt(fx * fx + fy * fy) * p->cosphi;
         const double w = in_sight ? 1.0 : p->out_of_view;
-        sum_x += w * fx; sum_y += w * fy;
+        cx = w * fx; cy = w * fy;
+    };
+    int b = 0;
+    for (; b + 1 < n; b += 2) {
+        Diff d0, d1;
+        diff(b, d0);
+        diff(b + 1, d1);
+        edge(d0);
+        edge(d1);
+        double c0x, c0y, c1x, c1y;
+        weigh(d0, c0x, c0y);
+        weigh(d1, c1x, c1y);
+        if (b != a) { sum_x += c0x; sum_y += c0y; }
+        if (b + 1 != a) { sum_x += c1x; sum_y += c1y; }
+    }
+    if (b < n && b != a) {
+        Diff d0;
+        double c0x, c0y;
+        diff(b, d0);
+        edge(d0);
+        weigh(d0, c0x, c0y);
+        sum_x += c0x; sum_y += c0y;
     }
     Fx += sum_x; Fy += sum_y;
     const double wx = sa[2] + p->delta_t * Fx, wy = sa[3] + p->delta_t * Fy;
