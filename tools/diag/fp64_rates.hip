@@ -44,7 +44,7 @@ static double run(double *out, int iters) {
 int main() {
     double *out;
     hipMalloc(&out, 256 * 8 * 256 * sizeof(double));
-    const int iters = 4096;
+    const int iters = 4096 * 16;
     const char *names[6] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rsq_f64 (+ add)", "v_rcp_f64 (+ add)", "v_sqrt_f64 (+ add)"};
     double ms[6] = {run<0>(out, iters), run<1>(out, iters), run<2>(out, iters), run<3>(out, iters), run<4>(out, iters), run<5>(out, iters)};
     hipDeviceProp_t p;
