@@ -1090,8 +1090,9 @@ def main():
                 empty_us = float(np.median([e0.elapsed_time(e1) for e0, e1 in pairs])) * 1e3
                 roof = dict(bound=('valu-f32' if sparse else 'mfma'), achieved=achieved, peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                             frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=None, kernel=kname,
-                            engine=('fp32 VALU FMA (same 157.3 TFLOP/s peak as the fp32 matrix cores)' if sparse
-                                    else 'fp32 MFMA'),
+                            engine=('fp32 VALU FMA (same 157.3 TFLOP/s peak as the fp32 matrix cores; a stream of independent '
+                                    'v_pk_fma_f32 alone sustains 127-138 TFLOP/s on this part: tools/diag/fp32_rates.hip, '
+                                    'profiles/round6_fp32_rates.txt)' if sparse else 'fp32 MFMA'),
                             formulation=('sparse gather (algorithmic FLOPs = 2*M*(A-1)*C*N1)' if sparse
                                          else 'dense GEMM (algorithmic FLOPs = 2*M*N1*C*n*n)'),
                             launches=n.value, avg_launch_us=avg_s * 1e6, flops_per_launch=flops,
