@@ -1048,15 +1048,29 @@ def main():
         roof = None
         if rank == 0 and not args.train and not is_sgan and not args.no_roofline:
             import ctypes
-            _lib.check(L.tnp_profile_begin(0), 'tnp_profile_begin')
-            torch.cuda.synchronize()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
-            _lib.check(L.tnp_profile_read(ctypes.byref(ms), ctypes.byref(n)), 'tnp_profile_read')
-            dispatch_timed = int(L.tnp_profile_dispatch_timed())
-            L.tnp_profile_end()
+
+            def profiled_pass():
+                _lib.check(L.tnp_profile_begin(0), 'tnp_profile_begin')
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                wall = (time.perf_counter() - t0) / args.steps
+                ms_, n_ = ctypes.c_double(0.0), ctypes.c_int(0)
+                _lib.check(L.tnp_profile_read(ctypes.byref(ms_), ctypes.byref(n_)), 'tnp_profile_read')
+                disp = int(L.tnp_profile_dispatch_timed())
+                L.tnp_profile_end()
+                return ms_, n_, disp, wall
+            # The library creates its event pairs on first use (two hipEventCreate per launch): on a slow host that makes the
+            # first profiled pass host-bound, the queue runs dry between launches, the clocks fall and every launch reads ~1.7x
+            # its duration (56 us against rocprofv3's 33 on one box of round 6).  The first pass only fills the pool; a pass whose
+            # wall clock still is not the timed region's is repeated (at most twice) and the fastest pass counts.
+            profiled_pass()
+            passes = [profiled_pass()]
+            while passes[-1][3] > 1.1 * elapsed / args.steps and len(passes) < 3:
+                passes.append(profiled_pass())
+            ms, n, dispatch_timed, leg_wall = min(passes, key=lambda q: q[0].value / max(q[1].value, 1))
             K0 = cfg['n'] * cfg['n'] * model.pool.pooling_dim
             N0 = model.pool.embedding_layers()[0].weight.shape[0]
             dense_flops = 2.0 * M * N0 * K0                # dense Linear(C*n*n -> N0) on the grid
@@ -1098,6 +1112,7 @@ def main():
                             launches=n.value, avg_launch_us=avg_s * 1e6, flops_per_launch=flops,
                             dense_equivalent_tflops=dense_flops / avg_s / 1e12,
                             share_of_step=ms.value * 1e-3 / elapsed,
+                            profiled_pass_ms_per_forward=leg_wall * 1e3, profiled_passes=len(passes),
                             event_pair_empty_us=empty_us, dispatch_timed_launches=dispatch_timed,
                             event_note=('avg_launch_us: the two HIP events of every launch travel IN its dispatch (hipExtLaunchKernelGGL '
                                         'start / stop events = begin / end timestamps of the kernel\'s own AQL packet, the quantity the '
