@@ -575,7 +575,7 @@ def classical_leg(device, scenes=4096, agents=128):
 
 # vector instructions per launch at BASELINE config 5 (4096 x 128), profiles/round6_pmc_classical.md; ORCA before round 6's
 # register form: 4.628e10 (profiles/archive/round3_d_pmc_classical.md)
-CLASSICAL_VALU_INSTS = {'socialforce': 2.277e10, 'orca': 5.416e9, 'kalman': 1.084e9}     # (start of round 6: 3.636e10 / 4.628e10 / 1.492e9)
+CLASSICAL_VALU_INSTS = {'socialforce': 2.297e10, 'orca': 5.416e9, 'kalman': 1.084e9}     # (start of round 6: 3.636e10 / 4.628e10 / 1.492e9)
 BOOST_CLOCK_GHZ = 2.4
 
 # the Python reference at its real operating point, measured in the build container (8 vCPUs) by tools/ref_operating_point.py
