@@ -536,6 +536,15 @@ def test_grouped_wgrad_column_sums_without_a_weight_part():
                 refw = dy.double().t() @ x.double()
                 assert (dw.double() - refw).abs().max() <= 1e-3 * max(1.0, float(refw.abs().max()))
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+    # rows with a leading dimension larger than Mo (a column slice of a wider matrix)
+    wide = torch.randn(1000, 300, generator=g).cuda()
+    view = wide[:, 17:17 + 200]
+    db = torch.empty(200, device='cuda')
+    one = (WgradProblem * 1)(WgradProblem(view.data_ptr(), view.stride(0), None, 0, 1000, 200, 0, None, 0, db.data_ptr()))
+    nb = L.tnp_wgrad_grouped_workspace_bytes(one, 1)
+    ws = torch.empty(nb, dtype=torch.uint8, device='cuda')
+    _lib.check(L.tnp_wgrad_grouped(one, 1, _lib.ptr(ws), nb, _lib.stream_ptr()), 'tnp_wgrad_grouped')
+    assert (db.double() - view.double().sum(0)).abs().max() <= 2e-5 * float(view.abs().sum(0).max())
     # a problem with neither a weight part nor a bias is skipped, as before
     empty = (WgradProblem * 1)(WgradProblem(keep[0][0].data_ptr(), 1024, None, 0, 5890, 1024, 0, None, 0, None))
     assert L.tnp_wgrad_grouped_workspace_bytes(empty, 1) == 0
