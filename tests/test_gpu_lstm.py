@@ -523,3 +523,43 @@ def test_predictor_modes_of_a_deterministic_model_share_one_forward():
         assert np.array_equal(b[0][0], b[2][0])
     arr, sp = pred.predict_xy_finish(pred.predict_xy_launch([trajdata.paths_to_xy(p) for p in scenes], goals, n_predict=12, modes=3), 12)
     assert arr.shape[0] == 3 and np.array_equal(arr[0], arr[2], equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('type_,n_predict', [('directional', 12), ('occupancy', 12), ('directional', 0)])
+def test_prepare_and_grid_in_one_launch_do_not_change_the_result(type_, n_predict):
+    """Round 6: for occupancy / directional grids the sequence driver builds a step's grid in the SAME launch as track_prepare
+    (the grid's workgroups form their scene's positions from the previous state themselves instead of waiting for the buffers
+    track_prepare writes).  Same arithmetic in the same order: predictions (free-running and teacher-forced, ragged scenes with
+    absent tracks, with and without goals) and training gradients are the same bit for bit as with two launches."""
+    from trajnetplusplusbaselines_amd import _lib, synth
+    from trajnetplusplusbaselines_amd.lstm import LSTM, GridBasedPooling, PredictionLoss
+    torch.manual_seed(5)
+    pool = GridBasedPooling(type_=type_, hidden_dim=128, cell_side=0.6, n=12, out_dim=256)
+    model = LSTM(pool=pool, goal_flag=(type_ == 'occupancy')).cuda()
+    xy, split = synth.ragged_crowd(9, 1, 70, seed=12, nan_frac=0.2)
+    xy = xy.cuda()
+    goals = torch.randn(xy.shape[1], 2, device='cuda')
+
+    def run():
+        model.eval()
+        with torch.no_grad():
+            if n_predict:
+                out = model(xy[:9], goals, split, n_predict=n_predict)
+            else:
+                out = model(xy[:9], goals, split, prediction_truth=xy[9:20])
+        model.train()
+        model.zero_grad(set_to_none=True)
+        rel, _ = model(xy[:9], goals, split, prediction_truth=xy[9:-1])
+        PredictionLoss()(rel[-12:], xy[9:21] - xy[8:20], split).backward()
+        return out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    try:
+        _lib.tuning_set('fuse_prepare_grid', 1)
+        (rel1, pred1), g1 = run()
+        _lib.tuning_set('fuse_prepare_grid', 0)
+        (rel0, pred0), g0 = run()
+    finally:
+        _lib.tuning_set('fuse_prepare_grid', 1)
+    assert torch.equal(torch.isnan(pred1), torch.isnan(pred0)) and torch.isfinite(pred1[:, split[:-1]]).all()
+    assert torch.equal(torch.nan_to_num(pred1), torch.nan_to_num(pred0)) and torch.equal(torch.nan_to_num(rel1), torch.nan_to_num(rel0))
+    assert g1.keys() == g0.keys() and all(torch.equal(g1[k], g0[k]) for k in g1)

@@ -11,7 +11,7 @@ OUT = os.path.join(OUT_DIR, 'libtrajnet_hip.so')
 SOURCES = ['gemm_f32_mfma.hip', 'gemm_skinny.hip', 'gemm_wgrad.hip', 'pool_grid.hip', 'pool_embed_sparse.hip', 'pool_nongrid.hip', 'lstm_seq.hip', 'lstm_bwd.hip', 'loss.hip',
            'optim.hip', 'classical.hip', 'ndjson_io.cpp']
 EXACT = ('classical.hip', 'pool_grid.hip', 'optim.hip')
-HEADERS = ['tnp_internal.h', 'lstm_cell.h', 'classical_core.h', os.path.join('..', '..', 'include', 'trajnet_hip.h'),
+HEADERS = ['tnp_internal.h', 'lstm_cell.h', 'classical_core.h', 'grid_build_body.h', os.path.join('..', '..', 'include', 'trajnet_hip.h'),
            os.path.join('..', '..', 'include', 'trajnet_hip_profile.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-fvisibility=hidden',
          '-Wall', '-Wno-unused-function']

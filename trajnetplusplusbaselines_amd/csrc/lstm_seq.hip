@@ -13,6 +13,8 @@
 //
 // All launches go to the caller's stream; nothing synchronises or allocates (graph capturable).
 #include "tnp_internal.h"
+#include "grid_build_body.h"
+#define TNP_MAX_DEVICES_SEQ 64
 
 #include <math.h>
 #include <string.h>
@@ -23,7 +25,7 @@ namespace tnp {
 
 Tuning &tuning() {
     static Tuning t = [] {
-        Tuning v = {0, 0, 0, 160, 512, 0, 128, 512};
+        Tuning v = {0, 0, 0, 160, 512, 0, 128, 512, 1};
         const char *e = getenv("TNP_SPARSE_TILE");
         if (e && sscanf(e, "%d,%d", &v.sparse_te, &v.sparse_ncs) != 2) v.sparse_te = v.sparse_ncs = 0;
         if ((e = getenv("TNP_SPARSE_MIN_WG")) != nullptr) v.sparse_min_wg = atol(e);
@@ -32,6 +34,7 @@ Tuning &tuning() {
         if ((e = getenv("TNP_SPARSE_WGRAD_PLAN")) != nullptr) v.sparse_wgrad_plan = atoi(e);
         if ((e = getenv("TNP_WGRAD_MIN_ROWS")) != nullptr && atoi(e) > 0) v.wgrad_min_rows = atoi(e);
         if ((e = getenv("TNP_WGRAD_TARGET")) != nullptr && atoi(e) > 0) v.wgrad_target_wgs = atoi(e);
+        if ((e = getenv("TNP_FUSE_PREPARE_GRID")) != nullptr) v.fuse_prepare_grid = atoi(e);
         return v;
     }();
     return t;
@@ -159,8 +162,7 @@ __device__ __forceinline__ float sigmoid_dev(float x) { return 1.0f / (1.0f + ex
 // 256 threads = 8 tracks x 32 lanes.  Phase 1: the 5 + C dot products of length H per track (h row and the
 // weight rows staged in LDS, weight stride H+1 -> conflict free).  Phase 2: per-track scalar bookkeeping.
 // Phase 3: the E-2 (+ goal) embedding outputs, 32 lanes per track.
-__global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float psm[];
+__device__ __forceinline__ void track_prepare_body(const PrepArgs &a, const int block, float *psm) {
     const int H = a.H;
     const int nout = (a.have_prev ? 5 : 0) + (a.have_next ? a.C : 0);  // rows of the stacked weight
     float *hs = psm;                        // [8][H]
@@ -169,7 +171,7 @@ __global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
     float *ob = outs + PREP_TRACKS * (nout > 0 ? nout : 1);  // [8][8]: obs1.xy obs2.xy mask goal.xy
     const int tid = threadIdx.x;
     const int t_local = tid >> 5, l32 = tid & 31;
-    const int m0 = blockIdx.x * PREP_TRACKS;
+    const int m0 = block * PREP_TRACKS;
     const int m = m0 + t_local;
     const bool valid = m < a.M;
 
@@ -368,6 +370,90 @@ __global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
     }
 }
 
+__global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    track_prepare_body(a, blockIdx.x, psm);
+}
+
+// ---- track_prepare + grid_build in ONE launch (occupancy / directional grids) ------------------------------------------------
+// The grid of step s needs the positions track_prepare writes for step s: two dependent ~5.6 us launches per recurrent step,
+// a sixth of the step at a strong-scaling shard (2048 tracks) and an eighth of an S-GAN generator step.  Here the grid's
+// workgroups do not wait for those buffers: a workgroup (four egos of one scene) forms the positions of ITS scene from what
+// track_prepare itself reads -- the previous state (Hidden2Normal's two mean rows, same four partial sums in the same order:
+// the same bits), the previous obs2, the external frames and the primaries' patches -- so both kinds of workgroups run side
+// by side in one launch.  ~2 x 128 FMAs per track of the scene and workgroup, against a launch boundary.
+__global__ void __launch_bounds__(256) prepare_grid_kernel(const PrepArgs pa, const GridArgs ga, int prep_blocks, int ego_blocks) {
+    extern __shared__ __attribute__((aligned(16))) float pgsm[];
+    if ((int)blockIdx.x < prep_blocks) { track_prepare_body(pa, blockIdx.x, pgsm); return; }
+    const int gid = (int)blockIdx.x - prep_blocks;
+    const int sc = gid / ego_blocks, bx = gid - sc * ego_blocks;
+    grid_build_body(ga, bx, sc, pgsm, [&](int start, int ns, float2 *pos, float2 *vel) {
+        const int tid = threadIdx.x, q = tid & 3, H = pa.H;
+        for (int j0 = 0; j0 < ns; j0 += 64) {                                // four lanes per track
+            const int j = j0 + (tid >> 2);
+            const bool on = j < ns;
+            const int m = start + (on ? j : 0);
+            float px = NAN, py = NAN;                                        // position predicted by the previous step
+            if (!pa.have_prev && pa.pos2) { px = pa.pos2[2 * m]; py = pa.pos2[2 * m + 1]; }
+            if (pa.have_prev) {
+                // rows 0 / 1 of Hidden2Normal as track_prepare sums them: lane q = partial sum q (k = q mod 4, ascending, the
+                // first one starting from the bias), combined as (p0 + p1) + (p2 + p3)
+                float p0 = q == 0 ? pa.bn[0] : 0.0f, p1 = q == 0 ? pa.bn[1] : 0.0f;
+                const float *hr = pa.h + (size_t)m * H + q, *w0 = pa.Wn + q, *w1 = pa.Wn + H + q;
+#pragma unroll 8
+                for (int k = 0; k < H; k += 4) {
+                    const float hv = hr[k];
+                    p0 = fmaf(hv, w0[k], p0);
+                    p1 = fmaf(hv, w1[k], p1);
+                }
+                p0 += __shfl_xor(p0, 1); p1 += __shfl_xor(p1, 1);
+                p0 += __shfl_xor(p0, 2); p1 += __shfl_xor(p1, 2);
+                const bool was = pa.mask_prev[m] != 0;
+                px = pa.obs2_prev[2 * m] + (was ? p0 : NAN);
+                py = pa.obs2_prev[2 * m + 1] + (was ? p1 : NAN);
+            }
+            const bool prim = pa.primary[m] != 0;
+            float2 o1, o2;
+            if (pa.ext1 && !(pa.patch1 && prim)) { o1.x = pa.ext1[2 * m]; o1.y = pa.ext1[2 * m + 1]; }
+            else if (pa.pos1) { o1.x = pa.pos1[2 * m]; o1.y = pa.pos1[2 * m + 1]; }
+            else { o1.x = NAN; o1.y = NAN; }
+            if (pa.ext2 && !(pa.patch2 && prim)) { o2.x = pa.ext2[2 * m]; o2.y = pa.ext2[2 * m + 1]; }
+            else { o2.x = px; o2.y = py; }
+            if (on && q == 0) grid_stage_track(ga.type, o1, o2, j, pos, vel);
+        }
+    });
+}
+
+static size_t prepare_smem_bytes(const PrepArgs &a) {
+    const int nout = (a.have_prev ? 5 : 0) + (a.have_next ? a.C : 0);
+    return ((size_t)PREP_TRACKS * a.H + (size_t)nout * (a.H + 4) + (size_t)PREP_TRACKS * (nout > 0 ? nout : 1) + PREP_TRACKS * 8) *
+           sizeof(float);
+}
+
+static int launch_prepare_grid(const PrepArgs &a, const GridArgs &g, hipStream_t s) {
+    size_t psm = prepare_smem_bytes(a), gsm = 0;
+    if (psm > 60000) TNP_FAIL(-1, "track_prepare: hidden_dim %d too large for the LDS staging", a.H);
+    GridArgs gb;
+    const int rc = grid_launch_plan(g, &gb, &gsm);
+    if (rc) return rc;
+    const size_t smem = psm > gsm ? psm : gsm;
+    // (egos per grid workgroup: every workgroup of a scene forms the scene's positions again, so more egos per workgroup would
+    // mean fewer repetitions -- and a longer ego loop, which is what counts: 4 / 8 / 16 egos -> 0.591 / 0.621 / 0.698 ms per
+    // forward at 32 x 64 directional, 1.488 / 1.525 / 1.675 ms per S-GAN forward)
+    const int prep_blocks = (a.M + PREP_TRACKS - 1) / PREP_TRACKS, ego_blocks = (g.n_max + TNP_GRID_EGOS - 1) / TNP_GRID_EGOS;
+    static size_t attr[TNP_MAX_DEVICES_SEQ] = {};
+    int dev = 0;
+    TNP_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < TNP_MAX_DEVICES_SEQ && smem > attr[dev] && smem > 48 * 1024) {
+        TNP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(prepare_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem));
+        attr[dev] = smem;
+    }
+    hipLaunchKernelGGL(prepare_grid_kernel, dim3(prep_blocks + ego_blocks * g.B), dim3(256), smem, s, a, gb, prep_blocks, ego_blocks);
+    TNP_HIP(hipGetLastError());
+    return 0;
+}
+
 static int launch_prepare(const PrepArgs &a, hipStream_t s) {
     const int nout = (a.have_prev ? 5 : 0) + (a.have_next ? a.C : 0);
     size_t smem = ((size_t)PREP_TRACKS * a.H + (size_t)nout * (a.H + 4) + (size_t)PREP_TRACKS * (nout > 0 ? nout : 1) +
@@ -410,6 +496,9 @@ struct Workspace {
     int32_t *row_end;                             // sparse path: one past the last row of every row's scene
     int32_t *row_padded;                          // sparse path: slots the reference pads the row's scene to
     int fuse_grid, save_winners;                  // winner tile built inside the sparse kernel; table wanted by the caller
+    int grid_prebuilt;                            // this step's grid came with the merged prepare + grid launch (run_step_body skips its own)
+    float *obs2_alt; uint8_t *mask_alt;           // second copies for that launch: its grid workgroups read the PREVIOUS obs2 / mask of
+                                                  // a whole scene while its prepare workgroups write the new ones
     size_t bytes;
     bool fine; float *grid_fine; int ldg_fine;   // pool_size / blur_size != 1: the fine grid in front of grid_finish_kernel
 };
@@ -456,9 +545,11 @@ static int plan_workspace(const tnp_lstm_model *md, int M, void *base, Workspace
     w.y[0] = (float *)take((size_t)M * maxmid * 4);
     w.y[1] = (float *)take((size_t)M * maxmid * 4);
     w.mask = (uint8_t *)take((size_t)M);
+    w.mask_alt = (uint8_t *)take((size_t)M);
+    w.obs2_alt = (float *)take((size_t)M * 2 * 4);
     w.sparse = grid_pool && !w.fine && md->pool_type == TNP_POOL_SOCIAL && md->Wp0_cell_major != nullptr && md->constant == 0.0f &&
                ((md->variant >> 16) & 1) == 0 && sparse_supported(md->C, md->dims[1], md->n * md->n) && (w.I % 4 == 0);
-    w.winners = nullptr; w.row_base = nullptr; w.partial = nullptr; w.row_end = nullptr; w.row_padded = nullptr; w.fuse_grid = 0;
+    w.winners = nullptr; w.row_base = nullptr; w.partial = nullptr; w.row_end = nullptr; w.row_padded = nullptr; w.fuse_grid = 0; w.grid_prebuilt = 0;
     w.save_winners = 0;
     if (w.sparse) {
         w.winners = (int16_t *)take((size_t)M * md->n * md->n * sizeof(int16_t));
@@ -555,6 +646,35 @@ static void fill_gates_args(GemmArgs &g, const tnp_lstm_model *md, int decoder, 
 }
 
 // pool + gates of one step; obs/mask/X[:,0:E+GD]/enc already prepared
+static GridArgs step_grid_args(const tnp_lstm_model *md, const Workspace &w, const int32_t *scene_start, int B, int n_max,
+                               const int32_t *scene_slots) {
+    GridArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.obs1 = w.obs1; ga.obs2 = w.obs2; ga.values = w.enc; ga.ldv = md->C; ga.scene_start = scene_start;
+    ga.B = B; ga.n_max = n_max; ga.scene_slots = scene_slots; ga.type = md->pool_type; ga.n = md->n; ga.C = md->C;
+    ga.cell = md->cell; ga.half_x = md->half_x; ga.half_y = md->half_y; ga.constant = md->constant;
+    ga.grid = w.sparse ? nullptr : w.grid; ga.ldg = w.ldg; ga.winners = w.sparse ? w.winners : nullptr;
+    if (w.fine) { ga.n = md->n * (md->pool_size > 1 ? md->pool_size : 1); ga.grid = w.grid_fine; ga.ldg = w.ldg_fine; }
+    return ga;
+}
+
+// track_prepare of a step and -- occupancy / directional grids -- the step's grid in the same launch (prepare_grid_kernel)
+static int prepare_step(const tnp_lstm_model *md, Workspace &w, const PrepArgs &p, const int32_t *scene_start, int B, int n_max,
+                        const int32_t *scene_slots, hipStream_t s) {
+    const bool grid_pool = md->pool_type == TNP_POOL_OCCUPANCY || md->pool_type == TNP_POOL_DIRECTIONAL;
+    if (p.have_next && grid_pool && !w.sparse && !w.fine && B > 0 && n_max > 0 && tuning().fuse_prepare_grid) {
+        // track_prepare updates obs2 / mask in place (a thread reads its track's previous value, then writes the new one); the
+        // grid workgroups of the same launch read the previous values of whole scenes: the new ones go to the second copies
+        PrepArgs q = p;
+        if (q.have_prev && q.obs2_prev == q.obs2_buf) { q.obs2_buf = w.obs2_alt; w.obs2_alt = w.obs2; w.obs2 = q.obs2_buf; }
+        if (q.have_prev && q.mask_prev == q.mask) { q.mask = w.mask_alt; w.mask_alt = w.mask; w.mask = q.mask; }
+        const int rc = launch_prepare_grid(q, step_grid_args(md, w, scene_start, B, n_max, scene_slots), s);
+        if (rc == 0) w.grid_prebuilt = 1;
+        return rc;
+    }
+    return launch_prepare(p, s);
+}
+
 static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, const float *h_in, float *h_out,
                          const float *c_in, float *c_out, const int32_t *scene_start, int B, int M, int n_max,
                          const int32_t *scene_slots, hipStream_t s) {
@@ -630,14 +750,10 @@ static int run_step_body(const tnp_lstm_model *md, int decoder, Workspace &w, co
         rc = launch_linear(g, 0, s);
         if (rc) return rc;
     } else if (md->pool_type != TNP_POOL_NONE) {
-        GridArgs ga;
-        ga.obs1 = w.obs1; ga.obs2 = w.obs2; ga.values = w.enc; ga.ldv = md->C; ga.scene_start = scene_start;
-        ga.B = B; ga.n_max = n_max; ga.scene_slots = scene_slots; ga.type = md->pool_type; ga.n = md->n; ga.C = md->C;
-        ga.cell = md->cell; ga.half_x = md->half_x; ga.half_y = md->half_y; ga.constant = md->constant;
-        ga.grid = w.sparse ? nullptr : w.grid; ga.ldg = w.ldg; ga.winners = w.sparse ? w.winners : nullptr;
-        if (w.fine) { ga.n = md->n * (md->pool_size > 1 ? md->pool_size : 1); ga.grid = w.grid_fine; ga.ldg = w.ldg_fine; }
+        const GridArgs ga = step_grid_args(md, w, scene_start, B, n_max, scene_slots);
         const bool fused_grid = w.sparse && w.fuse_grid && n_max <= 32767;
-        int rc = fused_grid ? 0 : launch_grid(ga, s);
+        int rc = (fused_grid || w.grid_prebuilt) ? 0 : launch_grid(ga, s);
+        w.grid_prebuilt = 0;
         if (rc) return rc;
         if (w.fine) {
             rc = launch_grid_finish(w.grid_fine, w.ldg_fine, M, md->C, md->n, md->pool_size > 1 ? md->pool_size : 1,
@@ -909,7 +1025,7 @@ static int lstm_forward_impl(const tnp_lstm_model *md, const float *observed, in
             p.have_prev = 0;
             p.pos2 = pred + (size_t)(npos - 1) * F;
         }
-        rc = launch_prepare(p, s);
+        rc = prepare_step(md, w, p, scene_start, B, n_max, scene_slots, s);
         if (rc) return rc;
         if (p.have_next) {
             float *hnext = sv ? sv->h_all + (size_t)(st + 1) * MH : w.h[cur ^ 1];
@@ -986,7 +1102,7 @@ static int lstm_step_impl(const tnp_lstm_model *md, int decoder, const float *h_
     p.ext1 = obs1; p.ext2 = obs2;
     // primary flags are only consulted when patching; none here
     p.primary = w.mask;  // any valid [M] byte buffer (unused: patch1 = patch2 = 0)
-    rc = launch_prepare(p, s);
+    rc = prepare_step(md, w, p, scene_start, B, n_max, scene_slots, s);
     if (rc) return rc;
     rc = run_step_body(md, decoder, w, h_in, h_out, c_in, c_out, scene_start, B, M, n_max, scene_slots, s);
     if (rc) return rc;
@@ -1035,11 +1151,12 @@ extern "C" TNP_API int tnp_tuning_set(const char *key, long value) {
     else if (k == "sparse_min_wg") t.sparse_min_wg = value;
     else if (k == "skinny_max_rows") t.skinny_max_rows = (int)value;
     else if (k == "skinny_gates_max_rows") t.skinny_gates_max_rows = (int)value;
+    else if (k == "fuse_prepare_grid") t.fuse_prepare_grid = value != 0;
     else if (k == "sparse_wgrad_plan") t.sparse_wgrad_plan = (int)value;
     else if (k == "wgrad_min_rows") { if (value <= 0) TNP_FAIL(-1, "tnp_tuning_set: wgrad_min_rows must be positive"); t.wgrad_min_rows = (int)value; }
     else if (k == "wgrad_target_wgs") { if (value <= 0) TNP_FAIL(-1, "tnp_tuning_set: wgrad_target_wgs must be positive"); t.wgrad_target_wgs = (int)value; }
     else TNP_FAIL(-1, "tnp_tuning_set: unknown key '%s' (sparse_tile, sparse_min_wg, skinny_max_rows, skinny_gates_max_rows, "
-                  "sparse_wgrad_plan, wgrad_min_rows, wgrad_target_wgs)", k.c_str());
+                  "sparse_wgrad_plan, wgrad_min_rows, wgrad_target_wgs, fuse_prepare_grid)", k.c_str());
     return 0;
 }
 

@@ -25,6 +25,7 @@ struct Tuning {
     int sparse_wgrad_plan;       // sparse first layer's weight gradient: 16 * waves + batches per trip (0 = by size)  TNP_SPARSE_WGRAD_PLAN
     int wgrad_min_rows;          // dense weight gradients: fewest rows of K per split ...                          TNP_WGRAD_MIN_ROWS
     int wgrad_target_wgs;        // ... and the workgroup count a contraction is split towards                       TNP_WGRAD_TARGET
+    int fuse_prepare_grid;       // occupancy / directional grids: track_prepare and the grid in one launch (1)       TNP_FUSE_PREPARE_GRID
 };
 Tuning &tuning();
 
@@ -80,6 +81,7 @@ struct GridArgs {
     int vec4;  // set by launch_grid
 };
 int launch_grid(const GridArgs &a, hipStream_t s);
+int grid_launch_plan(const GridArgs &a, GridArgs *planned, size_t *smem_bytes);   // checks, LDS bytes, vec4 flag
 // pool_size / blur_size reduction of a fine grid [M][C][(n ps)^2] to [M][C][n^2] (lstm/gridbased_pooling.py:297-304)
 int launch_grid_finish(const float *fine, int ldf, int M, int C, int n, int pool_size, int blur_size, float *out, int ldo,
                        hipStream_t s);
