@@ -1,0 +1,18 @@
+"""One of eight shards of config 3 (32 scenes x 64 agents, directional n=12 one_layer): inference forwards for rocprofv3
+--kernel-trace --stats (per-kernel time of the strong-scaling shard's recurrent step).  usage: python tools/diag/shard_forward.py [n]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from trajnetplusplusbaselines_amd import synth
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+dev = torch.device('cuda', 0)
+model = bench.build_model(bench.CONFIGS['directional'], dev, seed=1).eval()
+xy, split = synth.linear_crowd(32, 64, seed=3)
+obs, goals = xy[:9].cuda(), torch.zeros(xy.shape[1], 2).cuda()
+with torch.no_grad():
+    for _ in range(n):
+        model(obs, goals, split, n_predict=12)
+torch.cuda.synchronize()

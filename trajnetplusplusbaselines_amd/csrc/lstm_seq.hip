@@ -382,25 +382,42 @@ __global__ void __launch_bounds__(256) track_prepare_kernel(const PrepArgs a) {
 // track_prepare itself reads -- the previous state (Hidden2Normal's two mean rows, same four partial sums in the same order:
 // the same bits), the previous obs2, the external frames and the primaries' patches -- so both kinds of workgroups run side
 // by side in one launch.  ~2 x 128 FMAs per track of the scene and workgroup, against a launch boundary.
-__global__ void __launch_bounds__(256) prepare_grid_kernel(const PrepArgs pa, const GridArgs ga, int prep_blocks, int ego_blocks) {
+__global__ void __launch_bounds__(256) prepare_grid_kernel(const PrepArgs pa, const GridArgs ga, int prep_blocks, int ego_blocks,
+                                                           int wn_offset /* floats: behind the grid's own LDS */) {
     extern __shared__ __attribute__((aligned(16))) float pgsm[];
     if ((int)blockIdx.x < prep_blocks) { track_prepare_body(pa, blockIdx.x, pgsm); return; }
     const int gid = (int)blockIdx.x - prep_blocks;
     const int sc = gid / ego_blocks, bx = gid - sc * ego_blocks;
     grid_build_body(ga, bx, sc, pgsm, [&](int start, int ns, float2 *pos, float2 *vel) {
         const int tid = threadIdx.x, q = tid & 3, H = pa.H;
+        float *wn = pgsm + wn_offset;                                        // rows 0 / 1 of Hidden2Normal, once per workgroup
+        if (pa.have_prev) {
+            for (int k = tid; k < 2 * H; k += 256) wn[k] = pa.Wn[k];
+            __syncthreads();
+        }
         for (int j0 = 0; j0 < ns; j0 += 64) {                                // four lanes per track
             const int j = j0 + (tid >> 2);
             const bool on = j < ns;
             const int m = start + (on ? j : 0);
-            float px = NAN, py = NAN;                                        // position predicted by the previous step
-            if (!pa.have_prev && pa.pos2) { px = pa.pos2[2 * m]; py = pa.pos2[2 * m + 1]; }
+            // every operand that does not depend on the dot products is requested first (their round trip runs beside the h rows')
+            float2 prev2 = make_float2(NAN, NAN), e1 = make_float2(NAN, NAN), e2 = make_float2(NAN, NAN);
+            bool was = false;
+            if (pa.have_prev) { prev2 = reinterpret_cast<const float2 *>(pa.obs2_prev)[m]; was = pa.mask_prev[m] != 0; }
+            else if (pa.pos2) prev2 = reinterpret_cast<const float2 *>(pa.pos2)[m];
+            const bool prim = pa.primary[m] != 0;
+            const bool take1 = pa.ext1 && !(pa.patch1 && prim), take2 = pa.ext2 && !(pa.patch2 && prim);
+            if (take1) e1 = reinterpret_cast<const float2 *>(pa.ext1)[m];
+            else if (pa.pos1) e1 = reinterpret_cast<const float2 *>(pa.pos1)[m];
+            if (take2) e2 = reinterpret_cast<const float2 *>(pa.ext2)[m];
+            float px = prev2.x, py = prev2.y;                                // position predicted by the previous step
             if (pa.have_prev) {
                 // rows 0 / 1 of Hidden2Normal as track_prepare sums them: lane q = partial sum q (k = q mod 4, ascending, the
                 // first one starting from the bias), combined as (p0 + p1) + (p2 + p3)
                 float p0 = q == 0 ? pa.bn[0] : 0.0f, p1 = q == 0 ? pa.bn[1] : 0.0f;
-                const float *hr = pa.h + (size_t)m * H + q, *w0 = pa.Wn + q, *w1 = pa.Wn + H + q;
-#pragma unroll 8
+                const float *hr = pa.h + (size_t)m * H + q, *w0 = wn + q, *w1 = wn + H + q;
+                // (the h elements of the first 64 tracks requested ahead of the weight staging -- 32 more registers -- made the launch
+                // slower: 8.6 -> 9.3 us)
+#pragma unroll 16
                 for (int k = 0; k < H; k += 4) {
                     const float hv = hr[k];
                     p0 = fmaf(hv, w0[k], p0);
@@ -408,17 +425,11 @@ __global__ void __launch_bounds__(256) prepare_grid_kernel(const PrepArgs pa, co
                 }
                 p0 += __shfl_xor(p0, 1); p1 += __shfl_xor(p1, 1);
                 p0 += __shfl_xor(p0, 2); p1 += __shfl_xor(p1, 2);
-                const bool was = pa.mask_prev[m] != 0;
-                px = pa.obs2_prev[2 * m] + (was ? p0 : NAN);
-                py = pa.obs2_prev[2 * m + 1] + (was ? p1 : NAN);
+                px = prev2.x + (was ? p0 : NAN);
+                py = prev2.y + (was ? p1 : NAN);
             }
-            const bool prim = pa.primary[m] != 0;
-            float2 o1, o2;
-            if (pa.ext1 && !(pa.patch1 && prim)) { o1.x = pa.ext1[2 * m]; o1.y = pa.ext1[2 * m + 1]; }
-            else if (pa.pos1) { o1.x = pa.pos1[2 * m]; o1.y = pa.pos1[2 * m + 1]; }
-            else { o1.x = NAN; o1.y = NAN; }
-            if (pa.ext2 && !(pa.patch2 && prim)) { o2.x = pa.ext2[2 * m]; o2.y = pa.ext2[2 * m + 1]; }
-            else { o2.x = px; o2.y = py; }
+            const float2 o1 = e1;
+            const float2 o2 = take2 ? e2 : make_float2(px, py);
             if (on && q == 0) grid_stage_track(ga.type, o1, o2, j, pos, vel);
         }
     });
@@ -436,6 +447,8 @@ static int launch_prepare_grid(const PrepArgs &a, const GridArgs &g, hipStream_t
     GridArgs gb;
     const int rc = grid_launch_plan(g, &gb, &gsm);
     if (rc) return rc;
+    const int wn_offset = (int)(gsm / sizeof(float));
+    gsm += (size_t)2 * a.H * sizeof(float);
     const size_t smem = psm > gsm ? psm : gsm;
     // (egos per grid workgroup: every workgroup of a scene forms the scene's positions again, so more egos per workgroup would
     // mean fewer repetitions -- and a longer ego loop, which is what counts: 4 / 8 / 16 egos -> 0.591 / 0.621 / 0.698 ms per
@@ -449,7 +462,8 @@ static int launch_prepare_grid(const PrepArgs &a, const GridArgs &g, hipStream_t
                                     (int)smem));
         attr[dev] = smem;
     }
-    hipLaunchKernelGGL(prepare_grid_kernel, dim3(prep_blocks + ego_blocks * g.B), dim3(256), smem, s, a, gb, prep_blocks, ego_blocks);
+    hipLaunchKernelGGL(prepare_grid_kernel, dim3(prep_blocks + ego_blocks * g.B), dim3(256), smem, s, a, gb, prep_blocks, ego_blocks,
+                       wn_offset);
     TNP_HIP(hipGetLastError());
     return 0;
 }
