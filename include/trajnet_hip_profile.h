@@ -47,8 +47,9 @@ TNP_API int tnp_profile_end(void);
  *                     dense weight gradients: fewest rows of K per split (default 128) and the workgroup
  *                     count a contraction is split towards (512).  Plans only change the order of the sums.
  *   "fuse_prepare_grid"
- *                     occupancy / directional grids: track_prepare and the step's grid in one launch (default 1;
- *                     0 = two launches).  Bit-identical either way.
+ *                     occupancy / directional grids: track_prepare and the step's grid in one launch: 1 = while the
+ *                     repeated position work is small (tracks x largest scene <= 196608; default), 2 = always,
+ *                     0 = two launches.  Bit-identical either way.
  * Initial values: environment TNP_SPARSE_TILE="te,ncs", TNP_SPARSE_MIN_WG, TNP_SKINNY_MAX_M (both),
  * TNP_SKINNY_GATES_MAX_M, TNP_SPARSE_WGRAD_PLAN, TNP_WGRAD_MIN_ROWS, TNP_WGRAD_TARGET,
  * TNP_FUSE_PREPARE_GRID.

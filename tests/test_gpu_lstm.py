@@ -554,7 +554,7 @@ def test_prepare_and_grid_in_one_launch_do_not_change_the_result(type_, n_predic
         PredictionLoss()(rel[-12:], xy[9:21] - xy[8:20], split).backward()
         return out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
     try:
-        _lib.tuning_set('fuse_prepare_grid', 1)
+        _lib.tuning_set('fuse_prepare_grid', 2)
         (rel1, pred1), g1 = run()
         _lib.tuning_set('fuse_prepare_grid', 0)
         (rel0, pred0), g0 = run()

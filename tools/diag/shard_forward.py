@@ -8,11 +8,18 @@ import bench
 from trajnetplusplusbaselines_amd import synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+scenes = int(sys.argv[2]) if len(sys.argv) > 2 else 32        # 256 = the whole config-3 batch
 dev = torch.device('cuda', 0)
 model = bench.build_model(bench.CONFIGS['directional'], dev, seed=1).eval()
-xy, split = synth.linear_crowd(32, 64, seed=3)
+xy, split = synth.linear_crowd(scenes, 64, seed=3)
 obs, goals = xy[:9].cuda(), torch.zeros(xy.shape[1], 2).cuda()
+import time
 with torch.no_grad():
+    for _ in range(5):
+        model(obs, goals, split, n_predict=12)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for _ in range(n):
         model(obs, goals, split, n_predict=12)
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
+print('%d scenes x 64 agents: %.3f ms per forward' % (scenes, (time.perf_counter() - t0) / n * 1e3))

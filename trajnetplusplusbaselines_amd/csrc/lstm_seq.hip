@@ -676,7 +676,12 @@ static GridArgs step_grid_args(const tnp_lstm_model *md, const Workspace &w, con
 static int prepare_step(const tnp_lstm_model *md, Workspace &w, const PrepArgs &p, const int32_t *scene_start, int B, int n_max,
                         const int32_t *scene_slots, hipStream_t s) {
     const bool grid_pool = md->pool_type == TNP_POOL_OCCUPANCY || md->pool_type == TNP_POOL_DIRECTIONAL;
-    if (p.have_next && grid_pool && !w.sparse && !w.fine && B > 0 && n_max > 0 && tuning().fuse_prepare_grid) {
+    // ... while the repeated position work is small: every grid workgroup (four egos) reads the h rows of its whole scene, M *
+    // n_max / 4 rows per launch.  64-agent scenes: 32 / 64 / 128 / 256 scenes -> 0.584 / 0.883 / 1.367 / 2.503 ms per forward merged
+    // against 0.617 / 0.879 / 1.278 / 2.318 ms with two launches; 128 x 32 (S-GAN): 1.486 against 1.556.
+    const int fuse = tuning().fuse_prepare_grid;                     // 0 = never, 1 = by size, 2 = always
+    if (p.have_next && grid_pool && !w.sparse && !w.fine && B > 0 && n_max > 0 &&
+        (fuse == 2 || (fuse == 1 && (long)p.M * n_max <= 196608))) {
         // track_prepare updates obs2 / mask in place (a thread reads its track's previous value, then writes the new one); the
         // grid workgroups of the same launch read the previous values of whole scenes: the new ones go to the second copies
         PrepArgs q = p;
@@ -1165,7 +1170,7 @@ extern "C" TNP_API int tnp_tuning_set(const char *key, long value) {
     else if (k == "sparse_min_wg") t.sparse_min_wg = value;
     else if (k == "skinny_max_rows") t.skinny_max_rows = (int)value;
     else if (k == "skinny_gates_max_rows") t.skinny_gates_max_rows = (int)value;
-    else if (k == "fuse_prepare_grid") t.fuse_prepare_grid = value != 0;
+    else if (k == "fuse_prepare_grid") t.fuse_prepare_grid = (int)value;
     else if (k == "sparse_wgrad_plan") t.sparse_wgrad_plan = (int)value;
     else if (k == "wgrad_min_rows") { if (value <= 0) TNP_FAIL(-1, "tnp_tuning_set: wgrad_min_rows must be positive"); t.wgrad_min_rows = (int)value; }
     else if (k == "wgrad_target_wgs") { if (value <= 0) TNP_FAIL(-1, "tnp_tuning_set: wgrad_target_wgs must be positive"); t.wgrad_target_wgs = (int)value; }

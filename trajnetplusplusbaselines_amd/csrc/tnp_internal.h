@@ -25,7 +25,7 @@ struct Tuning {
     int sparse_wgrad_plan;       // sparse first layer's weight gradient: 16 * waves + batches per trip (0 = by size)  TNP_SPARSE_WGRAD_PLAN
     int wgrad_min_rows;          // dense weight gradients: fewest rows of K per split ...                          TNP_WGRAD_MIN_ROWS
     int wgrad_target_wgs;        // ... and the workgroup count a contraction is split towards                       TNP_WGRAD_TARGET
-    int fuse_prepare_grid;       // occupancy / directional grids: track_prepare and the grid in one launch (1)       TNP_FUSE_PREPARE_GRID
+    int fuse_prepare_grid;       // occupancy / directional grids: track_prepare + grid in one launch (0 / 1 by size / 2) TNP_FUSE_PREPARE_GRID
 };
 Tuning &tuning();
 
